@@ -1,0 +1,275 @@
+// BatchNorm statistics / apply / backward and the fused elementwise passes around the convs.
+// All of these are HBM-bound streaming kernels over NHWC [rows][c] tensors (roofline: HBM,
+// 4 B read + 4 B written per element for the apply passes); 16-B accesses per lane, channel =
+// fastest dim so per-channel parameters are read once per thread and stay in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int RS_MAX = 64;   // row slices of the two-stage column sum
+
+// ---- two-stage column sum of a [rows][cols] fp32 matrix into double ---------------------------
+// stage 1: grid (cols/32, RS); 256 threads = 8 row lanes x 32 columns
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int rows, int cols, int rs,
+                                                     double* __restrict__ ws) {
+  __shared__ double red[8][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + tx;
+  const int per = (rows + rs - 1) / rs;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s = 0.0;
+  if (col < cols)
+    for (int r = r0 + ty; r < r1; r += 8) s += (double)in[(size_t)r * cols + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < cols) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][tx];
+    ws[(size_t)blockIdx.y * cols + col] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ws, int rs, int c, double inv_count,
+                                                          double unbias, const float* gamma, const float* beta, float eps,
+                                                          float momentum, float* running_mean, float* running_var,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < rs; ++k) { s += ws[(size_t)k * 2 * c + ch]; ss += ws[(size_t)k * 2 * c + c + ch]; }
+  const double m = s * inv_count;
+  double var = ss * inv_count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)m; invstd[ch] = is;
+  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  const float sc = g * is;
+  scale[ch] = sc; shift[ch] = b - (float)m * sc;
+  if (running_mean) {
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)(var * unbias);
+  }
+}
+
+__global__ __launch_bounds__(256) void sums_finalize_kernel(const double* __restrict__ ws, int rs, int cols, float* out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  double s = 0.0;
+  for (int k = 0; k < rs; ++k) s += ws[(size_t)k * cols + col];
+  out[col] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                                      float eps, int c, float* scale, float* shift) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+  scale[ch] = sc; shift[ch] = beta[ch] - rm[ch] * sc;
+}
+
+// ---- per-channel partial sums of an NHWC tensor -------------------------------------------------
+// grid (rows/128, c/64): 256 threads = 4 row lanes x 64 channels, 32 rows per thread.
+// MODE 0: sum(x), sum(x^2).   MODE 1 (BN+act backward): sum(g), sum(g*xhat), g = dout*act'(bn(y)).
+template <int MODE>
+__global__ __launch_bounds__(256) void channel_partials_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dout,
+                                                               int lddo, const float* mean, const float* invstd,
+                                                               const float* gamma, const float* beta, int act, float slope,
+                                                               int64_t rows, int c, float* __restrict__ stats) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.x * 128;
+  float s = 0.f, ss = 0.f;
+  if (ch < c) {
+    float mu = 0.f, is = 1.f, g = 1.f, b = 0.f;
+    if (MODE == 1) { mu = mean[ch]; is = invstd[ch]; g = gamma ? gamma[ch] : 1.f; b = beta ? beta[ch] : 0.f; }
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const int64_t r = r0 + ty + 4 * k;
+      if (r < rows) {
+        const float v = x[r * ld + ch];
+        if (MODE == 0) { s += v; ss += v * v; }
+        else {
+          const float xh = (v - mu) * is;
+          float d = dout[r * lddo + ch];
+          if (act == DCN_ACT_LEAKY && (g * xh + b) <= 0.f) d *= slope;
+          s += d; ss += d * xh;
+        }
+      }
+    }
+  }
+  red[0][ty][tx] = s; red[1][ty][tx] = ss;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, t = threadIdx.x & 63, cc = blockIdx.y * 64 + t;
+    if (cc < c)
+      stats[((size_t)blockIdx.x * 2 + which) * c + cc] = red[which][0][t] + red[which][1][t] + red[which][2][t] + red[which][3][t];
+  }
+}
+
+// ---- out = act(scale*y + shift) + residual ---------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int act, float slope,
+                                                        const float* __restrict__ residual, float* __restrict__ out,
+                                                        int64_t rows, int c, int ldo) {
+  const int c4 = c >> 2;
+  const int64_t total = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + ch);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + ch);
+    v = v * sc + sh;
+    if (act == DCN_ACT_LEAKY) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * slope;
+    }
+    if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * c + ch);
+    *reinterpret_cast<f32x4*>(out + r * ldo + ch) = v;
+  }
+}
+
+// ---- dy = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ---------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout, int lddo,
+                                                               const float* mean, const float* invstd, const float* gamma,
+                                                               const float* beta, int act, float slope, const float* sums,
+                                                               float inv_count, int64_t rows, int c, float* __restrict__ dy) {
+  const int c4 = c >> 2;
+  const int64_t total = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dout + r * lddo + ch);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), is = *reinterpret_cast<const f32x4*>(invstd + ch);
+    f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + ch);
+    if (beta) b = *reinterpret_cast<const f32x4*>(beta + ch);
+    const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + ch), sgx = *reinterpret_cast<const f32x4*>(sums + c + ch);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (v[k] - mu[k]) * is[k];
+      float dd = d[k];
+      if (act == DCN_ACT_LEAKY && (g[k] * xh + b[k]) <= 0.f) dd *= slope;
+      o[k] = g[k] * is[k] * (dd - sg[k] * inv_count - xh * sgx[k] * inv_count);
+    }
+    *reinterpret_cast<f32x4*>(dy + r * c + ch) = o;
+  }
+}
+
+// plain activation backward (eval-style affine, no batch statistics): dy = dout*act'(scale*y+shift)*scale
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ outv, const float* __restrict__ dout, int lddo,
+                                                      float slope, int64_t rows, int c, float* __restrict__ dy) {
+  const int c4 = c >> 2;
+  const int64_t total = rows * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(outv + r * c + ch);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dout + r * lddo + ch);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (v[k] <= 0.f) d[k] *= slope;
+    *reinterpret_cast<f32x4*>(dy + r * c + ch) = d;
+  }
+}
+
+inline int stream_grid(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+inline int row_slices(int rows) { int rs = (rows + 63) / 64; return rs < 1 ? 1 : (rs > RS_MAX ? RS_MAX : rs); }
+
+}  // namespace
+
+extern "C" int64_t dcn_bn_ws(int c) { return (int64_t)RS_MAX * 2 * c * 2; }   // doubles stored in a float-typed scratch
+
+extern "C" int dcn_bn_finalize(const float* stats, int rows, int c, int64_t count,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var,
+                               float* mean, float* invstd, float* scale, float* shift, float* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(stats && mean && invstd && scale && shift && ws, "bn_finalize: null pointer");
+  DCN_CHECK_ARG(rows > 0 && c > 0 && count > 0, "bn_finalize: bad shape");
+  DCN_CHECK_ARG(((uintptr_t)ws & 7) == 0, "bn_finalize: ws must be 8-byte aligned");
+  const int rs = row_slices(rows);
+  hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(2 * c, 32), rs), dim3(256), 0, stream, stats, rows, 2 * c, rs, (double*)ws);
+  DCN_CHECK_LAUNCH("colsum_stage1");
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, stream, (const double*)ws, rs, c,
+                     1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var,
+                     mean, invstd, scale, shift);
+  DCN_CHECK_LAUNCH("bn_finalize");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, int c, float* scale, float* shift, void* stream) {
+  DCN_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && c > 0, "bn_fold: bad argument");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, eps, c, scale, shift);
+  DCN_CHECK_LAUNCH("bn_fold");
+  return DCN_OK;
+}
+
+extern "C" int dcn_channel_stats_rows(int64_t rows) { return cdiv(rows, 128); }
+
+extern "C" int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, float* stats, void* stream) {
+  DCN_CHECK_ARG(x && stats && rows > 0 && c > 0, "channel_stats: bad argument");
+  hipLaunchKernelGGL((channel_partials_kernel<0>), dim3(cdiv(rows, 128), cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream,
+                     x, ld > 0 ? ld : c, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, rows, c, stats);
+  DCN_CHECK_LAUNCH("channel_stats");
+  return DCN_OK;
+}
+
+extern "C" int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
+                             const float* residual, float* out, int64_t rows, int c, int ldo, void* stream) {
+  DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 4 == 0, "scale_act: bad argument (c=%d must be a multiple of 4)", c);
+  if (ldo <= 0) ldo = c;
+  DCN_CHECK_ARG(ldo % 4 == 0, "scale_act: ldo=%d must be a multiple of 4", ldo);
+  hipLaunchKernelGGL(scale_act_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
+                     y, scale, shift, act, slope, residual, out, rows, c, ldo);
+  DCN_CHECK_LAUNCH("scale_act");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, int act, float slope,
+                                     int64_t rows, int c, float* stats, void* stream) {
+  DCN_CHECK_ARG(y && dout && mean && invstd && stats && rows > 0 && c > 0, "bn_act_bwd_reduce: bad argument");
+  hipLaunchKernelGGL((channel_partials_kernel<1>), dim3(cdiv(rows, 128), cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream,
+                     y, c, dout, lddo > 0 ? lddo : c, mean, invstd, gamma, beta, act, slope, rows, c, stats);
+  DCN_CHECK_LAUNCH("bn_act_bwd_reduce");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums, float* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(stats && sums && ws && rows > 0 && c > 0, "bn_bwd_sums: bad argument");
+  const int rs = row_slices(rows);
+  hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(2 * c, 32), rs), dim3(256), 0, stream, stats, rows, 2 * c, rs, (double*)ws);
+  DCN_CHECK_LAUNCH("colsum_stage1");
+  hipLaunchKernelGGL(sums_finalize_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, stream, (const double*)ws, rs, 2 * c, sums);
+  DCN_CHECK_LAUNCH("sums_finalize");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, int act, float slope,
+                                    const float* sums, int64_t count, int64_t rows, int c, float* dy, void* stream) {
+  DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 4 == 0, "bn_act_bwd_apply: bad argument");
+  if (lddo <= 0) lddo = c;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
+                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy);
+  DCN_CHECK_LAUNCH("bn_act_bwd_apply");
+  return DCN_OK;
+}
+
+extern "C" int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int64_t rows, int c, float* dy, void* stream) {
+  DCN_CHECK_ARG(out && dout && dy && rows > 0 && c > 0 && c % 4 == 0, "act_bwd: bad argument");
+  if (lddo <= 0) lddo = c;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
+                     out, dout, lddo, slope, rows, c, dy);
+  DCN_CHECK_LAUNCH("act_bwd");
+  return DCN_OK;
+}

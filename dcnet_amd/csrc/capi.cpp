@@ -1,0 +1,15 @@
+// Error reporting and version of libdcnet_hip.so.
+#include "common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void dcn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* dcn_last_error(void) { return g_err; }
+extern "C" int dcn_version(void) { return 100; }

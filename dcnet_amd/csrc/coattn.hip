@@ -1,0 +1,224 @@
+// Inter-frame co-attention (model/DCNet_model.py:449-459, model/test_DCNet_model.py:259-274).
+//
+//   A[i,j]      = <f1_i, f2_j>                      (unit-norm features => A in [-1,1])
+//   f1_attn[i]  = sum_j softmax_j(t*A[i,j]) f2_j
+//   f2_attn[j]  = sum_i softmax_i(t*A[i,j]) f1_i
+//
+// MI355X design note.  fp32 MFMA peak is 157 TFLOP/s but HBM streams ~6 TB/s, i.e. the machine
+// balance is only ~25 FLOP/B for this dtype.  A flash-style kernel would recompute A for each
+// softmax direction (4 GEMM units forward, 14 in the backward).  Materialising E = exp(t*A - t)
+// ONCE in HBM (0.94 GB for 32 pairs at 52x52 — 288 GB is there to be used) needs 3 GEMM units
+// forward and 6 backward, at the price of ~6 streaming passes over E (<= 20 % of the GEMM time at
+// HW = 2704, less at the coarser scales).  Because |A| <= 1 the softmax needs no running max:
+// exp(t*A - t) is in [e^-2t, 1], so row sums and column sums of the same E give both directions.
+// All GEMMs run on the shared engines: NT and NN forms on igemm.hip, TN on wgrad.hip.
+#include "igemm.h"
+
+int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
+                    float* C, int ldc, long long c_bs, const float* row_scale,
+                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream);
+
+namespace {
+
+constexpr int EXP_ROWS = 32;
+
+// E = exp(t*A - t) in place (pad columns -> 0), row sums, per-row-block column partial sums.
+// grid (ceil(hw/32), b); each thread owns columns tid, tid+256, ... and walks the 32 rows.
+__global__ __launch_bounds__(256) void exp_sums_kernel(float* __restrict__ E, int hw, int ldE, float t,
+                                                       float* __restrict__ rsum, float* __restrict__ colpart) {
+  __shared__ float red[4][EXP_ROWS];
+  const int b = blockIdx.y, rb = blockIdx.x;
+  const int i0 = rb * EXP_ROWS;
+  float* e = E + ((size_t)b * hw + i0) * ldE;
+  float racc[EXP_ROWS];
+#pragma unroll
+  for (int r = 0; r < EXP_ROWS; ++r) racc[r] = 0.f;
+  for (int j = threadIdx.x; j < ldE; j += 256) {
+    float cs = 0.f;
+    const bool colok = j < hw;
+#pragma unroll
+    for (int r = 0; r < EXP_ROWS; ++r) {
+      if (i0 + r < hw) {
+        float v = 0.f;
+        if (colok) v = expf(t * e[(size_t)r * ldE + j] - t);
+        e[(size_t)r * ldE + j] = v;
+        cs += v; racc[r] += v;
+      }
+    }
+    colpart[((size_t)rb * gridDim.y + b) * ldE + j] = cs;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < EXP_ROWS; ++r) {
+    const float s = wave_sum(racc[r]);
+    if (lane == 0) red[wave][r] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < EXP_ROWS && i0 + threadIdx.x < hw)
+    rsum[(size_t)b * hw + i0 + threadIdx.x] = 1.f / (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// cinv[b][j] = 1 / sum_rb colpart[rb][b][j]
+__global__ __launch_bounds__(256) void colsum_inv_kernel(const float* __restrict__ colpart, int nrb, int b, int hw, int ldE,
+                                                         float* __restrict__ cinv) {
+  const int j = blockIdx.x * 256 + threadIdx.x, bb = blockIdx.y;
+  if (j >= hw) return;
+  float s = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) s += colpart[((size_t)rb * b + bb) * ldE + j];
+  cinv[(size_t)bb * hw + j] = 1.f / s;
+}
+
+// one wave per row: delta[row] = <d[row], o[row]>, ds[row] = d[row] * inv[row]
+__global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ o, int ldo,
+                                                           const float* __restrict__ inv, int64_t rows, int c,
+                                                           float* __restrict__ delta, float* __restrict__ ds) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float s = inv[row];
+  float acc = 0.f;
+  for (int k = lane * 4; k < c; k += 256) {
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + row * ldd + k);
+    const f32x4 ov = *reinterpret_cast<const f32x4*>(o + row * ldo + k);
+    acc += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
+    *reinterpret_cast<f32x4*>(ds + row * c + k) = dv * s;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) delta[row] = acc;
+}
+
+// dA = t * E * ((dP1 - d1[i]) * rinv[i] + (dP2 - d2[j]) * cinv[j]), written over dP1; pad columns -> 0
+__global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, float* __restrict__ dP1, const float* __restrict__ dP2,
+                                                 const float* __restrict__ rinv, const float* __restrict__ cinv,
+                                                 const float* __restrict__ d1, const float* __restrict__ d2,
+                                                 int hw, int ldE, float t, int64_t total4) {
+  const int l4 = ldE >> 2;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / l4;                 // = b*hw + i
+    const int j = (int)(idx - row * l4) * 4;
+    const int64_t bb = row / hw;
+    const f32x4 e = *reinterpret_cast<const f32x4*>(E + row * ldE + j);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(dP1 + row * ldE + j);
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(dP2 + row * ldE + j);
+    const float ri = rinv[row], di = d1[row];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = 0.f;
+      if (j + k < hw) v = t * e[k] * ((p1[k] - di) * ri + (p2[k] - d2[bb * hw + j + k]) * cinv[bb * hw + j + k]);
+      o[k] = v;
+    }
+    *reinterpret_cast<f32x4*>(dP1 + row * ldE + j) = o;
+  }
+}
+
+inline int ld_pad(int hw) { return (hw + 31) / 32 * 32; }
+
+void gemm_params(IgemmParams& p, const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
+                 float* C, int ldc, long long c_bs, int M, int N, int K, int batch) {
+  p = IgemmParams{};
+  p.osy = p.osx = p.isy = p.isx = 1; p.dense_out = 1;
+  p.in = A; p.ldi = lda; p.in_bs = a_bs; p.wt = B; p.ldw = ldb; p.wt_bs = b_bs; p.out = C; p.ldo = ldc; p.out_bs = c_bs;
+  p.ldr = ldc;
+  p.N = 1; p.Hi = 1; p.Wi = M; p.Ho = 1; p.Wo = M; p.Hs = 1; p.Ws = M; p.M = M;
+  p.Ci = K; p.Co = N; p.ntaps = 1; p.cpt = K / 32; p.kiters = p.cpt; p.batch = batch;
+}
+
+}  // namespace
+
+extern "C" int64_t dcn_coattn_fwd_ws(int b, int hw, int c) {
+  (void)c;
+  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw);
+}
+extern "C" int64_t dcn_coattn_e_size(int b, int hw) { return (int64_t)b * hw * ld_pad(hw); }
+
+extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* f1_attn, float* f2_attn, int ldo,
+                              float* E, float* rinv, float* cinv, float* ws,
+                              int b, int hw, int c, float temperature, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(f1 && f2 && f1_attn && E && rinv && cinv && ws, "coattn_fwd: null pointer");
+  DCN_CHECK_ARG(b > 0 && hw > 0 && c > 0 && c % 32 == 0, "coattn_fwd: bad shape (c=%d must be a multiple of 32)", c);
+  if (ldf <= 0) ldf = c;
+  if (ldo <= 0) ldo = c;
+  DCN_CHECK_ARG(ldf % 4 == 0 && ldo % 4 == 0, "coattn_fwd: ldf/ldo must be multiples of 4");
+  const int ldE = ld_pad(hw);
+  IgemmParams p;
+  // 1. A = f1 . f2^T  -> E                                             (NT)
+  gemm_params(p, f1, ldf, (long long)hw * ldf, f2, ldf, (long long)hw * ldf, E, ldE, (long long)hw * ldE, hw, hw, c, b);
+  int rc = igemm_launch(p, stream);
+  if (rc) return rc;
+  // 2. E = exp(t*A - t), rinv = 1/rowsum, cinv = 1/colsum
+  const int nrb = cdiv(hw, EXP_ROWS);
+  hipLaunchKernelGGL(exp_sums_kernel, dim3(nrb, b), dim3(256), 0, stream, E, hw, ldE, temperature, rinv, ws);
+  DCN_CHECK_LAUNCH("exp_sums");
+  hipLaunchKernelGGL(colsum_inv_kernel, dim3(cdiv(hw, 256), b), dim3(256), 0, stream, ws, nrb, b, hw, ldE, cinv);
+  DCN_CHECK_LAUNCH("colsum_inv");
+  // 3. f1_attn = diag(rinv) E f2                                       (NN, K = keys j)
+  gemm_params(p, E, ldE, (long long)hw * ldE, f2, ldf, (long long)hw * ldf, f1_attn, ldo, (long long)hw * ldo, hw, c, ldE, b);
+  p.bmode = 1; p.kvalid = hw; p.row_scale = rinv;
+  rc = igemm_launch(p, stream);
+  if (rc) return rc;
+  // 4. f2_attn = diag(cinv) E^T f1                                     (TN, K = queries i)
+  if (f2_attn)
+    rc = tn_gemm_batched(E, ldE, (long long)hw * ldE, f1, ldf, (long long)hw * ldf, f2_attn, ldo, (long long)hw * ldo,
+                         cinv, hw, ldE, c, hw, b, 0, stream);
+  return rc;
+}
+
+extern "C" int64_t dcn_coattn_bwd_ws(int b, int hw, int c) {
+  return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw;
+}
+
+extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
+                              const float* d_f1_attn, const float* d_f2_attn, int lddo,
+                              const float* f1_attn, const float* f2_attn, int ldo,
+                              const float* E, const float* rinv, const float* cinv,
+                              float* d_f1, float* d_f2, int lddf, int accumulate, float* ws,
+                              int b, int hw, int c, float temperature, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(f1 && f2 && d_f1_attn && d_f2_attn && f1_attn && f2_attn && E && rinv && cinv && d_f1 && d_f2 && ws,
+                "coattn_bwd: null pointer");
+  DCN_CHECK_ARG(b > 0 && hw > 0 && c > 0 && c % 32 == 0, "coattn_bwd: bad shape");
+  if (ldf <= 0) ldf = c;
+  if (ldo <= 0) ldo = c;
+  if (lddo <= 0) lddo = c;
+  if (lddf <= 0) lddf = c;
+  const int ldE = ld_pad(hw);
+  const long long rows = (long long)b * hw;
+  float* dP1 = ws;
+  float* dP2 = dP1 + rows * ldE;
+  float* dO1s = dP2 + rows * ldE;
+  float* dO2s = dO1s + rows * c;
+  float* del1 = dO2s + rows * c;
+  float* del2 = del1 + rows;
+  // 1. delta and pre-scaled upstream gradients
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f1_attn, lddo, f1_attn, ldo, rinv, rows, c, del1, dO1s);
+  DCN_CHECK_LAUNCH("rowdot_scale");
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, f2_attn, ldo, cinv, rows, c, del2, dO2s);
+  DCN_CHECK_LAUNCH("rowdot_scale");
+  IgemmParams p;
+  int rc;
+  // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                  (NT x2)
+  gemm_params(p, d_f1_attn, lddo, (long long)hw * lddo, f2, ldf, (long long)hw * ldf, dP1, ldE, (long long)hw * ldE, hw, hw, c, b);
+  if ((rc = igemm_launch(p, stream))) return rc;
+  gemm_params(p, f1, ldf, (long long)hw * ldf, d_f2_attn, lddo, (long long)hw * lddo, dP2, ldE, (long long)hw * ldE, hw, hw, c, b);
+  if ((rc = igemm_launch(p, stream))) return rc;
+  // 3. dA (over dP1)
+  const int64_t total4 = rows * (ldE / 4);
+  int64_t g = (total4 + 255) / 256; if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4);
+  DCN_CHECK_LAUNCH("dA");
+  // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                   (NN x2)
+  gemm_params(p, dP1, ldE, (long long)hw * ldE, f2, ldf, (long long)hw * ldf, d_f1, lddf, (long long)hw * lddf, hw, c, ldE, b);
+  p.bmode = 1; p.kvalid = hw; p.accumulate = accumulate;
+  if ((rc = igemm_launch(p, stream))) return rc;
+  gemm_params(p, E, ldE, (long long)hw * ldE, dO2s, c, (long long)hw * c, d_f1, lddf, (long long)hw * lddf, hw, c, ldE, b);
+  p.bmode = 1; p.kvalid = hw; p.accumulate = 1;
+  if ((rc = igemm_launch(p, stream))) return rc;
+  // 5. d_f2 (+)= dA^T f1 + E^T (dO1 / rowsum)                               (TN x2)
+  rc = tn_gemm_batched(dP1, ldE, (long long)hw * ldE, f1, ldf, (long long)hw * ldf, d_f2, lddf, (long long)hw * lddf,
+                       nullptr, hw, ldE, c, hw, b, accumulate, stream);
+  if (rc) return rc;
+  return tn_gemm_batched(E, ldE, (long long)hw * ldE, dO1s, c, (long long)hw * c, d_f2, lddf, (long long)hw * lddf,
+                         nullptr, hw, ldE, c, hw, b, 1, stream);
+}

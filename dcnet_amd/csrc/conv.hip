@@ -1,0 +1,133 @@
+// C-ABI convolution entry points: forward and data gradient, both lowered onto the
+// implicit-GEMM engine of igemm.hip.
+#include "igemm.h"
+
+namespace {
+
+// [Co][T][Ci] -> [Ci][T][Co]: the data-gradient GEMM contracts over Cout, so its "weights"
+// are the channel-transposed filters.  32x32 LDS tile transpose per tap, coalesced both ways.
+__global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                               int Co, int T, int Ci) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+    tile[ty + 8 * k][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + t) * Ci + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+    if (ci < Ci && co < Co) wt[((size_t)ci * T + t) * Co + co] = tile[tx][ty + 8 * k];
+  }
+}
+
+void base_params(IgemmParams& p) {
+  p = IgemmParams{};
+  p.osy = p.osx = 1; p.isy = p.isx = 1; p.dense_out = 1;
+}
+
+}  // namespace
+
+extern "C" int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride) {
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  return igemm_grid_m(n * ho * wo, cout);
+}
+
+extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
+                              int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                              const float* scale, const float* shift, int act, float slope,
+                              const float* residual, int ldr, int ldy,
+                              float* stats, void* stream) {
+  DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize=%d (1 or 3)", ksize);
+  DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride=%d (1 or 2)", stride);
+  DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0, "conv2d_fwd: bad shape");
+  DCN_CHECK_ARG(cin == 4 || cin % 32 == 0, "conv2d_fwd: cin=%d must be 4 or a multiple of 32 (pad channels)", cin);
+  DCN_CHECK_ARG(cin != 4 || (ksize == 3 && stride == 1), "conv2d_fwd: cin=4 path is the 3x3 stride-1 stem only");
+  const int pad = (ksize - 1) / 2;
+  IgemmParams p; base_params(p);
+  p.in = x; p.wt = w; p.out = y; p.scale = scale; p.shift = shift; p.residual = residual; p.stats = stats;
+  p.N = n; p.Hi = h; p.Wi = wd; p.Ci = cin; p.ldi = cin;
+  p.Ho = (h + 2 * pad - ksize) / stride + 1; p.Wo = (wd + 2 * pad - ksize) / stride + 1;
+  p.Hs = p.Ho; p.Ws = p.Wo; p.isy = p.isx = stride;
+  p.Co = cout; p.ldo = ldy > 0 ? ldy : cout; p.ldr = ldr > 0 ? ldr : cout;
+  DCN_CHECK_ARG(p.ldo >= cout, "conv2d_fwd: ldy=%d < cout=%d", ldy, cout);
+  p.M = n * p.Ho * p.Wo;
+  p.ntaps = ksize * ksize;
+  p.act = act; p.slope = slope;
+  if (cin == 4) {
+    // weights are [Co][64]: 9 taps x 4 channels then zero padding (host prepares them)
+    p.c4 = 1; p.ldw = 64; p.kiters = 2; p.cpt = 1;
+  } else {
+    p.ldw = p.ntaps * cin; p.cpt = cin / 32; p.kiters = p.ntaps * p.cpt;
+    for (int r = 0; r < ksize; ++r)
+      for (int s = 0; s < ksize; ++s) {
+        const int t = r * ksize + s;
+        p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
+      }
+  }
+  return igemm_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                                   int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                                   int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_data: ksize=%d", ksize);
+  DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_data: stride=%d", stride);
+  DCN_CHECK_ARG(cout % 32 == 0, "conv2d_bwd_data: cout=%d must be a multiple of 32 (pad the filter bank)", cout);
+  DCN_CHECK_ARG(dy && w && wt && dx, "conv2d_bwd_data: null pointer");
+  const int pad = (ksize - 1) / 2, T = ksize * ksize;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  if (lddy <= 0) lddy = cout;
+  hipLaunchKernelGGL(transpose_filter_kernel, dim3(cdiv(cin, 32), cdiv(cout, 32), T), dim3(256), 0, stream,
+                     w, wt, cout, T, cin);
+  DCN_CHECK_LAUNCH("transpose_filter");
+  IgemmParams p; base_params(p);
+  p.in = dy; p.wt = wt; p.out = dx;
+  p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
+  p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
+  p.cpt = cout / 32; p.accumulate = accumulate;
+  if (stride == 1) {
+    // dx[hi,wi] = sum_{r,s} dy[hi+pad-r, wi+pad-s] . w[:,r,s,:]
+    p.Hs = h; p.Ws = wd; p.M = n * h * wd; p.ntaps = T;
+    for (int r = 0; r < ksize; ++r)
+      for (int s = 0; s < ksize; ++s) {
+        const int t = r * ksize + s;
+        p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
+      }
+    p.kiters = p.ntaps * p.cpt;
+    return igemm_launch(p, stream);
+  }
+  // stride 2: output pixels of parity class (a,b) only see taps with (a+pad-r), (b+pad-s) even.
+  // Four dense sub-problems with 1/2/2/4 taps (3x3) instead of one 9-tap problem that is 3/4 zeros.
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      IgemmParams q = p;
+      q.dense_out = 0; q.oy0 = a; q.ox0 = b; q.osy = q.osx = 2;
+      q.Hs = (h - a + 1) / 2; q.Ws = (wd - b + 1) / 2;
+      if (q.Hs <= 0 || q.Ws <= 0) continue;
+      q.M = n * q.Hs * q.Ws;
+      q.ntaps = 0;
+      for (int r = 0; r < ksize; ++r)
+        for (int s = 0; s < ksize; ++s) {
+          if (((a + pad - r) & 1) || ((b + pad - s) & 1)) continue;
+          // hi = 2i+a  ->  ho = (2i + a + pad - r)/2 = i + (a+pad-r)/2
+          q.tap_dy[q.ntaps] = (a + pad - r) / 2; q.tap_dx[q.ntaps] = (b + pad - s) / 2;
+          q.tap_w[q.ntaps] = (r * ksize + s) * cout;
+          ++q.ntaps;
+        }
+      if (q.ntaps == 0) {
+        // 1x1 stride 2: odd pixels get no gradient.  (Not used by DCNet; keep semantics right.)
+        continue;
+      }
+      q.kiters = q.ntaps * q.cpt;
+      int rc = igemm_launch(q, stream);
+      if (rc != DCN_OK) return rc;
+    }
+  return DCN_OK;
+}

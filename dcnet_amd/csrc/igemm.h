@@ -1,0 +1,42 @@
+// Implicit-GEMM convolution engine (fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32).
+//
+//   out[pix(m)][co] (+)= epilogue( sum_{t < ntaps} sum_{c < Ci} in[src(m,t)][c] * wt[co][tap_w[t] + c] )
+//
+// m enumerates a (possibly strided) sub-grid of output pixels, src(m,t) is the gathered input
+// pixel for tap t.  The same kernel serves: forward 1x1/3x3 stride 1/2, the data gradient
+// (stride 1: flipped taps; stride 2: four parity classes with 1/2/2/4 taps each) and plain
+// GEMMs (1 tap).  See igemm.hip for the tiling.
+#pragma once
+#include "common.h"
+
+#define IGEMM_MAX_TAPS 16
+
+struct IgemmParams {
+  const float* in;        // gathered tensor, NHWC, pixel stride ldi
+  const float* wt;        // [Co][ldw] K-contiguous rows
+  float* out;             // NHWC, pixel stride ldo
+  const float* scale;     // per-Co, may be null
+  const float* shift;     // per-Co, may be null
+  const float* residual;  // same pixel indexing as out, stride ldr, may be null
+  float* stats;           // [grid_m][2][Co] raw-result sum / sumsq partials, may be null
+  const float* row_scale; // per output row m (index batch*M + m), may be null: out = acc*row_scale[m]
+  int batch;              // grid.y; operands advance by the strides below (0 = shared)
+  long long in_bs, wt_bs, out_bs;
+  int bmode;              // 0: wt is [Co][ldw] (K contiguous, "NT"); 1: wt is [K][ldw] (N contiguous, "NN")
+  int kvalid;             // bmode 1: rows k >= kvalid of wt read as zero (K tail)
+  int N, Hi, Wi, Ci, ldi;
+  int Ho, Wo;             // full output spatial dims (addressing)
+  int Hs, Ws;             // sub-grid of output pixels covered by this launch
+  int oy0, ox0, osy, osx; // output pixel = (oy0 + i*osy, ox0 + j*osx)
+  int isy, isx;           // gathered pixel = (i*isy + dy[t], j*isx + dx[t])
+  int Co, ldo, ldr, ldw;
+  int M;                  // N*Hs*Ws
+  int ntaps, cpt, kiters; // cpt = Ci/32 k-steps per tap; kiters = ntaps*cpt (c4: Kpad/32)
+  int act; float slope;
+  int accumulate, dense_out, c4;
+  int tap_dy[IGEMM_MAX_TAPS], tap_dx[IGEMM_MAX_TAPS], tap_w[IGEMM_MAX_TAPS];
+};
+
+// rows of the stats partial buffer (= number of M-blocks) the launch will use
+int igemm_grid_m(int M, int Co);
+int igemm_launch(const IgemmParams& p, hipStream_t stream);

@@ -1,0 +1,132 @@
+// Cross-modal scoring (HBM-bound): L2-normalise a feature map over channels and, in the same pass,
+// score every position against the per-image language vector.
+//   out[row,:] = x[row,:] / max(||x[row,:]||, 1e-12)        F.normalize(dim=1)   DCNet_model.py:359,469
+//   score[row] = <out[row,:], q[img(row),:]>                 sim_score            DCNet_model.py:530-535
+// Algorithmic bytes per row: c*4 read + c*4 written (+8); one wave per row, 16-B accesses per lane.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_V4 = 4;   // c <= 1024
+
+__global__ __launch_bounds__(256) void l2norm_score_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
+                                                               float* __restrict__ norm, const float* __restrict__ q,
+                                                               float* __restrict__ score, int64_t rows, int rpi, int c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[MAX_V4];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_V4; ++k) {
+    const int ch = (lane + 64 * k) * 4;
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < c) v[k] = *reinterpret_cast<const f32x4*>(x + row * ldx + ch);
+    ss += v[k][0] * v[k][0] + v[k][1] * v[k][1] + v[k][2] * v[k][2] + v[k][3] * v[k][3];
+  }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float inv = 1.f / fmaxf(nrm, 1e-12f);
+  const float* qq = q ? q + (row / rpi) * c : nullptr;
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_V4; ++k) {
+    const int ch = (lane + 64 * k) * 4;
+    if (ch < c) {
+      const f32x4 o = v[k] * inv;
+      *reinterpret_cast<f32x4*>(out + row * ldo + ch) = o;
+      if (qq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(qq + ch);
+        dot += o[0] * w[0] + o[1] * w[1] + o[2] * w[2] + o[3] * w[3];
+      }
+    }
+  }
+  if (qq) dot = wave_sum(dot);
+  if (lane == 0) {
+    if (norm) norm[row] = nrm;
+    if (qq) score[row] = dot;
+  }
+}
+
+// g = dout + dscore*q ;  dx = (g - out*<g,out>) / max(norm, eps)
+__global__ __launch_bounds__(256) void l2norm_score_bwd_kernel(const float* __restrict__ out, int ldo, const float* __restrict__ norm,
+                                                               const float* __restrict__ dout, int lddo, const float* __restrict__ q,
+                                                               const float* __restrict__ dscore, float* __restrict__ dx, int lddx,
+                                                               int64_t rows, int rpi, int c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float ds = (q && dscore) ? dscore[row] : 0.f;
+  const float* qq = (q && dscore) ? q + (row / rpi) * c : nullptr;
+  f32x4 g[MAX_V4], o[MAX_V4];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_V4; ++k) {
+    const int ch = (lane + 64 * k) * 4;
+    g[k] = f32x4{0.f, 0.f, 0.f, 0.f}; o[k] = g[k];
+    if (ch < c) {
+      o[k] = *reinterpret_cast<const f32x4*>(out + row * ldo + ch);
+      if (dout) g[k] = *reinterpret_cast<const f32x4*>(dout + row * lddo + ch);
+      if (qq) g[k] += *reinterpret_cast<const f32x4*>(qq + ch) * ds;
+      dot += g[k][0] * o[k][0] + g[k][1] * o[k][1] + g[k][2] * o[k][2] + g[k][3] * o[k][3];
+    }
+  }
+  dot = wave_sum(dot);
+  const float inv = 1.f / fmaxf(norm[row], 1e-12f);
+#pragma unroll
+  for (int k = 0; k < MAX_V4; ++k) {
+    const int ch = (lane + 64 * k) * 4;
+    if (ch < c) *reinterpret_cast<f32x4*>(dx + row * lddx + ch) = (g[k] - o[k] * dot) * inv;
+  }
+}
+
+// dq[img][ch] = sum_{rows of img} dscore[row] * out[row][ch];  grid (c/64, n_img), 4 row lanes x 64 channels
+__global__ __launch_bounds__(256) void score_dq_kernel(const float* __restrict__ out, int ldo, const float* __restrict__ dscore,
+                                                       float* __restrict__ dq, int rpi, int c) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + tx, img = blockIdx.y;
+  float s = 0.f;
+  if (ch < c)
+    for (int r = ty; r < rpi; r += 4) {
+      const int64_t row = (int64_t)img * rpi + r;
+      s += dscore[row] * out[row * ldo + ch];
+    }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && ch < c) dq[(size_t)img * c + ch] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+}  // namespace
+
+extern "C" int dcn_l2norm_score_fwd(const float* x, int ldx, float* out, int ldo, float* norm,
+                                    const float* q, float* score, int64_t rows, int rows_per_image, int c, void* stream) {
+  DCN_CHECK_ARG(x && out && rows > 0 && c > 0 && c % 4 == 0 && c <= 256 * MAX_V4, "l2norm_score_fwd: bad argument (c=%d)", c);
+  DCN_CHECK_ARG(!q || (score && rows_per_image > 0), "l2norm_score_fwd: q given without score/rows_per_image");
+  if (ldx <= 0) ldx = c;
+  if (ldo <= 0) ldo = c;
+  hipLaunchKernelGGL(l2norm_score_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     x, ldx, out, ldo, norm, q, score, rows, rows_per_image > 0 ? rows_per_image : 1, c);
+  DCN_CHECK_LAUNCH("l2norm_score_fwd");
+  return DCN_OK;
+}
+
+extern "C" int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm, const float* dout, int lddo,
+                                    const float* q, const float* dscore, float* dx, int lddx, float* dq,
+                                    int64_t rows, int rows_per_image, int c, void* stream) {
+  DCN_CHECK_ARG(out && norm && dx && rows > 0 && c > 0 && c % 4 == 0 && c <= 256 * MAX_V4, "l2norm_score_bwd: bad argument");
+  DCN_CHECK_ARG(dout || (q && dscore), "l2norm_score_bwd: no upstream gradient");
+  if (ldo <= 0) ldo = c;
+  if (lddo <= 0) lddo = c;
+  if (lddx <= 0) lddx = c;
+  hipLaunchKernelGGL(l2norm_score_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                     out, ldo, norm, dout, lddo, q, dscore, dx, lddx, rows, rows_per_image > 0 ? rows_per_image : 1, c);
+  DCN_CHECK_LAUNCH("l2norm_score_bwd");
+  if (dq && q && dscore) {
+    DCN_CHECK_ARG(rows_per_image > 0 && rows % rows_per_image == 0, "l2norm_score_bwd: rows %% rows_per_image != 0");
+    hipLaunchKernelGGL(score_dq_kernel, dim3(cdiv(c, 64), (int)(rows / rows_per_image)), dim3(256), 0, (hipStream_t)stream,
+                       out, ldo, dscore, dq, rows_per_image, c);
+    DCN_CHECK_LAUNCH("score_dq");
+  }
+  return DCN_OK;
+}

@@ -1,0 +1,305 @@
+// Weight gradient of the convolution as a split-K GEMM on v_mfma_f32_32x32x2_f32.
+//
+//   dw[co][t][ci] = sum_m dy[m][co] * x[src(m,t)][ci]        m = (n,ho,wo), t = (r,s)
+//
+// GEMM view: rows = Cout, cols = Cin (one tap per workgroup), K = the N*Ho*Wo output pixels.
+// Both operands are channel-contiguous in HBM, i.e. K is the STRIDED dimension, so the LDS tiles
+// are [k = 32 pixels][channels] straight copies (512-B coalesced rows) and MFMA fragments are
+// ds_read_b32 (lanes 0-31 consecutive channels, lanes 32-63 the next pixel: conflict-free).
+// K is split over workgroups (the early layers have 2.7 M pixels and a 64x32 filter bank);
+// partial slabs go to a workspace and are summed in a fixed order by reduce_slabs_kernel, so
+// the result is bitwise reproducible (no float atomics).
+// Roofline: MFMA (same 157.3 TFLOP/s fp32 peak as the forward).
+#include "common.h"
+
+namespace {
+
+struct WgradParams {
+  const float* x; const float* dy; float* out;   // out = dw or the slab workspace
+  int N, H, W, Ci, ldx;          // x dims (NHWC)
+  int Ho, Wo, Co, lddy;
+  int ksize, stride, pad, T;
+  int M, kchunk, splits;         // pixels per split (multiple of 32)
+  int tiles_co, tiles_ci;
+  int c4;                        // stem: x has 4 channels, "ci" axis = 16 taps x 4 (9 real)
+  int ld_out;                    // floats per co row of out = T*Ci (c4: 64)
+  // batched plain TN GEMM use (co-attention): grid.y = batch
+  long long x_bs, dy_bs, out_bs;
+  const float* row_scale;        // per output row (index batch*Co + co), may be null
+  int Co_ld;                     // dy columns that may be LOADED (>= Co, zero padded by the producer)
+  int accumulate;
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
+  constexpr int MI = TM / (32 * WM), NI = TN / (32 * WN);
+  constexpr int A_LD = TM / 32, B_LD = TN / 32;      // float4 loads per thread per K-step
+  constexpr int KS = 16 / WK;                        // k2-steps per wave per K-step
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][32][TM]
+  float* Bs = smem + 2 * 32 * TM;   // [2][32][TN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  const float* __restrict__ gx = p.x + (long long)blockIdx.y * p.x_bs;
+  const float* __restrict__ gdy = p.dy + (long long)blockIdx.y * p.dy_bs;
+
+  int b = blockIdx.x;
+  const int split = b % p.splits; b /= p.splits;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int t = b;                                   // tap (c4: always 0)
+  const int r = t / p.ksize, s = t - r * p.ksize;
+  const int co0 = tco * TM, ci0 = tci * TN;
+  const int m_begin = split * p.kchunk;
+  const int m_end = min(p.M, m_begin + p.kchunk);
+  const int iters = (m_end - m_begin + 31) / 32;
+  const int howo = p.Ho * p.Wo;
+
+  f32x4 a_reg[A_LD], b_reg[B_LD];
+  auto load_tiles = [&](int it) {
+    const int mb = m_begin + it * 32;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int idx = tid + 256 * j;
+      const int pix = idx / (TM / 4), c = (idx - pix * (TM / 4)) * 4;
+      const int m = mb + pix, co = co0 + c;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end && co < p.Co_ld) v = *reinterpret_cast<const f32x4*>(gdy + (size_t)m * p.lddy + co);
+      a_reg[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int idx = tid + 256 * j;
+      const int pix = idx / (TN / 4), c = (idx - pix * (TN / 4)) * 4;
+      const int m = mb + pix;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        const int n = m / howo, rem = m - n * howo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int rr = r, ss = s, ci = ci0 + c;
+        bool ok = ci < p.Ci;
+        if (p.c4) { const int tap = c >> 2; rr = tap / 3; ss = tap - 3 * rr; ci = 0; ok = tap < 9; }
+        const int iy = ho * p.stride + rr - p.pad, ix = wo * p.stride + ss - p.pad;
+        if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v = *reinterpret_cast<const f32x4*>(gx + ((size_t)(n * p.H + iy) * p.W + ix) * p.ldx + ci);
+      }
+      b_reg[j] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j)
+      *reinterpret_cast<f32x4*>(As + buf * 32 * TM + (tid + 256 * j) * 4) = a_reg[j];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j)
+      *reinterpret_cast<f32x4*>(Bs + buf * 32 * TN + (tid + 256 * j) * 4) = b_reg[j];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+
+  if (iters > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  // fragment element for k2-step ks: pixel row 2*ks + (lane>>5), channel (lane&31)
+  const int a_off = (wk * KS * 2 + (lane >> 5)) * TM + wm * (TM / WM) + (lane & 31);
+  const int b_off = (wk * KS * 2 + (lane >> 5)) * TN + wn * (TN / WN) + (lane & 31);
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < iters) load_tiles(it + 1);
+    const float* a = As + cur * 32 * TM + a_off;
+    const float* bb = Bs + cur * 32 * TN + b_off;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float af[MI], bf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi] = a[ks * 2 * TM + mi * 32];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = bb[ks * 2 * TN + ni * 32];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (it + 1 < iters) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- combine the WK wave-level K-slices through LDS, then store ---------------------------
+  if (WK > 1) {
+    float* red = smem;                                 // [(WK-1)][WM*WN][MI*NI*16][64]
+    if (wk > 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            red[((((wk - 1) * (WM * WN) + wmn) * (MI * NI) + mi * NI + ni) * 16 + q) * 64 + lane] = acc[mi][ni][q];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int k = 1; k < WK; ++k)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              acc[mi][ni][q] += red[((((k - 1) * (WM * WN) + wmn) * (MI * NI) + mi * NI + ni) * 16 + q) * 64 + lane];
+    }
+  }
+  if (wk != 0) return;
+  float* out = p.out + (size_t)split * p.Co * p.ld_out + (long long)blockIdx.y * p.out_bs;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + wm * (TM / WM) + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (co >= p.Co) continue;
+      const float rs = p.row_scale ? p.row_scale[(size_t)blockIdx.y * p.Co + co] : 1.f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int ci = ci0 + wn * (TN / WN) + ni * 32 + (lane & 31);
+        if (p.c4) { if (ci < 64) out[(size_t)co * 64 + ci] = acc[mi][ni][q]; }
+        else if (ci < p.Ci) {
+          float* o = out + (size_t)co * p.ld_out + t * p.Ci + ci;
+          float v = acc[mi][ni][q] * rs;
+          if (p.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           int64_t n4, int splits) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
+    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[i + (int64_t)k * n4];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+}
+
+struct Plan { int tm, tn, tiles_co, tiles_ci, T, splits, kchunk, M, ld_out; };
+int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream);
+
+Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  Plan pl;
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  pl.M = n * ho * wo;
+  const bool c4 = cin == 4;
+  const int ci_axis = c4 ? 64 : cin;
+  pl.tm = cout >= 128 ? 128 : (cout >= 64 ? 64 : 32);
+  pl.tn = ci_axis >= 128 ? 128 : (ci_axis >= 64 ? 64 : 32);
+  pl.tiles_co = cdiv(cout, pl.tm); pl.tiles_ci = cdiv(ci_axis, pl.tn);
+  pl.T = c4 ? 1 : ksize * ksize;
+  pl.ld_out = c4 ? 64 : pl.T * cin;
+  const int base = pl.tiles_co * pl.tiles_ci * pl.T;
+  int splits = cdiv(1024, base);                       // aim for ~4 workgroups per CU
+  const int max_splits = pl.M / 256 > 0 ? pl.M / 256 : 1;   // at least 8 K-steps per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  pl.kchunk = cdiv(cdiv(pl.M, splits), 32) * 32;
+  pl.splits = cdiv(pl.M, pl.kchunk);
+  return pl;
+}
+
+template <int TM, int TN>
+int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
+  constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
+  size_t lds = (size_t)2 * 32 * (TM + TN) * sizeof(float);
+  const size_t red = (size_t)(WK - 1) * TM * TN * sizeof(float);
+  if (red > lds) lds = red;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN>), dim3(grid, batch), dim3(256), lds, stream, p);
+  DCN_CHECK_LAUNCH("wgrad");
+  return DCN_OK;
+}
+
+int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream) {
+  if (tm == 128 && tn == 128) return launch_wgrad<128, 128>(p, grid, batch, stream);
+  if (tm == 128 && tn == 64) return launch_wgrad<128, 64>(p, grid, batch, stream);
+  if (tm == 128 && tn == 32) return launch_wgrad<128, 32>(p, grid, batch, stream);
+  if (tm == 64 && tn == 128) return launch_wgrad<64, 128>(p, grid, batch, stream);
+  if (tm == 64 && tn == 64) return launch_wgrad<64, 64>(p, grid, batch, stream);
+  if (tm == 64 && tn == 32) return launch_wgrad<64, 32>(p, grid, batch, stream);
+  if (tm == 32 && tn == 128) return launch_wgrad<32, 128>(p, grid, batch, stream);
+  if (tm == 32 && tn == 64) return launch_wgrad<32, 64>(p, grid, batch, stream);
+  return launch_wgrad<32, 32>(p, grid, batch, stream);
+}
+
+}  // namespace
+
+// C[b][m][n] (+)= row_scale[b][m] * sum_k A[b][k][m] * B[b][k][n]   ("TN" GEMM: K is the strided dim of
+// both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.
+int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
+                    float* C, int ldc, long long c_bs, const float* row_scale,
+                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream) {
+  DCN_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "tn_gemm: bad argument");
+  DCN_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && N % 4 == 0 && m_ld % 4 == 0 && m_ld >= M && m_ld <= lda,
+                "tn_gemm: alignment (lda=%d ldb=%d N=%d m_ld=%d)", lda, ldb, N, m_ld);
+  WgradParams p{};
+  p.dy = A; p.lddy = lda; p.dy_bs = a_bs; p.Co = M; p.Co_ld = m_ld;
+  p.x = B; p.ldx = ldb; p.x_bs = b_bs; p.Ci = N;
+  p.out = C; p.ld_out = ldc; p.out_bs = c_bs; p.row_scale = row_scale; p.accumulate = accumulate;
+  p.N = 1; p.H = 1; p.W = K; p.Ho = 1; p.Wo = K; p.ksize = 1; p.stride = 1; p.pad = 0; p.T = 1;
+  p.M = K; p.kchunk = cdiv(K, 32) * 32; p.splits = 1;
+  const int tm = M >= 128 ? 128 : (M >= 64 ? 64 : 32), tn = N >= 128 ? 128 : (N >= 64 ? 64 : 32);
+  p.tiles_co = cdiv(M, tm); p.tiles_ci = cdiv(N, tn);
+  return dispatch_wgrad(p, tm, tn, p.tiles_co * p.tiles_ci, batch, stream);
+}
+
+extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
+  return pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+}
+
+extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                                     int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_weight: ksize=%d", ksize);
+  DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_weight: stride=%d", stride);
+  DCN_CHECK_ARG(cin == 4 || cin % 4 == 0, "conv2d_bwd_weight: cin=%d must be a multiple of 4", cin);
+  DCN_CHECK_ARG(cin != 4 || (ksize == 3 && stride == 1), "conv2d_bwd_weight: cin=4 path is the 3x3 stride-1 stem only");
+  DCN_CHECK_ARG(cout % 4 == 0, "conv2d_bwd_weight: cout=%d must be a multiple of 4", cout);
+  DCN_CHECK_ARG(x && dy && dw, "conv2d_bwd_weight: null pointer");
+  const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = ldx > 0 ? ldx : cin;
+  p.ksize = ksize; p.stride = stride; p.pad = (ksize - 1) / 2; p.T = pl.T;
+  p.Ho = (h + 2 * p.pad - ksize) / stride + 1; p.Wo = (wd + 2 * p.pad - ksize) / stride + 1;
+  p.Co = cout; p.lddy = lddy > 0 ? lddy : cout;
+  p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = cin == 4; p.ld_out = pl.ld_out;
+  p.Co_ld = cout;
+  const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
+  int rc = dispatch_wgrad(p, pl.tm, pl.tn, grid, 1, stream);
+  if (rc != DCN_OK) return rc;
+  if (pl.splits > 1) {
+    const int64_t n4 = (int64_t)cout * pl.ld_out / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, pl.splits);
+    DCN_CHECK_LAUNCH("reduce_slabs");
+  }
+  return DCN_OK;
+}

@@ -1,0 +1,96 @@
+"""ctypes binding of libdcnet_hip.so (include/dcnet_hip.h).
+
+There is NO fallback: if the library is missing or a symbol is absent this module raises,
+and every wrapper raises on a non-zero return code with the library's own error text.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcnet_hip.so")
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes).  int-returning entries are status codes unless listed in _VALUE_FUNCS.
+SIGNATURES = {
+    "dcn_last_error": (c_char_p, []),
+    "dcn_version": (I, []),
+    "dcn_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
+    "dcn_nhwc_to_nchw": (I, [P, P, I, I, I, I, I, P]),
+    "dcn_oihw_to_ohwi": (I, [P, P, I, I, I, I, I, P]),
+    "dcn_ohwi_to_oihw": (I, [P, P, I, I, I, I, I, P]),
+    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, P]),
+    "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),
+    "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
+    "dcn_bn_ws": (L, [I]),
+    "dcn_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
+    "dcn_bn_fold": (I, [P, P, P, P, F, I, P, P, P]),
+    "dcn_channel_stats": (I, [P, L, I, I, P, P]),
+    "dcn_channel_stats_rows": (I, [L]),
+    "dcn_scale_act": (I, [P, P, P, I, F, P, P, L, I, I, P]),
+    "dcn_bn_act_bwd_reduce": (I, [P, P, I, P, P, P, P, I, F, L, I, P, P]),
+    "dcn_bn_bwd_sums": (I, [P, I, I, P, P, P]),
+    "dcn_bn_act_bwd_apply": (I, [P, P, I, P, P, P, P, I, F, P, L, L, I, P, P]),
+    "dcn_act_bwd": (I, [P, P, I, F, L, I, P, P]),
+    "dcn_coattn_e_size": (L, [I, I]),
+    "dcn_coattn_fwd_ws": (L, [I, I, I]),
+    "dcn_coattn_fwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, I, F, P]),
+    "dcn_coattn_bwd_ws": (L, [I, I, I]),
+    "dcn_coattn_bwd": (I, [P, P, I, P, P, I, P, P, I, P, P, P, P, P, I, I, P, I, I, I, F, P]),
+    "dcn_l2norm_score_fwd": (I, [P, I, P, I, P, P, P, L, I, I, P]),
+    "dcn_l2norm_score_bwd": (I, [P, I, P, P, I, P, P, P, I, P, L, I, I, P]),
+    "dcn_upsample2_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
+    "dcn_upsample2_nhwc_bwd": (I, [P, I, P, I, I, I, I, I, I, P]),
+    "dcn_copy_slice": (I, [P, I, P, I, L, I, I, P]),
+    "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
+    "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
+}
+_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows"}
+
+
+class DcnError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise DcnError(
+                f"{path} not found: build it with `python -m dcnet_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU or eager fallback.")
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise DcnError(f"{path} does not export {name}; rebuild the library") from e
+            fn.restype = res
+            fn.argtypes = args
+            if res is I and name not in _VALUE_FUNCS:
+                setattr(self, name[4:], self._checked(name, fn))
+            else:
+                setattr(self, name[4:], fn)
+
+    def _checked(self, name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise DcnError(f"{name} failed ({rc}): {self._dll.dcn_last_error().decode()}")
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    """The loaded library (loaded on first use; raises DcnError if it cannot be)."""
+    global _lib
+    if _lib is None:
+        _lib = _Lib(LIB_PATH)
+    return _lib

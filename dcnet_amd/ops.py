@@ -1,0 +1,289 @@
+"""Thin tensor-level wrappers over the C ABI (dcnet_amd.lib): torch supplies device memory and
+the stream, every computation below is a call into libdcnet_hip.so.
+
+Layout convention inside the package: activations NHWC (contiguous torch tensors of shape
+(N,H,W,C)), conv weights OHWI (Cout,k,k,Cin_padded).  Nothing here has a fallback path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .lib import lib
+
+ACT_NONE, ACT_LEAKY = 0, 1
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous fp32 CUDA tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+
+
+# ---- scratch -----------------------------------------------------------------------------------
+_scratch = {}
+
+
+def scratch(n_floats: int, device, slot: int = 0) -> torch.Tensor:
+    """A per-device, per-slot grow-only fp32 scratch buffer (ops are stream-ordered, so one
+    buffer per slot can be shared by every call on the stream)."""
+    key = (torch.device(device).index, slot)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+# ---- layout ------------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
+    _chk(x, "nchw_to_nhwc")
+    n, c, h, w = x.shape
+    c_pad = c if c_pad is None else c_pad
+    out = torch.empty((n, h, w, c_pad), dtype=torch.float32, device=x.device)
+    lib().nchw_to_nhwc(x.data_ptr(), out.data_ptr(), n, c, h, w, c_pad, _s())
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    _chk(x, "nhwc_to_nchw")
+    n, h, w, ld = x.shape
+    c = ld if c is None else c
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    lib().nhwc_to_nchw(x.data_ptr(), out.data_ptr(), n, c, h, w, ld, _s())
+    return out
+
+
+def weight_to_ohwi(w: torch.Tensor, ci_pad: Optional[int] = None, co_pad: Optional[int] = None) -> torch.Tensor:
+    """OIHW parameter -> OHWI kernel operand.  The 3-channel stem becomes the packed [Co][64]
+    form (9 taps x 4 channels, zero padded) that the c4 path of the conv engine reads."""
+    w = w.detach()
+    _chk(w, "weight_to_ohwi")
+    co, ci, kh, kw = w.shape
+    if ci <= 4:
+        tmp = torch.empty((co, kh, kw, 4), dtype=torch.float32, device=w.device)
+        lib().oihw_to_ohwi(w.data_ptr(), tmp.data_ptr(), co, ci, kh, kw, 4, _s())
+        out = torch.zeros((co, 64), dtype=torch.float32, device=w.device)
+        out[:, :kh * kw * 4] = tmp.view(co, -1)
+        return out
+    ci_pad = pad32(ci) if ci_pad is None else ci_pad
+    co_pad = co if co_pad is None else co_pad
+    alloc = torch.zeros if co_pad != co else torch.empty
+    out = alloc((co_pad, kh, kw, ci_pad), dtype=torch.float32, device=w.device)
+    lib().oihw_to_ohwi(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, ci_pad, _s())
+    return out
+
+
+def weight_grad_to_oihw(dw: torch.Tensor, shape: Tuple[int, int, int, int]) -> torch.Tensor:
+    """Adjoint of weight_to_ohwi: OHWI gradient (possibly channel/filter padded) -> OIHW."""
+    co, ci, kh, kw = shape
+    if ci <= 4:
+        tmp = dw[:, :kh * kw * 4].contiguous().view(co, kh, kw, 4)
+        out = torch.empty(shape, dtype=torch.float32, device=dw.device)
+        lib().ohwi_to_oihw(tmp.data_ptr(), out.data_ptr(), co, ci, kh, kw, 4, _s())
+        return out
+    _chk(dw, "weight_grad_to_oihw")
+    ci_pad = dw.shape[3]
+    out = torch.empty(shape, dtype=torch.float32, device=dw.device)
+    lib().ohwi_to_oihw(dw.data_ptr(), out.data_ptr(), co, ci, kh, kw, ci_pad, _s())
+    return out
+
+
+# ---- convolution ---------------------------------------------------------------------------------
+def conv_out_hw(h: int, w: int, k: int, stride: int) -> Tuple[int, int]:
+    pad = (k - 1) // 2
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
+               residual=None, out=None, want_stats=False):
+    """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
+    where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats)."""
+    _chk(x, "conv2d_fwd x")
+    n, h, wd, cin = x.shape
+    cout = w_ohwi.shape[0]
+    ho, wo = conv_out_hw(h, wd, ksize, stride)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    ldy = out.stride(2)
+    stats = None
+    if want_stats:
+        rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
+        stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
+                     _p(scale), _p(shift), act, float(slope), _p(residual),
+                     0 if residual is None else residual.stride(2), ldy, _p(stats), _s())
+    return out, stats
+
+
+def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False):
+    """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin)."""
+    n, ho, wo, cout = dy.shape
+    cin = w_ohwi.shape[3]
+    h, wd = in_hw
+    if out is None:
+        out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
+    wt = scratch(w_ohwi.numel(), dy.device, slot=1)
+    lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
+                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _s())
+    return out
+
+
+def conv2d_bwd_weight(x, dy, ksize, stride, cout=None):
+    """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem]."""
+    n, h, wd, cin = x.shape
+    cout = dy.shape[3] if cout is None else cout
+    dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
+    ws = scratch(nws, x.device, slot=0) if nws > 0 else None
+    lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws),
+                            n, h, wd, cin, cout, ksize, stride, _s())
+    return dw
+
+
+# ---- batch norm ------------------------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+    rows, _, c = stats.shape
+    dev = stats.device
+    res = torch.empty((4, c), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
+    ws = scratch(lib().bn_ws(c), dev, slot=2)
+    lib().bn_finalize(stats.data_ptr(), rows, c, int(count), _p(gamma), _p(beta), float(eps), float(momentum),
+                      _p(running_mean), _p(running_var), res[0].data_ptr(), res[1].data_ptr(),
+                      res[2].data_ptr(), res[3].data_ptr(), ws.data_ptr(), _s())
+    return res
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps=1e-5):
+    c = gamma.numel()
+    res = torch.empty((2, c), dtype=torch.float32, device=gamma.device)
+    lib().bn_fold(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), float(eps), c,
+                  res[0].data_ptr(), res[1].data_ptr(), _s())
+    return res
+
+
+def channel_stats(x2d):
+    """x2d [rows][c] contiguous -> partials [R][2][c]."""
+    rows, c = x2d.shape
+    r = lib().channel_stats_rows(rows)
+    stats = torch.empty((r, 2, c), dtype=torch.float32, device=x2d.device)
+    lib().channel_stats(x2d.data_ptr(), rows, c, c, stats.data_ptr(), _s())
+    return stats
+
+
+def scale_act(y, scale, shift, act, slope, residual=None, out=None):
+    c = y.shape[-1]
+    rows = y.numel() // c
+    if out is None:
+        out = torch.empty_like(y)
+    lib().scale_act(y.data_ptr(), _p(scale), _p(shift), act, float(slope), _p(residual), out.data_ptr(), rows, c,
+                    out.stride(-2), _s())
+    return out
+
+
+def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope):
+    """Returns (dy, dgamma, dbeta) for out = act(gamma*(y-mean)*invstd+beta) with batch statistics."""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    dev = y.device
+    r = lib().channel_stats_rows(rows)
+    part = scratch(r * 2 * c, dev, slot=0)
+    lddo = dout.stride(-2)
+    lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+                            act, float(slope), rows, c, part.data_ptr(), _s())
+    sums = torch.empty((2, c), dtype=torch.float32, device=dev)
+    ws = scratch(lib().bn_ws(c), dev, slot=2)
+    lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
+    dy = torch.empty_like(y)
+    lib().bn_act_bwd_apply(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+                           act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _s())
+    return dy, sums[1], sums[0]
+
+
+def act_bwd(out, dout, slope):
+    c = out.shape[-1]
+    rows = out.numel() // c
+    dy = torch.empty_like(out)
+    lib().act_bwd(out.data_ptr(), dout.data_ptr(), dout.stride(-2), float(slope), rows, c, dy.data_ptr(), _s())
+    return dy
+
+
+# ---- co-attention -----------------------------------------------------------------------------------
+def coattn_fwd(f1, f2, out1, out2, temperature):
+    """f1,f2 (b,hw,c) views with pixel stride ldf (last dim contiguous); out1/out2 (b,hw,c) views with
+    stride ldo (out2 may be None).  Returns the saved (E, rinv, cinv)."""
+    b, hw, c = f1.shape
+    dev = f1.device
+    E = torch.empty(lib().coattn_e_size(b, hw), dtype=torch.float32, device=dev)
+    rc = torch.empty((2, b, hw), dtype=torch.float32, device=dev)
+    ws = scratch(lib().coattn_fwd_ws(b, hw, c), dev, slot=0)
+    lib().coattn_fwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), out1.data_ptr(), _p(out2), out1.stride(1),
+                     E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(), ws.data_ptr(), b, hw, c, float(temperature), _s())
+    return E, rc
+
+
+def coattn_bwd(f1, f2, d_out1, d_out2, out1, out2, E, rc, d_f1, d_f2, accumulate, temperature):
+    b, hw, c = f1.shape
+    ws = scratch(lib().coattn_bwd_ws(b, hw, c), f1.device, slot=0)
+    lib().coattn_bwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), d_out1.data_ptr(), d_out2.data_ptr(), d_out1.stride(1),
+                     out1.data_ptr(), out2.data_ptr(), out1.stride(1), E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(),
+                     d_f1.data_ptr(), d_f2.data_ptr(), d_f1.stride(1), int(accumulate), ws.data_ptr(),
+                     b, hw, c, float(temperature), _s())
+
+
+# ---- scoring ------------------------------------------------------------------------------------------
+def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None):
+    """x (...,c) rows (pixel stride = x.stride(-2)).  Returns (out, norm, score|None)."""
+    c = x.shape[-1]
+    rows = x.numel() // c
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    score = torch.empty(rows, dtype=torch.float32, device=x.device) if q is not None else None
+    lib().l2norm_score_fwd(x.data_ptr(), x.stride(-2), out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(q), _p(score),
+                           rows, rows_per_image, c, _s())
+    return out, norm, score
+
+
+def l2norm_score_bwd(out, norm, dout, q, dscore, rows_per_image, want_dq=True):
+    c = out.shape[-1]
+    rows = out.numel() // c
+    dx = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+    dq = None
+    if q is not None and dscore is not None and want_dq:
+        dq = torch.empty((rows // rows_per_image, c), dtype=torch.float32, device=out.device)
+    lib().l2norm_score_bwd(out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(dout), 0 if dout is None else dout.stride(-2),
+                           _p(q), _p(dscore), dx.data_ptr(), c, _p(dq), rows, rows_per_image, c, _s())
+    return dx, dq
+
+
+# ---- data movers ---------------------------------------------------------------------------------------
+def upsample2_into(src, dst_view):
+    """src (N,h,w,c) -> dst_view (N,2h,2w,c) (a channel slice of a wider NHWC buffer)."""
+    n, h, w, c = src.shape
+    lib().upsample2_nhwc(src.data_ptr(), src.stride(2), dst_view.data_ptr(), dst_view.stride(2), n, h, w, c, _s())
+
+
+def upsample2_bwd(ddst_view, dsrc, accumulate):
+    n, h, w, c = dsrc.shape
+    lib().upsample2_nhwc_bwd(ddst_view.data_ptr(), ddst_view.stride(2), dsrc.data_ptr(), dsrc.stride(2), n, h, w, c,
+                             int(accumulate), _s())
+
+
+def copy_slice(src_view, dst_view, accumulate=False):
+    c = src_view.shape[-1]
+    rows = src_view.numel() // c
+    lib().copy_slice(src_view.data_ptr(), src_view.stride(-2), dst_view.data_ptr(), dst_view.stride(-2), rows, c,
+                     int(accumulate), _s())

@@ -1,0 +1,178 @@
+/*
+ * dcnet_hip.h — C ABI of libdcnet_hip.so, the MI355X (gfx950) kernels behind DCNet's
+ * dual-correspondence forward/backward hot path.
+ *
+ * The reference (mengcaopku/DCNet) has no native layer: its "operator API" for this
+ * path is the set of torch.nn ops that model/DCNet_model.py and model/darknet.py call.
+ * Each entry point below names the reference call site(s) it replaces (file:line in
+ * the reference checkout).  A maintainer binds them with ctypes; our
+ * own host side (dcnet_amd/) does exactly that.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to fp32 unless noted; buffers are caller-owned;
+ *   - activations are NHWC ("channels-last": [N][H][W][C]); conv weights are OHWI
+ *     ([Cout][kh][kw][Cin]) — the boundary kernels dcn_nchw_to_nhwc / dcn_nhwc_to_nchw
+ *     and dcn_oihw_to_ohwi convert from/to the reference's NCHW / OIHW;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), does no
+ *     allocation and no synchronisation, so it can be captured into a hipGraph;
+ *   - return value 0 = success, negative = error (dcn_last_error() gives the text).
+ */
+#ifndef DCNET_HIP_H
+#define DCNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCN_OK 0
+#define DCN_ERR_ARG (-1)      /* bad shape / null pointer / unsupported size */
+#define DCN_ERR_LAUNCH (-2)   /* hipLaunch failed */
+
+#define DCN_ACT_NONE 0
+#define DCN_ACT_LEAKY 1       /* y = x > 0 ? x : slope*x   (slope 0 == ReLU) */
+
+const char* dcn_last_error(void);
+int dcn_version(void);
+
+/* ---- layout boundary --------------------------------------------------------------- */
+/* NCHW -> NHWC with the channel dim zero-padded to c_pad (>= c).  Replaces the implicit
+ * layout of every nn.Conv2d input (model/darknet.py:399). */
+int dcn_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad, void* stream);
+/* NHWC (channel stride ld >= c) -> NCHW. */
+int dcn_nhwc_to_nchw(const float* src, float* dst, int n, int c, int h, int w, int ld, void* stream);
+/* OIHW -> OHWI with Cin zero-padded to ci_pad; and the adjoint (for weight gradients). */
+int dcn_oihw_to_ohwi(const float* src, float* dst, int co, int ci, int kh, int kw, int ci_pad, void* stream);
+int dcn_ohwi_to_oihw(const float* src, float* dst, int co, int ci, int kh, int kw, int ci_pad, void* stream);
+
+/* ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------- */
+/* y[n,ho,wo,co] = act( scale[co] * (sum_{r,s,ci} x[n,ho*stride+r-pad,wo*stride+s-pad,ci] * w[co,r,s,ci])
+ *                      + shift[co] ) + residual[n,ho,wo,co]
+ * ksize in {1,3}, pad = (ksize-1)/2, stride in {1,2}; cin % 4 == 0 (cin % 32 == 0 unless cin == 4).
+ * scale/shift/residual may be NULL.  y has pixel stride ldy >= cout (lets a layer write
+ * straight into a channel slice of a route-concat buffer); residual has pixel stride ldr.
+ * stats (optional, [grid_m][2][cout] floats, grid_m = dcn_conv2d_stats_rows(...)): per
+ * 128/256-row block partial sum and sum-of-squares of the RAW conv result (before
+ * scale/shift/act) per output channel — the batch statistics of train-mode BatchNorm.
+ * Replaces nn.Conv2d (+ eval-mode BatchNorm2d + LeakyReLU/ReLU + shortcut add):
+ * model/darknet.py:179-191,403-405 and ConvBatchNormReLU model/darknet.py:131-153. */
+int dcn_conv2d_fwd(const float* x, const float* w, float* y,
+                   int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                   const float* scale, const float* shift, int act, float slope,
+                   const float* residual, int ldr, int ldy,
+                   float* stats, void* stream);
+int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride);
+
+/* dx = conv_transpose(dy, w): gradient w.r.t. the conv input (autograd of nn.Conv2d,
+ * reached from loss.backward() at train_DCNet.py:645).  dy NHWC (n,ho,wo,cout) with pixel
+ * stride lddy, w OHWI as in the forward, wt = caller scratch of cout*k*k*cin floats
+ * (the tap-flipped, channel-transposed weights are built there), dx NHWC (n,h,wd,cin).
+ * accumulate != 0: dx += result (used where a tensor feeds two consumers). */
+int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                        int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                        int accumulate, void* stream);
+
+/* dw[co,r,s,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*stride+r-pad,wo*stride+s-pad,ci]
+ * (OHWI).  x has pixel stride ldx.  ws = caller scratch of dcn_conv2d_bwd_weight_ws(...) floats
+ * (split-K partial slabs, reduced deterministically). */
+int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                          int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
+int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+
+/* ---- BatchNorm (train mode) + activation + shortcut ---------------------------------- */
+/* Scratch (floats, 8-byte aligned) needed by dcn_bn_finalize / dcn_bn_bwd_sums for c channels. */
+int64_t dcn_bn_ws(int c);
+/* Reduce per-block partials [rows][2][c] (from dcn_conv2d_fwd's `stats` or dcn_channel_stats) to the
+ * batch mean / biased var, update the running stats (unbiased var, momentum; pointers may be NULL)
+ * and emit the per-channel affine scale = gamma*rsqrt(var+eps), shift = beta - mean*scale.
+ * count = number of rows reduced per channel (n*ho*wo).  Replaces the statistics half of
+ * F.batch_norm(training=True): nn.BatchNorm2d at model/darknet.py:189 (momentum 0.1) and
+ * :145-147 (momentum 0.999), nn.BatchNorm1d at model/DCNet_model.py:258-259,270,274. */
+int dcn_bn_finalize(const float* stats, int rows, int c, int64_t count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,
+                    float* mean, float* invstd, float* scale, float* shift, float* ws, void* stream);
+/* eval mode: scale = gamma*rsqrt(running_var+eps), shift = beta - running_mean*scale. */
+int dcn_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                float eps, int c, float* scale, float* shift, void* stream);
+/* Per-channel sum / sum-of-squares partials of an NHWC tensor [rows][c] (pixel stride ld) for
+ * BatchNorm inputs not produced by dcn_conv2d_fwd.  stats: [dcn_channel_stats_rows(rows)][2][c]. */
+int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, float* stats, void* stream);
+int dcn_channel_stats_rows(int64_t rows);
+/* out = act(scale[c]*y + shift[c]) + residual  over [rows][c] (y, residual pixel stride c; out ldo).
+ * The normalise+LeakyReLU/ReLU(+shortcut) half of a train-mode block: model/darknet.py:189-191,403-405. */
+int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
+                  const float* residual, float* out, int64_t rows, int c, int ldo, void* stream);
+/* Backward of out = act(bn(y)) (a residual's gradient is the identity and handled by the caller):
+ *   reduce: partials of g = dout*act'(.) and g*xhat per channel -> stats [dcn_channel_stats_rows(rows)][2][c]
+ *   sums:   totals [2][c]  (sums[0] = dbeta, sums[1] = dgamma)
+ *   apply:  dy = gamma*invstd*(g - sums[0]/count - xhat*sums[1]/count)                         */
+int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, int act, float slope,
+                          int64_t rows, int c, float* stats, void* stream);
+int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums, float* ws, void* stream);
+int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, int act, float slope,
+                         const float* sums, int64_t count, int64_t rows, int c, float* dy, void* stream);
+/* Backward of out = act(z) alone: dy = dout * (out > 0 ? 1 : slope). */
+int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int64_t rows, int c, float* dy, void* stream);
+
+/* ---- inter-frame co-attention ----------------------------------------------------------- */
+/* f1,f2: [b][hw][c] NHWC (pixel stride ldf), unit L2 norm over c.  With A[i,j] = <f1_i, f2_j>:
+ *   f1_attn[i,:] = sum_j softmax_j(t*A[i,j]) * f2[j,:]
+ *   f2_attn[j,:] = sum_i softmax_i(t*A[i,j]) * f1[i,:]      (f2_attn may be NULL: inference model)
+ * E (dcn_coattn_e_size floats) receives exp(t*A - t), rinv/cinv ([b][hw]) the inverse row / column
+ * sums; all three are kept for the backward.  ws: dcn_coattn_fwd_ws floats of scratch.
+ * Outputs have pixel stride ldo (they land in a channel slice of the concat [f, f_attn] buffer).
+ * Replaces the 3 bmm + 2 softmax of model/DCNet_model.py:449-459 / model/test_DCNet_model.py:259-274. */
+int64_t dcn_coattn_e_size(int b, int hw);
+int64_t dcn_coattn_fwd_ws(int b, int hw, int c);
+int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* f1_attn, float* f2_attn, int ldo,
+                   float* E, float* rinv, float* cinv, float* ws,
+                   int b, int hw, int c, float temperature, void* stream);
+/* d_f1, d_f2 (pixel stride lddf) (+)= gradient through both attention outputs; accumulate != 0 adds
+ * to what the buffers hold (the direct [f, .] half of the concat contributes there as well). */
+int64_t dcn_coattn_bwd_ws(int b, int hw, int c);
+int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
+                   const float* d_f1_attn, const float* d_f2_attn, int lddo,
+                   const float* f1_attn, const float* f2_attn, int ldo,
+                   const float* E, const float* rinv, const float* cinv,
+                   float* d_f1, float* d_f2, int lddf, int accumulate, float* ws,
+                   int b, int hw, int c, float temperature, void* stream);
+
+/* ---- cross-modal scoring (HBM-bound) --------------------------------------------------- */
+/* One pass over x [rows][c] (pixel stride ldx): out = x / max(||x||_2, 1e-12) over c
+ * (F.normalize(dim=1), model/DCNet_model.py:359,469) and, when q != NULL,
+ * score[row] = <out[row,:], q[img(row),:]> with img(row) = row / rows_per_image
+ * (sim_score, model/DCNet_model.py:530-535).  norm [rows] keeps ||x|| for the backward. */
+int dcn_l2norm_score_fwd(const float* x, int ldx, float* out, int ldo, float* norm,
+                         const float* q, float* score, int64_t rows, int rows_per_image, int c, void* stream);
+/* dx from (dout, dscore) (either may be NULL); dq [n_img][c] = sum_rows dscore*out (NULL to skip). */
+int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm, const float* dout, int lddo,
+                         const float* q, const float* dscore, float* dx, int lddx, float* dq,
+                         int64_t rows, int rows_per_image, int c, void* stream);
+
+/* ---- small data movers ------------------------------------------------------------------ */
+/* nearest x2 upsample of NHWC src (n,h,w,c) into dst (n,2h,2w,·) pixel stride ldd
+ * (MyUpsample2, model/darknet.py:158-160; fused with the route concat :400-402). */
+int dcn_upsample2_nhwc(const float* src, int lds, float* dst, int ldd, int n, int h, int w, int c, void* stream);
+/* adjoint: dsrc[n,y,x,c] (+)= sum of the 4 dst pixels. */
+int dcn_upsample2_nhwc_bwd(const float* ddst, int ldd, float* dsrc, int lds, int n, int h, int w, int c,
+                           int accumulate, void* stream);
+/* strided copy / accumulate of a [rows][c] channel slice: dst (+)= src. */
+int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows, int c, int accumulate, void* stream);
+
+/* ---- host-side negative sampling (CPU; bit-exact with Python's random.sample) -------------- */
+/* state = the 625 uint32 of random.getstate()[1], advanced in place.
+ * interframe: for each (pair, j) draws neg_n positions from range(hw) minus kpos[pair][j]
+ *   (model/DCNet_model.py:411-413); out [pairs][top_k][neg_n] int64.
+ * crossmodal: the N*N*rows draws of Crossmodal_corrspondence (model/DCNet_model.py:62-96), keeping
+ *   the index == N-1 draw of every (ii, jj); out [n][rows][neg_n] int64 (positions in image N-1). */
+int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, int pairs, int top_k, int hw, int neg_n, int64_t* out);
+int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int neg_n, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCNET_HIP_H */

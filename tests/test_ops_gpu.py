@@ -1,0 +1,231 @@
+"""GPU parity of every C-ABI kernel against a plain PyTorch fp32/fp64 CPU reference of the same op.
+All calls go through dcnet_amd.ops -> ctypes -> libdcnet_hip.so."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(a, b, tol, name=""):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    ref = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * ref, f"{name}: max err {err:.3e} vs tol {tol * ref:.3e}"
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride
+    (2, 13, 13, 64, 128, 3, 1),
+    (2, 13, 13, 128, 64, 1, 1),
+    (1, 26, 26, 32, 64, 3, 2),
+    (2, 16, 20, 64, 32, 1, 1),       # Cout 32 -> 256x32 tile
+    (1, 9, 11, 96, 160, 3, 1),       # ragged M and Cout (masks)
+    (3, 8, 8, 256, 255, 1, 1),       # Cout not a multiple of anything
+    (1, 32, 32, 3, 32, 3, 1),        # stem (c4 path)
+    (2, 7, 7, 512, 15, 1, 1),        # bbox head width
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_plain(dev, case):
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k, s = case
+    x = _rand(n, cin, h, w, seed=1); wt = _rand(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, s, (k - 1) // 2).float()
+    xd = ops.nchw_to_nhwc(x.to(dev), 4 if cin == 3 else None)
+    wd = ops.weight_to_ohwi(wt.to(dev))
+    y, _ = ops.conv2d_fwd(xd, wd, k, s)
+    _close(ops.nhwc_to_nchw(y), ref, 2e-5, "conv fwd")
+
+
+def test_conv2d_fwd_fused_epilogue_and_stats(dev):
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k, s = 2, 14, 14, 64, 96, 3, 1
+    x = _rand(n, cin, h, w, seed=3); wt = _rand(cout, cin, k, k, seed=4, scale=(cin * 9) ** -0.5)
+    scale = _rand(cout, seed=5).abs() + 0.5; shift = _rand(cout, seed=6); res = _rand(n, cout, h, w, seed=7)
+    raw = F.conv2d(x.double(), wt.double(), None, s, 1)
+    ref = F.leaky_relu(raw * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1), 0.1) + res.double()
+    xd = ops.nchw_to_nhwc(x.to(dev)); wd = ops.weight_to_ohwi(wt.to(dev))
+    y, stats = ops.conv2d_fwd(xd, wd, k, s, scale.to(dev), shift.to(dev), ops.ACT_LEAKY, 0.1,
+                              residual=ops.nchw_to_nhwc(res.to(dev)), want_stats=True)
+    _close(ops.nhwc_to_nchw(y), ref.float(), 2e-5, "fused epilogue")
+    tot = stats.sum(0).cpu().double()
+    _close(tot[0], raw.sum((0, 2, 3)), 1e-5, "stats sum")
+    _close(tot[1], (raw * raw).sum((0, 2, 3)), 1e-5, "stats sumsq")
+
+
+def test_conv2d_fwd_into_concat_slice(dev):
+    from dcnet_amd import ops
+    n, h, w, cin, cout = 2, 10, 10, 64, 64
+    x = _rand(n, cin, h, w, seed=8); wt = _rand(cout, cin, 1, 1, seed=9, scale=cin ** -0.5)
+    buf = torch.zeros(n, h, w, 192, device=dev)
+    ops.conv2d_fwd(ops.nchw_to_nhwc(x.to(dev)), ops.weight_to_ohwi(wt.to(dev)), 1, 1, out=buf[..., 64:128])
+    ref = F.conv2d(x, wt)
+    _close(_nchw(buf[..., 64:128]), ref, 2e-5, "slice")
+    assert float(buf[..., :64].abs().max()) == 0 and float(buf[..., 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[3] != 3 and c[4] % 32 == 0])
+def test_conv2d_bwd_data(dev, case):
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k, s = case
+    x = _rand(n, cin, h, w, seed=1).double().requires_grad_(True)
+    wt = _rand(cout, cin, k, k, seed=2, scale=(cin * k * k) ** -0.5)
+    y = F.conv2d(x, wt.double(), None, s, (k - 1) // 2)
+    dy = _rand(*y.shape, seed=11)
+    y.backward(dy.double())
+    dx = ops.conv2d_bwd_data(ops.nchw_to_nhwc(dy.to(dev)), ops.weight_to_ohwi(wt.to(dev)), (h, w), k, s)
+    _close(ops.nhwc_to_nchw(dx), x.grad.float(), 2e-5, "dgrad")
+    # accumulate form
+    base = _rand(n, cin, h, w, seed=12)
+    dx2 = ops.nchw_to_nhwc(base.to(dev))
+    ops.conv2d_bwd_data(ops.nchw_to_nhwc(dy.to(dev)), ops.weight_to_ohwi(wt.to(dev)), (h, w), k, s, out=dx2, accumulate=True)
+    _close(ops.nhwc_to_nchw(dx2), x.grad.float() + base, 2e-5, "dgrad accumulate")
+
+
+WGRAD_CASES = CONV_CASES[:5] + [CONV_CASES[6], (4, 52, 52, 32, 64, 3, 1), (2, 20, 20, 128, 128, 3, 1), (2, 12, 12, 32, 32, 1, 1),
+                                (2, 12, 12, 64, 32, 3, 1), (2, 12, 12, 32, 128, 1, 1)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_bwd_weight(dev, case):
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k, s = case
+    x = _rand(n, cin, h, w, seed=1)
+    wt = (_rand(cout, cin, k, k, seed=2) * 0.1).double().requires_grad_(True)
+    y = F.conv2d(x.double(), wt, None, s, (k - 1) // 2)
+    dy = _rand(*y.shape, seed=13)
+    y.backward(dy.double())
+    xd = ops.nchw_to_nhwc(x.to(dev), 4 if cin == 3 else None)
+    dw = ops.conv2d_bwd_weight(xd, ops.nchw_to_nhwc(dy.to(dev)), k, s)
+    got = ops.weight_grad_to_oihw(dw, (cout, cin, k, k))
+    _close(got, wt.grad.float(), 3e-5, "wgrad")
+
+
+def test_batchnorm_train_fwd_bwd(dev):
+    from dcnet_amd import ops
+    n, h, w, c = 3, 9, 7, 96
+    y = (_rand(n, c, h, w, seed=20) * 2 + 0.5)
+    gamma = _rand(c, seed=21).abs() + 0.5; beta = _rand(c, seed=22)
+    rm = _rand(c, seed=23); rv = _rand(c, seed=24).abs() + 0.5
+    res = _rand(n, c, h, w, seed=25)
+    yd = y.double().requires_grad_(True); gd = gamma.double().requires_grad_(True); bd = beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone().double(), rv.clone().double()
+    out_ref = F.leaky_relu(F.batch_norm(yd, rm_ref, rv_ref, gd, bd, True, 0.1, 1e-5), 0.1) + res.double()
+    dout = _rand(n, c, h, w, seed=26)
+    out_ref.backward(dout.double())
+
+    y_nhwc = ops.nchw_to_nhwc(y.to(dev))
+    stats = ops.channel_stats(y_nhwc.view(-1, c))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    mi = ops.bn_finalize(stats, n * h * w, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rmd, rvd)
+    out = ops.scale_act(y_nhwc, mi[2], mi[3], ops.ACT_LEAKY, 0.1, residual=ops.nchw_to_nhwc(res.to(dev)))
+    _close(ops.nhwc_to_nchw(out), out_ref.float(), 2e-5, "bn fwd")
+    _close(rmd, rm_ref.float(), 1e-5, "running_mean"); _close(rvd, rv_ref.float(), 1e-5, "running_var")
+    dy, dgamma, dbeta = ops.bn_act_bwd(y_nhwc, ops.nchw_to_nhwc(dout.to(dev)), mi[0], mi[1], gamma.to(dev), beta.to(dev),
+                                       ops.ACT_LEAKY, 0.1)
+    _close(ops.nhwc_to_nchw(dy), yd.grad.float(), 3e-5, "bn dy")
+    _close(dgamma, gd.grad.float(), 3e-5, "dgamma"); _close(dbeta, bd.grad.float(), 3e-5, "dbeta")
+
+
+def test_bn_fold_and_act_bwd(dev):
+    from dcnet_amd import ops
+    c = 64
+    gamma = _rand(c, seed=1).abs() + 0.5; beta = _rand(c, seed=2); rm = _rand(c, seed=3); rv = _rand(c, seed=4).abs() + 0.1
+    ss = ops.bn_fold(gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev))
+    sc = gamma / torch.sqrt(rv + 1e-5)
+    _close(ss[0], sc, 1e-6); _close(ss[1], beta - rm * sc, 1e-6)
+    o = _rand(5, 6, c, seed=5); d = _rand(5, 6, c, seed=6)
+    got = ops.act_bwd(o.to(dev), d.to(dev), 0.1)
+    _close(got, torch.where(o > 0, d, d * 0.1), 1e-6)
+
+
+@pytest.mark.parametrize("b,g,c", [(2, 8, 64), (1, 13, 512), (3, 5, 96)])
+def test_coattn_fwd_bwd(dev, b, g, c):
+    from dcnet_amd import ops
+    hw = g * g
+    f1 = F.normalize(_rand(b, hw, c, seed=30), dim=2); f2 = F.normalize(_rand(b, hw, c, seed=31), dim=2)
+    a = f1.double().requires_grad_(True); bb = f2.double().requires_grad_(True)
+    A = torch.bmm(a, bb.transpose(1, 2))
+    o1 = torch.bmm(F.softmax(A * 10, dim=2), bb)                       # f1_attn[i] = sum_j softmax_j
+    o2 = torch.bmm(F.softmax(A * 10, dim=1).transpose(1, 2), a)        # f2_attn[j] = sum_i softmax_i
+    d1 = _rand(b, hw, c, seed=32); d2 = _rand(b, hw, c, seed=33)
+    (o1 * d1.double()).sum().backward(retain_graph=True)
+    (o2 * d2.double()).sum().backward()
+    f1d, f2d = f1.to(dev), f2.to(dev)
+    cat = torch.zeros(2, b, hw, 2 * c, device=dev)                     # outputs land in a slice (ldo = 2c)
+    out1, out2 = cat[0, :, :, c:], cat[1, :, :, c:]
+    E, rc = ops.coattn_fwd(f1d, f2d, out1, out2, 10.0)
+    _close(out1, o1.float(), 2e-5, "f1_attn"); _close(out2, o2.float(), 2e-5, "f2_attn")
+    base1 = _rand(b, hw, c, seed=34); base2 = _rand(b, hw, c, seed=35)
+    g1, g2 = base1.to(dev).clone(), base2.to(dev).clone()
+    ops.coattn_bwd(f1d, f2d, d1.to(dev), d2.to(dev), out1, out2, E, rc, g1, g2, True, 10.0)
+    _close(g1, a.grad.float() + base1, 5e-5, "d_f1"); _close(g2, bb.grad.float() + base2, 5e-5, "d_f2")
+    # inference form: only f1_attn
+    o_only = torch.empty(b, hw, c, device=dev)
+    ops.coattn_fwd(f1d, f2d, o_only, None, 10.0)
+    _close(o_only, o1.float(), 2e-5, "f1_attn only")
+
+
+def test_l2norm_score_fwd_bwd(dev):
+    from dcnet_amd import ops
+    n, hw, c = 3, 37, 512
+    x = _rand(n, hw, c, seed=40); q = F.normalize(_rand(n, c, seed=41), dim=1)
+    xd = x.double().requires_grad_(True); qd = q.double().requires_grad_(True)
+    o = F.normalize(xd, dim=2); sc = (o * qd.unsqueeze(1)).sum(2)
+    do = _rand(n, hw, c, seed=42); ds = _rand(n, hw, seed=43)
+    ((o * do.double()).sum() + (sc * ds.double()).sum()).backward()
+    out, norm, score = ops.l2norm_score_fwd(x.to(dev), q.to(dev), hw)
+    _close(out, o.float(), 1e-6, "normalize"); _close(score.view(n, hw), sc.float(), 1e-5, "score")
+    dx, dq = ops.l2norm_score_bwd(out, norm, do.to(dev), q.to(dev), ds.to(dev).view(-1), hw)
+    _close(dx, xd.grad.float(), 2e-5, "dx"); _close(dq, qd.grad.float(), 2e-5, "dq")
+    out2, norm2, none = ops.l2norm_score_fwd(x.to(dev))
+    assert none is None
+    _close(out2, o.float(), 1e-6)
+    dx2, _ = ops.l2norm_score_bwd(out2, norm2, do.to(dev), None, None, 0)
+    xd2 = x.double().requires_grad_(True)
+    (F.normalize(xd2, dim=2) * do.double()).sum().backward()
+    _close(dx2, xd2.grad.float(), 2e-5, "dx (no score)")
+
+
+def test_layout_and_movers(dev):
+    from dcnet_amd import ops
+    x = _rand(2, 5, 7, 9, seed=50)
+    xd = ops.nchw_to_nhwc(x.to(dev), 8)
+    assert xd.shape == (2, 7, 9, 8)
+    _close(xd[..., :5], x.permute(0, 2, 3, 1), 0.0); assert float(xd[..., 5:].abs().max()) == 0
+    _close(ops.nhwc_to_nchw(xd, 5), x, 0.0)
+    w = _rand(6, 40, 3, 3, seed=51)
+    wo = ops.weight_to_ohwi(w.to(dev))
+    assert wo.shape == (6, 3, 3, 64)
+    _close(wo[..., :40], w.permute(0, 2, 3, 1), 0.0)
+    _close(ops.weight_grad_to_oihw(wo, (6, 40, 3, 3)), w, 0.0)
+    s = _rand(2, 4, 5, 8, seed=52).to(dev)
+    buf = torch.zeros(2, 8, 10, 24, device=dev)
+    ops.upsample2_into(s, buf[..., 8:16])
+    ref = s.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    _close(buf[..., 8:16], ref, 0.0)
+    g = _rand(2, 8, 10, 24, seed=53).to(dev)
+    ds = torch.ones(2, 4, 5, 8, device=dev)
+    ops.upsample2_bwd(g[..., 8:16], ds, True)
+    gr = g[..., 8:16].reshape(2, 4, 2, 5, 2, 8).sum((2, 4)) + 1
+    _close(ds, gr, 1e-6)
+    d = torch.ones(2, 8, 10, 8, device=dev)
+    ops.copy_slice(g[..., 16:24], d, True)
+    _close(d, g[..., 16:24] + 1, 1e-6)
