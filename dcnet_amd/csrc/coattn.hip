@@ -69,17 +69,19 @@ __global__ __launch_bounds__(256) void colsum_inv_kernel(const float* __restrict
 }
 
 // one wave per row: delta[row] = <d[row], o[row]>, ds[row] = d[row] * inv[row]
-__global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ o, int ldo,
+__global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ d, int ldd, int64_t bsd,
+                                                           const float* __restrict__ o, int ldo, int64_t bso, int hw,
                                                            const float* __restrict__ inv, int64_t rows, int c,
                                                            float* __restrict__ delta, float* __restrict__ ds) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const int64_t bb = row / hw, i = row - bb * hw;
   const float s = inv[row];
   float acc = 0.f;
   for (int k = lane * 4; k < c; k += 256) {
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + row * ldd + k);
-    const f32x4 ov = *reinterpret_cast<const f32x4*>(o + row * ldo + k);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + bb * bsd + i * ldd + k);
+    const f32x4 ov = *reinterpret_cast<const f32x4*>(o + bb * bso + i * ldo + k);
     acc += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
     *reinterpret_cast<f32x4*>(ds + row * c + k) = dv * s;
   }
@@ -132,8 +134,8 @@ extern "C" int64_t dcn_coattn_fwd_ws(int b, int hw, int c) {
 }
 extern "C" int64_t dcn_coattn_e_size(int b, int hw) { return (int64_t)b * hw * ld_pad(hw); }
 
-extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* f1_attn, float* f2_attn, int ldo,
-                              float* E, float* rinv, float* cinv, float* ws,
+extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t bsf, float* f1_attn, float* f2_attn, int ldo,
+                              int64_t bso, float* E, float* rinv, float* cinv, float* ws,
                               int b, int hw, int c, float temperature, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(f1 && f2 && f1_attn && E && rinv && cinv && ws, "coattn_fwd: null pointer");
@@ -141,10 +143,13 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* 
   if (ldf <= 0) ldf = c;
   if (ldo <= 0) ldo = c;
   DCN_CHECK_ARG(ldf % 4 == 0 && ldo % 4 == 0, "coattn_fwd: ldf/ldo must be multiples of 4");
+  if (bsf <= 0) bsf = (int64_t)hw * ldf;
+  if (bso <= 0) bso = (int64_t)hw * ldo;
+  DCN_CHECK_ARG(bsf % 4 == 0 && bso % 4 == 0, "coattn_fwd: batch strides must be multiples of 4");
   const int ldE = ld_pad(hw);
   IgemmParams p;
   // 1. A = f1 . f2^T  -> E                                             (NT)
-  gemm_params(p, f1, ldf, (long long)hw * ldf, f2, ldf, (long long)hw * ldf, E, ldE, (long long)hw * ldE, hw, hw, c, b);
+  gemm_params(p, f1, ldf, bsf, f2, ldf, bsf, E, ldE, (long long)hw * ldE, hw, hw, c, b);
   int rc = igemm_launch(p, stream);
   if (rc) return rc;
   // 2. E = exp(t*A - t), rinv = 1/rowsum, cinv = 1/colsum
@@ -154,13 +159,13 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* 
   hipLaunchKernelGGL(colsum_inv_kernel, dim3(cdiv(hw, 256), b), dim3(256), 0, stream, ws, nrb, b, hw, ldE, cinv);
   DCN_CHECK_LAUNCH("colsum_inv");
   // 3. f1_attn = diag(rinv) E f2                                       (NN, K = keys j)
-  gemm_params(p, E, ldE, (long long)hw * ldE, f2, ldf, (long long)hw * ldf, f1_attn, ldo, (long long)hw * ldo, hw, c, ldE, b);
+  gemm_params(p, E, ldE, (long long)hw * ldE, f2, ldf, bsf, f1_attn, ldo, bso, hw, c, ldE, b);
   p.bmode = 1; p.kvalid = hw; p.row_scale = rinv;
   rc = igemm_launch(p, stream);
   if (rc) return rc;
   // 4. f2_attn = diag(cinv) E^T f1                                     (TN, K = queries i)
   if (f2_attn)
-    rc = tn_gemm_batched(E, ldE, (long long)hw * ldE, f1, ldf, (long long)hw * ldf, f2_attn, ldo, (long long)hw * ldo,
+    rc = tn_gemm_batched(E, ldE, (long long)hw * ldE, f1, ldf, bsf, f2_attn, ldo, bso,
                          cinv, hw, ldE, c, hw, b, 0, stream);
   return rc;
 }
@@ -169,11 +174,11 @@ extern "C" int64_t dcn_coattn_bwd_ws(int b, int hw, int c) {
   return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw;
 }
 
-extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
-                              const float* d_f1_attn, const float* d_f2_attn, int lddo,
-                              const float* f1_attn, const float* f2_attn, int ldo,
+extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
+                              const float* d_f1_attn, const float* d_f2_attn, int lddo, int64_t bsdo,
+                              const float* f1_attn, const float* f2_attn, int ldo, int64_t bso,
                               const float* E, const float* rinv, const float* cinv,
-                              float* d_f1, float* d_f2, int lddf, int accumulate, float* ws,
+                              float* d_f1, float* d_f2, int lddf, int64_t bsdf, int accumulate, float* ws,
                               int b, int hw, int c, float temperature, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(f1 && f2 && d_f1_attn && d_f2_attn && f1_attn && f2_attn && E && rinv && cinv && d_f1 && d_f2 && ws,
@@ -183,6 +188,10 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
   if (ldo <= 0) ldo = c;
   if (lddo <= 0) lddo = c;
   if (lddf <= 0) lddf = c;
+  if (bsf <= 0) bsf = (int64_t)hw * ldf;
+  if (bso <= 0) bso = (int64_t)hw * ldo;
+  if (bsdo <= 0) bsdo = (int64_t)hw * lddo;
+  if (bsdf <= 0) bsdf = (int64_t)hw * lddf;
   const int ldE = ld_pad(hw);
   const long long rows = (long long)b * hw;
   float* dP1 = ws;
@@ -192,16 +201,16 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
   float* del1 = dO2s + rows * c;
   float* del2 = del1 + rows;
   // 1. delta and pre-scaled upstream gradients
-  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f1_attn, lddo, f1_attn, ldo, rinv, rows, c, del1, dO1s);
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f1_attn, lddo, bsdo, f1_attn, ldo, bso, hw, rinv, rows, c, del1, dO1s);
   DCN_CHECK_LAUNCH("rowdot_scale");
-  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, f2_attn, ldo, cinv, rows, c, del2, dO2s);
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, bsdo, f2_attn, ldo, bso, hw, cinv, rows, c, del2, dO2s);
   DCN_CHECK_LAUNCH("rowdot_scale");
   IgemmParams p;
   int rc;
   // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                  (NT x2)
-  gemm_params(p, d_f1_attn, lddo, (long long)hw * lddo, f2, ldf, (long long)hw * ldf, dP1, ldE, (long long)hw * ldE, hw, hw, c, b);
+  gemm_params(p, d_f1_attn, lddo, bsdo, f2, ldf, bsf, dP1, ldE, (long long)hw * ldE, hw, hw, c, b);
   if ((rc = igemm_launch(p, stream))) return rc;
-  gemm_params(p, f1, ldf, (long long)hw * ldf, d_f2_attn, lddo, (long long)hw * lddo, dP2, ldE, (long long)hw * ldE, hw, hw, c, b);
+  gemm_params(p, f1, ldf, bsf, d_f2_attn, lddo, bsdo, dP2, ldE, (long long)hw * ldE, hw, hw, c, b);
   if ((rc = igemm_launch(p, stream))) return rc;
   // 3. dA (over dP1)
   const int64_t total4 = rows * (ldE / 4);
@@ -209,16 +218,16 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
   hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4);
   DCN_CHECK_LAUNCH("dA");
   // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                   (NN x2)
-  gemm_params(p, dP1, ldE, (long long)hw * ldE, f2, ldf, (long long)hw * ldf, d_f1, lddf, (long long)hw * lddf, hw, c, ldE, b);
+  gemm_params(p, dP1, ldE, (long long)hw * ldE, f2, ldf, bsf, d_f1, lddf, bsdf, hw, c, ldE, b);
   p.bmode = 1; p.kvalid = hw; p.accumulate = accumulate;
   if ((rc = igemm_launch(p, stream))) return rc;
-  gemm_params(p, E, ldE, (long long)hw * ldE, dO2s, c, (long long)hw * c, d_f1, lddf, (long long)hw * lddf, hw, c, ldE, b);
+  gemm_params(p, E, ldE, (long long)hw * ldE, dO2s, c, (long long)hw * c, d_f1, lddf, bsdf, hw, c, ldE, b);
   p.bmode = 1; p.kvalid = hw; p.accumulate = 1;
   if ((rc = igemm_launch(p, stream))) return rc;
   // 5. d_f2 (+)= dA^T f1 + E^T (dO1 / rowsum)                               (TN x2)
-  rc = tn_gemm_batched(dP1, ldE, (long long)hw * ldE, f1, ldf, (long long)hw * ldf, d_f2, lddf, (long long)hw * lddf,
+  rc = tn_gemm_batched(dP1, ldE, (long long)hw * ldE, f1, ldf, bsf, d_f2, lddf, bsdf,
                        nullptr, hw, ldE, c, hw, b, accumulate, stream);
   if (rc) return rc;
-  return tn_gemm_batched(E, ldE, (long long)hw * ldE, dO1s, c, (long long)hw * c, d_f2, lddf, (long long)hw * lddf,
+  return tn_gemm_batched(E, ldE, (long long)hw * ldE, dO1s, c, (long long)hw * c, d_f2, lddf, bsdf,
                          nullptr, hw, ldE, c, hw, b, 1, stream);
 }

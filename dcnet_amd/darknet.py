@@ -1,0 +1,545 @@
+"""Darknet-53 / YOLOv3 visual backbone on the HIP conv engine.
+
+Mirrors the reference's model/darknet.py surface — ``parse_model_config``, ``create_modules``,
+``Darknet(config_path, img_size, obj_out)`` with ``.module_list`` (same sub-module names, hence the
+same 438 state_dict keys), ``.forward(x)`` returning the three taps, ``.load_weights`` /
+``.save_weights`` (darknet binary) — but executes a static layer plan with hand-written kernels:
+
+  * the graph is compiled once into a plan (dead YOLO heads removed: F7 of SURVEY.md; every
+    shortcut fused into the producing conv; upsample fused with the route concat);
+  * the whole backbone is ONE autograd node (``_DarknetFn``) whose backward is scheduled by hand:
+    BN+LeakyReLU backward, weight gradient, data gradient per layer, gradients of tensors with two
+    consumers accumulated inside the data-gradient kernel (no autograd add nodes);
+  * eval mode folds BatchNorm into the conv epilogue: one kernel per layer.
+
+Reference: model/darknet.py:99-116 (cfg parser), :162-237 (module factory), :391-431 (forward),
+:433-513 (weights io); graph: model/yolov3.cfg.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+# ----------------------------------------------------------------------------------------------------
+# cfg handling
+# ----------------------------------------------------------------------------------------------------
+
+def parse_model_config(path: str) -> List[dict]:
+    """darknet .cfg -> list of block dicts (first block is [net]).  Same contract as the
+    reference parser (model/darknet.py:99-116): '#' lines dropped, values kept as strings,
+    ``batch_normalize`` defaults to 0 for (yolo)convolutional blocks."""
+    blocks: List[dict] = []
+    with open(path, "r") as fh:
+        for raw in fh:
+            line = raw.strip()
+            if not line or line.startswith("#"):
+                continue
+            if line.startswith("["):
+                blocks.append({"type": line[1:-1].rstrip()})
+                if blocks[-1]["type"] in ("convolutional", "yoloconvolutional"):
+                    blocks[-1]["batch_normalize"] = 0
+            else:
+                key, value = line.split("=", 1)
+                blocks[-1][key.strip()] = value.strip()
+    return blocks
+
+
+_ANCHORS = "10,13,  16,30,  33,23,  30,61,  62,45,  59,119,  116,90,  156,198,  373,326"
+
+
+def yolov3_blocks(width: int = 416, height: int = 416) -> List[dict]:
+    """The YOLOv3 graph DCNet uses, built from the network's regular structure (52-conv
+    Darknet-53 trunk, then three neck/head groups with ``yoloconvolutional`` taps).  Produces
+    the same block list as parsing the reference's model/yolov3.cfg."""
+    blocks: List[dict] = [dict(type="net", batch="1", subdivisions="1", width=str(width), height=str(height),
+                               channels="3", momentum="0.9", decay="0.0005")]
+
+    def conv(filters, size, stride=1, bn=1, act="leaky", kind="convolutional"):
+        b = {"type": kind, "batch_normalize": bn} if bn else {"type": kind, "batch_normalize": 0}
+        if bn:
+            b["batch_normalize"] = "1"
+        b.update(filters=str(filters), size=str(size), stride=str(stride), pad="1", activation=act)
+        blocks.append(b)
+
+    def shortcut():
+        blocks.append({"type": "shortcut", "from": "-3", "activation": "linear"})
+
+    conv(32, 3)
+    for filters, reps in ((64, 1), (128, 2), (256, 8), (512, 8), (1024, 4)):
+        conv(filters, 3, 2)
+        for _ in range(reps):
+            conv(filters // 2, 1); conv(filters, 3); shortcut()
+    for mask, (filters, lateral) in zip(("6,7,8", "3,4,5", "0,1,2"), ((512, None), (256, 61), (128, 36))):
+        if lateral is not None:
+            blocks.append({"type": "route", "layers": "-4"})
+            conv(filters, 1)
+            blocks.append({"type": "upsample", "stride": "2"})
+            blocks.append({"type": "route", "layers": f"-1, {lateral}"})
+        for _ in range(2):
+            conv(filters, 1); conv(filters * 2, 3)
+        conv(filters, 1, kind="yoloconvolutional")
+        conv(filters * 2, 3)
+        conv(255, 1, bn=0, act="linear")
+        blocks.append({"type": "yolo", "mask": mask, "anchors": _ANCHORS, "classes": "80", "num": "9",
+                       "jitter": ".3", "ignore_thresh": ".7", "truth_thresh": "1", "random": "1"})
+    return blocks
+
+
+def write_cfg(path: str, blocks: Optional[Sequence[dict]] = None) -> None:
+    blocks = yolov3_blocks() if blocks is None else blocks
+    with open(path, "w") as fh:
+        for b in blocks:
+            fh.write(f"[{b['type']}]\n")
+            for k, v in b.items():
+                if k != "type" and not (k == "batch_normalize" and str(v) == "0"):
+                    fh.write(f"{k}={v}\n")
+            fh.write("\n")
+
+
+class EmptyLayer(nn.Module):
+    """Placeholder for route / shortcut slots (model/darknet.py:239-243)."""
+
+
+class MyUpsample2(nn.Module):
+    """Nearest x2 (model/darknet.py:158-160); only a slot marker here — the plan fuses it."""
+    def forward(self, x):
+        return x[:, :, :, None, :, None].expand(-1, -1, -1, 2, -1, 2).reshape(x.size(0), x.size(1), x.size(2) * 2, x.size(3) * 2)
+
+
+class YOLOLayer(nn.Module):
+    """Detection layer slot (model/darknet.py:245-375).  DCNet discards its output
+    (obj_out=False), so it is never executed; it has no parameters."""
+    def __init__(self, anchors, num_classes, img_dim):
+        super().__init__()
+        self.anchors, self.num_classes, self.image_dim = anchors, num_classes, img_dim
+
+
+def create_modules(module_defs: List[dict]):
+    """Parameter containers with the reference's names (model/darknet.py:162-237):
+    ``conv_%d`` (bias only when there is no BN), ``batch_norm_%d``, ``leaky_%d``."""
+    hyper = module_defs.pop(0)
+    filters_out = [int(hyper["channels"])]
+    module_list = nn.ModuleList()
+    for i, d in enumerate(module_defs):
+        seq = nn.Sequential()
+        t = d["type"]
+        if t in ("convolutional", "yoloconvolutional"):
+            bn = int(d["batch_normalize"]); filters = int(d["filters"]); k = int(d["size"])
+            pad = (k - 1) // 2 if int(d["pad"]) else 0
+            seq.add_module(f"conv_{i}", nn.Conv2d(filters_out[-1], filters, k, int(d["stride"]), pad, bias=not bn))
+            if bn:
+                seq.add_module(f"batch_norm_{i}", nn.BatchNorm2d(filters))
+            if d["activation"] == "leaky":
+                seq.add_module(f"leaky_{i}", nn.LeakyReLU(0.1))
+        elif t == "upsample":
+            assert int(d["stride"]) == 2
+            seq.add_module(f"upsample_{i}", MyUpsample2())
+            filters = filters_out[-1]
+        elif t == "route":
+            layers = [int(x) for x in d["layers"].split(",")]
+            filters = sum(filters_out[1:][l] if l >= 0 else filters_out[l] for l in layers)
+            seq.add_module(f"route_{i}", EmptyLayer())
+        elif t == "shortcut":
+            filters = filters_out[int(d["from"])]
+            seq.add_module(f"shortcut_{i}", EmptyLayer())
+        elif t == "yolo":
+            idx = [int(x) for x in d["mask"].split(",")]
+            a = [int(x) for x in d["anchors"].split(",")]
+            a = [(a[j], a[j + 1]) for j in range(0, len(a), 2)]
+            seq.add_module(f"yolo_{i}", YOLOLayer([a[j] for j in idx], int(d["classes"]), 256))
+            filters = filters_out[-1]
+        else:
+            raise ValueError(f"unsupported cfg block type {t!r}")
+        module_list.append(seq)
+        filters_out.append(filters)
+    return hyper, module_list
+
+
+# ----------------------------------------------------------------------------------------------------
+# plan
+# ----------------------------------------------------------------------------------------------------
+
+class _ConvOp:
+    __slots__ = ("slot", "src", "dst", "res", "cin", "cout", "k", "stride", "bn", "leaky", "need_dx")
+
+
+class _UpCatOp:
+    __slots__ = ("dst", "up_src", "lat_src", "c_up", "c_lat")
+
+
+class _AliasOp:
+    __slots__ = ("dst", "src")
+
+
+def build_plan(module_defs: List[dict], in_channels: int = 3):
+    """Compile the slot list into executable ops.  Returns (ops, tap_slots, channels_per_slot)."""
+    n = len(module_defs)
+    ch: List[int] = []
+    prev = in_channels
+    for i, d in enumerate(module_defs):
+        t = d["type"]
+        if t in ("convolutional", "yoloconvolutional"):
+            prev = int(d["filters"])
+        elif t == "route":
+            ls = [int(x) for x in d["layers"].split(",")]
+            prev = sum(ch[l if l >= 0 else i + l] for l in ls)
+        elif t == "shortcut":
+            prev = ch[i + int(d["from"])]
+        ch.append(prev)
+    # liveness: what can reach a tap (input of each yoloconvolutional)
+    taps = [i - 1 for i, d in enumerate(module_defs) if d["type"] == "yoloconvolutional"]
+    live = [False] * n
+    stack = list(taps)
+    while stack:
+        i = stack.pop()
+        if i < 0 or live[i]:
+            continue
+        live[i] = True
+        d = module_defs[i]; t = d["type"]
+        if t in ("convolutional", "yoloconvolutional", "upsample"):
+            stack.append(i - 1)
+        elif t == "shortcut":
+            stack += [i - 1, i + int(d["from"])]
+        elif t == "route":
+            stack += [l if l >= 0 else i + l for l in (int(x) for x in d["layers"].split(","))]
+    consumers: Dict[int, List[int]] = {i: [] for i in range(-1, n)}
+    for i, d in enumerate(module_defs):
+        if not live[i]:
+            continue
+        t = d["type"]
+        if t in ("convolutional", "yoloconvolutional", "upsample"):
+            consumers[i - 1].append(i)
+        elif t == "shortcut":
+            consumers[i - 1].append(i); consumers[i + int(d["from"])].append(i)
+        elif t == "route":
+            for l in (int(x) for x in d["layers"].split(",")):
+                consumers[l if l >= 0 else i + l].append(i)
+    plan = []
+    fused_shortcuts = set(); fused_upsamples = set()
+    for i, d in enumerate(module_defs):
+        if not live[i]:
+            continue
+        t = d["type"]
+        if t in ("convolutional", "yoloconvolutional"):
+            op = _ConvOp()
+            op.slot = i; op.src = i - 1; op.dst = i; op.res = None
+            op.cin = in_channels if i == 0 else ch[i - 1]; op.cout = int(d["filters"])
+            op.k = int(d["size"]); op.stride = int(d["stride"])
+            op.bn = bool(int(d["batch_normalize"])); op.leaky = d["activation"] == "leaky"
+            op.need_dx = i > 0
+            nxt = module_defs[i + 1] if i + 1 < n else None
+            if (nxt is not None and nxt["type"] == "shortcut" and live[i + 1] and consumers[i] == [i + 1]
+                    and i not in taps):
+                op.dst = i + 1; op.res = i + 1 + int(nxt["from"])
+                fused_shortcuts.add(i + 1)
+            plan.append(op)
+        elif t == "shortcut":
+            if i not in fused_shortcuts:
+                raise NotImplementedError("unfused shortcut (pattern not present in YOLOv3)")
+        elif t == "upsample":
+            nxt = module_defs[i + 1]
+            ok = nxt["type"] == "route" and consumers[i] == [i + 1]
+            ls = [int(x) for x in nxt["layers"].split(",")] if ok else []
+            if not (ok and len(ls) == 2 and ls[0] == -1):
+                raise NotImplementedError("upsample not followed by route(-1, k)")
+            fused_upsamples.add(i + 1)
+            op = _UpCatOp()
+            op.dst = i + 1; op.up_src = i - 1; op.lat_src = ls[1] if ls[1] >= 0 else i + 1 + ls[1]
+            op.c_up = ch[i - 1]; op.c_lat = ch[op.lat_src]
+            plan.append(op)
+        elif t == "route":
+            if i in fused_upsamples:
+                continue
+            ls = [int(x) for x in d["layers"].split(",")]
+            if len(ls) != 1:
+                raise NotImplementedError("route concat without upsample")
+            op = _AliasOp(); op.dst = i; op.src = ls[0] if ls[0] >= 0 else i + ls[0]
+            plan.append(op)
+    return plan, taps, ch
+
+
+# ----------------------------------------------------------------------------------------------------
+# execution
+# ----------------------------------------------------------------------------------------------------
+
+def _cpad(c: int) -> int:
+    return 4 if c <= 4 else ops.pad32(c)
+
+
+def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
+    """P[slot] = dict(w=OIHW weight, b=conv bias|None, gamma, beta, rm, rv).  Returns tap tensors."""
+    out: Dict[int, torch.Tensor] = {-1: x_nhwc}
+    for op in plan:
+        if isinstance(op, _ConvOp):
+            p = P[op.slot]
+            x = out[op.src]
+            w = ops.weight_to_ohwi(p["w"])
+            res = out[op.res] if op.res is not None else None
+            act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
+            if op.bn and training:
+                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True)
+                cnt = y.numel() // op.cout
+                mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
+                o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res)
+                if save is not None:
+                    save[op.slot] = (x, y, mi, w)
+            else:
+                if op.bn:
+                    ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5)
+                    scale, shift = ss[0], ss[1]
+                else:
+                    scale, shift = None, p["b"]
+                if save is None:      # inference: one kernel per layer, shortcut fused in the epilogue
+                    o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res)
+                else:                 # frozen-BN fine-tuning: keep the pre-shortcut activation for act'
+                    a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1)
+                    o = a if res is None else ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res)
+                    save[op.slot] = (x, a, scale, w)
+            out[op.dst] = o
+        elif isinstance(op, _UpCatOp):
+            up, lat = out[op.up_src], out[op.lat_src]
+            n, h, w_, _ = lat.shape
+            buf = torch.empty((n, h, w_, op.c_up + op.c_lat), dtype=torch.float32, device=lat.device)
+            ops.upsample2_into(up, buf[..., :op.c_up])
+            ops.copy_slice(lat, buf[..., op.c_up:])
+            out[op.dst] = buf
+        else:
+            out[op.dst] = out[op.src]
+    return [out[t] for t in taps]
+
+
+def _run_backward(plan, taps, grads_taps, P, save, training: bool):
+    """Hand-scheduled reverse sweep.  Returns {slot: dict(w=, b=, gamma=, beta=)} parameter grads."""
+    g: Dict[int, Optional[torch.Tensor]] = {}
+
+    def add(slot, t):
+        cur = g.get(slot)
+        if cur is None:
+            if not t.is_contiguous():
+                buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+                ops.copy_slice(t, buf)
+                t = buf
+            g[slot] = t
+        else:
+            ops.copy_slice(t, cur, accumulate=True)
+
+    for t, gt in zip(taps, grads_taps):
+        if gt is not None:
+            add(t, gt.clone(memory_format=torch.contiguous_format))   # never accumulate into autograd's tensor
+    pg: Dict[int, dict] = {}
+    for op in reversed(plan):
+        dout = g.pop(op.dst, None)
+        if dout is None:
+            continue
+        if isinstance(op, _AliasOp):
+            add(op.src, dout)
+        elif isinstance(op, _UpCatOp):
+            n, h2, w2, _ = dout.shape
+            cur = g.get(op.up_src)
+            if cur is None:
+                cur = torch.empty((n, h2 // 2, w2 // 2, op.c_up), dtype=torch.float32, device=dout.device)
+                ops.upsample2_bwd(dout[..., :op.c_up], cur, False)
+                g[op.up_src] = cur
+            else:
+                ops.upsample2_bwd(dout[..., :op.c_up], cur, True)
+            add(op.lat_src, dout[..., op.c_up:])
+        else:
+            p = P[op.slot]
+            x, y, aux, w = save.pop(op.slot)
+            shape = tuple(p["w"].shape)
+            d = {}
+            if op.bn and training:
+                mi = aux
+                dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], p["gamma"], p["beta"],
+                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1)
+                d["gamma"], d["beta"] = dgamma, dbeta
+            else:
+                # frozen statistics: y holds act(scale*conv+shift) before the shortcut add
+                dz = ops.act_bwd(y, dout, 0.1) if op.leaky else dout
+                if aux is not None:       # folded BN: z = scale*conv + shift
+                    xhat_like = None
+                    dy = dz * aux
+                    d["beta"] = dz.reshape(-1, op.cout).sum(0)
+                    # dgamma = sum(dz * (conv - rm) * rsqrt(rv+eps)); recover conv from y only where act is
+                    # invertible (leaky/none are), z = y>0 ? y : y/slope
+                    z = torch.where(y > 0, y, y / 0.1) if op.leaky else y
+                    gsafe = torch.where(p["gamma"] == 0, torch.ones_like(p["gamma"]), p["gamma"])
+                    d["gamma"] = (dz * (z - p["beta"]) / gsafe).reshape(-1, op.cout).sum(0)
+                else:
+                    dy = dz
+                    if p["b"] is not None:
+                        d["b"] = dz.reshape(-1, op.cout).sum(0)
+            if op.res is not None:
+                add(op.res, dout)
+            d["w"] = ops.weight_grad_to_oihw(ops.conv2d_bwd_weight(x, dy, op.k, op.stride), shape)
+            if op.need_dx:
+                cur = g.get(op.src)
+                hw = (x.shape[1], x.shape[2])
+                if cur is None:
+                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride)
+                else:
+                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True)
+            pg[op.slot] = d
+    return pg
+
+
+class _DarknetFn(torch.autograd.Function):
+    """The whole backbone as one autograd node.  Flat parameter order per conv slot:
+    weight, (bias | gamma, beta)."""
+
+    @staticmethod
+    def forward(ctx, net: "Darknet", training: bool, image: torch.Tensor, *flat):
+        plan, taps = net._plan, net._taps
+        P = net._param_table(flat)
+        x = ops.nchw_to_nhwc(image.contiguous(), 4)
+        need_grad = any(ctx.needs_input_grad[3:])
+        save = {} if need_grad else None
+        outs = _run_forward(plan, taps, x, P, training, save)
+        if save is not None:
+            # outputs must go through save_for_backward (an attribute reference would make a
+            # ctx <-> output cycle and pin the whole activation set until the GC runs)
+            for slot, tup in list(save.items()):
+                for k, o in enumerate(outs):
+                    if tup[0] is o:
+                        save[slot] = (("tap", k),) + tup[1:]
+            ctx.save_for_backward(*outs)
+        ctx.net, ctx.training, ctx.save, ctx.nflat = net, training, save, len(flat)
+        ctx.P = P
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        net = ctx.net
+        outs = ctx.saved_tensors
+        save = {slot: ((outs[t[0][1]],) + t[1:] if isinstance(t[0], tuple) else t) for slot, t in ctx.save.items()}
+        ctx.save = None
+        pg = _run_backward(net._plan, net._taps, grads, ctx.P, save, ctx.training)
+        flat_grads: List[Optional[torch.Tensor]] = []
+        for op in net._conv_ops:
+            d = pg.get(op.slot, {})
+            flat_grads.append(d.get("w"))
+            if op.bn:
+                flat_grads += [d.get("gamma"), d.get("beta")]
+            else:
+                flat_grads.append(d.get("b"))
+        return (None, None, None) + tuple(flat_grads)
+
+
+class Darknet(nn.Module):
+    """YOLOv3 backbone (drop-in for model/darknet.py:377-431).  ``forward`` returns the list of
+    taps [1024@S/32, 512@S/16, 256@S/8] in NCHW like the reference; ``forward_nhwc`` hands the
+    NHWC tensors to the rest of this package without a layout round trip."""
+
+    def __init__(self, config_path: str = "./model/yolov3.cfg", img_size: int = 416, obj_out: bool = False):
+        super().__init__()
+        if obj_out:
+            raise NotImplementedError("obj_out=True (YOLO detection output) is outside the DCNet hot path")
+        self.config_path = config_path
+        self.obj_out = obj_out
+        if config_path and os.path.exists(config_path):
+            self.module_defs = parse_model_config(config_path)
+        else:
+            self.module_defs = yolov3_blocks()
+        self.hyperparams, self.module_list = create_modules(self.module_defs)
+        self.img_size = img_size
+        self.seen = 0
+        self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
+        self._plan, self._taps, self._ch = build_plan(self.module_defs, int(self.hyperparams["channels"]))
+        self._conv_ops = [op for op in self._plan if isinstance(op, _ConvOp)]
+
+    # -- parameter plumbing -------------------------------------------------------------------
+    def _flat_params(self) -> List[torch.Tensor]:
+        flat = []
+        for op in self._conv_ops:
+            seq = self.module_list[op.slot]
+            conv = seq[0]
+            flat.append(conv.weight)
+            if op.bn:
+                flat += [seq[1].weight, seq[1].bias]
+            else:
+                flat.append(conv.bias)
+        return flat
+
+    def _param_table(self, flat):
+        P = {}
+        it = iter(flat)
+        for op in self._conv_ops:
+            seq = self.module_list[op.slot]
+            d = dict(w=next(it).detach(), b=None, gamma=None, beta=None, rm=None, rv=None, momentum=0.1)
+            if op.bn:
+                bn = seq[1]
+                d["gamma"], d["beta"] = next(it).detach(), next(it).detach()
+                d["rm"], d["rv"], d["momentum"] = bn.running_mean, bn.running_var, bn.momentum
+            else:
+                d["b"] = next(it).detach()
+            P[op.slot] = d
+        return P
+
+    def forward_nhwc(self, x: torch.Tensor) -> List[torch.Tensor]:
+        if not x.is_cuda:
+            raise RuntimeError("dcnet_amd.Darknet runs on an MI355X only: move the model and inputs to cuda "
+                               "(there is no CPU path; the CPU restatement lives in oracle/ for tests)")
+        training = self.training
+        if training:
+            torch._foreach_add_([self.module_list[op.slot][1].num_batches_tracked for op in self._conv_ops if op.bn], 1)
+        return list(_DarknetFn.apply(self, training, x, *self._flat_params()))
+
+    def forward(self, x, targets=None):
+        if targets is not None:
+            raise NotImplementedError("YOLO detection training (targets=...) is outside the DCNet hot path")
+        return [t.permute(0, 3, 1, 2) for t in self.forward_nhwc(x)]
+
+    # -- darknet binary weights (model/darknet.py:433-513) -----------------------------------
+    def load_weights(self, weights_path: str) -> None:
+        """[5 x int32 header] then per conv slot: (bn.bias, bn.weight, running_mean, running_var | conv.bias),
+        conv.weight — for EVERY conv slot incl. the dead YOLO heads (file compatibility)."""
+        with open(weights_path, "rb") as fp:
+            header = np.fromfile(fp, dtype=np.int32, count=5)
+            weights = np.fromfile(fp, dtype=np.float32)
+        self.header_info = header
+        self.seen = int(header[3])
+        ptr = 0
+
+        def take(t: torch.Tensor):
+            nonlocal ptr
+            n = t.numel()
+            if ptr + n > weights.size:
+                raise ValueError(f"{weights_path}: truncated weights file")
+            t.data.copy_(torch.from_numpy(weights[ptr:ptr + n]).view_as(t))
+            ptr += n
+
+        for d, seq in zip(self.module_defs, self.module_list):
+            if d["type"] in ("convolutional", "yoloconvolutional"):
+                conv = seq[0]
+                if int(d["batch_normalize"]):
+                    bn = seq[1]
+                    take(bn.bias); take(bn.weight); take(bn.running_mean); take(bn.running_var)
+                else:
+                    take(conv.bias)
+                take(conv.weight)
+
+    def save_weights(self, path: str, cutoff: int = -1) -> None:
+        """Writes every conv slot (the reference's writer skips ``yoloconvolutional`` slots,
+        model/darknet.py:498, which makes its own files unreadable by its loader; we write the
+        loader's format)."""
+        hdr = np.array(self.header_info, dtype=np.int32).copy()
+        hdr[3] = self.seen
+        defs = self.module_defs if cutoff == -1 else self.module_defs[:cutoff]
+        with open(path, "wb") as fp:
+            hdr.tofile(fp)
+            for d, seq in zip(defs, self.module_list):
+                if d["type"] in ("convolutional", "yoloconvolutional"):
+                    conv = seq[0]
+                    if int(d["batch_normalize"]):
+                        bn = seq[1]
+                        for t in (bn.bias, bn.weight, bn.running_mean, bn.running_var):
+                            t.detach().cpu().numpy().astype(np.float32).tofile(fp)
+                    else:
+                        conv.bias.detach().cpu().numpy().astype(np.float32).tofile(fp)
+                    conv.weight.detach().cpu().numpy().astype(np.float32).tofile(fp)

@@ -1,0 +1,196 @@
+"""autograd nodes of the DCNet head.  Each forward/backward is a sequence of libdcnet_hip.so
+kernels (dcnet_amd.ops); torch only carries the tensors between them.  All feature maps are NHWC.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class ConvBNAct(torch.autograd.Function):
+    """ConvBatchNormReLU (model/darknet.py:118-156): conv (no bias) + BatchNorm2d(momentum 0.999)
+    + ReLU.  x may carry zero-padded channels beyond the weight's Cin (K-padding to 32)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float):
+        w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3])
+        cout = weight.shape[0]
+        if training:
+            y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True)
+            mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
+                                 bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope)
+            ctx.save_for_backward(x, y, mi, w, gamma, beta)
+        else:
+            ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
+            out, _ = ops.conv2d_fwd(x, w, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope)
+            ctx.save_for_backward(x, out, ss, w, gamma, beta)
+        ctx.meta = (ksize, training, slope, tuple(weight.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, aux, w, gamma, beta = ctx.saved_tensors
+        gamma, beta = gamma.detach(), beta.detach()
+        ksize, training, slope, wshape = ctx.meta
+        dout = dout.contiguous()
+        if training:
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, slope)
+        else:
+            dz = ops.act_bwd(y, dout, slope)
+            dy = dz * aux[0]
+            dbeta = dz.reshape(-1, wshape[0]).sum(0)
+            z = y if slope == 0 else torch.where(y > 0, y, y / slope)
+            gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
+            dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
+        dw = ops.conv2d_bwd_weight(x, dy, ksize, 1)
+        dwt = ops.weight_grad_to_oihw(dw, wshape)
+        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1) if ctx.needs_input_grad[0] else None
+        return dx, dwt, dgamma, dbeta, None, None, None, None
+
+
+class ConvBias(torch.autograd.Function):
+    """Plain 1x1 conv with bias (the 256 -> 15 bbox head, model/DCNet_model.py:331).  The filter
+    bank is zero-padded to 32 outputs so the data gradient's contraction is MFMA-aligned; the
+    caller slices [..., :cout]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        cout = weight.shape[0]
+        cop = ops.pad32(cout)
+        w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3], co_pad=cop)
+        b = torch.zeros(cop, dtype=torch.float32, device=x.device)
+        b[:cout] = bias.detach()
+        y, _ = ops.conv2d_fwd(x, w, weight.shape[2], 1, None, b)
+        ctx.save_for_backward(x, w)
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        co, ci, k, _ = ctx.wshape
+        dy = dy.contiguous()
+        dw = ops.conv2d_bwd_weight(x, dy, k, 1)
+        dwt = ops.weight_grad_to_oihw(dw[:co].contiguous(), ctx.wshape)
+        db = dy.reshape(-1, dy.shape[-1]).sum(0)[:co]
+        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1) if ctx.needs_input_grad[0] else None
+        return dx, dwt, db
+
+
+class L2Norm(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=channel) on an NHWC map (model/DCNet_model.py:359)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, norm, _ = ops.l2norm_score_fwd(x)
+        ctx.save_for_backward(out, norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, norm = ctx.saved_tensors
+        dx, _ = ops.l2norm_score_bwd(out, norm, dout.contiguous(), None, None, 0)
+        return dx
+
+
+class NormScoreFuse(torch.autograd.Function):
+    """One pass over the corr_conv output x (N,H,W,E):
+         corr = x / ||x||                       (model/DCNet_model.py:469)
+         sim  = <corr, q>                       (model/DCNet_model.py:530-535, q = flang_attn)
+       and assembly of the fusion tensor [corr | tile(flang) | coord | 0-pad] (:491-499) that the
+       first fcn_emb conv consumes: corr is written straight into its channel slice.
+    Returns (fusion (N,H,W,Cpad), sim (N,H,W)); corr is fusion[..., :E]."""
+
+    @staticmethod
+    def forward(ctx, x, q, flang, coord):
+        n, h, w, e = x.shape
+        cpad = ops.pad32(2 * e + coord.shape[-1])
+        buf = torch.zeros((n, h, w, cpad), dtype=torch.float32, device=x.device)
+        _, norm, score = ops.l2norm_score_fwd(x, q.contiguous(), h * w, out=buf[..., :e])
+        buf[..., e:2 * e] = flang.view(n, 1, 1, e)
+        buf[..., 2 * e:2 * e + coord.shape[-1]] = coord
+        ctx.save_for_backward(buf, norm, q)
+        ctx.e = e
+        return buf, score.view(n, h, w)
+
+    @staticmethod
+    def backward(ctx, dbuf, dscore):
+        buf, norm, q = ctx.saved_tensors
+        q = q.detach()
+        e = ctx.e
+        n, h, w, _ = buf.shape
+        corr = buf[..., :e]
+        dout = dbuf[..., :e] if dbuf is not None else None
+        ds = dscore.contiguous().view(-1) if dscore is not None else None
+        dx, dq = ops.l2norm_score_bwd(corr, norm, dout, q if ds is not None else None, ds, h * w)
+        dflang = dbuf[..., e:2 * e].sum((1, 2)) if dbuf is not None else None
+        return dx, dq, dflang, None
+
+
+class CoAttentionPairs(torch.autograd.Function):
+    """Inter-frame co-attention over consecutive frame pairs (model/DCNet_model.py:449-464).
+    fv (N,H,W,C), unit norm over C, images 2p and 2p+1 form pair p.  Returns the concat
+    [f | f_attn] (N,H,W,2C) in image order — the input of corr_conv."""
+
+    @staticmethod
+    def forward(ctx, fv, temperature: float):
+        n, h, w, c = fv.shape
+        hw = h * w
+        cat = torch.empty((n, hw, 2 * c), dtype=torch.float32, device=fv.device)
+        f = fv.view(n, hw, c)
+        ops.copy_slice(f, cat[..., :c])
+        E, rc = ops.coattn_fwd(f[0::2], f[1::2], cat[0::2, :, c:], cat[1::2, :, c:], temperature)
+        out = cat.view(n, h, w, 2 * c)
+        ctx.save_for_backward(fv, out, E, rc)
+        ctx.temperature = temperature
+        return out
+
+    @staticmethod
+    def backward(ctx, dcat):
+        fv, out, E, rc = ctx.saved_tensors
+        n, h, w, c = fv.shape
+        hw = h * w
+        f, cat = fv.view(n, hw, c), out.view(n, hw, 2 * c)
+        dcat = dcat.contiguous().view(n, hw, 2 * c)
+        df = torch.empty((n, hw, c), dtype=torch.float32, device=f.device)
+        ops.copy_slice(dcat[..., :c], df)
+        ops.coattn_bwd(f[0::2], f[1::2], dcat[0::2, :, c:], dcat[1::2, :, c:], cat[0::2, :, c:], cat[1::2, :, c:],
+                       E, rc, df[0::2], df[1::2], True, ctx.temperature)
+        return df.view(n, h, w, c), None
+
+
+class CoAttentionCenter(torch.autograd.Function):
+    """Centre-frame co-attention of the inference model (model/test_DCNet_model.py:247-282):
+    f1 = centre frame, f2 = another frame of the clip; only f1_attn is consumed.
+    clips (B,T,HW,C); returns [f1 | f1_attn] (B,HW,2C).  Forward only."""
+
+    @staticmethod
+    def forward(ctx, clips, ctr: int, idx: int, temperature: float):
+        b, t, hw, c = clips.shape
+        cat = torch.empty((b, hw, 2 * c), dtype=torch.float32, device=clips.device)
+        cat[..., :c].copy_(clips[:, ctr])        # batch-strided source: plain torch copy
+        ops.coattn_fwd(clips[:, ctr], clips[:, idx], cat[..., c:], None, temperature)
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("the n_frame (inference) model has no backward; train with pair semantics")
+
+
+class ToNCHW(torch.autograd.Function):
+    """NHWC (first c channels) -> contiguous NCHW, for tensors the callers .view() (outbox)."""
+
+    @staticmethod
+    def forward(ctx, x, c: int):
+        ctx.shape = tuple(x.shape)
+        return ops.nhwc_to_nchw(x.contiguous(), c)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, ld = ctx.shape
+        return ops.nchw_to_nhwc(g.contiguous(), ld), None

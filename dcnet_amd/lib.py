@@ -39,9 +39,9 @@ SIGNATURES = {
     "dcn_act_bwd": (I, [P, P, I, F, L, I, P, P]),
     "dcn_coattn_e_size": (L, [I, I]),
     "dcn_coattn_fwd_ws": (L, [I, I, I]),
-    "dcn_coattn_fwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, I, F, P]),
+    "dcn_coattn_fwd": (I, [P, P, I, L, P, P, I, L, P, P, P, P, I, I, I, F, P]),
     "dcn_coattn_bwd_ws": (L, [I, I, I]),
-    "dcn_coattn_bwd": (I, [P, P, I, P, P, I, P, P, I, P, P, P, P, P, I, I, P, I, I, I, F, P]),
+    "dcn_coattn_bwd": (I, [P, P, I, L, P, P, I, L, P, P, I, L, P, P, P, P, P, I, L, I, P, I, I, I, F, P]),
     "dcn_l2norm_score_fwd": (I, [P, I, P, I, P, P, P, L, I, I, P]),
     "dcn_l2norm_score_bwd": (I, [P, I, P, P, I, P, P, P, I, P, L, I, I, P]),
     "dcn_upsample2_nhwc": (I, [P, I, P, I, I, I, I, I, P]),

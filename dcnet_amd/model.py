@@ -1,0 +1,372 @@
+"""DCNet grounding model on the MI355X kernel library.
+
+Drop-in for the reference's ``model/DCNet_model.py::grounding_model`` (train model, T = 2 frame
+pairs) and ``model/test_DCNet_model.py::grounding_model`` (inference model, ``n_frame``): same
+constructor arguments, same ``forward(image, word_id, word_mask[, n_frame])`` signature, same
+return tuples, same sub-module names and therefore the same 597 state_dict keys.
+
+Differences that are deliberate:
+  * ``img_size`` / ``query_len`` / ``weights_path`` / ``config_path`` keyword arguments replace the
+    literals 1344 (= P at 256x256), 20 and the cwd-relative file names (F3, F4, F6);
+  * the dead YOLO heads are not executed (F7) — their parameters stay in the state_dict;
+  * ``forward`` accepts an optional 4th argument ``n_frame`` and then follows the inference model's
+    semantics (F2);
+  * the location module uses the rank-8 identity of SURVEY.md K13 (no PxP tensor);
+  * negative sampling runs natively on the host with Python's own MT19937 stream (bit-exact with
+    ``random.sample``; see csrc/sampling.cpp).
+"""
+from __future__ import annotations
+
+import os
+import random
+from collections import OrderedDict
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .darknet import Darknet
+from .functions import (CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, L2Norm, NormScoreFuse, ToNCHW)
+from .lib import lib
+
+
+class ConvBatchNormReLU(nn.Sequential):
+    """Parameter container with the reference's layout (model/darknet.py:118-156): ``conv`` (no bias),
+    ``bn`` (eps 1e-5, momentum 0.999), ``relu``.  Executed through functions.ConvBNAct on NHWC maps."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, leaky=False, relu=True):
+        super().__init__()
+        if stride != 1 or dilation != 1 or padding != (kernel_size - 1) // 2:
+            raise NotImplementedError("DCNet head blocks are stride 1, dilation 1, 'same' padding")
+        self.add_module("conv", nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, bias=False))
+        self.add_module("bn", nn.BatchNorm2d(out_channels, eps=1e-5, momentum=0.999, affine=True))
+        self.slope = 0.1 if leaky else 0.0
+        if leaky:
+            self.add_module("relu", nn.LeakyReLU(0.1))
+        elif relu:
+            self.add_module("relu", nn.ReLU())
+        else:
+            raise NotImplementedError("relu=False is not used by DCNet")
+
+    def forward(self, x_nhwc):
+        return ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
+                               self.conv.kernel_size[0], self.training, self.slope)
+
+
+class RNNEncoder(nn.Module):
+    """model/DCNet_model.py:124-188.  Every row is processed to its own length exactly like the
+    packed BiLSTM of the reference; with the reference's tokenizer all lengths equal L (F4)."""
+
+    def __init__(self, vocab_size, word_embedding_size, word_vec_size, hidden_size, bidirectional=False,
+                 input_dropout_p=0, dropout_p=0, n_layers=1, rnn_type="lstm", variable_lengths=True):
+        super().__init__()
+        self.variable_lengths = variable_lengths
+        self.embedding = nn.Embedding(vocab_size, word_embedding_size)
+        self.input_dropout = nn.Dropout(input_dropout_p)
+        self.mlp = nn.Sequential(nn.Linear(word_embedding_size, word_vec_size), nn.ReLU())
+        self.rnn_type = rnn_type
+        self.rnn = getattr(nn, rnn_type.upper())(word_vec_size, hidden_size, n_layers, batch_first=True,
+                                                 bidirectional=bidirectional, dropout=dropout_p)
+        self.num_dirs = 2 if bidirectional else 1
+
+    def forward(self, input_labels):
+        lengths = (input_labels != 0).sum(1)
+        lens = lengths.tolist()
+        if max(lens) != input_labels.size(1):
+            raise AssertionError("max(len) must equal the padded width (model/DCNet_model.py:158)")
+        embedded = self.mlp(self.input_dropout(self.embedding(input_labels)))
+        if min(lens) == max(lens):
+            output, _ = self.rnn(embedded)
+        else:
+            packed = nn.utils.rnn.pack_padded_sequence(embedded, lengths.cpu(), batch_first=True, enforce_sorted=False)
+            output, _ = self.rnn(packed)
+            output, _ = nn.utils.rnn.pad_packed_sequence(output, batch_first=True, total_length=input_labels.size(1))
+            embedded = embedded * (torch.arange(input_labels.size(1), device=embedded.device)[None, :]
+                                   < lengths[:, None]).unsqueeze(2).to(embedded.dtype)
+        sent = output[torch.arange(output.size(0), device=output.device), lengths - 1]
+        return sent, output, embedded
+
+
+class PhraseAttention(nn.Module):
+    """model/DCNet_model.py:190-219."""
+
+    def __init__(self, input_dim):
+        super().__init__()
+        self.fc = nn.Linear(input_dim, 1)
+
+    def forward(self, context, embedded, input_labels):
+        attn = F.softmax(self.fc(context).squeeze(2), dim=1)
+        attn = attn * (input_labels != 0).float()
+        attn = attn / attn.sum(1, keepdim=True)
+        return attn, torch.bmm(attn.unsqueeze(1), embedded).squeeze(1)
+
+
+def generate_coord_nhwc(height: int, width: int, device) -> torch.Tensor:
+    """The 8-channel coordinate map of model/DCNet_model.py:23-39 as an (H,W,8) NHWC constant
+    (it is identical for every image).  ``xv`` indexes rows, as in the reference."""
+    xv, yv = torch.meshgrid([torch.arange(0, height), torch.arange(0, width)], indexing="ij")
+    xv_min = (xv.float() * 2 - width) / width
+    yv_min = (yv.float() * 2 - height) / height
+    xv_max = ((xv + 1).float() * 2 - width) / width
+    yv_max = ((yv + 1).float() * 2 - height) / height
+    xv_ctr = (xv_min + xv_max) / 2
+    yv_ctr = (yv_min + yv_max) / 2
+    hmap = torch.ones(height, width) * (1. / height)
+    wmap = torch.ones(height, width) * (1. / width)
+    return torch.stack([xv_min, yv_min, xv_max, yv_max, xv_ctr, yv_ctr, hmap, wmap], dim=2).to(device)
+
+
+def generate_coord(batch, height, width, device="cuda"):
+    """NCHW form with the reference's signature (model/DCNet_model.py:23)."""
+    return generate_coord_nhwc(height, width, device).permute(2, 0, 1).unsqueeze(0).repeat(batch, 1, 1, 1)
+
+
+def _mt_state():
+    st = random.getstate()
+    return st, np.array(st[1], dtype=np.uint32)
+
+
+def _mt_restore(st, arr):
+    random.setstate((st[0], tuple(int(v) for v in arr), st[2]))
+
+
+class grounding_model(nn.Module):
+    def __init__(self, corpus=None, emb_size=256, jemb_drop_out=0.1, bert_model="bert-base-uncased",
+                 coordmap=True, leaky=False, dataset=None, light=False,
+                 img_size: int = 256, query_len: int = 20, config_path: str = "./model/yolov3.cfg",
+                 weights_path: Optional[str] = "./saved_models/yolov3.weights"):
+        super().__init__()
+        if corpus is None:
+            raise NotImplementedError("corpus=None selects the BERT text encoder, which is outside the LSTM hot path "
+                                      "(train_DCNet.py is run with --lstm); pass the dataset corpus")
+        if light:
+            raise NotImplementedError("light=True (1-layer fcn_emb) is not used by the released scripts")
+        if not coordmap:
+            raise NotImplementedError("coordmap=False is not used by the released scripts")
+        self.coordmap, self.light, self.lstm, self.emb_size = coordmap, light, True, emb_size
+        self.img_size, self.query_len = img_size, query_len
+        self.grids = [img_size // 32, img_size // 16, img_size // 8]
+        self.num_pos = sum(g * g for g in self.grids)          # 1344 at 256x256 (model/DCNet_model.py:259,584)
+        self.textdim, self.embdim = 1024, 512
+        ## Visual model
+        self.visumodel = Darknet(config_path=config_path)
+        if weights_path and os.path.exists(weights_path):
+            self.visumodel.load_weights(weights_path)
+        ## Text model
+        self.textmodel = RNNEncoder(vocab_size=len(corpus), word_embedding_size=self.embdim,
+                                    word_vec_size=self.textdim // 2, hidden_size=self.textdim // 2,
+                                    bidirectional=True, input_dropout_p=0.2, variable_lengths=True)
+        self.temperature = 10.
+        self.sub_attn = PhraseAttention(self.textdim)
+        self.loc_embedding = nn.Sequential(nn.Linear(8, 8), nn.BatchNorm1d(8), nn.ReLU())
+        self.loc_text_embedding = nn.Sequential(nn.Linear(self.num_pos, self.embdim), nn.BatchNorm1d(self.embdim), nn.ReLU())
+        self.loc_attn = PhraseAttention(self.textdim)
+        self.mapping_visu = nn.Sequential(OrderedDict([
+            ("0", ConvBatchNormReLU(1024, emb_size, 1, 1, 0, 1, leaky=leaky)),
+            ("1", ConvBatchNormReLU(512, emb_size, 1, 1, 0, 1, leaky=leaky)),
+            ("2", ConvBatchNormReLU(256, emb_size, 1, 1, 0, 1, leaky=leaky))]))
+        self.mapping_lang = nn.Sequential(
+            nn.Linear(self.textdim, emb_size), nn.BatchNorm1d(emb_size), nn.ReLU(), nn.Dropout(jemb_drop_out),
+            nn.Linear(emb_size, emb_size), nn.BatchNorm1d(emb_size), nn.ReLU())
+        self.corr_conv = nn.Sequential(OrderedDict([
+            (str(i), nn.Sequential(ConvBatchNormReLU(emb_size * 2, emb_size, 1, 1, 0, 1, leaky=leaky))) for i in range(3)]))
+        self.feature_map = nn.Sequential(
+            nn.Conv1d(in_channels=query_len, out_channels=query_len, stride=1, kernel_size=3, padding=1, bias=True),
+            nn.Softmax(dim=1))
+        embin_size = emb_size * 2 + 8
+        self.fcn_emb = nn.Sequential(OrderedDict([
+            (str(i), nn.Sequential(ConvBatchNormReLU(embin_size, emb_size, 1, 1, 0, 1, leaky=leaky),
+                                   ConvBatchNormReLU(emb_size, emb_size, 3, 1, 1, 1, leaky=leaky),
+                                   ConvBatchNormReLU(emb_size, emb_size, 1, 1, 0, 1, leaky=leaky))) for i in range(3)]))
+        self.fcn_out = nn.Sequential(OrderedDict([
+            (str(i), nn.Sequential(ConvBatchNormReLU(emb_size, emb_size // 2, 1, 1, 0, 1, leaky=leaky),
+                                   nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
+        self._coord_cache = {}
+        self.exact_sampling = True
+
+    # ------------------------------------------------------------------------------------------
+    def _coord(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._coord_cache:
+            self._coord_cache[key] = generate_coord_nhwc(h, w, device)
+        return self._coord_cache[key]
+
+    def _language(self, word_id):
+        max_len = int((word_id != 0).sum(1).max().item())                      # DCNet_model.py:474
+        word_id = word_id[:, :max_len]
+        raw_flang, context, embedded = self.textmodel(word_id)
+        flang = F.normalize(self.mapping_lang(raw_flang), p=2, dim=1)          # :485-487
+        return word_id, flang, context, embedded
+
+    def _head(self, corr_raw: List[torch.Tensor], word_id, flang, context, embedded, premean=None):
+        """corr_raw[s]: corr_conv output (B,H,W,E) before normalisation (or, for the n_frame model,
+        ``premean`` holds the already normalised+averaged maps).  Returns NHWC head tensors."""
+        B = flang.shape[0]
+        dev = flang.device
+        _, flang_attn = self.sub_attn(context, embedded, word_id)               # :525
+        flang_attn = F.normalize(flang_attn, p=2, dim=1)                        # :526
+        corr_feat, sim_score, outbox = [], [], []
+        for s in range(3):
+            if premean is None:
+                x = corr_raw[s]
+                h, w = x.shape[1], x.shape[2]
+                fusion, sim = NormScoreFuse.apply(x, flang_attn, flang, self._coord(h, w, dev))
+                corr = fusion[..., :self.emb_size]
+            else:
+                corr = premean[s]
+                h, w = corr.shape[1], corr.shape[2]
+                sim = torch.sum(corr * flang_attn.view(B, 1, 1, -1), dim=3)
+                fusion = torch.zeros((B, h, w, ops.pad32(2 * self.emb_size + 8)), dtype=torch.float32, device=dev)
+                fusion[..., :self.emb_size] = corr
+                fusion[..., self.emb_size:2 * self.emb_size] = flang.view(B, 1, 1, -1)
+                fusion[..., 2 * self.emb_size:2 * self.emb_size + 8] = self._coord(h, w, dev)
+            z = fusion
+            for blk in self.fcn_emb[s]:
+                z = blk(z)                                                       # :505
+            z = self.fcn_out[s][0](z)
+            last = self.fcn_out[s][1]
+            z = ConvBias.apply(z, last.weight, last.bias)[..., :15]              # :506
+            corr_feat.append(corr); sim_score.append(sim); outbox.append(z)
+
+        conf = [ob.reshape(B, ob.shape[1], ob.shape[2], 3, 5)[..., 4] for ob in outbox]   # (B,H,W,3)
+        only_obj = [c.mean(dim=3) for c in conf]                                 # :551
+        obj_score = [o * s for o, s in zip(only_obj, sim_score)]                 # :550
+
+        _, flang_loc = self.loc_attn(context, embedded, word_id)                 # :556
+        flang_loc = F.normalize(flang_loc, p=2, dim=1)
+        # ---- location module, rank-8 form (reference :559-597 builds a PxP tensor) ----
+        coord_map = torch.cat([self._coord(c.shape[1], c.shape[2], dev).reshape(-1, 8) for c in corr_feat], dim=0)  # (P,8)
+        P = coord_map.shape[0]
+        obj_map = F.normalize(torch.cat([o.reshape(B, -1) for o in obj_score], dim=1), p=2, dim=1)       # :566-569
+        lin, bn = self.loc_embedding[0], self.loc_embedding[1]
+        ce = F.linear(coord_map, lin.weight, lin.bias)                           # identical rows for every image
+        if self.training:
+            # BN over the B*P rows == BN over the P distinct rows (each repeated B times); the
+            # unbiased running_var uses the true row count B*P
+            mean = ce.mean(0); var = ce.var(0, unbiased=False)
+            with torch.no_grad():
+                cnt = B * P
+                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean)
+                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * cnt / (cnt - 1))
+                bn.num_batches_tracked += 1
+            ce = (ce - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+        else:
+            ce = F.batch_norm(ce, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        E8 = F.normalize(F.relu(ce), p=2, dim=1)                                 # (P,8)   :578
+        lt, bn2 = self.loc_text_embedding[0], self.loc_text_embedding[1]
+        # rel[n,i,:] = sum_j <E_i,E_j> obj[n,j] W[:,j] + b  =  E_i . (E^T diag(obj_n) W^T) + b
+        M = torch.matmul((E8.t().unsqueeze(0) * obj_map.unsqueeze(1)), lt.weight.t())     # (B,8,512)
+        rel = torch.matmul(E8.unsqueeze(0), M) + lt.bias                         # (B,P,512)  :581-585
+        rel = F.relu(F.batch_norm(rel.reshape(B * P, -1), bn2.running_mean, bn2.running_var, bn2.weight, bn2.bias,
+                                  self.training, bn2.momentum, bn2.eps)).view(B, P, -1)
+        if self.training:
+            bn2.num_batches_tracked += 1
+        rel = F.normalize(rel, p=2, dim=2)                                       # over channels  :589
+        loc_map = torch.sum(rel * flang_loc.unsqueeze(1), dim=2)                 # (B,P)   :593-594
+        mn = loc_map.min(dim=1, keepdim=True)[0]; mx = loc_map.max(dim=1, keepdim=True)[0]
+        loc_map = (loc_map - mn) / (mx - mn + 1e-6)                              # :597
+        loc_score, st = [], 0
+        for c in corr_feat:
+            h, w = c.shape[1], c.shape[2]
+            loc_score.append(loc_map[:, st:st + h * w].reshape(B, h, w)); st += h * w
+        final = []
+        for s in range(3):                                                       # :612-621
+            ob = outbox[s].reshape(B, outbox[s].shape[1], outbox[s].shape[2], 3, 5)
+            c4 = ob[..., 4] * (sim_score[s] * loc_score[s]).unsqueeze(3)
+            ob = torch.cat([ob[..., :4], c4.unsqueeze(4)], dim=4).reshape(B, ob.shape[1], ob.shape[2], 15)
+            final.append(ToNCHW.apply(ob, 15))
+        return final, sim_score, loc_score, corr_feat, flang_attn.view(B, -1, 1, 1), only_obj
+
+    # ------------------------------------------------------------------------------------------
+    def _interframe_sampling(self, fv0, top_k=30, neg_n=10):
+        """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E)."""
+        n, g, _, e = fv0.shape
+        hw = g * g
+        f = fv0.reshape(n // 2, 2, hw, e)
+        p1, p2 = f[:, 0], f[:, 1]
+        cmap = torch.bmm(p1, p2.transpose(1, 2)).flatten(1)                      # :390  [i*hw + j]
+        _, index = cmap.topk(top_k, dim=1, largest=True, sorted=True)            # :395
+        qi, ki = index // hw, index % hw                                         # :407,409
+        ki_host = ki.cpu().numpy().astype(np.int64)
+        st, arr = _mt_state()
+        neg = np.empty((n // 2, top_k, neg_n), dtype=np.int64)
+        lib().mt_sample_interframe(arr.ctypes.data, ki_host.ctypes.data, n // 2, top_k, hw, neg_n, neg.ctypes.data)
+        _mt_restore(st, arr)
+        ni = torch.from_numpy(neg).to(fv0.device)
+        ar = torch.arange(n // 2, device=fv0.device)
+        frame = [p1[ar, qi[:, j]] for j in range(top_k)]
+        corr = [p2[ar, ki[:, j]] for j in range(top_k)]
+        negf = [p2[ar.unsqueeze(1), ni[:, j]] for j in range(top_k)]
+        return frame, corr, negf
+
+    def _crossmodal(self, fv0, context, neg_n=5):
+        """model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112."""
+        n, g, _, e = fv0.shape
+        hw = g * g
+        v = fv0.reshape(n, hw, e)
+        vit = F.normalize(v, dim=1)                                              # over positions (:629)
+        lag = F.normalize(context[:, :, 0::2], dim=1)                            # interpolate(0.5) + over L (:631-632)
+        lv = torch.bmm(lag, vit.transpose(1, 2))                                 # (N,L,HW0)  :634
+        lv = self.feature_map(lv)                                                # :635
+        cols = lv.argmax(dim=1)                                                  # top-1 word per position (:48)
+        st, arr = _mt_state()
+        neg = np.empty((n, hw, neg_n), dtype=np.int64)
+        lib().mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_n, neg.ctypes.data)
+        _mt_restore(st, arr)
+        ni = torch.from_numpy(neg).to(fv0.device)
+        ar = torch.arange(n, device=fv0.device)
+        vit_pos = [vit[:, j, :] for j in range(hw)]
+        lag_pos = [lag[ar, cols[:, j], :].unsqueeze(1) for j in range(hw)]
+        neg_cross = [vit[n - 1][ni[:, j]] for j in range(hw)]
+        return vit_pos, lag_pos, neg_cross
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, image, word_id, word_mask=None, n_frame: Optional[int] = None):
+        if not image.is_cuda:
+            raise RuntimeError("dcnet_amd.grounding_model runs on an MI355X only (HIP kernels, no CPU path)")
+        if n_frame is not None:
+            return self._forward_nframe(image, word_id, n_frame)
+        N = image.size(0)
+        if N % 2:
+            raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")
+        raw = self.visumodel.forward_nhwc(image)                                 # :344
+        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
+        frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0])   # :381-430
+        corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
+        word_id, flang, context, embedded = self._language(word_id)
+        outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)
+        vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context)       # :625-637 (runs in eval too)
+        if self.training:
+            return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn,
+                    frame_feature, corrspendence_feature, neg_feature, vit_posit, lag_posit, neg_cross)
+        return outbox, sim, loc, only_obj
+
+    def _forward_nframe(self, image, word_id, n_frame: int):
+        """model/test_DCNet_model.py:284-483."""
+        if image.size(0) % n_frame:
+            raise ValueError("batch must be a multiple of n_frame (model/test_DCNet_model.py:287)")
+        B = image.size(0) // n_frame
+        raw = self.visumodel.forward_nhwc(image)
+        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]
+        ctr = n_frame // 2                                                       # :303
+        premean = []
+        for i in range(3):
+            _, h, w, e = fv[i].shape
+            clips = fv[i].view(B, n_frame, h * w, e)
+            acc = None
+            for idx in range(n_frame):                                           # :312-320
+                if idx == ctr:
+                    continue
+                cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
+                z = L2Norm.apply(self.corr_conv[i][0](cat))                      # :277-280
+                acc = z if acc is None else acc + z
+            premean.append(acc / (n_frame - 1))                                  # :324-332
+        word_id, flang, context, embedded = self._language(word_id)
+        outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(None, word_id, flang, context, embedded, premean)
+        corr_nchw = [c.permute(0, 3, 1, 2) for c in corr_feat]
+        if self.training:
+            return outbox, sim, loc, corr_nchw, flang_attn
+        return outbox, sim, loc, corr_nchw, only_obj

@@ -29,6 +29,22 @@ def _chk(t: torch.Tensor, name: str):
                          f"contiguous={t.is_contiguous()}")
 
 
+def _rows_ok(t: torch.Tensor) -> bool:
+    """True if t, read as [rows][c] with row stride t.stride(-2), is addressed uniformly."""
+    if t.stride(-1) != 1:
+        return False
+    for i in range(t.dim() - 2):
+        if t.shape[i] != 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            return False
+    return True
+
+
+def _rows(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and _rows_ok(t)):
+        raise ValueError(f"{name}: expected an fp32 CUDA [rows][c] view with one uniform row stride, got shape "
+                         f"{tuple(t.shape)} strides {t.stride()}")
+
+
 # ---- scratch -----------------------------------------------------------------------------------
 _scratch = {}
 
@@ -188,6 +204,7 @@ def scale_act(y, scale, shift, act, slope, residual=None, out=None):
     rows = y.numel() // c
     if out is None:
         out = torch.empty_like(y)
+    _chk(y, "scale_act y"); _rows(out, "scale_act out")
     lib().scale_act(y.data_ptr(), _p(scale), _p(shift), act, float(slope), _p(residual), out.data_ptr(), rows, c,
                     out.stride(-2), _s())
     return out
@@ -229,17 +246,23 @@ def coattn_fwd(f1, f2, out1, out2, temperature):
     E = torch.empty(lib().coattn_e_size(b, hw), dtype=torch.float32, device=dev)
     rc = torch.empty((2, b, hw), dtype=torch.float32, device=dev)
     ws = scratch(lib().coattn_fwd_ws(b, hw, c), dev, slot=0)
-    lib().coattn_fwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), out1.data_ptr(), _p(out2), out1.stride(1),
-                     E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(), ws.data_ptr(), b, hw, c, float(temperature), _s())
+    assert f1.stride() == f2.stride() and (out2 is None or out1.stride() == out2.stride())
+    lib().coattn_fwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), f1.stride(0), out1.data_ptr(), _p(out2), out1.stride(1),
+                     out1.stride(0), E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(), ws.data_ptr(), b, hw, c,
+                     float(temperature), _s())
     return E, rc
 
 
 def coattn_bwd(f1, f2, d_out1, d_out2, out1, out2, E, rc, d_f1, d_f2, accumulate, temperature):
     b, hw, c = f1.shape
     ws = scratch(lib().coattn_bwd_ws(b, hw, c), f1.device, slot=0)
-    lib().coattn_bwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), d_out1.data_ptr(), d_out2.data_ptr(), d_out1.stride(1),
-                     out1.data_ptr(), out2.data_ptr(), out1.stride(1), E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(),
-                     d_f1.data_ptr(), d_f2.data_ptr(), d_f1.stride(1), int(accumulate), ws.data_ptr(),
+    assert f1.stride() == f2.stride() and d_out1.stride() == d_out2.stride() and out1.stride() == out2.stride()
+    assert d_f1.stride() == d_f2.stride()
+    lib().coattn_bwd(f1.data_ptr(), f2.data_ptr(), f1.stride(1), f1.stride(0),
+                     d_out1.data_ptr(), d_out2.data_ptr(), d_out1.stride(1), d_out1.stride(0),
+                     out1.data_ptr(), out2.data_ptr(), out1.stride(1), out1.stride(0),
+                     E.data_ptr(), rc[0].data_ptr(), rc[1].data_ptr(),
+                     d_f1.data_ptr(), d_f2.data_ptr(), d_f1.stride(1), d_f1.stride(0), int(accumulate), ws.data_ptr(),
                      b, hw, c, float(temperature), _s())
 
 
@@ -250,6 +273,7 @@ def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None):
     rows = x.numel() // c
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _rows(x, "l2norm x"); _rows(out, "l2norm out")
     norm = torch.empty(rows, dtype=torch.float32, device=x.device)
     score = torch.empty(rows, dtype=torch.float32, device=x.device) if q is not None else None
     lib().l2norm_score_fwd(x.data_ptr(), x.stride(-2), out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(q), _p(score),
@@ -260,6 +284,9 @@ def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None):
 def l2norm_score_bwd(out, norm, dout, q, dscore, rows_per_image, want_dq=True):
     c = out.shape[-1]
     rows = out.numel() // c
+    _rows(out, "l2norm_bwd out")
+    if dout is not None:
+        _rows(dout, "l2norm_bwd dout")
     dx = torch.empty(out.shape, dtype=torch.float32, device=out.device)
     dq = None
     if q is not None and dscore is not None and want_dq:
@@ -285,5 +312,6 @@ def upsample2_bwd(ddst_view, dsrc, accumulate):
 def copy_slice(src_view, dst_view, accumulate=False):
     c = src_view.shape[-1]
     rows = src_view.numel() // c
+    _rows(src_view, "copy_slice src"); _rows(dst_view, "copy_slice dst")
     lib().copy_slice(src_view.data_ptr(), src_view.stride(-2), dst_view.data_ptr(), dst_view.stride(-2), rows, c,
                      int(accumulate), _s())

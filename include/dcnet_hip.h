@@ -125,20 +125,23 @@ int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int6
  * E (dcn_coattn_e_size floats) receives exp(t*A - t), rinv/cinv ([b][hw]) the inverse row / column
  * sums; all three are kept for the backward.  ws: dcn_coattn_fwd_ws floats of scratch.
  * Outputs have pixel stride ldo (they land in a channel slice of the concat [f, f_attn] buffer).
+ * bsf / bso (and bsdo / bsdf in the backward) are the strides, in floats, between consecutive batch
+ * items of the feature / output (gradient) tensors — frames of a pair are interleaved in the image
+ * batch, so f1 = x[0::2], f2 = x[1::2] without a copy; <= 0 means densely packed.
  * Replaces the 3 bmm + 2 softmax of model/DCNet_model.py:449-459 / model/test_DCNet_model.py:259-274. */
 int64_t dcn_coattn_e_size(int b, int hw);
 int64_t dcn_coattn_fwd_ws(int b, int hw, int c);
-int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, float* f1_attn, float* f2_attn, int ldo,
-                   float* E, float* rinv, float* cinv, float* ws,
+int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t bsf, float* f1_attn, float* f2_attn, int ldo,
+                   int64_t bso, float* E, float* rinv, float* cinv, float* ws,
                    int b, int hw, int c, float temperature, void* stream);
 /* d_f1, d_f2 (pixel stride lddf) (+)= gradient through both attention outputs; accumulate != 0 adds
  * to what the buffers hold (the direct [f, .] half of the concat contributes there as well). */
 int64_t dcn_coattn_bwd_ws(int b, int hw, int c);
-int dcn_coattn_bwd(const float* f1, const float* f2, int ldf,
-                   const float* d_f1_attn, const float* d_f2_attn, int lddo,
-                   const float* f1_attn, const float* f2_attn, int ldo,
+int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
+                   const float* d_f1_attn, const float* d_f2_attn, int lddo, int64_t bsdo,
+                   const float* f1_attn, const float* f2_attn, int ldo, int64_t bso,
                    const float* E, const float* rinv, const float* cinv,
-                   float* d_f1, float* d_f2, int lddf, int accumulate, float* ws,
+                   float* d_f1, float* d_f2, int lddf, int64_t bsdf, int accumulate, float* ws,
                    int b, int hw, int c, float temperature, void* stream);
 
 /* ---- cross-modal scoring (HBM-bound) --------------------------------------------------- */

@@ -1,0 +1,146 @@
+"""End-to-end parity of the HIP-backed grounding_model against the CPU oracle (and, through the
+oracle, against the reference's own outputs stored in tests/golden).  Tolerance: 1e-3 absolute on
+outbox / sim_score / loc_score / decoded boxes (north_star), on seeded identical inputs."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from util import GOLD, build_product, maxdiff, synth_sd
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _nchw(t):      # sim/loc/only_obj are (N,H,W) on both sides; corr_feat comes as a permuted NHWC view
+    return t
+
+
+@pytest.mark.parametrize("size,n", [(256, 2), (416, 2), (256, 4)])
+def test_eval_forward_matches_oracle_and_golden(dev, size, n):
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=size + n, n_words=10 if (size, n) == (416, 2) else None)
+    m = build_product(size, sd, dev).eval()
+    random.seed(13)
+    with torch.no_grad():
+        outbox, sim, loc, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image, word_id, training=False, sample=False)
+    gold = np.load(os.path.join(GOLD, f"eval_S{size}_N{n}.npz"))
+    for s in range(3):
+        assert maxdiff(outbox[s], o["outbox"][s]) < TOL, ("outbox", s, maxdiff(outbox[s], o["outbox"][s]))
+        assert maxdiff(sim[s], o["sim_score"][s]) < TOL
+        assert maxdiff(loc[s], o["loc_score"][s]) < TOL, ("loc", s, maxdiff(loc[s], o["loc_score"][s]))
+        assert maxdiff(only_obj[s], o["only_obj"][s]) < TOL
+        # reference's own outputs
+        assert maxdiff(outbox[s], torch.from_numpy(gold[f"outbox{s}"])) < TOL
+        assert maxdiff(sim[s], torch.from_numpy(gold[f"sim{s}"])) < TOL
+        assert maxdiff(loc[s], torch.from_numpy(gold[f"loc{s}"])) < TOL
+    boxes = O.decode_boxes([x.cpu() for x in outbox], size)
+    ref_boxes = torch.from_numpy(gold["boxes"])
+    assert maxdiff(boxes, ref_boxes) < 0.05          # pixels
+    iou = O.bbox_iou_xyxy(boxes, ref_boxes)
+    assert float(iou.min()) > 0.999
+
+
+def test_backbone_taps_match_oracle(dev):
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    size, n = 256, 2
+    sd = synth_sd(size)
+    image, _, _ = synth_inputs(n, size, seed=5)
+    m = build_product(size, sd, dev).eval()
+    with torch.no_grad():
+        taps = m.visumodel(image.to(dev))
+        ref = O.darknet_forward({k: v.clone() for k, v in sd.items()}, image, False)
+    for a, b in zip(taps, ref):
+        assert a.shape == b.shape
+        assert maxdiff(a, b) < 1e-3 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("size,b,t", [(256, 1, 5), (256, 2, 2), (416, 1, 8)])
+def test_nframe_forward_matches_oracle_and_golden(dev, size, b, t):
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(b * t, size, n_queries=b, seed=size + 7 * t)
+    m = build_product(size, sd, dev, test_model=True).eval()
+    with torch.no_grad():
+        outbox, sim, loc, corr, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev), t)
+    gold = np.load(os.path.join(GOLD, f"nframe_S{size}_B{b}_T{t}.npz"))
+    for s in range(3):
+        assert tuple(corr[s].shape) == (b, 512, outbox[s].shape[2], outbox[s].shape[3])
+        assert maxdiff(outbox[s], torch.from_numpy(gold[f"outbox{s}"])) < TOL
+        assert maxdiff(sim[s], torch.from_numpy(gold[f"sim{s}"])) < TOL
+        assert maxdiff(loc[s], torch.from_numpy(gold[f"loc{s}"])) < TOL
+        assert maxdiff(only_obj[s], torch.from_numpy(gold[f"only_obj{s}"])) < TOL
+    boxes = O.decode_boxes([x.cpu() for x in outbox], size)
+    assert float(O.bbox_iou_xyxy(boxes, torch.from_numpy(gold["boxes"])).min()) > 0.999
+
+
+def test_train_forward_backward_matches_oracle(dev):
+    """Train mode (batch-stat BN, p_dropout = 0), N = 4 (the well-conditioned golden case): the 11
+    outputs, the five losses, the sampled indices, BN running stats and parameter gradients."""
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    from oracle import dcnet_oracle as O
+    from oracle import train_oracle as TO
+    size, n = 256, 4
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=size + n)
+    bbox = synth_boxes(n, size, seed=size + n)
+    gold = np.load(os.path.join(GOLD, f"train_S{size}_N{n}.npz"), allow_pickle=True)
+    m = build_product(size, sd, dev).train()
+    random.seed(13)
+    outs = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+    assert len(outs) == 11
+    names = ["outbox", "sim_score", "loc_score", "corr_feat", "flang_attn", "frame_feature", "corrspendence_feature",
+             "neg_feature", "vit_posit", "lag_posit", "neg_cross"]
+    out = dict(zip(names, outs))
+    loss, parts = TO.total_loss(out, bbox.to(dev), size)
+    loss.backward()
+
+    sdo = {k: v.clone() for k, v in sd.items()}
+    params = {k: sdo[k].requires_grad_(True) for k, _ in m.named_parameters()}
+    random.seed(13)
+    o = O.grounding_forward_pairs(sdo, image, word_id, training=True, skip_dead=True)
+    oloss, oparts = TO.total_loss(o, bbox, size)
+    oloss.backward()
+
+    for s in range(3):
+        assert maxdiff(out["outbox"][s], o["outbox"][s]) < TOL
+        assert maxdiff(out["sim_score"][s], o["sim_score"][s]) < TOL
+        assert maxdiff(out["loc_score"][s], o["loc_score"][s]) < TOL
+        assert maxdiff(out["corr_feat"][s], o["corr_feat"][s]) < TOL
+        assert maxdiff(out["outbox"][s], torch.from_numpy(gold[f"outbox{s}"])) < TOL      # the reference itself
+    for k in ("frame_feature", "corrspendence_feature", "neg_feature", "vit_posit", "lag_posit", "neg_cross"):
+        assert len(out[k]) == len(o[k])
+        assert max(maxdiff(a, b) for a, b in zip(out[k], o[k])) < TOL, k
+    gl = dict(zip(("yolo", "rank", "interframe", "cross", "loc"), gold["losses"]))
+    for k in parts:
+        assert abs(float(parts[k]) - float(oparts[k])) < 2e-3 * max(1.0, abs(float(oparts[k]))), (k, float(parts[k]), float(oparts[k]))
+        assert abs(float(parts[k]) - float(gl[k])) < 2e-3 * max(1.0, abs(float(gl[k]))), (k, float(parts[k]), float(gl[k]))
+    # gradients: relative to each tensor's max |g| (see the conditioning note in oracle/make_goldens.py)
+    rels = {}
+    for k, p in m.named_parameters():
+        og = params[k].grad
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k}: product has a grad, oracle has none"
+            continue
+        assert p.grad is not None, f"{k}: no gradient"
+        gm = float(og.abs().max())
+        if gm < 1e-3 or k in ("mapping_lang.0.bias", "mapping_lang.4.bias", "loc_embedding.0.bias", "loc_text_embedding.0.bias"):
+            continue
+        rels[k] = maxdiff(p.grad, og) / gm
+    worst = max(rels, key=rels.get)
+    assert rels[worst] < 2e-2, (worst, rels[worst])
+    assert float(np.median(list(rels.values()))) < 2e-3
+    # BN running statistics
+    psd = m.state_dict()
+    for k in ("visumodel.module_list.0.batch_norm_0.running_mean", "mapping_visu.0.bn.running_var",
+              "fcn_emb.2.1.bn.running_mean", "loc_text_embedding.1.running_var", "loc_embedding.1.running_mean"):
+        assert maxdiff(psd[k], sdo[k]) < 1e-4 * max(1.0, float(sdo[k].abs().max())), k
+    assert maxdiff(psd["visumodel.module_list.0.batch_norm_0.running_mean"],
+                   torch.from_numpy(gold["bn_rm::visumodel.module_list.0.batch_norm_0"])) < 1e-4
