@@ -185,7 +185,10 @@ class grounding_model(nn.Module):
             (str(i), nn.Sequential(ConvBatchNormReLU(emb_size, emb_size // 2, 1, 1, 0, 1, leaky=leaky),
                                    nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
-        self.exact_sampling = True
+        # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
+        # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
+        # between fp32 implementations) and so that a caller can log what was sampled
+        self.last_choices = {}
 
     # ------------------------------------------------------------------------------------------
     def _coord(self, h, w, device):
@@ -296,6 +299,8 @@ class grounding_model(nn.Module):
         lib().mt_sample_interframe(arr.ctypes.data, ki_host.ctypes.data, n // 2, top_k, hw, neg_n, neg.ctypes.data)
         _mt_restore(st, arr)
         ni = torch.from_numpy(neg).to(fv0.device)
+        self.last_choices["k9_index"] = index.detach()
+        self.last_choices["k9_neg"] = ni
         ar = torch.arange(n // 2, device=fv0.device)
         frame = [p1[ar, qi[:, j]] for j in range(top_k)]
         corr = [p2[ar, ki[:, j]] for j in range(top_k)]
@@ -317,6 +322,8 @@ class grounding_model(nn.Module):
         lib().mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_n, neg.ctypes.data)
         _mt_restore(st, arr)
         ni = torch.from_numpy(neg).to(fv0.device)
+        self.last_choices["k14_cols"] = cols.detach()
+        self.last_choices["k14_neg"] = ni
         ar = torch.arange(n, device=fv0.device)
         vit_pos = [vit[:, j, :] for j in range(hw)]
         lag_pos = [lag[ar, cols[:, j], :].unsqueeze(1) for j in range(hw)]

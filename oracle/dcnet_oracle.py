@@ -248,12 +248,15 @@ def co_attention(f1: Tensor, f2: Tensor, temperature: float = 10.0) -> Tuple[Ten
     return f1_attn, f2_attn
 
 
-def interframe_sampling(f1: Tensor, f2: Tensor, top_k: int = 30, neg_n: int = 10):
+def interframe_sampling(f1: Tensor, f2: Tensor, top_k: int = 30, neg_n: int = 10, index: Optional[Tensor] = None):
     """Correspondence-patch sampling at scale 0, model/DCNet_model.py:381-430.
     f1,f2: (b,C,H,W).  Uses Python's global ``random`` in the reference's call
     order.  Returns (frame_feature, corrspendence_feature, neg_feature, idx) where
     the first three are lists of ``top_k`` tensors (b,C),(b,C),(b,neg_n,C) and idx
-    = dict(q=(b,top_k), k=(b,top_k), neg=(b,top_k,neg_n)) int64 position indices."""
+    = dict(q=(b,top_k), k=(b,top_k), neg=(b,top_k,neg_n), flat=(b,top_k), values=(b,top_k)).
+    ``index`` (b,top_k) overrides the top-k selection: two fp32 implementations can order
+    near-tied affinities differently, so parity tests feed the device's choice in here and
+    check separately that it is a valid top-k up to rounding."""
     b, c, h, w = f1.shape
     hw = h * w
     p1, p2 = f1.flatten(-2), f2.flatten(-2)
@@ -261,11 +264,16 @@ def interframe_sampling(f1: Tensor, f2: Tensor, top_k: int = 30, neg_n: int = 10
     qi = torch.empty(b, top_k, dtype=torch.long)
     ki = torch.empty(b, top_k, dtype=torch.long)
     ni = torch.empty(b, top_k, neg_n, dtype=torch.long)
+    flat = torch.empty(b, top_k, dtype=torch.long)
+    vals = torch.empty(b, top_k)
     for ii in range(b):
-        _, index = cmap[ii].topk(top_k, dim=0, largest=True, sorted=True)   # :395
+        v_, index_ = cmap[ii].topk(top_k, dim=0, largest=True, sorted=True)   # :395
+        if index is not None:
+            index_ = index[ii]
+        flat[ii] = index_; vals[ii] = v_.detach()
         for jj in range(top_k):
-            qi[ii, jj] = index[jj] // hw                             # :407
-            kk = int(index[jj] % hw)                                 # :409
+            qi[ii, jj] = index_[jj] // hw                            # :407
+            kk = int(index_[jj] % hw)                                # :409
             ki[ii, jj] = kk
             lst = list(range(hw)); lst.remove(kk)                    # :411-412
             ni[ii, jj] = torch.tensor(random.sample(lst, neg_n))     # :413
@@ -273,16 +281,17 @@ def interframe_sampling(f1: Tensor, f2: Tensor, top_k: int = 30, neg_n: int = 10
     frame = [p1[ar, :, qi[:, j]] for j in range(top_k)]
     corr = [p2[ar, :, ki[:, j]] for j in range(top_k)]
     neg = [p2.permute(0, 2, 1)[ar.unsqueeze(1), ni[:, j]] for j in range(top_k)]
-    return frame, corr, neg, dict(q=qi, k=ki, neg=ni)
+    return frame, corr, neg, dict(q=qi, k=ki, neg=ni, flat=flat, values=vals, cmap=cmap.detach())
 
 
-def crossmodal_correspondence(lag: Tensor, vit: Tensor, lv_map: Tensor, neg_n: int = 5):
+def crossmodal_correspondence(lag: Tensor, vit: Tensor, lv_map: Tensor, neg_n: int = 5, cols: Optional[Tensor] = None):
     """Crossmodal_corrspondence, model/DCNet_model.py:41-112 (top_k=1).
     lag (N,L,E) vit (N,E,HW0) lv_map (N,L,HW0).  The ``index`` loop (:81-90) draws
     N samples per (ii,jj) but only the last one (index=N-1) is kept (:94)."""
     lv = lv_map.permute(0, 2, 1); v = vit.permute(0, 2, 1); l = lag.permute(0, 2, 1)   # :43-45
     N, rows = v.shape[0], v.shape[1]
-    cols = lv.topk(1, dim=2, largest=True, sorted=True)[1][..., 0]   # (N,rows)   :48
+    if cols is None:
+        cols = lv.topk(1, dim=2, largest=True, sorted=True)[1][..., 0]   # (N,rows)   :48
     ni = torch.empty(N, rows, neg_n, dtype=torch.long)
     for ii in range(N):
         for jj in range(rows):
@@ -296,7 +305,7 @@ def crossmodal_correspondence(lag: Tensor, vit: Tensor, lv_map: Tensor, neg_n: i
     vit_pos = [v[:, j, :] for j in range(rows)]                              # (N,E)
     lag_pos = [l[ar, :, cols[:, j]].unsqueeze(1) for j in range(rows)]       # (N,1,E)
     neg = [v[N - 1][ni[:, j]] for j in range(rows)]                          # (N,neg_n,E) from image N-1
-    return vit_pos, lag_pos, neg, dict(word=cols, neg=ni)
+    return vit_pos, lag_pos, neg, dict(word=cols, neg=ni, lv=lv.detach())
 
 
 # --------------------------------------------------------------------------
@@ -382,7 +391,8 @@ def _map_norm(sd: SD, raw: List[Tensor], training: bool) -> List[Tensor]:
 
 
 def grounding_forward_pairs(sd: SD, image: Tensor, word_id: Tensor, training: bool,
-                            sample: bool = True, drop_p: float = 0.0, skip_dead: bool = True) -> dict:
+                            sample: bool = True, drop_p: float = 0.0, skip_dead: bool = True,
+                            k9_index: Optional[Tensor] = None, k14_cols: Optional[Tensor] = None) -> dict:
     """grounding_model.forward of model/DCNet_model.py:340-650 (T=2 pair
     semantics, F1).  Returns a dict with every tensor of the 11-tuple (train) /
     4-tuple (eval) plus a few intermediates used by the parity tests."""
@@ -394,7 +404,7 @@ def grounding_forward_pairs(sd: SD, image: Tensor, word_id: Tensor, training: bo
     in1 = [p[:, 0] for p in pairs]; in2 = [p[:, 1] for p in pairs]               # :370-374
     res = dict(taps=raw, fvisu=fv)
     if sample:
-        fr, co, ng, idx = interframe_sampling(in1[0], in2[0])                    # :381-430
+        fr, co, ng, idx = interframe_sampling(in1[0], in2[0], index=k9_index)    # :381-430
         res.update(frame_feature=fr, corrspendence_feature=co, neg_feature=ng, k9_idx=idx)
     corr = []
     for ii in range(3):                                                          # :449-464
@@ -414,7 +424,7 @@ def grounding_forward_pairs(sd: SD, image: Tensor, word_id: Tensor, training: bo
         lv = torch.bmm(lag, vit)                                                 # :634
         lv = F.conv1d(lv, sd["feature_map.0.weight"], sd["feature_map.0.bias"], padding=1)
         lv = F.softmax(lv, dim=1)                                                # :287-290,635
-        vp, lp, nc, idx = crossmodal_correspondence(lag, vit, lv)                # :637
+        vp, lp, nc, idx = crossmodal_correspondence(lag, vit, lv, cols=k14_cols) # :637
         res.update(vit_posit=vp, lag_posit=lp, neg_cross=nc, k14_idx=idx)
     return res
 

@@ -64,7 +64,12 @@ def _import_reference():
     for k in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
         del sys.modules[k]
     sys.path.insert(0, REF)
+    # the reference's model/ has no __init__.py (namespace package) and would lose against our own
+    # regular ``model`` package whatever the path order: bind the name to the reference explicitly
+    pkg = types.ModuleType("model"); pkg.__path__ = [os.path.join(REF, "model")]; pkg.__package__ = "model"
+    sys.modules["model"] = pkg
     import model.darknet as rdark
+    assert rdark.__file__.startswith(REF), rdark.__file__
     rdark.Darknet.load_weights = lambda self, p: None        # saved_models is a dangling symlink (F6)
     return rdark
 
