@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""DCNet hot-path benchmark: clips/s, forward + backward (+ optimizer step), T=8 frames of
+416x416, batch 8 clips per GPU (BASELINE.json configs[1]: fp32, synthetic data, random init).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; clips are sharded data-parallel (weak scaling: 8 clips per GPU), gradients are
+all-reduced by RCCL through DistributedDataParallel.  A step = forward of the drop-in
+``grounding_model`` on 64 images (= 8 clips x T 8, pair semantics: SURVEY.md F1), the five training
+losses, backward, RMSprop step — nothing skipped.  Prints ONE JSON line on rank 0.
+
+The ``roofline`` object is measured live: the library records a HIP event pair around every launch
+of the conv engine on the launch stream during the timed steps (dcn_prof_*).  ``cpu_baseline`` times
+the CPU oracle (oracle/, a restatement pinned against the reference) on 1 clip of the same shape.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, == fp32 vector rate
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clips", type=int, default=8, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=8, help="T")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int, frames: int, steps: int):
+    """Oracle forward+backward on the host cores, 1 clip (bs 8 would need ~80 GB of host RAM)."""
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs, synth_state_dict
+    from oracle import dcnet_oracle as O
+    from oracle import train_oracle as TO
+    import random
+    with open(os.path.join(ROOT, "tests", "golden", "state_dict_keys_256.json")) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    P = sum((size // 32 * 2 ** i) ** 2 for i in range(3))
+    shapes["loc_text_embedding.0.weight"] = (512, P)
+    sd0 = synth_state_dict(shapes, seed=0)
+    image, word_id, _ = synth_inputs(frames, size, seed=1)
+    bbox = synth_boxes(frames, size, seed=1)
+    times = []
+    for it in range(steps + 1):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k, v in sd.items():
+            if v.dtype == torch.float32 and "running" not in k:
+                v.requires_grad_(True)
+        random.seed(13)
+        t0 = time.perf_counter()
+        o = O.grounding_forward_pairs(sd, image, word_id, training=True)
+        loss, _ = TO.total_loss(o, bbox, size)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": 1.0 / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ (CPU restatement pinned to the reference) fwd+5 losses+bwd on 1 clip T={frames} "
+                      f"{size}x{size}, {steps} timed steps after 1 warm-up, median; host has {os.cpu_count()} cpus"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+
+    from dcnet_amd import losses
+    from dcnet_amd.lib import lib
+    from dcnet_amd.model import grounding_model
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+
+    torch.manual_seed(1234)            # identical initial weights on every rank (DDP also broadcasts rank 0's)
+    model = grounding_model(corpus=list(range(1000)), light=False, emb_size=512, coordmap=True,
+                            bert_model="bert-base-uncased", dataset="vid", img_size=args.size,
+                            config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None).to(dev)
+    model.train()
+    # parameters that never receive a gradient in the reference either (dead YOLO heads F7, feature_map F8):
+    # freezing them gives DDP a static graph instead of find_unused_parameters=True (train_DCNet.py:483)
+    live = {op.slot for op in model.visumodel._conv_ops}
+    for i, seq in enumerate(model.visumodel.module_list):
+        if i not in live:
+            for p in seq.parameters():
+                p.requires_grad_(False)
+    for p in model.feature_map.parameters():
+        p.requires_grad_(False)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True,
+                                                        gradient_as_bucket_view=True)
+    visu = [p for p in model.visumodel.parameters() if p.requires_grad]
+    vis_ids = {id(p) for p in visu}
+    rest = [p for p in model.parameters() if p.requires_grad and id(p) not in vis_ids]
+    opt = torch.optim.RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)  # :533
+
+    n_img = args.clips * args.frames
+    image, word_id, word_mask = synth_inputs(n_img, args.size, seed=100 + rank)
+    bbox = synth_boxes(n_img, args.size, seed=100 + rank)
+    image, word_id, word_mask, bbox = image.to(dev), word_id.to(dev), word_mask.to(dev), bbox.to(dev)
+    import random
+    random.seed(13 + rank)
+
+    def step():
+        out = net(image, word_id, word_mask)
+        loss, _ = losses.total_loss(out, bbox, args.size)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L = lib()
+    L.prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    counts = (ctypes.c_int64 * 16)(); ms = (ctypes.c_double * 16)(); work = (ctypes.c_double * 16)()
+    L.prof_collect(ctypes.addressof(counts), ctypes.addressof(ms), ctypes.addressof(work))
+
+    if rank == 0:
+        clips_total = args.clips * world * args.steps
+        names = {0: "igemm_kernel<128,128,2,2,0>", 1: "igemm_kernel<128,64,2,2,0>", 2: "igemm_kernel<256,32,4,1,0>",
+                 3: "igemm_kernel<128,128,2,2,1>", 4: "igemm_kernel<128,64,2,2,1>", 5: "wgrad_kernel<*>",
+                 8: "l2norm_score_fwd_kernel", 9: "l2norm_score_bwd_kernel", 10: "scale_act_kernel",
+                 11: "bn_act_bwd_apply_kernel", 12: "exp_sums_kernel"}
+        kern = {}
+        for t, nm in names.items():
+            if counts[t]:
+                unit = "TFLOP/s" if t <= 5 else "GB/s"
+                rate = work[t] / (ms[t] * 1e-3) / (1e12 if t <= 5 else 1e9)
+                kern[nm] = {"launches_per_step": counts[t] / args.steps, "avg_ms": ms[t] / counts[t],
+                            "ms_per_step": ms[t] / args.steps, "achieved": rate, "unit": unit}
+        dom = 0   # the 128x128 NT tile of the conv engine carries most of the FLOPs
+        mfma_ms = sum(ms[t] for t in range(6)); mfma_work = sum(work[t] for t in range(6))
+        roofline = {"bound": "mfma", "kernel": names[dom],
+                    "achieved": work[dom] / (ms[dom] * 1e-3) / 1e12 if counts[dom] else None,
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": (work[dom] / (ms[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if counts[dom] else None,
+                    "traffic": None,
+                    "avg_launch_ms": ms[dom] / counts[dom] if counts[dom] else None,
+                    "flop_per_launch": work[dom] / counts[dom] if counts[dom] else None,
+                    "all_mfma_kernels": {"achieved": mfma_work / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None,
+                                         "frac": mfma_work / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if mfma_ms else None,
+                                         "ms_per_step": mfma_ms / args.steps,
+                                         "share_of_step": mfma_ms / args.steps / (dt / args.steps * 1e3)},
+                    "hbm_scoring": {"kernel": names[8], "achieved": kern.get(names[8], {}).get("achieved"),
+                                    "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": (kern[names[8]]["achieved"] / PEAK_HBM_GBS) if names[8] in kern else None},
+                    "kernels": kern}
+        res = {"metric": "clips/sec (T=8, 416x416, bs8) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips} clips/GPU, 20-token query, fp32, "
+                                      f"pair semantics ({n_img} images/GPU/step), fwd + 5 losses + bwd + RMSprop",
+                          "images_per_gpu": n_img, "parallelism": f"dp{world}"},
+               "loss": float(last.detach()), "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.size, args.frames, args.cpu_steps)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

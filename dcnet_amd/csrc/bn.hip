@@ -3,6 +3,7 @@
 // 4 B read + 4 B written per element for the apply passes); 16-B accesses per lane, channel =
 // fastest dim so per-channel parameters are read once per thread and stay in registers.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -227,8 +228,10 @@ extern "C" int dcn_scale_act(const float* y, const float* scale, const float* sh
   DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 4 == 0, "scale_act: bad argument (c=%d must be a multiple of 4)", c);
   if (ldo <= 0) ldo = c;
   DCN_CHECK_ARG(ldo % 4 == 0, "scale_act: ldo=%d must be a multiple of 4", ldo);
+  const int pid = prof_begin(10, (double)rows * c * 4.0 * (residual ? 3 : 2), (hipStream_t)stream);
   hipLaunchKernelGGL(scale_act_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
                      y, scale, shift, act, slope, residual, out, rows, c, ldo);
+  prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("scale_act");
   return DCN_OK;
 }
@@ -259,8 +262,10 @@ extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo,
                                     const float* sums, int64_t count, int64_t rows, int c, float* dy, void* stream) {
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 4 == 0, "bn_act_bwd_apply: bad argument");
   if (lddo <= 0) lddo = c;
+  const int pid = prof_begin(11, (double)rows * c * 4.0 * 3, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
                      y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy);
+  prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply");
   return DCN_OK;
 }

@@ -1,6 +1,8 @@
-// Error reporting and version of libdcnet_hip.so.
+// Error reporting, version and the optional HIP-event kernel profiler of libdcnet_hip.so.
 #include "common.h"
+#include "prof.h"
 #include <string.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -13,3 +15,50 @@ void dcn_set_error(const char* fmt, ...) {
 
 extern "C" const char* dcn_last_error(void) { return g_err; }
 extern "C" int dcn_version(void) { return 100; }
+
+// ---- profiler ---------------------------------------------------------------------------------
+namespace {
+struct Rec { hipEvent_t a, b; int tag; double work; };
+std::vector<Rec> g_recs;
+size_t g_used = 0;
+bool g_on = false;
+constexpr size_t kMaxRecs = 1 << 16;
+}  // namespace
+
+int prof_begin(int tag, double work, hipStream_t s) {
+  if (!g_on || g_used >= kMaxRecs) return -1;
+  if (g_used == g_recs.size()) {
+    Rec r{};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    g_recs.push_back(r);
+  }
+  Rec& r = g_recs[g_used];
+  r.tag = tag; r.work = work;
+  (void)hipEventRecord(r.a, s);
+  return (int)g_used++;
+}
+
+void prof_end(int id, hipStream_t s) {
+  if (id >= 0) (void)hipEventRecord(g_recs[id].b, s);
+}
+
+// on != 0: start a fresh recording window; on == 0: stop recording (records are kept for collect)
+extern "C" int dcn_prof_enable(int on) {
+  if (on) g_used = 0;
+  g_on = on != 0;
+  return DCN_OK;
+}
+
+// Host-synchronising: waits for every recorded event, then sums per tag.  counts/ms/work: [DCN_PROF_TAGS].
+extern "C" int dcn_prof_collect(int64_t* counts, double* ms, double* work) {
+  DCN_CHECK_ARG(counts && ms && work, "prof_collect: null pointer");
+  for (int t = 0; t < DCN_PROF_TAGS; ++t) { counts[t] = 0; ms[t] = 0.0; work[t] = 0.0; }
+  for (size_t i = 0; i < g_used; ++i) {
+    Rec& r = g_recs[i];
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    if (r.tag >= 0 && r.tag < DCN_PROF_TAGS) { counts[r.tag]++; ms[r.tag] += t; work[r.tag] += r.work; }
+  }
+  return DCN_OK;
+}

@@ -13,6 +13,7 @@
 // exp(t*A - t) is in [e^-2t, 1], so row sums and column sums of the same E give both directions.
 // All GEMMs run on the shared engines: NT and NN forms on igemm.hip, TN on wgrad.hip.
 #include "igemm.h"
+#include "prof.h"
 
 int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
                     float* C, int ldc, long long c_bs, const float* row_scale,
@@ -154,7 +155,9 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   if (rc) return rc;
   // 2. E = exp(t*A - t), rinv = 1/rowsum, cinv = 1/colsum
   const int nrb = cdiv(hw, EXP_ROWS);
+  const int pid = prof_begin(12, (double)b * hw * ldE * 8.0, stream);
   hipLaunchKernelGGL(exp_sums_kernel, dim3(nrb, b), dim3(256), 0, stream, E, hw, ldE, temperature, rinv, ws);
+  prof_end(pid, stream);
   DCN_CHECK_LAUNCH("exp_sums");
   hipLaunchKernelGGL(colsum_inv_kernel, dim3(cdiv(hw, 256), b), dim3(256), 0, stream, ws, nrb, b, hw, ldE, cinv);
   DCN_CHECK_LAUNCH("colsum_inv");

@@ -21,6 +21,7 @@
 // statistics, deterministic: no atomics), scale/shift (folded eval BatchNorm or bias),
 // LeakyReLU/ReLU, the shortcut add, and accumulate-into-destination.
 #include "igemm.h"
+#include "prof.h"
 
 namespace {
 
@@ -247,7 +248,12 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE>), dim3(gm * gn, p.batch > 0 ? p.batch : 1), dim3(256), lds, stream, p);
+  const int nb = p.batch > 0 ? p.batch : 1;
+  const int tag = BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
+  const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
+  const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
 }

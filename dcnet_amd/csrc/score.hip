@@ -4,6 +4,7 @@
 //   score[row] = <out[row,:], q[img(row),:]>                 sim_score            DCNet_model.py:530-535
 // Algorithmic bytes per row: c*4 read + c*4 written (+8); one wave per row, 16-B accesses per lane.
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -105,8 +106,11 @@ extern "C" int dcn_l2norm_score_fwd(const float* x, int ldx, float* out, int ldo
   DCN_CHECK_ARG(!q || (score && rows_per_image > 0), "l2norm_score_fwd: q given without score/rows_per_image");
   if (ldx <= 0) ldx = c;
   if (ldo <= 0) ldo = c;
+  // algorithmic bytes: read x, write out (+ norm, score)
+  const int pid = prof_begin(8, (double)rows * (2.0 * c * 4 + 8), (hipStream_t)stream);
   hipLaunchKernelGGL(l2norm_score_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                      x, ldx, out, ldo, norm, q, score, rows, rows_per_image > 0 ? rows_per_image : 1, c);
+  prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("l2norm_score_fwd");
   return DCN_OK;
 }
@@ -119,8 +123,10 @@ extern "C" int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm
   if (ldo <= 0) ldo = c;
   if (lddo <= 0) lddo = c;
   if (lddx <= 0) lddx = c;
+  const int pid = prof_begin(9, (double)rows * ((dout ? 3.0 : 2.0) * c * 4 + 8), (hipStream_t)stream);
   hipLaunchKernelGGL(l2norm_score_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                      out, ldo, norm, dout, lddo, q, dscore, dx, lddx, rows, rows_per_image > 0 ? rows_per_image : 1, c);
+  prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("l2norm_score_bwd");
   if (dq && q && dscore) {
     DCN_CHECK_ARG(rows_per_image > 0 && rows % rows_per_image == 0, "l2norm_score_bwd: rows %% rows_per_image != 0");

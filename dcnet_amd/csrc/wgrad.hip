@@ -11,6 +11,7 @@
 // the result is bitwise reproducible (no float atomics).
 // Roofline: MFMA (same 157.3 TFLOP/s fp32 peak as the forward).
 #include "common.h"
+#include "prof.h"
 
 namespace {
 
@@ -229,7 +230,10 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
+  const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
+  const int pid = prof_begin(5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
   hipLaunchKernelGGL((wgrad_kernel<TM, TN>), dim3(grid, batch), dim3(256), lds, stream, p);
+  prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
   return DCN_OK;
 }

@@ -166,6 +166,14 @@ int dcn_upsample2_nhwc_bwd(const float* ddst, int ldd, float* dsrc, int lds, int
 /* strided copy / accumulate of a [rows][c] channel slice: dst (+)= src. */
 int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows, int c, int accumulate, void* stream);
 
+/* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
+/* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
+ * returns, per kernel tag (16 slots: 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
+ * 5 weight-gradient/TN GEMM, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward, 12 exp+sums),
+ * the launch count, the summed kernel milliseconds and the summed algorithmic work (FLOP or bytes). */
+int dcn_prof_enable(int on);
+int dcn_prof_collect(int64_t* counts, double* ms, double* work);
+
 /* ---- host-side negative sampling (CPU; bit-exact with Python's random.sample) -------------- */
 /* state = the 625 uint32 of random.getstate()[1], advanced in place.
  * interframe: for each (pair, j) draws neg_n positions from range(hw) minus kpos[pair][j]
