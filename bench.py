@@ -173,12 +173,19 @@ def main():
                 kern[nm] = {"launches_per_step": counts[t] / args.steps, "avg_ms": ms[t] / counts[t],
                             "ms_per_step": ms[t] / args.steps, "achieved": rate, "unit": unit}
         dom = 0   # the 128x128 NT tile of the conv engine carries most of the FLOPs
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
+            with open(pmc_file) as f:
+                pmc = json.load(f)
+            if pmc.get("kernel") == names[dom]:
+                traffic = pmc.get("hbm_bytes_per_launch")
         mfma_ms = sum(ms[t] for t in range(6)); mfma_work = sum(work[t] for t in range(6))
         roofline = {"bound": "mfma", "kernel": names[dom],
                     "achieved": work[dom] / (ms[dom] * 1e-3) / 1e12 if counts[dom] else None,
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": (work[dom] / (ms[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if counts[dom] else None,
-                    "traffic": None,
+                    "traffic": traffic,
                     "avg_launch_ms": ms[dom] / counts[dom] if counts[dom] else None,
                     "flop_per_launch": work[dom] / counts[dom] if counts[dom] else None,
                     "all_mfma_kernels": {"achieved": mfma_work / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None,
