@@ -105,17 +105,9 @@ def main():
     model.train()
     # parameters that never receive a gradient in the reference either (dead YOLO heads F7, feature_map F8):
     # freezing them gives DDP a static graph instead of find_unused_parameters=True (train_DCNet.py:483)
-    live = {op.slot for op in model.visumodel._conv_ops}
-    for i, seq in enumerate(model.visumodel.module_list):
-        if i not in live:
-            for p in seq.parameters():
-                p.requires_grad_(False)
-    for p in model.feature_map.parameters():
-        p.requires_grad_(False)
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=True,
-                                                        gradient_as_bucket_view=True)
+    from dcnet_amd.parallel import freeze_gradless, wrap_ddp
+    freeze_gradless(model)
+    net = wrap_ddp(model, local_rank) if world > 1 else model
     visu = [p for p in model.visumodel.parameters() if p.requires_grad]
     vis_ids = {id(p) for p in visu}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in vis_ids]

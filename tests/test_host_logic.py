@@ -1,0 +1,125 @@
+"""CPU: host-side logic of the product — cfg/plan compiler, checkpoint key contract, darknet weight
+file io, the native MT19937 sampler, sharding."""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from util import GOLD, ROOT, ref_shapes
+
+
+def test_generated_cfg_roundtrip_and_plan():
+    from dcnet_amd import darknet as D
+    blocks = D.yolov3_blocks()
+    parsed = D.parse_model_config(os.path.join(ROOT, "model", "yolov3.cfg"))
+    assert len(parsed) == len(blocks) == 108
+    for a, b in zip(parsed, blocks):
+        assert a["type"] == b["type"]
+        for k in ("filters", "size", "stride", "activation", "layers", "from"):
+            assert str(a.get(k)) == str(b.get(k)), (a, b)
+        assert int(a.get("batch_normalize", 0)) == int(b.get("batch_normalize", 0))
+    plan, taps, ch = D.build_plan(parsed[1:], 3)
+    assert taps == [78, 90, 102] and [ch[t] for t in taps] == [1024, 512, 256]
+    convs = [op for op in plan if isinstance(op, D._ConvOp)]
+    assert len(convs) == 68                                     # 75 convs - 7 in the dead YOLO heads
+    assert sum(op.res is not None for op in convs) == 23        # every residual add is fused
+    assert not any(op.slot in (80, 81, 92, 93, 103, 104, 105) for op in convs)
+    live_flops = sum(2 * op.cout * op.cin * op.k * op.k * (416 // _stride(plan, op, D)) ** 2 for op in convs)
+    assert abs(live_flops / 1e9 - 60.28) < 0.6                  # 60.28 GF/image @416 (live layers)
+
+
+def _stride(plan, op, D):
+    # cumulative output stride of a conv slot in the 416 graph
+    table = {}
+    s = 1
+    for o in plan:
+        if isinstance(o, D._ConvOp):
+            src = table.get(o.src, 1)
+            table[o.dst] = src * o.stride
+        elif isinstance(o, D._UpCatOp):
+            table[o.dst] = table[o.lat_src]
+        else:
+            table[o.dst] = table[o.src]
+    return table[op.dst]
+
+
+def test_state_dict_contract():
+    from model.DCNet_model import grounding_model
+    m = grounding_model(corpus=list(range(1000)), emb_size=512, img_size=256, weights_path=None,
+                        config_path=os.path.join(ROOT, "model", "yolov3.cfg"))
+    sd = m.state_dict()
+    ref = ref_shapes(256)
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == ref[k] for k in ref)
+    assert sum(p.numel() for p in m.parameters()) == 80770344
+    m416 = grounding_model(corpus=list(range(1000)), emb_size=512, img_size=416, weights_path=None, config_path="")
+    assert m416.loc_text_embedding[0].weight.shape == (512, 3549)
+    # the gradient-less set is exactly the reference's (captured with the real model)
+    from dcnet_amd.parallel import gradless_parameter_names
+    gold = np.load(os.path.join(GOLD, "train_S256_N4.npz"), allow_pickle=True)
+    assert sorted(gradless_parameter_names(m)) == sorted(str(k) for k in gold["nograd"])
+
+
+def test_darknet_weights_file_roundtrip(tmp_path):
+    from dcnet_amd.darknet import Darknet
+    torch.manual_seed(0)
+    a = Darknet(config_path="")
+    for p in a.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    for b in a.buffers():
+        if b.dtype == torch.float32:
+            b.uniform_(0.5, 1.5)
+    a.seen = 1234
+    path = str(tmp_path / "w.weights")
+    a.save_weights(path)
+    assert os.path.getsize(path) == 248007048 or os.path.getsize(path) == 5 * 4 + 62001757 * 4
+    b = Darknet(config_path="")
+    b.load_weights(path)
+    assert b.seen == 1234
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if "num_batches_tracked" not in k:
+            assert torch.equal(va, vb), k
+
+
+def test_native_sampler_is_bit_exact_with_python_random():
+    from dcnet_amd.lib import lib
+    L = lib()
+    for hw, top_k, neg_n, pairs in ((64, 30, 10, 3), (169, 30, 10, 2), (361, 30, 10, 1)):
+        random.seed(13)
+        kpos = np.array([[random.randrange(hw) for _ in range(top_k)] for _ in range(pairs)], dtype=np.int64)
+        st = random.getstate()
+        ref = np.zeros((pairs, top_k, neg_n), dtype=np.int64)
+        for p in range(pairs):
+            for j in range(top_k):
+                lst = list(range(hw)); lst.remove(int(kpos[p, j]))
+                ref[p, j] = random.sample(lst, neg_n)
+        after = random.getstate()
+        state = np.array(st[1], dtype=np.uint32); out = np.zeros_like(ref)
+        L.mt_sample_interframe(state.ctypes.data, kpos.ctypes.data, pairs, top_k, hw, neg_n, out.ctypes.data)
+        assert (out == ref).all() and tuple(int(x) for x in state) == after[1]
+    for n, rows in ((2, 64), (3, 169)):
+        random.seed(5); st = random.getstate()
+        ref = np.zeros((n, rows, 5), dtype=np.int64)
+        for ii in range(n):
+            for jj in range(rows):
+                for index in range(n):
+                    lst = list(range(rows))
+                    if index == ii:
+                        lst.remove(jj)
+                    s = random.sample(lst, 5)
+                ref[ii, jj] = s
+        after = random.getstate()
+        state = np.array(st[1], dtype=np.uint32); out = np.zeros_like(ref)
+        L.mt_sample_crossmodal(state.ctypes.data, n, rows, 5, out.ctypes.data)
+        assert (out == ref).all() and tuple(int(x) for x in state) == after[1]
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    from dcnet_amd.parallel import shard_indices
+    for n, w in ((64, 8), (10, 4), (7, 2), (3, 8)):
+        for r in range(w):
+            ref = list(DistributedSampler(range(n), num_replicas=w, rank=r, shuffle=False))
+            assert shard_indices(n, r, w) == ref
