@@ -46,12 +46,15 @@ def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
                         torch.ones(N, device=dev)], 1)                                     # :314-322
     bbox_list, center_list = [], []
     for s, g in enumerate(grids):
+        # samples whose best scale is not s write a zero vector into cell (0,0) of anchor 0 — a no-op on
+        # the zero tensor unless another sample owns that cell, hence the max-combine via index_put(accumulate)
+        m = (best_scale == s).float().unsqueeze(1)
+        a_s = torch.where(best_scale == s, best_n % 3, torch.zeros_like(best_n))
+        gj_s = torch.where(best_scale == s, gj, torch.zeros_like(gj)); gi_s = torch.where(best_scale == s, gi, torch.zeros_like(gi))
         b = torch.zeros(N, 3, 5, g, g, device=dev); c = torch.zeros(N, 5, g, g, device=dev)
-        m = best_scale == s
-        if bool(m.any()):
-            idx = ar[m]
-            b[idx, best_n[m] % 3, :, gj[m], gi[m]] = tvec[m]
-            c[idx, :, gj[m], gi[m]] = tvec[m]
+        k5 = torch.arange(5, device=dev).unsqueeze(0)
+        b.index_put_((ar.unsqueeze(1), a_s.unsqueeze(1), k5, gj_s.unsqueeze(1), gi_s.unsqueeze(1)), tvec * m, accumulate=True)
+        c.index_put_((ar.unsqueeze(1), k5, gj_s.unsqueeze(1), gi_s.unsqueeze(1)), tvec * m, accumulate=True)
         bbox_list.append(b); center_list.append(c)
     return bbox_list, gi, gj, best_n, center_list
 
@@ -74,11 +77,13 @@ def yolo_loss(pred5: Sequence[torch.Tensor], target: Sequence[torch.Tensor], gi,
     pb = torch.zeros(N, 4, device=dev); gb = torch.zeros(N, 4, device=dev)
     for s in range(3):
         m = (best_n // 3) == s
-        if not bool(m.any()):
-            continue
-        t = pred5[s][ar[m], best_n[m] % 3, :, gj[m], gi[m]]                               # (k,5)
-        pb[m] = torch.cat([torch.sigmoid(t[:, 0:2]), t[:, 2:4]], 1)
-        gb[m] = target[s][ar[m], best_n[m] % 3, :4, gj[m], gi[m]]
+        g = pred5[s].shape[-1]
+        a_s = torch.where(m, best_n % 3, torch.zeros_like(best_n))
+        gj_s = torch.where(m, gj, torch.zeros_like(gj)); gi_s = torch.where(m, gi, torch.zeros_like(gi))
+        t = pred5[s][ar, a_s, :, gj_s, gi_s]                                              # (N,5); rows of other scales masked below
+        mf = m.float().unsqueeze(1)
+        pb = pb + mf * torch.cat([torch.sigmoid(t[:, 0:2]), t[:, 2:4]], 1)
+        gb = gb + mf * target[s][ar, a_s, :4, gj_s, gi_s]
     l = sum(F.mse_loss(pb[:, k], gb[:, k]) for k in range(4))
     pred_conf = torch.cat([x[:, :, 4].reshape(N, -1) for x in pred5], dim=1)
     grids = [x.shape[-1] for x in pred5]
@@ -167,8 +172,8 @@ def decode_boxes(outbox: List[torch.Tensor], size: int, anchor_imsize: int = 416
     t = torch.zeros(N, 4, device=dev)
     for s in range(3):
         m = sc == s
-        if bool(m.any()):
-            t[m] = ob[s][ar[m], a[m], :4, gj[m], gi[m]]
+        z = torch.zeros_like(a)
+        t = t + m.float().unsqueeze(1) * ob[s][ar, torch.where(m, a, z), :4, torch.where(m, gj, z), torch.where(m, gi, z)]
     anc = torch.tensor(ANCHORS_FULL, dtype=torch.float32, device=dev)[sc * 3 + a] / (anchor_imsize / g.float()).unsqueeze(1)
     stride = (size // g).float()
     x = (torch.sigmoid(t[:, 0]) + gi) * stride; y = (torch.sigmoid(t[:, 1]) + gj) * stride

@@ -301,11 +301,12 @@ class grounding_model(nn.Module):
         ni = torch.from_numpy(neg).to(fv0.device)
         self.last_choices["k9_index"] = index.detach()
         self.last_choices["k9_neg"] = ni
+        # one batched gather per output; the reference's lists are zero-copy unbinds of them
         ar = torch.arange(n // 2, device=fv0.device)
-        frame = [p1[ar, qi[:, j]] for j in range(top_k)]
-        corr = [p2[ar, ki[:, j]] for j in range(top_k)]
-        negf = [p2[ar.unsqueeze(1), ni[:, j]] for j in range(top_k)]
-        return frame, corr, negf
+        frame = p1[ar.unsqueeze(1), qi]                                          # (b,top_k,E)
+        corr = p2[ar.unsqueeze(1), ki]
+        negf = p2[ar.view(-1, 1, 1), ni]                                         # (b,top_k,neg_n,E)
+        return list(frame.unbind(1)), list(corr.unbind(1)), list(negf.unbind(1))
 
     def _crossmodal(self, fv0, context, neg_n=5):
         """model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112."""
@@ -325,10 +326,9 @@ class grounding_model(nn.Module):
         self.last_choices["k14_cols"] = cols.detach()
         self.last_choices["k14_neg"] = ni
         ar = torch.arange(n, device=fv0.device)
-        vit_pos = [vit[:, j, :] for j in range(hw)]
-        lag_pos = [lag[ar, cols[:, j], :].unsqueeze(1) for j in range(hw)]
-        neg_cross = [vit[n - 1][ni[:, j]] for j in range(hw)]
-        return vit_pos, lag_pos, neg_cross
+        lag_pos = lag[ar.unsqueeze(1), cols].unsqueeze(2)                        # (N,HW0,1,E)
+        neg_cross = vit[n - 1][ni]                                               # (N,HW0,neg_n,E)
+        return list(vit.unbind(1)), list(lag_pos.unbind(1)), list(neg_cross.unbind(1))
 
     # ------------------------------------------------------------------------------------------
     def forward(self, image, word_id, word_mask=None, n_frame: Optional[int] = None):

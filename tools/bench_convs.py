@@ -1,0 +1,79 @@
+"""Per-layer micro-benchmark of the conv engine at the C2 workload (N=64 images of 416x416):
+forward, data gradient and weight gradient of every distinct conv shape of the backbone and head.
+Usage (on the GPU box): python tools/bench_convs.py [--n 64] [--size 416]"""
+import argparse
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dcnet_amd import darknet as D, ops  # noqa: E402
+
+
+def shapes(size):
+    d = D.Darknet(config_path="")
+    table = {}
+    res = {-1: size}
+    out = collections.Counter()
+    for op in d._plan:
+        if isinstance(op, D._ConvOp):
+            h = res[op.src]
+            res[op.dst] = h // op.stride
+            out[(op.cin if op.cin > 4 else 4, op.cout, op.k, op.stride, h)] += 1
+        elif isinstance(op, D._UpCatOp):
+            res[op.dst] = res[op.lat_src]
+        else:
+            res[op.dst] = res[op.src]
+    for s, g in enumerate((size // 32, size // 16, size // 8)):
+        cin = (1024, 512, 256)[s]
+        out[(cin, 512, 1, 1, g)] += 1        # mapping_visu
+        out[(1024, 512, 1, 1, g)] += 1       # corr_conv
+        out[(1056, 512, 1, 1, g)] += 1       # fcn_emb.0 (1032 padded)
+        out[(512, 512, 3, 1, g)] += 1
+        out[(512, 512, 1, 1, g)] += 1
+        out[(512, 256, 1, 1, g)] += 1
+        out[(256, 32, 1, 1, g)] += 1         # bbox head (15 padded to 32)
+    return out
+
+
+def timeit(fn, iters=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=416)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    tot = collections.Counter()
+    rows = []
+    for (cin, cout, k, st, h), cnt in sorted(shapes(args.size).items(), key=lambda kv: -kv[0][4]):
+        x = torch.randn(args.n, h, h, cin, device=dev)
+        w = torch.randn((cout, 64) if cin == 4 else (cout, k, k, cin), device=dev) * 0.05
+        ho = h // st
+        dy = torch.randn(args.n, ho, ho, cout, device=dev)
+        flop = 2.0 * args.n * ho * ho * cout * k * k * (3 if cin == 4 else cin)
+        t_f = timeit(lambda: ops.conv2d_fwd(x, w, k, st, want_stats=True))
+        t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
+        t_d = timeit(lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st)) if cin != 4 and cout % 32 == 0 else 0.0
+        rows.append((cin, cout, k, st, h, cnt, flop / 1e9, t_f, t_d, t_w))
+        tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w
+        tot["flop"] += cnt * flop
+    print("%5s %5s k s %4s cnt %8s | %8s %6s | %8s %6s | %8s %6s" % ("cin", "cout", "H", "GF", "fwd ms", "TF/s", "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+    for (cin, cout, k, st, h, cnt, gf, tf, td, tw) in rows:
+        print("%5d %5d %d %d %4d %3d %8.1f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f" % (
+            cin, cout, k, st, h, cnt, gf, tf, gf / tf, td, gf / td if td else 0, tw, gf / tw))
+    for k in ("fwd", "dgrad", "wgrad"):
+        print("total %-6s %8.2f ms  -> %6.1f TF/s" % (k, tot[k], tot["flop"] / 1e9 / tot[k]))
+
+
+if __name__ == "__main__":
+    main()
