@@ -81,13 +81,15 @@ void sample_positions(MT& g, int n, int k, std::vector<int>& pool, std::vector<u
 // state: uint32[625].  kpos: [pairs][top_k] matched frame-2 positions.  out: [pairs][top_k][neg_n].
 extern "C" int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, int pairs, int top_k, int hw, int neg_n,
                                         int64_t* out) {
-  DCN_CHECK_ARG(state && kpos && out && pairs > 0 && top_k > 0 && hw > 1 && neg_n > 0 && neg_n <= hw - 1 && neg_n <= 64,
+  DCN_CHECK_ARG(state && out && pairs > 0 && top_k > 0 && hw > 1 && neg_n > 0 && neg_n <= hw - 1 && neg_n <= 64,
                 "mt_sample_interframe: bad argument");
   MT g{state, state + 624};
   std::vector<int> pool; std::vector<uint8_t> seen; int tmp[64];
   for (int p = 0; p < pairs; ++p)
     for (int j = 0; j < top_k; ++j) {
-      const int64_t kp = kpos[(size_t)p * top_k + j];
+      // kpos == NULL: emit the raw list positions; the caller maps them (pos >= kp ? pos+1 : pos) on the
+      // device, so the draw — which does not depend on kp — can run while the GPU is still computing kp
+      const int64_t kp = kpos ? kpos[(size_t)p * top_k + j] : (int64_t)hw;
       sample_positions(g, hw - 1, neg_n, pool, seen, tmp);       // list(range(hw)) with kp removed
       for (int e = 0; e < neg_n; ++e) out[((size_t)p * top_k + j) * neg_n + e] = tmp[e] < kp ? tmp[e] : tmp[e] + 1;
     }

@@ -185,6 +185,7 @@ class grounding_model(nn.Module):
             (str(i), nn.Sequential(ConvBatchNormReLU(emb_size, emb_size // 2, 1, 1, 0, 1, leaky=leaky),
                                    nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
+        self._pinned = {}
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
@@ -284,7 +285,26 @@ class grounding_model(nn.Module):
         return final, sim_score, loc_score, corr_feat, flang_attn.view(B, -1, 1, 1), only_obj
 
     # ------------------------------------------------------------------------------------------
-    def _interframe_sampling(self, fv0, top_k=30, neg_n=10):
+    def _presample(self, n, g0, device, top_k=30, neg_n=10, neg_c=5):
+        """Draw the negatives of both correspondence heads from Python's global MT19937 stream, in the
+        reference's order (K9 then K14), natively on the host.  The draws depend only on shapes, so this
+        runs right after the backbone kernels have been queued and overlaps with them."""
+        hw = g0 * g0
+        key = (n, hw, top_k, neg_n, neg_c)
+        if key not in self._pinned:
+            # page-locked staging so the upload is a true async copy (a pageable H2D would block the host
+            # until the queued backbone kernels drain).  Reuse is safe: the language branch of the next
+            # forward syncs the stream before these buffers are written again.
+            self._pinned[key] = (torch.empty((n // 2, top_k, neg_n), dtype=torch.int64).pin_memory(),
+                                 torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory())
+        k9, k14 = self._pinned[key]
+        st, arr = _mt_state()
+        lib().mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
+        lib().mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+        _mt_restore(st, arr)
+        return {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
+
+    def _interframe_sampling(self, fv0, presampled, top_k=30, neg_n=10):
         """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E)."""
         n, g, _, e = fv0.shape
         hw = g * g
@@ -293,12 +313,8 @@ class grounding_model(nn.Module):
         cmap = torch.bmm(p1, p2.transpose(1, 2)).flatten(1)                      # :390  [i*hw + j]
         _, index = cmap.topk(top_k, dim=1, largest=True, sorted=True)            # :395
         qi, ki = index // hw, index % hw                                         # :407,409
-        ki_host = ki.cpu().numpy().astype(np.int64)
-        st, arr = _mt_state()
-        neg = np.empty((n // 2, top_k, neg_n), dtype=np.int64)
-        lib().mt_sample_interframe(arr.ctypes.data, ki_host.ctypes.data, n // 2, top_k, hw, neg_n, neg.ctypes.data)
-        _mt_restore(st, arr)
-        ni = torch.from_numpy(neg).to(fv0.device)
+        raw = presampled["k9"]                                                   # list positions, drawn on the host
+        ni = raw + (raw >= ki.unsqueeze(2)).long()                               # skip the removed element (:411-413)
         self.last_choices["k9_index"] = index.detach()
         self.last_choices["k9_neg"] = ni
         # one batched gather per output; the reference's lists are zero-copy unbinds of them
@@ -308,7 +324,7 @@ class grounding_model(nn.Module):
         negf = p2[ar.view(-1, 1, 1), ni]                                         # (b,top_k,neg_n,E)
         return list(frame.unbind(1)), list(corr.unbind(1)), list(negf.unbind(1))
 
-    def _crossmodal(self, fv0, context, neg_n=5):
+    def _crossmodal(self, fv0, context, presampled, neg_n=5):
         """model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112."""
         n, g, _, e = fv0.shape
         hw = g * g
@@ -318,11 +334,7 @@ class grounding_model(nn.Module):
         lv = torch.bmm(lag, vit.transpose(1, 2))                                 # (N,L,HW0)  :634
         lv = self.feature_map(lv)                                                # :635
         cols = lv.argmax(dim=1)                                                  # top-1 word per position (:48)
-        st, arr = _mt_state()
-        neg = np.empty((n, hw, neg_n), dtype=np.int64)
-        lib().mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_n, neg.ctypes.data)
-        _mt_restore(st, arr)
-        ni = torch.from_numpy(neg).to(fv0.device)
+        ni = presampled["k14"]
         self.last_choices["k14_cols"] = cols.detach()
         self.last_choices["k14_neg"] = ni
         ar = torch.arange(n, device=fv0.device)
@@ -339,13 +351,17 @@ class grounding_model(nn.Module):
         N = image.size(0)
         if N % 2:
             raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")
-        raw = self.visumodel.forward_nhwc(image)                                 # :344
-        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
-        frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0])   # :381-430
-        corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
+        # The language branch is independent of the images and contains the only host syncs of the forward
+        # (sequence lengths): run it first, while the device queue is empty.
         word_id, flang, context, embedded = self._language(word_id)
+        raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
+        presampled = self._presample(N, self.img_size // 32 if image.shape[-1] == self.img_size else image.shape[-1] // 32,
+                                     image.device)                               # host work under the backbone
+        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
+        frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
+        corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
         outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)
-        vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context)       # :625-637 (runs in eval too)
+        vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context, presampled)   # :625-637 (runs in eval too)
         if self.training:
             return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn,
                     frame_feature, corrspendence_feature, neg_feature, vit_posit, lag_posit, neg_cross)

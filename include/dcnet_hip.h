@@ -177,7 +177,8 @@ int dcn_prof_collect(int64_t* counts, double* ms, double* work);
 /* ---- host-side negative sampling (CPU; bit-exact with Python's random.sample) -------------- */
 /* state = the 625 uint32 of random.getstate()[1], advanced in place.
  * interframe: for each (pair, j) draws neg_n positions from range(hw) minus kpos[pair][j]
- *   (model/DCNet_model.py:411-413); out [pairs][top_k][neg_n] int64.
+ *   (model/DCNet_model.py:411-413); out [pairs][top_k][neg_n] int64.  kpos == NULL returns the raw list
+ *   positions p (the final index is p + (p >= kpos)), which lets the draw overlap with the GPU work.
  * crossmodal: the N*N*rows draws of Crossmodal_corrspondence (model/DCNet_model.py:62-96), keeping
  *   the index == N-1 draw of every (ii, jj); out [n][rows][neg_n] int64 (positions in image N-1). */
 int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, int pairs, int top_k, int hw, int neg_n, int64_t* out);
