@@ -59,6 +59,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int howo = p.Ho * p.Wo;
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
+  // Each thread stages the same B_LD pixel slots of every K-step; their (n, ho, wo) coordinates advance by
+  // 32 pixels per step, so they are decoded once (two integer divisions) and then updated incrementally.
+  int b_n[B_LD], b_ho[B_LD], b_wo[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int pix = (tid + 256 * j) / (TN / 4);
+    const int m = m_begin + pix;
+    const int n = m / howo, rem = m - n * howo;
+    b_n[j] = n; b_ho[j] = rem / p.Wo; b_wo[j] = rem - b_ho[j] * p.Wo;
+  }
   auto load_tiles = [&](int it) {
     const int mb = m_begin + it * 32;
 #pragma unroll
@@ -77,16 +87,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       const int m = mb + pix;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (m < m_end) {
-        const int n = m / howo, rem = m - n * howo;
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         int rr = r, ss = s, ci = ci0 + c;
         bool ok = ci < p.Ci;
         if (p.c4) { const int tap = c >> 2; rr = tap / 3; ss = tap - 3 * rr; ci = 0; ok = tap < 9; }
-        const int iy = ho * p.stride + rr - p.pad, ix = wo * p.stride + ss - p.pad;
+        const int iy = b_ho[j] * p.stride + rr - p.pad, ix = b_wo[j] * p.stride + ss - p.pad;
         if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          v = *reinterpret_cast<const f32x4*>(gx + ((size_t)(n * p.H + iy) * p.W + ix) * p.ldx + ci);
+          v = *reinterpret_cast<const f32x4*>(gx + ((size_t)(b_n[j] * p.H + iy) * p.W + ix) * p.ldx + ci);
       }
       b_reg[j] = v;
+      // advance this slot by 32 pixels (Wo >= 1: a few wrap iterations at most for the 13-wide maps)
+      b_wo[j] += 32;
+      while (b_wo[j] >= p.Wo) { b_wo[j] -= p.Wo; ++b_ho[j]; }
+      while (b_ho[j] >= p.Ho) { b_ho[j] -= p.Ho; ++b_n[j]; }
     }
   };
   auto store_tiles = [&](int buf) {

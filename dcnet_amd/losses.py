@@ -16,6 +16,19 @@ import torch.nn.functional as F
 ANCHORS_FULL = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119),
                 (116, 90), (156, 198), (373, 326)][::-1]          # train_DCNet.py:404-406 (reversed)
 
+_const_cache = {}
+
+
+def _const(key, device, builder):
+    """Small constant tensors, uploaded once per (key, device): a ``torch.tensor(list, device=...)`` in the
+    step would be a pageable H2D copy that blocks the host until the queued forward kernels have drained."""
+    k = (key, str(device))
+    t = _const_cache.get(k)
+    if t is None:
+        t = builder().to(device)
+        _const_cache[k] = t
+    return t
+
 
 def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
     """train_DCNet.py:265-332, batched.  raw_coord (N,4) xyxy pixels.  Returns
@@ -28,8 +41,9 @@ def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
     coords = [base * g for g in grids]                                                     # :270-274
     ious = []
     for s, g in enumerate(grids):
-        anc = torch.tensor([(a[0] / (anchor_imsize / g), a[1] / (anchor_imsize / g)) for a in ANCHORS_FULL[3 * s:3 * s + 3]],
-                           dtype=torch.float32, device=dev)                                # (3,2)
+        anc = _const(("anc", s, g, anchor_imsize), dev, lambda: torch.tensor(
+            [(a[0] / (anchor_imsize / g), a[1] / (anchor_imsize / g)) for a in ANCHORS_FULL[3 * s:3 * s + 3]],
+            dtype=torch.float32))                                                          # (3,2)
         gw, gh = coords[s][:, 2:3], coords[s][:, 3:4]
         inter = torch.clamp(torch.min(gw, anc[None, :, 0]), min=0) * torch.clamp(torch.min(gh, anc[None, :, 1]), min=0)
         ious.append(inter / (gw * gh + anc[None, :, 0] * anc[None, :, 1] - inter + 1e-16))   # utils.bbox_iou :76-104
@@ -38,8 +52,8 @@ def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
     ar = torch.arange(N, device=dev)
     cs = torch.stack(coords, 0)[best_scale, ar]                                            # (N,4) at the best scale
     gi, gj = cs[:, 0].long(), cs[:, 1].long()
-    anc_all = torch.tensor(ANCHORS_FULL, dtype=torch.float32, device=dev)                  # (9,2)
-    gsel = torch.tensor(grids, dtype=torch.float32, device=dev)[best_scale]
+    anc_all = _const("anc_all", dev, lambda: torch.tensor(ANCHORS_FULL, dtype=torch.float32))   # (9,2)
+    gsel = _const(("gridsf", tuple(grids)), dev, lambda: torch.tensor(grids, dtype=torch.float32))[best_scale]
     sa = anc_all[best_n] / (anchor_imsize / gsel).unsqueeze(1)                             # scaled anchor (N,2)
     tvec = torch.stack([cs[:, 0] - gi.float(), cs[:, 1] - gj.float(),
                         torch.log(cs[:, 2] / sa[:, 0] + 1e-16), torch.log(cs[:, 3] / sa[:, 1] + 1e-16),
@@ -52,7 +66,7 @@ def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
         a_s = torch.where(best_scale == s, best_n % 3, torch.zeros_like(best_n))
         gj_s = torch.where(best_scale == s, gj, torch.zeros_like(gj)); gi_s = torch.where(best_scale == s, gi, torch.zeros_like(gi))
         b = torch.zeros(N, 3, 5, g, g, device=dev); c = torch.zeros(N, 5, g, g, device=dev)
-        k5 = torch.arange(5, device=dev).unsqueeze(0)
+        k5 = _const("k5", dev, lambda: torch.arange(5)).unsqueeze(0)
         b.index_put_((ar.unsqueeze(1), a_s.unsqueeze(1), k5, gj_s.unsqueeze(1), gi_s.unsqueeze(1)), tvec * m, accumulate=True)
         c.index_put_((ar.unsqueeze(1), k5, gj_s.unsqueeze(1), gi_s.unsqueeze(1)), tvec * m, accumulate=True)
         bbox_list.append(b); center_list.append(c)
@@ -62,9 +76,10 @@ def build_target(raw_coord: torch.Tensor, size: int, anchor_imsize: int = 416):
 def _flat_index(best_n, gi, gj, grids, with_anchor: bool):
     """Index of each sample's positive cell in the scale-concatenated, flattened map."""
     dev = best_n.device
-    g = torch.tensor(grids, device=dev)[best_n // 3]
-    per = torch.tensor([(3 if with_anchor else 1) * x * x for x in grids], device=dev)
-    off = torch.cumsum(per, 0) - per
+    g = _const(("gridsl", tuple(grids)), dev, lambda: torch.tensor(grids))[best_n // 3]
+    mult = 3 if with_anchor else 1
+    off = _const(("off", tuple(grids), mult), dev, lambda: torch.tensor(
+        [sum(mult * x * x for x in grids[:i]) for i in range(len(grids))]))
     a = (best_n % 3) if with_anchor else torch.zeros_like(best_n)
     return off[best_n // 3] + a * g * g + gj * g + gi
 
@@ -162,10 +177,9 @@ def decode_boxes(outbox: List[torch.Tensor], size: int, anchor_imsize: int = 416
     grids = [o.shape[-1] for o in outbox]
     conf = torch.cat([o[:, :, 4].reshape(N, -1) for o in ob], dim=1)
     loc = conf.argmax(dim=1)
-    per = torch.tensor([3 * g * g for g in grids], device=dev)
-    off = torch.cumsum(per, 0) - per
+    off = _const(("off", tuple(grids), 3), dev, lambda: torch.tensor([sum(3 * x * x for x in grids[:i]) for i in range(len(grids))]))
     sc = (loc.unsqueeze(1) >= off.unsqueeze(0)).sum(1) - 1
-    g = torch.tensor(grids, device=dev)[sc]
+    g = _const(("gridsl", tuple(grids)), dev, lambda: torch.tensor(grids))[sc]
     l = loc - off[sc]
     a = l // (g * g); gj = (l % (g * g)) // g; gi = l % g
     ar = torch.arange(N, device=dev)
@@ -174,7 +188,7 @@ def decode_boxes(outbox: List[torch.Tensor], size: int, anchor_imsize: int = 416
         m = sc == s
         z = torch.zeros_like(a)
         t = t + m.float().unsqueeze(1) * ob[s][ar, torch.where(m, a, z), :4, torch.where(m, gj, z), torch.where(m, gi, z)]
-    anc = torch.tensor(ANCHORS_FULL, dtype=torch.float32, device=dev)[sc * 3 + a] / (anchor_imsize / g.float()).unsqueeze(1)
+    anc = _const("anc_all", dev, lambda: torch.tensor(ANCHORS_FULL, dtype=torch.float32))[sc * 3 + a] / (anchor_imsize / g.float()).unsqueeze(1)
     stride = (size // g).float()
     x = (torch.sigmoid(t[:, 0]) + gi) * stride; y = (torch.sigmoid(t[:, 1]) + gj) * stride
     w = torch.exp(t[:, 2]) * anc[:, 0] * stride; h = torch.exp(t[:, 3]) * anc[:, 1] * stride
