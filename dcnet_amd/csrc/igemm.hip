@@ -28,86 +28,131 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-template <int BM, int BN, int WM, int WN, int BMODE>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;   // voffset sentinel: beyond every descriptor (num_records <= 0x7FFFFFF0) -> load returns 0
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+  const unsigned n = bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0u : (unsigned)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, n, 0x00020000);
+}
+
+// Loader design: every global access is a raw buffer load whose out-of-range lanes return zero, so the
+// padding halo, the M / Cout / K tails and the stem's tap padding need no branches and no zero-fill moves.
+// Per thread the row byte offsets and a per-row bit mask of in-bounds taps are computed ONCE; a K-step then
+// costs ~4 VALU per activation load (add the wave-uniform tap delta, test the mask bit, select the sentinel)
+// and none per weight load (constant voffset, wave-uniform soffset).  With 64 MFMAs per K-step per wave this
+// keeps the vector ALU out of the matrix pipe's way (it was 3.4 VALU per MFMA with pointer arithmetic).
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // float4 global loads per thread per K-step
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // 16-B global loads per thread per K-step
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                      // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;    // BMODE 0: [2][BN][LDS_LD]   BMODE 1: [2][BK][BN]
   constexpr int B_TILE = BMODE == 0 ? BN * LDS_LD : BK * BN;
-  const float* __restrict__ gin = p.in + (long long)blockIdx.y * p.in_bs;
-  const float* __restrict__ gwt = p.wt + (long long)blockIdx.y * p.wt_bs;
-  float* __restrict__ gout = p.out + (long long)blockIdx.y * p.out_bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int gn = (p.Co + BN - 1) / BN;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = lin / gn, bn = lin - bm * gn;
-
-  // ---- per-thread gather coordinates for the A rows this thread stages -----------------
-  const int chunk = tid & 7;             // which float4 of the 32-wide K-step
+  const int chunk = tid & 7;             // which 16-B piece of the 32-float K-step
   const int row0 = tid >> 3;             // rows row0 + 32*j
-  int a_nb[A_LD], a_iy[A_LD], a_ix[A_LD];
-  {
-    const int hsws = p.Hs * p.Ws;
+  const int hsws = p.Hs * p.Ws;
+
+  // ---- descriptors (wave-uniform) ---------------------------------------------------------------
+  const int n0 = (bm * BM) / hsws;                                   // image of the block's first row
+  const long long img = (long long)p.Hi * p.Wi * p.ldi;              // floats per image of the gathered tensor
+  const float* a_base = p.in + (long long)blockIdx.y * p.in_bs + (long long)n0 * img;
+  const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(a_base, ((long long)(p.N - n0) * img) * 4);
+  const float* b_base = p.wt + (long long)blockIdx.y * p.wt_bs;
+  const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(b_base, (long long)(BMODE == 0 ? p.Co : p.kvalid) * p.ldw * 4);
+  float* __restrict__ gout = p.out + (long long)blockIdx.y * p.out_bs;
+
+  // ---- per-thread row state, computed once ------------------------------------------------------
+  unsigned a_off[A_LD];                  // byte offset of (row, tap 0,0, this chunk) from a_base
+  unsigned a_msk[A_LD];                  // bit t set <=> tap t of this row reads inside the image
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      const int m = bm * BM + row0 + 32 * j;
-      if (m < p.M) {
-        const int n = m / hsws, rem = m - n * hsws;
-        const int i = rem / p.Ws, jx = rem - i * p.Ws;
-        a_nb[j] = n * p.Hi; a_iy[j] = i * p.isy; a_ix[j] = jx * p.isx;
-      } else {
-        a_nb[j] = -1; a_iy[j] = 0; a_ix[j] = 0;
+  for (int j = 0; j < A_LD; ++j) {
+    const int m = bm * BM + row0 + 32 * j;
+    a_off[j] = 0; a_msk[j] = 0;
+    if (m < p.M) {
+      const int n = m / hsws, rem = m - n * hsws;
+      const int i = rem / p.Ws, jx = rem - i * p.Ws;
+      const int iy0 = i * p.isy, ix0 = jx * p.isx;
+      a_off[j] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * 4 + chunk * 16 * (C4 ? 0 : 1));
+      unsigned msk = 0;
+      for (int t = 0; t < p.ntaps; ++t) {
+        int dy, dx;
+        if (C4) { const int r = t / 3; dy = r - 1; dx = t - 3 * r - 1; }
+        else { dy = p.tap_dy[t]; dx = p.tap_dx[t]; }
+        if ((unsigned)(iy0 + dy) < (unsigned)p.Hi && (unsigned)(ix0 + dx) < (unsigned)p.Wi) msk |= 1u << t;
       }
+      a_msk[j] = msk;
     }
   }
-  f32x4 a_reg[A_LD], b_reg[B_LD];
-
-  auto load_tiles = [&](int it) {
-    int dy, dx, koff_a, koff_b;
-    bool tap_ok = true;
-    if (p.c4) {                          // first layer: Ci == 4, eight 3x3 taps per K-step
-      const int t = it * 8 + chunk;
-      tap_ok = t < p.ntaps;
-      const int r = t / 3;
-      dy = r - 1; dx = t - 3 * r - 1;
-      koff_a = 0; koff_b = it * 32 + chunk * 4;
+  unsigned b_off[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    if (BMODE == 0) {
+      const int co = bn * BN + row0 + 32 * j;
+      b_off[j] = co < p.Co ? (unsigned)(co * p.ldw * 4 + chunk * 16) : OOB;
     } else {
-      const int t = it / p.cpt;
-      const int c0 = (it - t * p.cpt) * 32;
-      dy = p.tap_dy[t]; dx = p.tap_dx[t];
-      koff_a = c0 + chunk * 4; koff_b = p.tap_w[t] + c0 + chunk * 4;
+      const int idx = tid + 256 * j;
+      const int k = idx / (BN / 4), col = bn * BN + (idx - k * (BN / 4)) * 4;
+      b_off[j] = col < p.Co ? (unsigned)((k * p.ldw + col) * 4) : OOB;
     }
+  }
+  // stem (C4): this thread's chunk IS a tap: taps chunk (K-step 0) and 8+chunk (K-step 1)
+  int c4_delta[2]; unsigned c4_bit[2];
+  if (C4) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = h * 8 + chunk, r = t / 3;
+      c4_delta[h] = ((r - 1) * p.Wi + (t - 3 * r - 1)) * p.ldi * 4;
+      c4_bit[h] = t < p.ntaps ? 1u << t : 0u;
+    }
+  }
+
+  // ---- wave-uniform K iterator: (tap, channel step) -> activation byte delta, weight byte offset ----
+  int k_tap = 0, k_c = 0;
+  int a_delta = C4 ? 0 : (p.tap_dy[0] * p.Wi + p.tap_dx[0]) * p.ldi * 4;
+  unsigned tap_bit = 1u;
+  unsigned a_soff = 0;                                  // channel offset inside the tap (bytes)
+  unsigned b_soff = C4 ? 0u : (unsigned)p.tap_w[0] * 4; // BMODE 0: K offset in the filter row; BMODE 1: k0*ldw
+  int kbase = 0;                                        // BMODE 1: first k of the step (K tail masking)
+
+  f32x4 a_reg[A_LD], b_reg[B_LD];
+  auto load_tiles = [&](int it) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int iy = a_iy[j] + dy, ix = a_ix[j] + dx;
-      const bool ok = tap_ok && a_nb[j] >= 0 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(gin + ((size_t)(a_nb[j] + iy) * p.Wi + ix) * p.ldi + koff_a);
-      a_reg[j] = v;
+      unsigned v;
+      if (C4) v = (a_msk[j] & c4_bit[it & 1]) ? a_off[j] + (unsigned)c4_delta[it & 1] : OOB;
+      else v = (a_msk[j] & tap_bit) ? a_off[j] + (unsigned)a_delta : OOB;
+      a_reg[j] = buf_load16(a_rs, v, a_soff);
     }
-    if (BMODE == 0) {
 #pragma unroll
-      for (int j = 0; j < B_LD; ++j) {
-        const int co = bn * BN + row0 + 32 * j;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (co < p.Co) v = *reinterpret_cast<const f32x4*>(gwt + (size_t)co * p.ldw + koff_b);
-        b_reg[j] = v;
-      }
-    } else {                             // wt rows are K, columns are output channels
-      const int kbase = koff_b - chunk * 4;
-#pragma unroll
-      for (int j = 0; j < B_LD; ++j) {
-        const int idx = tid + 256 * j;
-        const int k = idx / (BN / 4), n4 = (idx - k * (BN / 4)) * 4;
-        const int col = bn * BN + n4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kbase + k < p.kvalid && col < p.Co) v = *reinterpret_cast<const f32x4*>(gwt + (size_t)(kbase + k) * p.ldw + col);
-        b_reg[j] = v;
+    for (int j = 0; j < B_LD; ++j) {
+      unsigned v = b_off[j];
+      if (BMODE == 1) { const int k = (tid + 256 * j) / (BN / 4); v = (kbase + k < p.kvalid) ? v : OOB; }
+      b_reg[j] = buf_load16(b_rs, v, b_soff);
+    }
+    // advance to the next K-step (scalar unit)
+    if (C4) { b_soff += 128; }
+    else {
+      ++k_c; a_soff += 128;
+      if (BMODE == 0) b_soff += 128; else { b_soff += 32 * p.ldw * 4; kbase += 32; }
+      if (k_c == p.cpt) {
+        k_c = 0; a_soff = 0; ++k_tap;
+        if (k_tap < p.ntaps) {
+          a_delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * 4;
+          tap_bit = 1u << k_tap;
+          if (BMODE == 0) b_soff = (unsigned)p.tap_w[k_tap] * 4;
+        }
       }
     }
   };
@@ -207,7 +252,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     sc[ni] = (p.scale && co < p.Co) ? p.scale[co] : 1.f;
     sh[ni] = (p.shift && co < p.Co) ? p.shift[co] : 0.f;
   }
-  const int hsws = p.Hs * p.Ws;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -238,32 +282,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const size_t lds = (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const int nb = p.batch > 0 ? p.batch : 1;
-  const int tag = BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2));
+  const int tag = BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
 }
 
-// tile choice: narrow-N tiles for the 32/64-channel layers so no MFMA column is wasted
-inline int tile_bm(int Co) { return Co <= 32 ? 256 : 128; }
+// Tile choice.  Narrow-N tiles for the 32/64-channel layers so no MFMA column is wasted; for wide layers
+// the 128x128 tile unless the grid would leave most of a round of the 512 workgroup slots (256 CUs x 2
+// resident workgroups) empty: the 13x13 and 26x26 maps give 340-680 tiles of 128 rows, i.e. 66 % fill, and a
+// 64x128 tile (measured ~0.9x the per-tile efficiency) doubles the workgroup count.
+inline double fill(long long blocks) { return (double)blocks / (double)(((blocks + 511) / 512) * 512); }
+inline int tile_bm(int M, int Co) {
+  if (Co <= 32) return 256;
+  if (Co <= 64) return 128;
+  const long long gn = cdiv(Co, 128);
+  const double e128 = fill((long long)cdiv(M, 128) * gn), e64 = 0.9 * fill((long long)cdiv(M, 64) * gn);
+  return e64 > e128 ? 64 : 128;
+}
 
 }  // namespace
 
-int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(Co)); }
+int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
 
 int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.in && p.wt && p.out, "igemm: null pointer");
@@ -273,12 +327,25 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.ldi % 4 == 0 && p.ldw % 4 == 0, "igemm: ldi=%d ldw=%d must be multiples of 4 floats", p.ldi, p.ldw);
   DCN_CHECK_ARG(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wt & 15) == 0, "igemm: in/wt must be 16-byte aligned");
   DCN_CHECK_ARG(p.stats == nullptr || p.batch <= 1, "igemm: stats are not supported on batched launches");
+  // 32-bit offset windows: one M-tile spans at most ceil(BM/(Hs*Ws))+1 images of the gathered tensor
+  {
+    const long long img_bytes = (long long)p.Hi * p.Wi * p.ldi * 4;
+    const long long span = (256 / (p.Hs * p.Ws) + 2) * img_bytes;
+    DCN_CHECK_ARG(span < 0x7FFFFFF0LL, "igemm: image too large for 32-bit buffer offsets (%lld bytes per M-tile window)", span);
+    DCN_CHECK_ARG((long long)(p.bmode == 1 ? p.kvalid : p.Co) * p.ldw * 4 < 0x7FFFFFF0LL, "igemm: filter bank exceeds 2 GB");
+  }
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);
     if (p.Co <= 64) return launch_variant<128, 64, 2, 2, 1>(p, stream);
+    if (tile_bm(p.M, p.Co) == 64) return launch_variant<64, 128, 2, 2, 1>(p, stream);
     return launch_variant<128, 128, 2, 2, 1>(p, stream);
+  }
+  if (p.c4) {
+    DCN_CHECK_ARG(p.Co <= 32 && p.ntaps == 9 && p.bmode == 0, "igemm: c4 (stem) path needs Co <= 32 and 9 taps");
+    return launch_variant<256, 32, 4, 1, 0, true>(p, stream);
   }
   if (p.Co <= 32) return launch_variant<256, 32, 4, 1, 0>(p, stream);
   if (p.Co <= 64) return launch_variant<128, 64, 2, 2, 0>(p, stream);
+  if (tile_bm(p.M, p.Co) == 64) return launch_variant<64, 128, 2, 2, 0>(p, stream);
   return launch_variant<128, 128, 2, 2, 0>(p, stream);
 }

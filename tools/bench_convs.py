@@ -39,7 +39,11 @@ def shapes(size):
     return out
 
 
-def timeit(fn, iters=5):
+ITERS = 5
+
+
+def timeit(fn, iters=None):
+    iters = ITERS if iters is None else iters
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -51,11 +55,19 @@ def timeit(fn, iters=5):
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--only", type=str, default="", help="cin,cout,k,stride,h: benchmark a single shape")
+    ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tot = collections.Counter()
     rows = []
-    for (cin, cout, k, st, h), cnt in sorted(shapes(args.size).items(), key=lambda kv: -kv[0][4]):
+    table = shapes(args.size)
+    if args.only:
+        key = tuple(int(v) for v in args.only.split(","))
+        table = {key: table.get(key, 1)}
+    global ITERS
+    ITERS = args.iters
+    for (cin, cout, k, st, h), cnt in sorted(table.items(), key=lambda kv: -kv[0][4]):
         x = torch.randn(args.n, h, h, cin, device=dev)
         w = torch.randn((cout, 64) if cin == 4 else (cout, k, k, cin), device=dev) * 0.05
         ho = h // st
