@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
     return ap.parse_args()
 
 
@@ -89,9 +90,13 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"       # keep RCCL's version banner out of stdout (one JSON line only)
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from dcnet_amd import losses
     from dcnet_amd.lib import lib
@@ -107,7 +112,7 @@ def main():
     # freezing them gives DDP a static graph instead of find_unused_parameters=True (train_DCNet.py:483)
     from dcnet_amd.parallel import freeze_gradless, wrap_ddp
     freeze_gradless(model)
-    net = wrap_ddp(model, local_rank) if world > 1 else model
+    net = wrap_ddp(model, local_rank) if use_ddp else model
     visu = [p for p in model.visumodel.parameters() if p.requires_grad]
     vis_ids = {id(p) for p in visu}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in vis_ids]
@@ -129,7 +134,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.prof_enable(0)
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -198,8 +203,9 @@ def main():
                "loss": float(last.detach()), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.size, args.frames, args.cpu_steps)
-        print(json.dumps(res))
-    if world > 1:
+        sys.stdout.write(json.dumps(res) + "\n")
+        sys.stdout.flush()
+    if use_ddp:
         torch.distributed.destroy_process_group()
 
 
