@@ -124,7 +124,7 @@ void gemm_params(IgemmParams& p, const float* A, int lda, long long a_bs, const 
   p.in = A; p.ldi = lda; p.in_bs = a_bs; p.wt = B; p.ldw = ldb; p.wt_bs = b_bs; p.out = C; p.ldo = ldc; p.out_bs = c_bs;
   p.ldr = ldc;
   p.N = 1; p.Hi = 1; p.Wi = M; p.Ho = 1; p.Wo = M; p.Hs = 1; p.Ws = M; p.M = M;
-  p.Ci = K; p.Co = N; p.ntaps = 1; p.cpt = K / 32; p.kiters = p.cpt; p.batch = batch;
+  p.Ci = K; p.Co = N; p.ntaps = 1; p.batch = batch;
 }
 
 }  // namespace

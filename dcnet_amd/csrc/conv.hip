@@ -61,9 +61,9 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   p.act = act; p.slope = slope;
   if (cin == 4) {
     // weights are [Co][64]: 9 taps x 4 channels then zero padding (host prepares them)
-    p.c4 = 1; p.ldw = 64; p.kiters = 2; p.cpt = 1;
+    p.c4 = 1; p.ldw = 64;
   } else {
-    p.ldw = p.ntaps * cin; p.cpt = cin / 32; p.kiters = p.ntaps * p.cpt;
+    p.ldw = p.ntaps * cin; 
     for (int r = 0; r < ksize; ++r)
       for (int s = 0; s < ksize; ++s) {
         const int t = r * ksize + s;
@@ -91,7 +91,7 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   p.in = dy; p.wt = wt; p.out = dx;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
-  p.cpt = cout / 32; p.accumulate = accumulate;
+  p.accumulate = accumulate;
   if (stride == 1) {
     // dx[hi,wi] = sum_{r,s} dy[hi+pad-r, wi+pad-s] . w[:,r,s,:]
     p.Hs = h; p.Ws = wd; p.M = n * h * wd; p.ntaps = T;
@@ -100,7 +100,6 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
         const int t = r * ksize + s;
         p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
       }
-    p.kiters = p.ntaps * p.cpt;
     return igemm_launch(p, stream);
   }
   // stride 2: output pixels of parity class (a,b) only see taps with (a+pad-r), (b+pad-s) even.
@@ -125,7 +124,6 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
         // 1x1 stride 2: odd pixels get no gradient.  (Not used by DCNet; keep semantics right.)
         continue;
       }
-      q.kiters = q.ntaps * q.cpt;
       int rc = igemm_launch(q, stream);
       if (rc != DCN_OK) return rc;
     }

@@ -11,6 +11,7 @@
 
 #define IGEMM_MAX_TAPS 16
 
+
 struct IgemmParams {
   const float* in;        // gathered tensor, NHWC, pixel stride ldi
   const float* wt;        // [Co][ldw] K-contiguous rows
@@ -31,7 +32,8 @@ struct IgemmParams {
   int isy, isx;           // gathered pixel = (i*isy + dy[t], j*isx + dx[t])
   int Co, ldo, ldr, ldw;
   int M;                  // N*Hs*Ws
-  int ntaps, cpt, kiters; // cpt = Ci/32 k-steps per tap; kiters = ntaps*cpt (c4: Kpad/32)
+  int ntaps;              // taps; Ci must be a multiple of 32
+  int cpt, kiters;        // filled by igemm_launch: K-steps per tap / in total for the chosen K-step size
   int act; float slope;
   int accumulate, dense_out, c4;
   int tap_dy[IGEMM_MAX_TAPS], tap_dx[IGEMM_MAX_TAPS], tap_w[IGEMM_MAX_TAPS];

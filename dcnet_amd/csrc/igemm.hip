@@ -25,8 +25,6 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;   // voffset sentinel: beyond every descriptor (num_records <= 0x7FFFFFF0) -> load returns 0
@@ -45,10 +43,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // costs ~4 VALU per activation load (add the wave-uniform tap delta, test the mask bit, select the sentinel)
 // and none per weight load (constant voffset, wave-uniform soffset).  With 64 MFMAs per K-step per wave this
 // keeps the vector ALU out of the matrix pipe's way (it was 3.4 VALU per MFMA with pointer arithmetic).
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
+  constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
+  constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;   // 16-B global loads per thread per K-step
+  constexpr int A_LD = BM / RPP;                                       // 16-B global loads per thread per K-step
+  constexpr int B_LD = BMODE == 0 ? (BN >= RPP ? BN / RPP : 1) : BK * BN / 4 / 256;
+  constexpr bool B_PART = BMODE == 0 && BN < RPP;                      // only threads with row0 < BN stage B
+  constexpr int C4_STEPS = 64 / BK;
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                      // [2][BM][LDS_LD]
@@ -60,8 +64,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int gn = (p.Co + BN - 1) / BN;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = lin / gn, bn = lin - bm * gn;
-  const int chunk = tid & 7;             // which 16-B piece of the 32-float K-step
-  const int row0 = tid >> 3;             // rows row0 + 32*j
+  const int chunk = tid & (CPR - 1);     // which 16-B piece of the K-step row
+  const int row0 = tid / CPR;            // rows row0 + RPP*j
   const int hsws = p.Hs * p.Ws;
 
   // ---- descriptors (wave-uniform) ---------------------------------------------------------------
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   unsigned a_msk[A_LD];                  // bit t set <=> tap t of this row reads inside the image
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int m = bm * BM + row0 + 32 * j;
+    const int m = bm * BM + row0 + RPP * j;
     a_off[j] = 0; a_msk[j] = 0;
     if (m < p.M) {
       const int n = m / hsws, rem = m - n * hsws;
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     if (BMODE == 0) {
-      const int co = bn * BN + row0 + 32 * j;
-      b_off[j] = co < p.Co ? (unsigned)(co * p.ldw * 4 + chunk * 16) : OOB;
+      const int co = bn * BN + row0 + RPP * j;
+      b_off[j] = (co < p.Co && (!B_PART || row0 < BN)) ? (unsigned)(co * p.ldw * 4 + chunk * 16) : OOB;
     } else {
       const int idx = tid + 256 * j;
       const int k = idx / (BN / 4), col = bn * BN + (idx - k * (BN / 4)) * 4;
@@ -108,11 +112,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
   // stem (C4): this thread's chunk IS a tap: taps chunk (K-step 0) and 8+chunk (K-step 1)
-  int c4_delta[2]; unsigned c4_bit[2];
+  int c4_delta[C4_STEPS]; unsigned c4_bit[C4_STEPS];
   if (C4) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int t = h * 8 + chunk, r = t / 3;
+    for (int h = 0; h < C4_STEPS; ++h) {
+      const int t = h * CPR + chunk, r = t / 3;
       c4_delta[h] = ((r - 1) * p.Wi + (t - 3 * r - 1)) * p.ldi * 4;
       c4_bit[h] = t < p.ntaps ? 1u << t : 0u;
     }
@@ -131,7 +135,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       unsigned v;
-      if (C4) v = (a_msk[j] & c4_bit[it & 1]) ? a_off[j] + (unsigned)c4_delta[it & 1] : OOB;
+      if (C4) {
+        int dlt = c4_delta[0]; unsigned bit = c4_bit[0];
+#pragma unroll
+        for (int h = 1; h < C4_STEPS; ++h) if (it == h) { dlt = c4_delta[h]; bit = c4_bit[h]; }
+        v = (a_msk[j] & bit) ? a_off[j] + (unsigned)dlt : OOB;
+      }
       else v = (a_msk[j] & tap_bit) ? a_off[j] + (unsigned)a_delta : OOB;
       a_reg[j] = buf_load16(a_rs, v, a_soff);
     }
@@ -142,10 +151,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       b_reg[j] = buf_load16(b_rs, v, b_soff);
     }
     // advance to the next K-step (scalar unit)
-    if (C4) { b_soff += 128; }
+    if (C4) { b_soff += BK * 4; }
     else {
-      ++k_c; a_soff += 128;
-      if (BMODE == 0) b_soff += 128; else { b_soff += 32 * p.ldw * 4; kbase += 32; }
+      ++k_c; a_soff += BK * 4;
+      if (BMODE == 0) b_soff += BK * 4; else { b_soff += BK * p.ldw * 4; kbase += BK; }
       if (k_c == p.cpt) {
         k_c = 0; a_soff = 0; ++k_tap;
         if (k_tap < p.ntaps) {
@@ -161,10 +170,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     float* b = Bs + buf * B_TILE;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
-      *reinterpret_cast<f32x4*>(a + (row0 + 32 * j) * LDS_LD + chunk * 4) = a_reg[j];
+      *reinterpret_cast<f32x4*>(a + (row0 + RPP * j) * LDS_LD + chunk * 4) = a_reg[j];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      if (BMODE == 0) *reinterpret_cast<f32x4*>(b + (row0 + 32 * j) * LDS_LD + chunk * 4) = b_reg[j];
+      if (BMODE == 0) { if (!B_PART || row0 < BN) *reinterpret_cast<f32x4*>(b + (row0 + RPP * j) * LDS_LD + chunk * 4) = b_reg[j]; }
       else *reinterpret_cast<f32x4*>(b + (tid + 256 * j) * 4) = b_reg[j];
     }
   };
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const float* a = As + cur * BM * LDS_LD + a_frag;
     const float* b = Bs + cur * B_TILE + b_frag;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[MI], bf[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(a + mi * 32 * LDS_LD + kk * 8);
@@ -282,13 +291,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
-int launch_variant(const IgemmParams& p, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK>
+int launch_bk(const IgemmParams& p0, hipStream_t stream) {
+  IgemmParams p = p0;
+  p.cpt = p.c4 ? 1 : p.Ci / BK;
+  p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
+  constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const size_t lds = (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
@@ -296,10 +309,19 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
   const int tag = BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
+}
+
+// K-step choice (measured per layer, tools/bench_convs.py): 16 floats per step keeps the LDS footprint at
+// ~40 KB so three workgroups share a CU — better latency hiding on the long-M layers (+3..+60 %, most on the
+// narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
+int launch_variant(const IgemmParams& p, hipStream_t stream) {
+  if (p.M <= 16384) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
+  return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
 }
 
 // Tile choice.  Narrow-N tiles for the 32/64-channel layers so no MFMA column is wasted; for wide layers
@@ -321,7 +343,7 @@ int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
 
 int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.in && p.wt && p.out, "igemm: null pointer");
-  DCN_CHECK_ARG(p.M > 0 && p.Co > 0 && p.kiters > 0, "igemm: empty problem (M=%d Co=%d kiters=%d)", p.M, p.Co, p.kiters);
+  DCN_CHECK_ARG(p.M > 0 && p.Co > 0 && p.Ci > 0, "igemm: empty problem (M=%d Co=%d Ci=%d)", p.M, p.Co, p.Ci);
   DCN_CHECK_ARG(p.c4 ? (p.Ci == 4) : (p.Ci % 32 == 0), "igemm: Ci=%d must be a multiple of 32 (or 4 in c4 mode)", p.Ci);
   DCN_CHECK_ARG(p.ntaps >= 1 && p.ntaps <= IGEMM_MAX_TAPS, "igemm: ntaps=%d", p.ntaps);
   DCN_CHECK_ARG(p.ldi % 4 == 0 && p.ldw % 4 == 0, "igemm: ldi=%d ldw=%d must be multiples of 4 floats", p.ldi, p.ldw);
