@@ -19,6 +19,8 @@ OUT = os.path.join(HERE, "libdcnet_hip.so")
 SOURCES = ["igemm.hip", "conv.hip", "wgrad.hip", "bn.hip", "layout.hip", "coattn.hip", "score.hip",
            "sampling.cpp", "capi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+if os.environ.get("DCN_WGRAD_KP"):          # experiment knob: pixels per K-step of the weight-gradient kernel
+    FLAGS.append("-DWGRAD_KP=" + os.environ["DCN_WGRAD_KP"])
 
 
 def _hipcc() -> str:
