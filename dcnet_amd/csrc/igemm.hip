@@ -21,6 +21,7 @@
 // statistics, deterministic: no atomics), scale/shift (folded eval BatchNorm or bias),
 // LeakyReLU/ReLU, the shortcut add, and accumulate-into-destination.
 #include "igemm.h"
+#include <stdlib.h>
 #include "prof.h"
 
 namespace {
@@ -325,15 +326,18 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
 }
 
 // Tile choice.  Narrow-N tiles for the 32/64-channel layers so no MFMA column is wasted; for wide layers
-// the 128x128 tile unless the grid would leave most of a round of the 512 workgroup slots (256 CUs x 2
+// the 128x128 tile unless the grid would leave most of a round of the workgroup slots (256 CUs x 2-3
 // resident workgroups) empty: the 13x13 and 26x26 maps give 340-680 tiles of 128 rows, i.e. 66 % fill, and a
 // 64x128 tile (measured ~0.9x the per-tile efficiency) doubles the workgroup count.
-inline double fill(long long blocks) { return (double)blocks / (double)(((blocks + 511) / 512) * 512); }
+inline double fill(long long blocks, long long slots) { return (double)blocks / (double)(((blocks + slots - 1) / slots) * slots); }
 inline int tile_bm(int M, int Co) {
   if (Co <= 32) return 256;
   if (Co <= 64) return 128;
+  static const char* force = getenv("DCN_FORCE_BM");       // experiment knob (tools/bench_convs.py)
+  if (force && force[0]) return atoi(force);
   const long long gn = cdiv(Co, 128);
-  const double e128 = fill((long long)cdiv(M, 128) * gn), e64 = 0.9 * fill((long long)cdiv(M, 64) * gn);
+  const long long slots = M > 16384 ? 768 : 512;     // K-step 16 (long M): 3 workgroups per CU, else 2
+  const double e128 = fill((long long)cdiv(M, 128) * gn, slots), e64 = 0.9 * fill((long long)cdiv(M, 64) * gn, slots);
   return e64 > e128 ? 64 : 128;
 }
 
