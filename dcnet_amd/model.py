@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import os
 import random
+import threading
 from collections import OrderedDict
 from typing import List, Optional
 
@@ -285,10 +286,10 @@ class grounding_model(nn.Module):
         return final, sim_score, loc_score, corr_feat, flang_attn.view(B, -1, 1, 1), only_obj
 
     # ------------------------------------------------------------------------------------------
-    def _presample(self, n, g0, device, top_k=30, neg_n=10, neg_c=5):
+    def _presample_start(self, n, g0, top_k=30, neg_n=10, neg_c=5):
         """Draw the negatives of both correspondence heads from Python's global MT19937 stream, in the
-        reference's order (K9 then K14), natively on the host.  The draws depend only on shapes, so this
-        runs right after the backbone kernels have been queued and overlaps with them."""
+        reference's order (K9 then K14), natively and on a worker thread (ctypes drops the GIL inside the
+        call): the draws depend only on shapes, so they overlap with queueing and running the backbone."""
         hw = g0 * g0
         key = (n, hw, top_k, neg_n, neg_c)
         if key not in self._pinned:
@@ -299,8 +300,20 @@ class grounding_model(nn.Module):
                                  torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory())
         k9, k14 = self._pinned[key]
         st, arr = _mt_state()
-        lib().mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
-        lib().mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+        L = lib()
+
+        def work():
+            L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
+            L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        return th, st, arr, k9, k14
+
+    @staticmethod
+    def _presample_join(handle, device):
+        th, st, arr, k9, k14 = handle
+        th.join()
         _mt_restore(st, arr)
         return {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
 
@@ -354,10 +367,10 @@ class grounding_model(nn.Module):
         # The language branch is independent of the images and contains the only host syncs of the forward
         # (sequence lengths): run it first, while the device queue is empty.
         word_id, flang, context, embedded = self._language(word_id)
+        handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
-        presampled = self._presample(N, self.img_size // 32 if image.shape[-1] == self.img_size else image.shape[-1] // 32,
-                                     image.device)                               # host work under the backbone
         fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
+        presampled = self._presample_join(handle, image.device)
         frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
         corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
         outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)
