@@ -23,3 +23,19 @@ print("gaps > %.0f us: %d totalling %.1f ms; small gaps total %.1f ms" % (thr / 
                                                                       sum(g[0] for g in gaps if g[0] <= thr) / 1e6))
 for g in sorted(big, reverse=True)[:25]:
     print("  %8.1f us  after %-60s before %s" % (g[0] / 1e3, g[1], g[2]))
+
+if len(sys.argv) > 4:      # context: the kernels around the N largest gaps
+    srt = sorted(rows)
+    ends = {}
+    big2 = sorted(big, reverse=True)[: int(sys.argv[4])]
+    for g in big2:
+        # locate by gap size: find consecutive pair
+        cur = srt[0][1]
+        for i, (s_, e_, n_) in enumerate(srt):
+            if s_ - cur == g[0]:
+                print("---- gap %.1f us at +%.2f ms" % (g[0] / 1e3, (s_ - srt[0][0]) / 1e6))
+                for k in range(max(0, i - 6), min(len(srt), i + 5)):
+                    print("   %s %10.3f ms  dur %8.1f us  %s" % (">>" if k == i else "  ", (srt[k][0] - srt[0][0]) / 1e6,
+                                                                  (srt[k][1] - srt[k][0]) / 1e3, srt[k][2]))
+                break
+            cur = max(cur, e_)
