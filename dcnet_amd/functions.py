@@ -194,3 +194,128 @@ class ToNCHW(torch.autograd.Function):
     def backward(ctx, g):
         n, h, w, ld = ctx.shape
         return ops.nchw_to_nhwc(g.contiguous(), ld), None
+
+
+class LinearAct(torch.autograd.Function):
+    """nn.Linear (+ optional ReLU) on the conv engine's GEMM forms: forward NT, input gradient NN, weight
+    gradient TN.  x (M,K) with K % 32 == 0, weight (N,K) in nn.Linear's own layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        x = x.contiguous()
+        out = ops.gemm_nt(x, weight.detach(), None if bias is None else bias.detach(), ops.ACT_LEAKY if relu else ops.ACT_NONE)
+        ctx.save_for_backward(x, weight, out if relu else x.new_empty(0))
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        dz = dout.contiguous()
+        if ctx.relu:
+            dz = ops.act_bwd(out, dz, 0.0)
+        dx = ops.gemm_nn(dz, weight.detach()) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm_tn(dz, x)
+        db = dz.sum(0) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class BatchNormRowsAct(torch.autograd.Function):
+    """nn.BatchNorm1d (+ ReLU) over [rows][c] with the same HIP kernels as the 2-D case
+    (model/DCNet_model.py:270,274)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, training: bool, relu: bool):
+        x = x.contiguous()
+        act = ops.ACT_LEAKY if relu else ops.ACT_NONE
+        if training:
+            mi = ops.bn_finalize(ops.channel_stats(x), x.shape[0], gamma.detach(), beta.detach(), bn.eps, bn.momentum,
+                                 bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+            out = ops.scale_act(x, mi[2], mi[3], act, 0.0)
+            ctx.save_for_backward(x, mi, gamma, beta)
+        else:
+            ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
+            out = ops.scale_act(x, ss[0], ss[1], act, 0.0)
+            ctx.save_for_backward(out, ss, gamma, beta)
+        ctx.training, ctx.relu = training, relu
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, aux, gamma, beta = ctx.saved_tensors
+        gamma, beta = gamma.detach(), beta.detach()
+        dout = dout.contiguous()
+        act = ops.ACT_LEAKY if ctx.relu else ops.ACT_NONE
+        if ctx.training:
+            dx, dgamma, dbeta = ops.bn_act_bwd(a, dout, aux[0], aux[1], gamma, beta, act, 0.0)
+        else:
+            dz = ops.act_bwd(a, dout, 0.0) if ctx.relu else dout
+            dx = dz * aux[0]
+            dbeta = dz.sum(0)
+            gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
+            dgamma = (dz * (a - beta) / gs).sum(0)
+        return dx, dgamma, dbeta, None, None, None
+
+
+class BiLSTM(torch.autograd.Function):
+    """One-layer bidirectional LSTM over (N,L,I) with per-row lengths (packed-sequence semantics:
+    model/DCNet_model.py:172-183): input projections of all steps as one GEMM per direction, then per
+    step a recurrent GEMM (M = N rows) with the projected input added in the epilogue, and the gate
+    kernel.  Returns (N,L,2H).  Parameter order: w_ih, w_hh, b_ih, b_hh for the forward direction, then
+    the reverse direction."""
+
+    @staticmethod
+    def forward(ctx, x, lengths, *params):
+        n, L, I = x.shape
+        H = params[1].shape[1]
+        dev = x.device
+        x2d = x.contiguous().view(n * L, I)
+        out = torch.empty((n, L, 2 * H), dtype=torch.float32, device=dev)
+        acts = torch.empty((2, L, n, 5 * H), dtype=torch.float32, device=dev)
+        hs = torch.zeros((2, L + 1, n, H), dtype=torch.float32, device=dev)
+        cs = torch.zeros((2, L + 1, n, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((n, 4 * H), dtype=torch.float32, device=dev)
+        lens = lengths.contiguous()
+        for d in range(2):
+            w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * d:4 * d + 4])
+            xg = ops.gemm_nt(x2d, w_ih, (b_ih + b_hh)).view(n, L, 4 * H)
+            order = range(L) if d == 0 else range(L - 1, -1, -1)
+            for s, t in enumerate(order):
+                ops.gemm_nt(hs[d, s], w_hh, residual=xg[:, t], out=gates)
+                ops.lstm_cell_fwd(gates, cs[d, s], hs[d, s], lens, t, acts[d, s], cs[d, s + 1], hs[d, s + 1],
+                                  out[:, t, d * H:(d + 1) * H])
+        ctx.save_for_backward(x2d, lens, acts, hs, cs, *params)
+        ctx.dims = (n, L, I, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, lens, acts, hs, cs, *params = ctx.saved_tensors
+        n, L, I, H = ctx.dims
+        dev = x2d.device
+        dout = dout.contiguous()
+        dx = torch.empty((n * L, I), dtype=torch.float32, device=dev)
+        grads = []
+        for d in range(2):
+            w_ih, w_hh = params[4 * d].detach(), params[4 * d + 1].detach()
+            dxg = torch.empty((n, L, 4 * H), dtype=torch.float32, device=dev)
+            dw_hh = torch.zeros_like(w_hh)
+            dh = torch.zeros((n, H), dtype=torch.float32, device=dev)
+            dc = torch.zeros((n, H), dtype=torch.float32, device=dev)
+            dc2 = torch.empty_like(dc); dh2 = torch.empty_like(dh)
+            order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
+            for s in range(L - 1, -1, -1):
+                t = order[s]
+                g = dxg[:, t]                                   # (n,4H) view, row stride L*4H
+                ops.lstm_cell_bwd(dout[:, t, d * H:(d + 1) * H], dh, dc, acts[d, s], cs[d, s], lens, t, g, dc2, dh2)
+                ops.gemm_nn(g, w_hh, out=dh2, accumulate=True)                  # dh_{s-1} = dgates . W_hh + pass-through
+                ops.gemm_tn(g, hs[d, s], out=dw_hh, accumulate=True)            # dW_hh += dgates^T . h_{s-1}
+                dh, dh2 = dh2, dh
+                dc, dc2 = dc2, dc
+            dxg2 = dxg.view(n * L, 4 * H)
+            dw_ih = ops.gemm_tn(dxg2, x2d)
+            ops.gemm_nn(dxg2, w_ih, out=dx, accumulate=(d == 1))
+            db = dxg2.sum(0)
+            grads += [dw_ih, dw_hh, db, db]
+        return (dx.view(n, L, I), None) + tuple(grads)

@@ -30,7 +30,8 @@ import torch.nn.functional as F
 
 from . import ops
 from .darknet import Darknet
-from .functions import (CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, L2Norm, NormScoreFuse, ToNCHW)
+from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, L2Norm,
+                        LinearAct, NormScoreFuse, ToNCHW)
 from .lib import lib
 
 
@@ -78,14 +79,16 @@ class RNNEncoder(nn.Module):
         lens = lengths.tolist()
         if max(lens) != input_labels.size(1):
             raise AssertionError("max(len) must equal the padded width (model/DCNet_model.py:158)")
-        embedded = self.mlp(self.input_dropout(self.embedding(input_labels)))
-        if min(lens) == max(lens):
-            output, _ = self.rnn(embedded)
-        else:
-            packed = nn.utils.rnn.pack_padded_sequence(embedded, lengths.cpu(), batch_first=True, enforce_sorted=False)
-            output, _ = self.rnn(packed)
-            output, _ = nn.utils.rnn.pad_packed_sequence(output, batch_first=True, total_length=input_labels.size(1))
-            embedded = embedded * (torch.arange(input_labels.size(1), device=embedded.device)[None, :]
+        n, L = input_labels.shape
+        emb = self.input_dropout(self.embedding(input_labels))                              # :168-169
+        lin = self.mlp[0]
+        embedded = LinearAct.apply(emb.view(n * L, -1), lin.weight, lin.bias, True).view(n, L, -1)     # :170
+        r = self.rnn
+        output = BiLSTM.apply(embedded, lengths,
+                              r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
+                              r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse)
+        if min(lens) != max(lens):                                                          # :178 pad_packed zeros
+            embedded = embedded * (torch.arange(L, device=embedded.device)[None, :]
                                    < lengths[:, None]).unsqueeze(2).to(embedded.dtype)
         sent = output[torch.arange(output.size(0), device=output.device), lengths - 1]
         return sent, output, embedded
@@ -203,7 +206,13 @@ class grounding_model(nn.Module):
         max_len = int((word_id != 0).sum(1).max().item())                      # DCNet_model.py:474
         word_id = word_id[:, :max_len]
         raw_flang, context, embedded = self.textmodel(word_id)
-        flang = F.normalize(self.mapping_lang(raw_flang), p=2, dim=1)          # :485-487
+        ml = self.mapping_lang                                                  # Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU
+        z = LinearAct.apply(raw_flang, ml[0].weight, ml[0].bias, False)
+        z = BatchNormRowsAct.apply(z, ml[1].weight, ml[1].bias, ml[1], self.training, True)
+        z = ml[3](z)
+        z = LinearAct.apply(z, ml[4].weight, ml[4].bias, False)
+        z = BatchNormRowsAct.apply(z, ml[5].weight, ml[5].bias, ml[5], self.training, True)
+        flang = F.normalize(z, p=2, dim=1)                                      # :485-487
         return word_id, flang, context, embedded
 
     def _head(self, corr_raw: List[torch.Tensor], word_id, flang, context, embedded, premean=None):

@@ -315,3 +315,49 @@ def copy_slice(src_view, dst_view, accumulate=False):
     _rows(src_view, "copy_slice src"); _rows(dst_view, "copy_slice dst")
     lib().copy_slice(src_view.data_ptr(), src_view.stride(-2), dst_view.data_ptr(), dst_view.stride(-2), rows, c,
                      int(accumulate), _s())
+
+
+# ---- plain GEMMs / LSTM cell (language branch) ------------------------------------------------------------
+def gemm_nt(a, b, bias=None, act=ACT_NONE, residual=None, out=None, accumulate=False):
+    """out[M,N] (+)= act(a[M,K] @ b[N,K]^T + bias) + residual; a/residual/out may be row-strided views."""
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    lib().gemm_nt(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), m, n, k,
+                  _p(bias), act, _p(residual), 0 if residual is None else residual.stride(0), int(accumulate), _s())
+    return out
+
+
+def gemm_nn(a, b, out=None, accumulate=False, kvalid=0):
+    """out[M,N] (+)= a[M,K] @ b[K,N]."""
+    m, k = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    lib().gemm_nn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), m, n, k, kvalid,
+                  int(accumulate), _s())
+    return out
+
+
+def gemm_tn(a, b, out=None, accumulate=False):
+    """out[M,N] (+)= a[K,M]^T @ b[K,N]."""
+    k, m = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    lib().gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), m, n, k,
+                  int(accumulate), _s())
+    return out
+
+
+def lstm_cell_fwd(gates, c_prev, h_prev, lens, t, act, c_out, h_out, y):
+    n, h4 = gates.shape
+    lib().lstm_cell_fwd(gates.data_ptr(), c_prev.data_ptr(), h_prev.data_ptr(), _p(lens), t, act.data_ptr(), c_out.data_ptr(),
+                        h_out.data_ptr(), y.data_ptr(), y.stride(0), n, h4 // 4, _s())
+
+
+def lstm_cell_bwd(dy, dh_rec, dc_next, act, c_prev, lens, t, dgates, dc_prev, dh_pass):
+    n, h = c_prev.shape
+    lib().lstm_cell_bwd(dy.data_ptr(), dy.stride(0), _p(dh_rec), _p(dc_next), act.data_ptr(), c_prev.data_ptr(), _p(lens), t,
+                        dgates.data_ptr(), dc_prev.data_ptr(), dh_pass.data_ptr(), n, h, _s())

@@ -156,6 +156,26 @@ int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm, const flo
                          const float* q, const float* dscore, float* dx, int lddx, float* dq,
                          int64_t rows, int rows_per_image, int c, void* stream);
 
+/* ---- plain GEMMs on the conv engines and the LSTM cell (language branch) -------------------- */
+/* C[M][N] (+)= act(A[M][K].B[N][K]^T + bias[N]) + residual     nn.Linear (model/DCNet_model.py:131,194,269,273)
+ * and the BiLSTM input / recurrent projections (:134-137).  K % 32 == 0.  act: DCN_ACT_* with slope 0. */
+int dcn_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                const float* bias, int act, const float* residual, int ldr, int accumulate, void* stream);
+/* C[M][N] (+)= A[M][K].B[K][N] (rows k >= kvalid of B read as 0): input gradient of a Linear layer. */
+int dcn_gemm_nn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int kvalid,
+                int accumulate, void* stream);
+/* C[M][N] (+)= A[K][M]^T.B[K][N]: weight gradient of a Linear layer. */
+int dcn_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                int accumulate, void* stream);
+/* One LSTM step for n rows, gate order i,f,g,o like nn.LSTM: gates [n][4H] -> (c_out, h_out), y[n][ldy] = h
+ * (0 and state carried over for rows with t >= lens[r]; lens may be NULL), act [n][5H] saved for the backward. */
+int dcn_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_prev, const int64_t* lens, int t,
+                      float* act, float* c_out, float* h_out, float* y, int ldy, int n, int hidden, void* stream);
+/* Backward of one step: dgates [n][4H], dc_prev, dh_pass (gradient that bypasses a finished row). */
+int dcn_lstm_cell_bwd(const float* dy, int lddy, const float* dh_rec, const float* dc_next, const float* act,
+                      const float* c_prev, const int64_t* lens, int t, float* dgates, float* dc_prev, float* dh_pass,
+                      int n, int hidden, void* stream);
+
 /* ---- small data movers ------------------------------------------------------------------ */
 /* nearest x2 upsample of NHWC src (n,h,w,c) into dst (n,2h,2w,·) pixel stride ldd
  * (MyUpsample2, model/darknet.py:158-160; fused with the route concat :400-402). */

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
     assert set(SIGNATURES) <= set(names), sorted(set(SIGNATURES) - set(names))
     L = lib()
     assert L.version() >= 100
-    assert L.conv2d_stats_rows(2, 13, 13, 128, 3, 1) == 3          # pure host arithmetic, no GPU touched
+    assert L.conv2d_stats_rows(2, 13, 13, 128, 3, 1) in (3, 6)     # 338 rows in 128- or 64-row tiles: pure host arithmetic
     assert L.channel_stats_rows(1000) == 8
     assert L.coattn_e_size(2, 169) == 2 * 169 * 192
 

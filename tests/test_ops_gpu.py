@@ -229,3 +229,59 @@ def test_layout_and_movers(dev):
     d = torch.ones(2, 8, 10, 8, device=dev)
     ops.copy_slice(g[..., 16:24], d, True)
     _close(d, g[..., 16:24] + 1, 1e-6)
+
+
+def test_linear_bn1d_functions(dev):
+    from dcnet_amd.functions import BatchNormRowsAct, LinearAct
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(1024, 512); bn = torch.nn.BatchNorm1d(512)
+    x = _rand(64, 1024, seed=60)
+    xr = x.double().requires_grad_(True)
+    lr = torch.nn.Linear(1024, 512).double(); lr.load_state_dict(lin.state_dict()); br = torch.nn.BatchNorm1d(512).double()
+    ref = torch.relu(br(lr(xr)))
+    g = _rand(64, 512, seed=61)
+    ref.backward(g.double())
+    lin, bn = lin.to(dev), bn.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    z = LinearAct.apply(xd, lin.weight, lin.bias, False)
+    out = BatchNormRowsAct.apply(z, bn.weight, bn.bias, bn, True, True)
+    out.backward(g.to(dev))
+    _close(out, ref.float(), 2e-5, "linear+bn1d fwd")
+    _close(xd.grad, xr.grad.float(), 5e-5, "dx"); _close(lin.weight.grad, lr.weight.grad.float(), 5e-5, "dW")
+    _close(lin.bias.grad, lr.bias.grad.float(), 5e-5, "db")
+    _close(bn.weight.grad, br.weight.grad.float(), 5e-5, "dgamma"); _close(bn.running_var, br.running_var.float(), 1e-5, "rv")
+    # Linear + ReLU
+    x2 = _rand(40, 512, seed=62); l2 = torch.nn.Linear(512, 512)
+    x2r = x2.double().requires_grad_(True); l2r = torch.nn.Linear(512, 512).double(); l2r.load_state_dict(l2.state_dict())
+    r2 = torch.relu(l2r(x2r)); g2 = _rand(40, 512, seed=63); r2.backward(g2.double())
+    l2 = l2.to(dev); x2d = x2.to(dev).requires_grad_(True)
+    o2 = LinearAct.apply(x2d, l2.weight, l2.bias, True); o2.backward(g2.to(dev))
+    _close(o2, r2.float(), 2e-5); _close(x2d.grad, x2r.grad.float(), 5e-5); _close(l2.weight.grad, l2r.weight.grad.float(), 5e-5)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bilstm_matches_torch_packed_lstm(dev, ragged):
+    from dcnet_amd.functions import BiLSTM
+    torch.manual_seed(1)
+    n, L, I, H = 6, 20, 512, 512
+    ref = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True).double()
+    x = _rand(n, L, I, seed=70)
+    lengths = torch.tensor([20, 7, 20, 13, 1, 20]) if ragged else torch.full((n,), L)
+    xr = x.double().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lengths, batch_first=True, enforce_sorted=False)
+    yr, _ = ref(packed)
+    yr, _ = torch.nn.utils.rnn.pad_packed_sequence(yr, batch_first=True, total_length=L)
+    g = _rand(n, L, 2 * H, seed=71)
+    (yr * g.double()).sum().backward()
+    params = [p.detach().float().to(dev).requires_grad_(True) for p in
+              (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0,
+               ref.weight_ih_l0_reverse, ref.weight_hh_l0_reverse, ref.bias_ih_l0_reverse, ref.bias_hh_l0_reverse)]
+    xd = x.to(dev).requires_grad_(True)
+    y = BiLSTM.apply(xd, lengths.to(dev), *params)
+    (y * g.to(dev)).sum().backward()
+    _close(y, yr.float(), 2e-5, "lstm out")
+    _close(xd.grad, xr.grad.float(), 1e-4, "lstm dx")
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+             "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
+    for p, nm in zip(params, names):
+        _close(p.grad, getattr(ref, nm).grad.float(), 1e-4, nm)
