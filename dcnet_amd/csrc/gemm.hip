@@ -47,14 +47,14 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ dh_rec,
                                                             const float* __restrict__ dc_next, const float* __restrict__ act,
                                                             const float* __restrict__ c_prev, const int64_t* __restrict__ lens, int t,
-                                                            float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                                            float* __restrict__ dgates, int ldg, float* __restrict__ dc_prev,
                                                             float* __restrict__ dh_pass, int n, int H) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * H) return;
   const int r = idx / H, k = idx - r * H;
   const bool live = lens == nullptr || t < lens[r];
   const float* a = act + (size_t)r * 5 * H;
-  float* dg = dgates + (size_t)r * 4 * H;
+  float* dg = dgates + (size_t)r * ldg;
   const float dhr = dh_rec ? dh_rec[idx] : 0.f, dcn = dc_next ? dc_next[idx] : 0.f;
   if (!live) {             // state was copied through: gradients pass straight to the previous step
     dg[k] = 0.f; dg[H + k] = 0.f; dg[2 * H + k] = 0.f; dg[3 * H + k] = 0.f;
@@ -109,11 +109,11 @@ extern "C" int dcn_lstm_cell_fwd(const float* gates, const float* c_prev, const 
 }
 
 extern "C" int dcn_lstm_cell_bwd(const float* dy, int lddy, const float* dh_rec, const float* dc_next, const float* act,
-                                 const float* c_prev, const int64_t* lens, int t, float* dgates, float* dc_prev, float* dh_pass,
-                                 int n, int hidden, void* stream) {
+                                 const float* c_prev, const int64_t* lens, int t, float* dgates, int ldg, float* dc_prev,
+                                 float* dh_pass, int n, int hidden, void* stream) {
   DCN_CHECK_ARG(dy && act && c_prev && dgates && dc_prev && dh_pass && n > 0 && hidden > 0, "lstm_cell_bwd: bad argument");
   hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(cdiv((int64_t)n * hidden, 256)), dim3(256), 0, (hipStream_t)stream,
-                     dy, lddy, dh_rec, dc_next, act, c_prev, lens, t, dgates, dc_prev, dh_pass, n, hidden);
+                     dy, lddy, dh_rec, dc_next, act, c_prev, lens, t, dgates, ldg > 0 ? ldg : 4 * hidden, dc_prev, dh_pass, n, hidden);
   DCN_CHECK_LAUNCH("lstm_cell_bwd");
   return DCN_OK;
 }

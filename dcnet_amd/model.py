@@ -75,10 +75,11 @@ class RNNEncoder(nn.Module):
         self.num_dirs = 2 if bidirectional else 1
 
     def forward(self, input_labels):
+        # No host synchronisation: lengths stay on the device and the LSTM kernels mask finished rows
+        # themselves.  The reference trims the batch to its longest row first (model/DCNet_model.py:474-475);
+        # computing the padded steps instead changes nothing that is consumed (padded outputs are zero,
+        # PhraseAttention renormalises over the valid positions, the sentence vector is read at len-1).
         lengths = (input_labels != 0).sum(1)
-        lens = lengths.tolist()
-        if max(lens) != input_labels.size(1):
-            raise AssertionError("max(len) must equal the padded width (model/DCNet_model.py:158)")
         n, L = input_labels.shape
         emb = self.input_dropout(self.embedding(input_labels))                              # :168-169
         lin = self.mlp[0]
@@ -87,9 +88,8 @@ class RNNEncoder(nn.Module):
         output = BiLSTM.apply(embedded, lengths,
                               r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
                               r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse)
-        if min(lens) != max(lens):                                                          # :178 pad_packed zeros
-            embedded = embedded * (torch.arange(L, device=embedded.device)[None, :]
-                                   < lengths[:, None]).unsqueeze(2).to(embedded.dtype)
+        embedded = embedded * (torch.arange(L, device=embedded.device)[None, :]
+                               < lengths[:, None]).unsqueeze(2).to(embedded.dtype)              # :178 pad_packed zeros
         sent = output[torch.arange(output.size(0), device=output.device), lengths - 1]
         return sent, output, embedded
 
@@ -190,6 +190,7 @@ class grounding_model(nn.Module):
                                    nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
         self._pinned = {}
+        self._pin_event = None
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
@@ -203,9 +204,7 @@ class grounding_model(nn.Module):
         return self._coord_cache[key]
 
     def _language(self, word_id):
-        max_len = int((word_id != 0).sum(1).max().item())                      # DCNet_model.py:474
-        word_id = word_id[:, :max_len]
-        raw_flang, context, embedded = self.textmodel(word_id)
+        raw_flang, context, embedded = self.textmodel(word_id)                  # DCNet_model.py:474-476 (untrimmed, see RNNEncoder)
         ml = self.mapping_lang                                                  # Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU
         z = LinearAct.apply(raw_flang, ml[0].weight, ml[0].bias, False)
         z = BatchNormRowsAct.apply(z, ml[1].weight, ml[1].bias, ml[1], self.training, True)
@@ -308,6 +307,8 @@ class grounding_model(nn.Module):
             self._pinned[key] = (torch.empty((n // 2, top_k, neg_n), dtype=torch.int64).pin_memory(),
                                  torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory())
         k9, k14 = self._pinned[key]
+        if self._pin_event is not None:
+            self._pin_event.synchronize()        # the previous forward's upload of these buffers has completed
         st, arr = _mt_state()
         L = lib()
 
@@ -319,12 +320,13 @@ class grounding_model(nn.Module):
         th.start()
         return th, st, arr, k9, k14
 
-    @staticmethod
-    def _presample_join(handle, device):
+    def _presample_join(self, handle, device):
         th, st, arr, k9, k14 = handle
         th.join()
         _mt_restore(st, arr)
-        return {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
+        out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
+        ev = torch.cuda.Event(); ev.record()
+        return out, ev
 
     def _interframe_sampling(self, fv0, presampled, top_k=30, neg_n=10):
         """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E)."""
@@ -373,13 +375,13 @@ class grounding_model(nn.Module):
         N = image.size(0)
         if N % 2:
             raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")
-        # The language branch is independent of the images and contains the only host syncs of the forward
-        # (sequence lengths): run it first, while the device queue is empty.
+        # The forward issues no host synchronisation at all (lengths are handled on the device), so the
+        # host can queue step k+1 while the GPU still runs step k.
         word_id, flang, context, embedded = self._language(word_id)
         handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
         fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
-        presampled = self._presample_join(handle, image.device)
+        presampled, self._pin_event = self._presample_join(handle, image.device)
         frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
         corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
         outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)

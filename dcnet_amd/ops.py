@@ -360,4 +360,4 @@ def lstm_cell_fwd(gates, c_prev, h_prev, lens, t, act, c_out, h_out, y):
 def lstm_cell_bwd(dy, dh_rec, dc_next, act, c_prev, lens, t, dgates, dc_prev, dh_pass):
     n, h = c_prev.shape
     lib().lstm_cell_bwd(dy.data_ptr(), dy.stride(0), _p(dh_rec), _p(dc_next), act.data_ptr(), c_prev.data_ptr(), _p(lens), t,
-                        dgates.data_ptr(), dc_prev.data_ptr(), dh_pass.data_ptr(), n, h, _s())
+                        dgates.data_ptr(), dgates.stride(0), dc_prev.data_ptr(), dh_pass.data_ptr(), n, h, _s())

@@ -171,10 +171,10 @@ int dcn_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int 
  * (0 and state carried over for rows with t >= lens[r]; lens may be NULL), act [n][5H] saved for the backward. */
 int dcn_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_prev, const int64_t* lens, int t,
                       float* act, float* c_out, float* h_out, float* y, int ldy, int n, int hidden, void* stream);
-/* Backward of one step: dgates [n][4H], dc_prev, dh_pass (gradient that bypasses a finished row). */
+/* Backward of one step: dgates [n][4H] (row stride ldg), dc_prev, dh_pass (gradient that bypasses a finished row). */
 int dcn_lstm_cell_bwd(const float* dy, int lddy, const float* dh_rec, const float* dc_next, const float* act,
-                      const float* c_prev, const int64_t* lens, int t, float* dgates, float* dc_prev, float* dh_pass,
-                      int n, int hidden, void* stream);
+                      const float* c_prev, const int64_t* lens, int t, float* dgates, int ldg, float* dc_prev,
+                      float* dh_pass, int n, int hidden, void* stream);
 
 /* ---- small data movers ------------------------------------------------------------------ */
 /* nearest x2 upsample of NHWC src (n,h,w,c) into dst (n,2h,2w,·) pixel stride ldd
