@@ -191,12 +191,19 @@ class grounding_model(nn.Module):
         self._coord_cache = {}
         self._pinned = {}
         self._pin_event = None
+        self._streams = {}
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
         self.last_choices = {}
 
     # ------------------------------------------------------------------------------------------
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
     def _coord(self, h, w, device):
         key = (h, w, str(device))
         if key not in self._coord_cache:
@@ -376,12 +383,21 @@ class grounding_model(nn.Module):
         if N % 2:
             raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")
         # The forward issues no host synchronisation at all (lengths are handled on the device), so the
-        # host can queue step k+1 while the GPU still runs step k.
-        word_id, flang, context, embedded = self._language(word_id)
+        # host can queue step k+1 while the GPU still runs step k.  The language branch (a chain of ~100
+        # latency-bound small kernels) goes on a side stream: it runs under the backbone, and autograd
+        # replays its backward on the same side stream under the backbone's backward.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(image.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            word_id, flang, context, embedded = self._language(word_id)
         handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
         fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
         presampled, self._pin_event = self._presample_join(handle, image.device)
+        main.wait_stream(side)
+        for t_ in (flang, context, embedded):
+            t_.record_stream(main)
         frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
         corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
         outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)

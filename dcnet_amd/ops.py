@@ -52,7 +52,8 @@ _scratch = {}
 def scratch(n_floats: int, device, slot: int = 0) -> torch.Tensor:
     """A per-device, per-slot grow-only fp32 scratch buffer (ops are stream-ordered, so one
     buffer per slot can be shared by every call on the stream)."""
-    key = (torch.device(device).index, slot)
+    # one buffer per (device, slot, stream): kernels on different streams may run concurrently
+    key = (torch.device(device).index, slot, torch.cuda.current_stream().cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
