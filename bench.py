@@ -162,12 +162,14 @@ def main():
                  3: "igemm_kernel<128,128,2,2,1>", 4: "igemm_kernel<128,64,2,2,1>", 5: "wgrad_kernel<*>",
                  6: "igemm_kernel<64,128,2,2,0>", 7: "igemm_kernel<64,128,2,2,1>",
                  8: "l2norm_score_fwd_kernel", 9: "l2norm_score_bwd_kernel", 10: "scale_act_kernel",
-                 11: "bn_act_bwd_apply_kernel", 12: "exp_sums_kernel"}
+                 11: "bn_act_bwd_apply_kernel", 12: "exp_sums_kernel",
+                 13: "igemm_kernel<...> (LSTM-step GEMMs, <1024 rows, side stream)",
+                 14: "wgrad_kernel<...> (LSTM-step GEMMs, side stream)"}
         kern = {}
         for t, nm in names.items():
             if counts[t]:
-                unit = "TFLOP/s" if t <= 7 else "GB/s"
-                rate = work[t] / (ms[t] * 1e-3) / (1e12 if t <= 7 else 1e9)
+                unit = "TFLOP/s" if (t <= 7 or t >= 13) else "GB/s"
+                rate = work[t] / (ms[t] * 1e-3) / (1e12 if (t <= 7 or t >= 13) else 1e9)
                 kern[nm] = {"launches_per_step": counts[t] / args.steps, "avg_ms": ms[t] / counts[t],
                             "ms_per_step": ms[t] / args.steps, "achieved": rate, "unit": unit}
         dom = 0   # the 128x128 NT tile of the conv engine carries most of the FLOPs

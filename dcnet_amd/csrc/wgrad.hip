@@ -282,7 +282,7 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
     attr_done = true;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
-  const int pid = prof_begin(5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
+  const int pid = prof_begin(p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
   hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");

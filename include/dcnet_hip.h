@@ -189,7 +189,8 @@ int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows,
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
  * returns, per kernel tag (16 slots: 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
- * 5 weight-gradient/TN GEMM, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward, 12 exp+sums),
+ * 5 weight-gradient/TN GEMM, 6-7 64x128 tiles, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward,
+ * 12 exp+sums, 13/14 small latency-bound GEMMs of the LSTM steps),
  * the launch count, the summed kernel milliseconds and the summed algorithmic work (FLOP or bytes). */
 int dcn_prof_enable(int on);
 int dcn_prof_collect(int64_t* counts, double* ms, double* work);
