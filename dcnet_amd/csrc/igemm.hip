@@ -308,7 +308,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = p.M < 1024 ? 13 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
