@@ -165,3 +165,32 @@ def test_train_forward_backward_matches_oracle(dev):
         assert maxdiff(psd[k], sdo[k]) < 1e-4 * max(1.0, float(sdo[k].abs().max())), k
     assert maxdiff(psd["visumodel.module_list.0.batch_norm_0.running_mean"],
                    torch.from_numpy(gold["bn_rm::visumodel.module_list.0.batch_norm_0"])) < 1e-4
+
+
+def test_large_input_608_nframe_and_pairs(dev):
+    """BASELINE config 4 geometry (608x608: P = 7581, 76x76 = 5776-position co-attention) at a size the CPU
+    oracle finishes in seconds: the n_frame model with T = 4 and the pair model with N = 2, eval mode."""
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    size = 608
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(4, size, n_queries=1, seed=608)
+    m = build_product(size, sd, dev, test_model=True).eval()
+    with torch.no_grad():
+        outbox, sim, loc, corr, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev), 4)
+        o = O.grounding_forward_nframe({k: v.clone() for k, v in sd.items()}, image, word_id, 4)
+    assert outbox[2].shape == (1, 15, 76, 76)
+    for s in range(3):
+        assert maxdiff(outbox[s], o["outbox"][s]) < TOL and maxdiff(sim[s], o["sim_score"][s]) < TOL
+        assert maxdiff(loc[s], o["loc_score"][s]) < TOL and maxdiff(corr[s], o["corr_feat"][s]) < TOL
+    del m
+    image2, word2, mask2 = synth_inputs(2, size, seed=609)
+    m2 = build_product(size, sd, dev).eval()
+    random.seed(3)
+    with torch.no_grad():
+        ob2, sim2, loc2, oo2 = m2(image2.to(dev), word2.to(dev), mask2.to(dev))
+        o2 = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image2, word2, training=False, sample=False)
+    for s in range(3):
+        assert maxdiff(ob2[s], o2["outbox"][s]) < TOL and maxdiff(loc2[s], o2["loc_score"][s]) < TOL
+    iou = O.bbox_iou_xyxy(O.decode_boxes([x.cpu() for x in ob2], size), O.decode_boxes(o2["outbox"], size))
+    assert float(iou.min()) > 0.999
