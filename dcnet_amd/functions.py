@@ -319,3 +319,20 @@ class BiLSTM(torch.autograd.Function):
             db = dxg2.sum(0)
             grads += [dw_ih, dw_hh, db, db]
         return (dx.view(n, L, I), None) + tuple(grads)
+
+
+class LocModule(torch.autograd.Function):
+    """loc[n,i] = < normalize(relu(E_i . Mp_n + bp)), q_n >  — the fused rank-8 location module
+    (csrc/locmod.hip; reference model/DCNet_model.py:581-594).  E (P,8), Mp (N,8,512), bp (512), q (N,512)."""
+
+    @staticmethod
+    def forward(ctx, E, Mp, bp, q):
+        E, Mp, bp, q = E.contiguous(), Mp.contiguous(), bp.contiguous(), q.contiguous()
+        ctx.save_for_backward(E, Mp, bp, q)
+        return ops.locmod_fwd(E, Mp, bp, q)
+
+    @staticmethod
+    def backward(ctx, dloc):
+        E, Mp, bp, q = ctx.saved_tensors
+        dE_part, dsum = ops.locmod_bwd(E, Mp, bp, q, dloc.contiguous())
+        return dE_part.sum(0), dsum[:, :8], dsum[:, 8].sum(0), dsum[:, 9]

@@ -47,6 +47,9 @@ SIGNATURES = {
     "dcn_upsample2_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
     "dcn_upsample2_nhwc_bwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "dcn_copy_slice": (I, [P, I, P, I, L, I, I, P]),
+    "dcn_locmod_fwd": (I, [P, P, P, P, P, I, I, I, P]),
+    "dcn_locmod_bwd_ws": (L, [I, I]),
+    "dcn_locmod_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "dcn_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
     "dcn_gemm_nn": (I, [P, I, P, I, P, I, I, I, I, I, I, P]),
     "dcn_gemm_tn": (I, [P, I, P, I, P, I, I, I, I, I, P]),

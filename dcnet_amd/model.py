@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import ops
 from .darknet import Darknet
 from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, L2Norm,
-                        LinearAct, NormScoreFuse, ToNCHW)
+                        LinearAct, LocModule, NormScoreFuse, ToNCHW)
 from .lib import lib
 
 
@@ -277,15 +277,31 @@ class grounding_model(nn.Module):
             ce = F.batch_norm(ce, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
         E8 = F.normalize(F.relu(ce), p=2, dim=1)                                 # (P,8)   :578
         lt, bn2 = self.loc_text_embedding[0], self.loc_text_embedding[1]
-        # rel[n,i,:] = sum_j <E_i,E_j> obj[n,j] W[:,j] + b  =  E_i . (E^T diag(obj_n) W^T) + b
-        M = torch.matmul((E8.t().unsqueeze(0) * obj_map.unsqueeze(1)), lt.weight.t())     # (B,8,512)
-        rel = torch.matmul(E8.unsqueeze(0), M) + lt.bias                         # (B,P,512)  :581-585
-        rel = F.relu(F.batch_norm(rel.reshape(B * P, -1), bn2.running_mean, bn2.running_var, bn2.weight, bn2.bias,
-                                  self.training, bn2.momentum, bn2.eps)).view(B, P, -1)
+        # rel[n,i,:] = sum_j <E_i,E_j> obj[n,j] W[:,j] + b  =  E_i . (E^T diag(obj_n) W^T) + b = E_i . M_n + b
+        M = torch.matmul((E8.t().unsqueeze(0) * obj_map.unsqueeze(1)), lt.weight.t())     # (B,8,512)   :581-585
+        # BatchNorm1d over the B*P rows of rel, from the 8x8 moments of E (no (B,P,512) tensor): with
+        # s1 = sum_i E_i and S2 = sum_i E_i E_i^T,  sum(rel) = sum_n s1.M_n + BP b,
+        # sum(rel^2) = sum_n M_n^T S2 M_n + 2 b sum_n s1.M_n + BP b^2   (fp64 on these tiny tensors)
+        cnt = float(B * P)
         if self.training:
-            bn2.num_batches_tracked += 1
-        rel = F.normalize(rel, p=2, dim=2)                                       # over channels  :589
-        loc_map = torch.sum(rel * flang_loc.unsqueeze(1), dim=2)                 # (B,P)   :593-594
+            Ed, Md, bd = E8.double(), M.double(), lt.bias.double()
+            s1 = Ed.sum(0); S2 = Ed.t() @ Ed
+            t1 = torch.einsum("k,nkc->c", s1, Md)
+            mean = t1 / cnt + bd
+            ex2 = (torch.einsum("nkc,kl,nlc->c", Md, S2, Md) + 2 * bd * t1) / cnt + bd * bd
+            var = torch.clamp(ex2 - mean * mean, min=0)
+            with torch.no_grad():
+                bn2.running_mean.mul_(1 - bn2.momentum).add_(bn2.momentum * mean.float())
+                bn2.running_var.mul_(1 - bn2.momentum).add_(bn2.momentum * (var * cnt / (cnt - 1)).float())
+                bn2.num_batches_tracked += 1
+            scale = bn2.weight.double() * torch.rsqrt(var + bn2.eps)
+            shift = bn2.bias.double() - mean * scale
+            scale, shift = scale.float(), shift.float()
+        else:
+            scale = bn2.weight * torch.rsqrt(bn2.running_var + bn2.eps)
+            shift = bn2.bias - bn2.running_mean * scale
+        # relu(bn(rel)) -> normalize over channels -> <., flang_loc>, fused on the device   :585-594
+        loc_map = LocModule.apply(E8, M * scale, lt.bias * scale + shift, flang_loc)       # (B,P)
         mn = loc_map.min(dim=1, keepdim=True)[0]; mx = loc_map.max(dim=1, keepdim=True)[0]
         loc_map = (loc_map - mn) / (mx - mn + 1e-6)                              # :597
         loc_score, st = [], 0

@@ -362,3 +362,23 @@ def lstm_cell_bwd(dy, dh_rec, dc_next, act, c_prev, lens, t, dgates, dc_prev, dh
     n, h = c_prev.shape
     lib().lstm_cell_bwd(dy.data_ptr(), dy.stride(0), _p(dh_rec), _p(dc_next), act.data_ptr(), c_prev.data_ptr(), _p(lens), t,
                         dgates.data_ptr(), dgates.stride(0), dc_prev.data_ptr(), dh_pass.data_ptr(), n, h, _s())
+
+
+# ---- location module core ------------------------------------------------------------------------------------
+def locmod_fwd(E, Mp, bp, q):
+    n, _, c = Mp.shape
+    p = E.shape[0]
+    loc = torch.empty((n, p), dtype=torch.float32, device=E.device)
+    lib().locmod_fwd(E.data_ptr(), Mp.data_ptr(), bp.data_ptr(), q.data_ptr(), loc.data_ptr(), n, p, c, _s())
+    return loc
+
+
+def locmod_bwd(E, Mp, bp, q, dloc):
+    n, _, c = Mp.shape
+    p = E.shape[0]
+    dE_part = torch.empty((n, p, 8), dtype=torch.float32, device=E.device)
+    dsum = torch.empty((n, 10, c), dtype=torch.float32, device=E.device)
+    ws = scratch(lib().locmod_bwd_ws(n, p), E.device, slot=0)
+    lib().locmod_bwd(E.data_ptr(), Mp.data_ptr(), bp.data_ptr(), q.data_ptr(), dloc.data_ptr(), dE_part.data_ptr(),
+                     dsum.data_ptr(), ws.data_ptr(), n, p, c, _s())
+    return dE_part, dsum

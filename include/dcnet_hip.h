@@ -156,6 +156,18 @@ int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm, const flo
                          const float* q, const float* dscore, float* dx, int lddx, float* dq,
                          int64_t rows, int rows_per_image, int c, void* stream);
 
+/* ---- location module core (rank-8 form of model/DCNet_model.py:581-594) ------------------------- */
+/* loc[n,i] = < normalize_c( relu( E[i,:8] . Mp[n,:8,:c] + bp[:c] ) ), q[n,:c] >   for i < p, c == 512.
+ * Mp/bp already carry the BatchNorm1d affine (train-mode statistics follow from the 8x8 moments of E on the
+ * host side).  Replaces bmm (P x P) + Linear(P,512) + BatchNorm1d + ReLU + F.normalize + the phrase dot. */
+int dcn_locmod_fwd(const float* E, const float* Mp, const float* bp, const float* q, float* loc,
+                   int n, int p, int c, void* stream);
+/* Gradients for dloc [n][p]: dE_part [n][p][8] (sum over n = dE), dsum [n][10][c] with rows 0-7 = dMp[n],
+ * row 8 = per-image part of dbp (sum over n), row 9 = dq[n].  ws: dcn_locmod_bwd_ws(n, p) floats. */
+int64_t dcn_locmod_bwd_ws(int n, int p);
+int dcn_locmod_bwd(const float* E, const float* Mp, const float* bp, const float* q, const float* dloc,
+                   float* dE_part, float* dsum, float* ws, int n, int p, int c, void* stream);
+
 /* ---- plain GEMMs on the conv engines and the LSTM cell (language branch) -------------------- */
 /* C[M][N] (+)= act(A[M][K].B[N][K]^T + bias[N]) + residual     nn.Linear (model/DCNet_model.py:131,194,269,273)
  * and the BiLSTM input / recurrent projections (:134-137).  K % 32 == 0.  act: DCN_ACT_* with slope 0. */

@@ -285,3 +285,21 @@ def test_bilstm_matches_torch_packed_lstm(dev, ragged):
              "bias_ih_l0_reverse", "bias_hh_l0_reverse"]
     for p, nm in zip(params, names):
         _close(p.grad, getattr(ref, nm).grad.float(), 1e-4, nm)
+
+
+def test_location_module_core(dev):
+    from dcnet_amd.functions import LocModule
+    n, p, c = 3, 341, 512
+    E = F.normalize(torch.relu(_rand(p, 8, seed=80)) + 0.01, dim=1)
+    M = _rand(n, 8, c, seed=81) * 0.3; b = _rand(c, seed=82) * 0.1; q = F.normalize(_rand(n, c, seed=83), dim=1)
+    Er, Mr, br, qr = (t.double().requires_grad_(True) for t in (E, M, b, q))
+    rel = torch.relu(torch.matmul(Er.unsqueeze(0), Mr) + br)              # (n,p,c)
+    ref = (F.normalize(rel, dim=2) * qr.unsqueeze(1)).sum(2)
+    g = _rand(n, p, seed=84)
+    (ref * g.double()).sum().backward()
+    Ed, Md, bd, qd = (t.to(dev).requires_grad_(True) for t in (E, M, b, q))
+    out = LocModule.apply(Ed, Md, bd, qd)
+    (out * g.to(dev)).sum().backward()
+    _close(out, ref.float(), 1e-5, "loc fwd")
+    _close(Ed.grad, Er.grad.float(), 5e-5, "dE"); _close(Md.grad, Mr.grad.float(), 5e-5, "dM")
+    _close(bd.grad, br.grad.float(), 5e-5, "db"); _close(qd.grad, qr.grad.float(), 5e-5, "dq")
