@@ -288,7 +288,7 @@ class grounding_model(nn.Module):
             s1 = Ed.sum(0); S2 = Ed.t() @ Ed
             t1 = torch.einsum("k,nkc->c", s1, Md)
             mean = t1 / cnt + bd
-            ex2 = (torch.einsum("nkc,kl,nlc->c", Md, S2, Md) + 2 * bd * t1) / cnt + bd * bd
+            ex2 = ((Md * torch.matmul(S2, Md)).sum((0, 1)) + 2 * bd * t1) / cnt + bd * bd     # M_n^T S2 M_n per channel
             var = torch.clamp(ex2 - mean * mean, min=0)
             with torch.no_grad():
                 bn2.running_mean.mul_(1 - bn2.momentum).add_(bn2.momentum * mean.float())
