@@ -123,3 +123,39 @@ def test_shard_indices_match_distributed_sampler():
         for r in range(w):
             ref = list(DistributedSampler(range(n), num_replicas=w, rank=r, shuffle=False))
             assert shard_indices(n, r, w) == ref
+
+
+def test_lr_schedule_and_optimizer_groups():
+    from dcnet_amd import train as T
+    from model.DCNet_model import grounding_model
+    m = grounding_model(corpus=list(range(50)), emb_size=512, img_size=256, weights_path=None, config_path="")
+    from dcnet_amd.parallel import freeze_gradless
+    freeze_gradless(m)
+    opt = T.make_optimizer(m, 1e-4)
+    assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == 1e-5 and opt.param_groups[0]["weight_decay"] == 0.0005
+    n_visu = sum(p.numel() for p in opt.param_groups[1]["params"]); n_rest = sum(p.numel() for p in opt.param_groups[0]["params"])
+    assert n_visu + n_rest == sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n_visu == 61949149 - 6686285                     # backbone minus the dead YOLO heads
+    lr = T.adjust_learning_rate(opt, 30, 1e-4, 100, 0.9)
+    assert abs(lr - 1e-4 * 0.7 ** 0.9) < 1e-12 and opt.param_groups[1]["lr"] == lr / 10
+    assert T.lr_poly(1.0, 0, 10, 0.9) == 1.0
+
+
+def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
+    from dcnet_amd import train as T
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    opt = torch.optim.RMSprop(a.parameters(), lr=0.1)
+    a(torch.randn(5, 4)).sum().backward(); opt.step()
+    wrapped = {"module." + k: v for k, v in a.state_dict().items()}          # as saved from a DDP wrapper
+    path = T.save_checkpoint({"epoch": 7, "state_dict": wrapped, "best_loss": 1.5, "optimizer": opt.state_dict()},
+                             True, "t", str(tmp_path))
+    assert os.path.exists(os.path.join(str(tmp_path), "t_model_best.pth.tar"))
+    b = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    opt_b = torch.optim.RMSprop(b.parameters(), lr=0.1)
+    ep, best = T.load_checkpoint(b, path, opt_b)
+    assert (ep, best) == (7, 1.5)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    c = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(5))  # shape mismatch on the BN: skipped
+    assert T.load_pretrain(c, path) == 2

@@ -194,3 +194,28 @@ def test_large_input_608_nframe_and_pairs(dev):
         assert maxdiff(ob2[s], o2["outbox"][s]) < TOL and maxdiff(loc2[s], o2["loc_score"][s]) < TOL
     iou = O.bbox_iou_xyxy(O.decode_boxes([x.cpu() for x in ob2], size), O.decode_boxes(o2["outbox"], size))
     assert float(iou.min()) > 0.999
+
+
+def test_training_loop_reduces_loss_and_eval_runs(dev):
+    """The harness of dcnet_amd.train: a few RMSprop steps on one synthetic batch must lower the loss,
+    and the evaluation path (decode + Acc@0.5) must run on the result."""
+    from dcnet_amd import train as T
+    from dcnet_amd.parallel import freeze_gradless
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n = 256, 4
+    m = build_product(size, synth_sd(size), dev)
+    freeze_gradless(m)
+    opt = T.make_optimizer(m, 1e-4)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n, size, seed=11))
+    bbox = synth_boxes(n, size, seed=11).to(dev)
+    random.seed(0)
+    first = last = None
+    for it in range(6):
+        T.adjust_learning_rate(opt, it, 1e-4, 6, 0.9)
+        loss, parts = T.train_step(m, opt, image, word_id, word_mask, bbox, size)
+        assert torch.isfinite(loss)
+        first = float(loss) if first is None else first
+        last = float(loss)
+    assert last < first, (first, last)
+    acc, miou, boxes = T.evaluate(m, image, word_id, word_mask, bbox, size)
+    assert boxes.shape == (n, 4) and 0.0 <= float(acc) <= 1.0 and torch.isfinite(miou)
