@@ -135,7 +135,7 @@ def test_lr_schedule_and_optimizer_groups():
     assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == 1e-5 and opt.param_groups[0]["weight_decay"] == 0.0005
     n_visu = sum(p.numel() for p in opt.param_groups[1]["params"]); n_rest = sum(p.numel() for p in opt.param_groups[0]["params"])
     assert n_visu + n_rest == sum(p.numel() for p in m.parameters() if p.requires_grad)
-    assert n_visu == 61949149 - 6686285                     # backbone minus the dead YOLO heads
+    assert n_visu == 61949149 - 6687485                     # backbone minus the dead YOLO heads
     lr = T.adjust_learning_rate(opt, 30, 1e-4, 100, 0.9)
     assert abs(lr - 1e-4 * 0.7 ** 0.9) < 1e-12 and opt.param_groups[1]["lr"] == lr / 10
     assert T.lr_poly(1.0, 0, 10, 0.9) == 1.0
@@ -158,4 +158,4 @@ def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
     for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(va, vb), k
     c = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(5))  # shape mismatch on the BN: skipped
-    assert T.load_pretrain(c, path) == 2
+    assert T.load_pretrain(c, path) == 3                     # Linear weight + bias + the shape-less num_batches_tracked
