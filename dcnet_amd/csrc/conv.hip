@@ -42,7 +42,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride,
                               const float* scale, const float* shift, int act, float slope,
                               const float* residual, int ldr, int ldy,
-                              float* stats, void* stream) {
+                              float* stats, int accumulate, void* stream) {
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize=%d (1 or 3)", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride=%d (1 or 2)", stride);
   DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0, "conv2d_fwd: bad shape");
@@ -58,7 +58,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   DCN_CHECK_ARG(p.ldo >= cout, "conv2d_fwd: ldy=%d < cout=%d", ldy, cout);
   p.M = n * p.Ho * p.Wo;
   p.ntaps = ksize * ksize;
-  p.act = act; p.slope = slope;
+  p.act = act; p.slope = slope; p.accumulate = accumulate;
   if (cin == 4) {
     // weights are [Co][64]: 9 taps x 4 channels then zero padding (host prepares them)
     p.c4 = 1; p.ldw = 64;

@@ -225,6 +225,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
+  // (0) accumulate: the destination's current content joins the RAW accumulator, i.e. before the
+  //     statistics and before scale/shift/activation (dX += ..., or a pre-filled per-image/per-position
+  //     bias term of the fusion layer).
+  if (p.accumulate) {
+    const int hsws0 = p.Hs * p.Ws;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = bm * BM + row;
+        if (m >= p.M) continue;
+        size_t pix;
+        if (p.dense_out) pix = (size_t)m;
+        else {
+          const int n = m / hsws0, rem = m - n * hsws0;
+          const int i = rem / p.Ws, jx = rem - i * p.Ws;
+          pix = ((size_t)n * p.Ho + p.oy0 + i * p.osy) * p.Wo + p.ox0 + jx * p.osx;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int co = bn * BN + wn * (BN / WN) + ni * 32 + (lane & 31);
+          if (co < p.Co) acc[mi][ni][r] += gout[pix * p.ldo + co];
+        }
+      }
+    }
+  }
   // (a) BatchNorm batch statistics of the raw result.  Rows beyond M gathered zeros, so they add 0.
   if (p.stats) {
     float* red = smem;                    // [2][WM][BN]  (LDS is free after the last barrier)
@@ -284,9 +311,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         float v = acc[mi][ni][r] * rs * sc[ni] + sh[ni];
         if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
         if (p.residual) v += p.residual[pix * p.ldr + co_[ni]];
-        float* o = gout + pix * p.ldo + co_[ni];
-        if (p.accumulate) v += *o;
-        *o = v;
+        gout[pix * p.ldo + co_[ni]] = v;
       }
     }
   }

@@ -98,38 +98,86 @@ class L2Norm(torch.autograd.Function):
         return dx
 
 
-class NormScoreFuse(torch.autograd.Function):
-    """One pass over the corr_conv output x (N,H,W,E):
-         corr = x / ||x||                       (model/DCNet_model.py:469)
-         sim  = <corr, q>                       (model/DCNet_model.py:530-535, q = flang_attn)
-       and assembly of the fusion tensor [corr | tile(flang) | coord | 0-pad] (:491-499) that the
-       first fcn_emb conv consumes: corr is written straight into its channel slice.
-    Returns (fusion (N,H,W,Cpad), sim (N,H,W)); corr is fusion[..., :E]."""
+class NormScore(torch.autograd.Function):
+    """One pass over the corr_conv output x (N,H,W,E):  corr = x / ||x||  (model/DCNet_model.py:469) and
+    sim = <corr, q>  (:530-535, q = flang_attn).  Returns (corr (N,H,W,E), sim (N,H,W))."""
 
     @staticmethod
-    def forward(ctx, x, q, flang, coord):
+    def forward(ctx, x, q):
         n, h, w, e = x.shape
-        cpad = ops.pad32(2 * e + coord.shape[-1])
-        buf = torch.zeros((n, h, w, cpad), dtype=torch.float32, device=x.device)
-        _, norm, score = ops.l2norm_score_fwd(x, q.contiguous(), h * w, out=buf[..., :e])
-        buf[..., e:2 * e] = flang.view(n, 1, 1, e)
-        buf[..., 2 * e:2 * e + coord.shape[-1]] = coord
-        ctx.save_for_backward(buf, norm, q)
-        ctx.e = e
-        return buf, score.view(n, h, w)
+        q = q.contiguous()
+        corr, norm, score = ops.l2norm_score_fwd(x, q, h * w)
+        ctx.save_for_backward(corr, norm, q)
+        return corr, score.view(n, h, w)
 
     @staticmethod
-    def backward(ctx, dbuf, dscore):
-        buf, norm, q = ctx.saved_tensors
+    def backward(ctx, dcorr, dscore):
+        corr, norm, q = ctx.saved_tensors
         q = q.detach()
-        e = ctx.e
-        n, h, w, _ = buf.shape
-        corr = buf[..., :e]
-        dout = dbuf[..., :e] if dbuf is not None else None
+        n, h, w, _ = corr.shape
+        dout = dcorr.contiguous() if dcorr is not None else None
         ds = dscore.contiguous().view(-1) if dscore is not None else None
         dx, dq = ops.l2norm_score_bwd(corr, norm, dout, q if ds is not None else None, ds, h * w)
-        dflang = dbuf[..., e:2 * e].sum((1, 2)) if dbuf is not None else None
-        return dx, dq, dflang, None
+        return dx, dq
+
+
+class FusionConvBNAct(torch.autograd.Function):
+    """First fcn_emb block (model/DCNet_model.py:491-505) with the constant channels folded away.  The
+    reference convolves the concat [corr (E) | tile(flang) (E) | coord (8)] with a 1x1 filter bank W = [W1|W2|W3];
+    the tiled language vector and the coordinate map are constant over positions / images, so
+        conv = W1 . corr[n,p] + (W2 . flang[n]) + (W3 . coord[p])
+    i.e. a K = E convolution accumulated onto a pre-filled per-image + per-position term — half the MFMA work
+    of the 1032-channel form, and no (N,H,W,1032) tensor.  Then BatchNorm2d (momentum 0.999) + ReLU."""
+
+    @staticmethod
+    def forward(ctx, corr, flang, coord, weight, gamma, beta, bn, training: bool):
+        n, h, w, e = corr.shape
+        co = weight.shape[0]
+        wd = weight.detach().view(co, -1)
+        w1 = wd[:, :e].contiguous().view(co, e, 1, 1)
+        w2, w3 = wd[:, e:2 * e], wd[:, 2 * e:]
+        coord2d = coord.reshape(h * w, -1)
+        y = (torch.matmul(flang.detach(), w2.t()).view(n, 1, co) + torch.matmul(coord2d, w3.t()).view(1, h * w, co)).view(n, h, w, co)
+        wk = ops.weight_to_ohwi(w1)
+        if training:
+            y, stats = ops.conv2d_fwd(corr, wk, 1, 1, out=y, want_stats=True, accumulate=True)
+            mi = ops.bn_finalize(stats, n * h * w, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0)
+            ctx.save_for_backward(corr, y, mi, wk, gamma, beta, flang, weight)
+        else:
+            ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
+            out, _ = ops.conv2d_fwd(corr, wk, 1, 1, ss[0], ss[1], ops.ACT_LEAKY, 0.0, out=y, accumulate=True)
+            ctx.save_for_backward(corr, out, ss, wk, gamma, beta, flang, weight)
+        ctx.training = training
+        ctx.coord2d = coord2d
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        corr, y, aux, wk, gamma, beta, flang, weight = ctx.saved_tensors
+        gamma, beta = gamma.detach(), beta.detach()
+        n, h, w, e = corr.shape
+        co = weight.shape[0]
+        dout = dout.contiguous()
+        if ctx.training:
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, 0.0)
+        else:
+            dz = ops.act_bwd(y, dout, 0.0)
+            dy = dz * aux[0]
+            dbeta = dz.reshape(-1, co).sum(0)
+            gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
+            dgamma = (dz * (y - beta) / gs).reshape(-1, co).sum(0)
+        wd = weight.detach().view(co, -1)
+        dw1 = ops.weight_grad_to_oihw(ops.conv2d_bwd_weight(corr, dy, 1, 1), (co, e, 1, 1)).view(co, e)
+        dcorr = ops.conv2d_bwd_data(dy, wk, (h, w), 1, 1) if ctx.needs_input_grad[0] else None
+        d_img = dy.sum((1, 2))                                  # (N,co): gradient of the per-image term
+        d_pos = dy.sum(0).view(h * w, co)                       # (HW,co): gradient of the per-position term
+        dflang = torch.matmul(d_img, wd[:, e:2 * e])
+        dw2 = torch.matmul(d_img.t(), flang.detach())
+        dw3 = torch.matmul(d_pos.t(), ctx.coord2d)
+        dweight = torch.cat([dw1, dw2, dw3], dim=1).view_as(weight)
+        return dcorr, dflang, None, dweight, dgamma, dbeta, None, None
 
 
 class CoAttentionPairs(torch.autograd.Function):

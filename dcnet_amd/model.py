@@ -30,8 +30,8 @@ import torch.nn.functional as F
 
 from . import ops
 from .darknet import Darknet
-from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, L2Norm,
-                        LinearAct, LocModule, NormScoreFuse, ToNCHW)
+from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, FusionConvBNAct,
+                        L2Norm, LinearAct, LocModule, NormScore, ToNCHW)
 from .lib import lib
 
 
@@ -231,21 +231,16 @@ class grounding_model(nn.Module):
         corr_feat, sim_score, outbox = [], [], []
         for s in range(3):
             if premean is None:
-                x = corr_raw[s]
-                h, w = x.shape[1], x.shape[2]
-                fusion, sim = NormScoreFuse.apply(x, flang_attn, flang, self._coord(h, w, dev))
-                corr = fusion[..., :self.emb_size]
+                corr, sim = NormScore.apply(corr_raw[s], flang_attn)
             else:
                 corr = premean[s]
-                h, w = corr.shape[1], corr.shape[2]
                 sim = torch.sum(corr * flang_attn.view(B, 1, 1, -1), dim=3)
-                fusion = torch.zeros((B, h, w, ops.pad32(2 * self.emb_size + 8)), dtype=torch.float32, device=dev)
-                fusion[..., :self.emb_size] = corr
-                fusion[..., self.emb_size:2 * self.emb_size] = flang.view(B, 1, 1, -1)
-                fusion[..., 2 * self.emb_size:2 * self.emb_size + 8] = self._coord(h, w, dev)
-            z = fusion
-            for blk in self.fcn_emb[s]:
-                z = blk(z)                                                       # :505
+            h, w = corr.shape[1], corr.shape[2]
+            blk0 = self.fcn_emb[s][0]                                            # [corr | tile(flang) | coord] -> 1x1 :491-505
+            z = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, dev), blk0.conv.weight,
+                                      blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training)
+            z = self.fcn_emb[s][1](z)
+            z = self.fcn_emb[s][2](z)
             z = self.fcn_out[s][0](z)
             last = self.fcn_out[s][1]
             z = ConvBias.apply(z, last.weight, last.bias)[..., :15]              # :506

@@ -126,7 +126,7 @@ def conv_out_hw(h: int, w: int, k: int, stride: int) -> Tuple[int, int]:
 
 
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
-               residual=None, out=None, want_stats=False):
+               residual=None, out=None, want_stats=False, accumulate=False):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
     where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats)."""
     _chk(x, "conv2d_fwd x")
@@ -142,7 +142,7 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
-                     0 if residual is None else residual.stride(2), ldy, _p(stats), _s())
+                     0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _s())
     return out, stats
 
 

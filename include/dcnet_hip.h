@@ -50,6 +50,9 @@ int dcn_ohwi_to_oihw(const float* src, float* dst, int co, int ci, int kh, int k
 /* y[n,ho,wo,co] = act( scale[co] * (sum_{r,s,ci} x[n,ho*stride+r-pad,wo*stride+s-pad,ci] * w[co,r,s,ci])
  *                      + shift[co] ) + residual[n,ho,wo,co]
  * ksize in {1,3}, pad = (ksize-1)/2, stride in {1,2}; cin % 4 == 0 (cin % 32 == 0 unless cin == 4).
+ * accumulate != 0: the current content of y is added to the raw sum first (before stats / scale / act) — the
+ * fusion layer pre-fills y with its per-image language term and per-position coordinate term
+ * (model/DCNet_model.py:491-499 tiles them as 520 extra input channels instead).
  * scale/shift/residual may be NULL.  y has pixel stride ldy >= cout (lets a layer write
  * straight into a channel slice of a route-concat buffer); residual has pixel stride ldr.
  * stats (optional, [grid_m][2][cout] floats, grid_m = dcn_conv2d_stats_rows(...)): per
@@ -61,7 +64,7 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
                    const float* scale, const float* shift, int act, float slope,
                    const float* residual, int ldr, int ldy,
-                   float* stats, void* stream);
+                   float* stats, int accumulate, void* stream);
 int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride);
 
 /* dx = conv_transpose(dy, w): gradient w.r.t. the conv input (autograd of nn.Conv2d,

@@ -303,3 +303,30 @@ def test_location_module_core(dev):
     _close(out, ref.float(), 1e-5, "loc fwd")
     _close(Ed.grad, Er.grad.float(), 5e-5, "dE"); _close(Md.grad, Mr.grad.float(), 5e-5, "dM")
     _close(bd.grad, br.grad.float(), 5e-5, "db"); _close(qd.grad, qr.grad.float(), 5e-5, "dq")
+
+
+def test_fusion_conv_fold_matches_concat_form(dev):
+    """FusionConvBNAct == ConvBatchNormReLU over the concat [corr | tile(flang) | coord] (DCNet_model.py:491-505)."""
+    from dcnet_amd.functions import FusionConvBNAct
+    from dcnet_amd.model import generate_coord_nhwc
+    torch.manual_seed(3)
+    n, g, e, co = 3, 7, 512, 512
+    corr = F.normalize(_rand(n, e, g, g, seed=90), dim=1); flang = F.normalize(_rand(n, e, seed=91), dim=1)
+    coord = generate_coord_nhwc(g, g, "cpu")                                   # (g,g,8)
+    conv = torch.nn.Conv2d(2 * e + 8, co, 1, bias=False); bn = torch.nn.BatchNorm2d(co, momentum=0.999)
+    torch.nn.init.normal_(conv.weight, std=0.03)
+    cr, fr = corr.double().requires_grad_(True), flang.double().requires_grad_(True)
+    convr = torch.nn.Conv2d(2 * e + 8, co, 1, bias=False).double(); convr.load_state_dict(conv.state_dict())
+    bnr = torch.nn.BatchNorm2d(co, momentum=0.999).double()
+    cat = torch.cat([cr, fr.view(n, e, 1, 1).repeat(1, 1, g, g), coord.permute(2, 0, 1).unsqueeze(0).repeat(n, 1, 1, 1).double()], 1)
+    ref = torch.relu(bnr(convr(cat)))
+    gup = _rand(n, co, g, g, seed=92)
+    ref.backward(gup.double())
+    conv, bn = conv.to(dev), bn.to(dev)
+    cd = corr.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True); fd = flang.to(dev).requires_grad_(True)
+    out = FusionConvBNAct.apply(cd, fd, coord.to(dev), conv.weight, bn.weight, bn.bias, bn, True)
+    out.backward(gup.permute(0, 2, 3, 1).contiguous().to(dev))
+    _close(out.permute(0, 3, 1, 2), ref.float(), 3e-5, "fusion fwd")
+    _close(cd.grad.permute(0, 3, 1, 2), cr.grad.float(), 5e-5, "dcorr"); _close(fd.grad, fr.grad.float(), 5e-5, "dflang")
+    _close(conv.weight.grad, convr.weight.grad.float(), 5e-5, "dW"); _close(bn.weight.grad, bnr.weight.grad.float(), 5e-5, "dgamma")
+    _close(bn.running_var, bnr.running_var.float(), 1e-5, "running_var")
