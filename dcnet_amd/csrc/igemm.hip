@@ -21,7 +21,6 @@
 // statistics, deterministic: no atomics), scale/shift (folded eval BatchNorm or bias),
 // LeakyReLU/ReLU, the shortcut add, and accumulate-into-destination.
 #include "igemm.h"
-#include <stdlib.h>
 #include "prof.h"
 
 namespace {
@@ -270,8 +269,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       }
     }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid - which * BN;
+    for (int idx = tid; idx < 2 * BN; idx += 256) {
+      const int which = idx / BN, col = idx - which * BN;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
@@ -356,11 +355,12 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
 // resident workgroups) empty: the 13x13 and 26x26 maps give 340-680 tiles of 128 rows, i.e. 66 % fill, and a
 // 64x128 tile (measured ~0.9x the per-tile efficiency) doubles the workgroup count.
 inline double fill(long long blocks, long long slots) { return (double)blocks / (double)(((blocks + slots - 1) / slots) * slots); }
+int g_force_bm = 0;       // experiment knob, set through dcn_set_tuning (tools/bench_convs.py)
+
 inline int tile_bm(int M, int Co) {
   if (Co <= 32) return 256;
   if (Co <= 64) return 128;
-  static const char* force = getenv("DCN_FORCE_BM");       // experiment knob (tools/bench_convs.py)
-  if (force && force[0]) return atoi(force);
+  if (g_force_bm) return g_force_bm;
   const long long gn = cdiv(Co, 128);
   const long long slots = M > 16384 ? 768 : 512;     // K-step 16 (long M): 3 workgroups per CU, else 2
   const double e128 = fill((long long)cdiv(M, 128) * gn, slots), e64 = 0.9 * fill((long long)cdiv(M, 64) * gn, slots);
@@ -370,6 +370,13 @@ inline int tile_bm(int M, int Co) {
 }  // namespace
 
 int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
+
+extern "C" int dcn_set_tuning(const char* key, int value) {
+  const char k = key ? key[0] : 0;
+  if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
+  else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
+  return DCN_OK;
+}
 
 int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.in && p.wt && p.out, "igemm: null pointer");

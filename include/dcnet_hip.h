@@ -201,6 +201,10 @@ int dcn_upsample2_nhwc_bwd(const float* ddst, int ldd, float* dsrc, int lds, int
 /* strided copy / accumulate of a [rows][c] channel slice: dst (+)= src. */
 int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows, int c, int accumulate, void* stream);
 
+/* Experiment knob of the conv engine's tile heuristic ("bm": force the M tile to 64 or 128, 0 = automatic).
+ * Used by tools/bench_convs.py for in-process A/B runs (a 128x256 tile measured 10-25 % slower and was dropped). */
+int dcn_set_tuning(const char* key, int value);
+
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
  * returns, per kernel tag (16 slots: 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,

@@ -57,6 +57,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--only", type=str, default="", help="cin,cout,k,stride,h: benchmark a single shape")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ab", type=str, default="", help="key=value tuning knob (dcn_set_tuning) measured against the default, same process")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tot = collections.Counter()
@@ -73,9 +74,20 @@ def main():
         ho = h // st
         dy = torch.randn(args.n, ho, ho, cout, device=dev)
         flop = 2.0 * args.n * ho * ho * cout * k * k * (3 if cin == 4 else cin)
-        t_f = timeit(lambda: ops.conv2d_fwd(x, w, k, st, want_stats=True))
+        f_fwd = lambda: ops.conv2d_fwd(x, w, k, st, want_stats=True)
+        f_dg = lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st)
+        has_dg = cin != 4 and cout % 32 == 0
+        t_f = timeit(f_fwd)
         t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
-        t_d = timeit(lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st)) if cin != 4 and cout % 32 == 0 else 0.0
+        t_d = timeit(f_dg) if has_dg else 0.0
+        if args.ab:
+            from dcnet_amd.lib import lib
+            key, val = args.ab.split("=")
+            lib().set_tuning(key.encode(), int(val))
+            t_f2 = timeit(f_fwd); t_d2 = timeit(f_dg) if has_dg else 0.0
+            lib().set_tuning(key.encode(), 0)
+            t_f3 = timeit(f_fwd)          # default again: drift check
+            print("AB %5d %5d k%d s%d H%4d  fwd %.3f -> %.3f (recheck %.3f)  dgrad %.3f -> %.3f" % (cin, cout, k, st, h, t_f, t_f2, t_f3, t_d, t_d2))
         rows.append((cin, cout, k, st, h, cnt, flop / 1e9, t_f, t_d, t_w))
         tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w
         tot["flop"] += cnt * flop
