@@ -344,9 +344,12 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 // K-step choice (measured per layer, tools/bench_convs.py): 16 floats per step keeps the LDS footprint at
 // ~40 KB so three workgroups share a CU — better latency hiding on the long-M layers (+3..+60 %, most on the
 // narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
+int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
+
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
-  if (p.M <= 16384) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
+  const int bk = g_force_bk ? g_force_bk : (p.M <= 16384 ? 32 : 16);
+  if (bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
   return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
 }
 
@@ -361,10 +364,11 @@ inline int tile_bm(int M, int Co) {
   if (Co <= 32) return 256;
   if (Co <= 64) return 128;
   if (g_force_bm) return g_force_bm;
-  const long long gn = cdiv(Co, 128);
-  const long long slots = M > 16384 ? 768 : 512;     // K-step 16 (long M): 3 workgroups per CU, else 2
-  const double e128 = fill((long long)cdiv(M, 128) * gn, slots), e64 = 0.9 * fill((long long)cdiv(M, 64) * gn, slots);
-  return e64 > e128 ? 64 : 128;
+  // In-process A/B (tools/bench_convs.py --ab bm=64 / bm=128): with the current K-steps the 64-row tile only
+  // wins by 3-4 % on the 3x3 layers of the 13x13 maps and loses 10-70 % everywhere else, so it is kept as a
+  // knob (dcn_set_tuning("bm", 64)) but not selected automatically.
+  (void)M;
+  return 128;
 }
 
 }  // namespace
@@ -374,6 +378,7 @@ int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
+  else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
   return DCN_OK;
 }
