@@ -219,3 +219,39 @@ def test_training_loop_reduces_loss_and_eval_runs(dev):
     assert last < first, (first, last)
     acc, miou, boxes = T.evaluate(m, image, word_id, word_mask, bbox, size)
     assert boxes.shape == (n, 4) and 0.0 <= float(acc) <= 1.0 and torch.isfinite(miou)
+
+
+def test_eval_mode_backward_and_argument_errors(dev):
+    """model.eval() with gradients enabled (frozen BatchNorm statistics: the folded-BN kernels' own backward
+    path) against the oracle's eval-mode autograd, and the argument errors of the boundary."""
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    size, n = 256, 2
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=21)
+    m = build_product(size, sd, dev).eval()
+    random.seed(5)
+    outbox, sim, loc, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+    gen = torch.Generator().manual_seed(9)
+    gs = [torch.randn(o.shape, generator=gen) for o in outbox] + [torch.randn(s_.shape, generator=gen) for s_ in sim]
+    (sum((o * g.to(dev)).sum() for o, g in zip(outbox, gs[:3])) + sum((s_ * g.to(dev)).sum() for s_, g in zip(sim, gs[3:]))).backward()
+    sdo = {k: v.clone() for k, v in sd.items()}
+    params = {k: sdo[k].requires_grad_(True) for k, _ in m.named_parameters()}
+    o = O.grounding_forward_pairs(sdo, image, word_id, training=False, sample=False)
+    (sum((a * g).sum() for a, g in zip(o["outbox"], gs[:3])) + sum((a * g).sum() for a, g in zip(o["sim_score"], gs[3:]))).backward()
+    checked = 0
+    for k, p in m.named_parameters():
+        og = params[k].grad
+        if og is None or float(og.abs().max()) < 1e-4 or "loc_" in k:      # loc branch: min-max amplification (see DESIGN.md)
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.cpu().flatten().double(), og.flatten().double(), dim=0))
+        assert cos > 0.999, (k, cos)          # N = 2: LeakyReLU sign flips through 75 layers (measured 0.99987 worst)
+        checked += 1
+    assert checked > 200
+    with pytest.raises(ValueError):
+        m(image[:1].to(dev), word_id[:1].to(dev), None)                    # odd batch in pair mode
+    with pytest.raises(ValueError):
+        m(image.to(dev), word_id[:1].to(dev), None, 3)                      # batch not a multiple of n_frame
+    from model.DCNet_model import grounding_model
+    with pytest.raises(NotImplementedError):
+        grounding_model(corpus=None)                                        # BERT encoder is out of scope
