@@ -348,7 +348,8 @@ int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
-  const int bk = g_force_bk ? g_force_bk : (p.M <= 16384 ? 32 : 16);
+  const long long rows = (long long)p.M * (p.batch > 0 ? p.batch : 1);       // batched GEMMs fill the chip like one long M
+  const int bk = g_force_bk ? g_force_bk : (rows <= 16384 ? 32 : 16);
   if (bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
   return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
 }
