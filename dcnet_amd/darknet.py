@@ -377,7 +377,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
                         d["b"] = dz.reshape(-1, op.cout).sum(0)
             if op.res is not None:
                 add(op.res, dout)
-            d["w"] = ops.weight_grad_to_oihw(ops.conv2d_bwd_weight(x, dy, op.k, op.stride), shape)
+            d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape)     # overlaps with the data gradient below
             if op.need_dx:
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
@@ -386,6 +386,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
                 else:
                     ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True)
             pg[op.slot] = d
+    if pg:
+        ops.join_side(next(iter(P.values()))["w"].device)
     return pg
 
 

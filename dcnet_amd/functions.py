@@ -47,9 +47,9 @@ class ConvBNAct(torch.autograd.Function):
             z = y if slope == 0 else torch.where(y > 0, y, y / slope)
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
-        dw = ops.conv2d_bwd_weight(x, dy, ksize, 1)
-        dwt = ops.weight_grad_to_oihw(dw, wshape)
+        dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape)
         dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1) if ctx.needs_input_grad[0] else None
+        ops.join_side(x.device)
         return dx, dwt, dgamma, dbeta, None, None, None, None
 
 
@@ -75,10 +75,10 @@ class ConvBias(torch.autograd.Function):
         x, w = ctx.saved_tensors
         co, ci, k, _ = ctx.wshape
         dy = dy.contiguous()
-        dw = ops.conv2d_bwd_weight(x, dy, k, 1)
-        dwt = ops.weight_grad_to_oihw(dw[:co].contiguous(), ctx.wshape)
+        dwt = ops.wgrad_on_side(x, dy, k, 1, ctx.wshape)
         db = dy.reshape(-1, dy.shape[-1]).sum(0)[:co]
         dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1) if ctx.needs_input_grad[0] else None
+        ops.join_side(x.device)
         return dx, dwt, db
 
 
@@ -169,8 +169,9 @@ class FusionConvBNAct(torch.autograd.Function):
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (y - beta) / gs).reshape(-1, co).sum(0)
         wd = weight.detach().view(co, -1)
-        dw1 = ops.weight_grad_to_oihw(ops.conv2d_bwd_weight(corr, dy, 1, 1), (co, e, 1, 1)).view(co, e)
+        dw1 = ops.wgrad_on_side(corr, dy, 1, 1, (co, e, 1, 1)).view(co, e)      # overlaps with the data gradient
         dcorr = ops.conv2d_bwd_data(dy, wk, (h, w), 1, 1) if ctx.needs_input_grad[0] else None
+        ops.join_side(corr.device)
         d_img = dy.sum((1, 2))                                  # (N,co): gradient of the per-image term
         d_pos = dy.sum(0).view(h * w, co)                       # (HW,co): gradient of the per-position term
         dflang = torch.matmul(d_img, wd[:, e:2 * e])

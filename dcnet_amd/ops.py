@@ -159,16 +159,60 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     return out
 
 
-def conv2d_bwd_weight(x, dy, ksize, stride, cout=None):
-    """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem]."""
+def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0):
+    """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
+    ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0)."""
     n, h, wd, cin = x.shape
     cout = dy.shape[3] if cout is None else cout
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
-    ws = scratch(nws, x.device, slot=0) if nws > 0 else None
+    ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws),
                             n, h, wd, cin, cout, ksize, stride, _s())
     return dw
+
+
+# ---- side stream for the weight gradient --------------------------------------------------------------
+# dW and dX of a layer both depend only on dY, so they are launched on two streams: the partially filled
+# last round of one kernel's grid is topped up with workgroups of the other (256 CUs x 2 slots).
+_side = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+WGRAD_SIDE = True      # A/B switch: False runs the weight gradient on the caller's stream
+
+
+def wgrad_on_side(x, dy, ksize, stride, wshape):
+    """Launch the weight gradient (+ its OHWI->OIHW conversion) on the side stream.  Returns the OIHW
+    gradient; the caller must make the main stream wait for side_stream() before the result is consumed."""
+    if not WGRAD_SIDE:
+        dw = conv2d_bwd_weight(x, dy, ksize, stride)
+        if wshape[0] != dw.shape[0]:
+            dw = dw[:wshape[0]].contiguous()
+        return weight_grad_to_oihw(dw, wshape)
+    main = torch.cuda.current_stream()
+    side = side_stream(x.device)
+    side.wait_stream(main)                       # dy (and x) are produced on the main stream
+    with torch.cuda.stream(side):
+        dw = conv2d_bwd_weight(x, dy, ksize, stride, slot=3)
+        if wshape[0] != dw.shape[0]:
+            dw = dw[:wshape[0]].contiguous()
+        out = weight_grad_to_oihw(dw, wshape)
+    for t in (x, dy):
+        t.record_stream(side)                    # keep the allocator from recycling them under the side kernels
+    out.record_stream(main)
+    return out
+
+
+def join_side(device) -> None:
+    if WGRAD_SIDE:
+        torch.cuda.current_stream().wait_stream(side_stream(device))
 
 
 # ---- batch norm ------------------------------------------------------------------------------------
