@@ -192,14 +192,15 @@ class grounding_model(nn.Module):
         self._pinned = {}
         self._pin_event = None
         self._streams = {}
+        self.scale_streams = True            # run the three per-scale branches on separate streams
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
         self.last_choices = {}
 
     # ------------------------------------------------------------------------------------------
-    def _side_stream(self, device):
-        key = str(device)
+    def _side_stream(self, device, name: str = "lang"):
+        key = (str(device), name)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
@@ -221,31 +222,68 @@ class grounding_model(nn.Module):
         flang = F.normalize(z, p=2, dim=1)                                      # :485-487
         return word_id, flang, context, embedded
 
-    def _head(self, corr_raw: List[torch.Tensor], word_id, flang, context, embedded, premean=None):
-        """corr_raw[s]: corr_conv output (B,H,W,E) before normalisation (or, for the n_frame model,
-        ``premean`` holds the already normalised+averaged maps).  Returns NHWC head tensors."""
+    def _fusion_head(self, s: int, corr, flang):
+        """fcn_emb[s] + fcn_out[s] on one scale: corr (B,H,W,E) -> outbox logits (B,H,W,15)  (:491-506)."""
+        h, w = corr.shape[1], corr.shape[2]
+        blk0 = self.fcn_emb[s][0]                                                # [corr | tile(flang) | coord] -> 1x1
+        z = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
+                                  blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training)
+        z = self.fcn_emb[s][1](z)
+        z = self.fcn_emb[s][2](z)
+        z = self.fcn_out[s][0](z)
+        last = self.fcn_out[s][1]
+        return ConvBias.apply(z, last.weight, last.bias)[..., :15]
+
+    def _scale_pairs(self, s: int, raw_s, flang, flang_attn):
+        """Everything of scale s that depends only on its backbone tap (pair semantics): mapping + norm
+        (:356-359), co-attention + corr_conv (:449-468), normalise + sim (:469,530-535), fusion head."""
+        fv = L2Norm.apply(self.mapping_visu[s](raw_s))
+        corr_raw = self.corr_conv[s][0](CoAttentionPairs.apply(fv, self.temperature))
+        corr, sim = NormScore.apply(corr_raw, flang_attn)
+        return fv, corr, sim, self._fusion_head(s, corr, flang)
+
+    def _scale_nframe(self, s: int, raw_s, flang, flang_attn, B: int, n_frame: int):
+        """Scale s of the inference model: centre frame vs every other frame, mean of the normalised
+        correspondence features (model/test_DCNet_model.py:299-332), then the shared head."""
+        fv = L2Norm.apply(self.mapping_visu[s](raw_s))
+        _, h, w, e = fv.shape
+        clips = fv.view(B, n_frame, h * w, e)
+        ctr, acc = n_frame // 2, None                                            # :303
+        for idx in range(n_frame):                                               # :312-320
+            if idx == ctr:
+                continue
+            cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
+            z = L2Norm.apply(self.corr_conv[s][0](cat))                          # :277-280
+            acc = z if acc is None else acc + z
+        corr = acc / (n_frame - 1)                                               # :324-332
+        sim = torch.sum(corr * flang_attn.view(B, 1, 1, -1), dim=3)
+        return fv, corr, sim, self._fusion_head(s, corr, flang)
+
+    def _run_scales(self, branch, raws, main):
+        """Run the three per-scale branches on their own streams (finest scale first): the 13x13 and 26x26
+        branches are chains of small grids that fit under the 52x52 branch's kernels.  Autograd replays
+        each branch's backward on the same stream."""
+        dev = raws[0].device
+        res = [None] * 3
+        if not self.scale_streams:
+            return [branch(s_, raws[s_]) for s_ in range(3)]
+        for s_ in (2, 1, 0):
+            st = self._side_stream(dev, f"scale{s_}")
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                res[s_] = branch(s_, raws[s_])
+            raws[s_].record_stream(st)
+        for s_ in range(3):
+            main.wait_stream(self._side_stream(dev, f"scale{s_}"))
+            for t_ in res[s_]:
+                t_.record_stream(main)
+        return res
+
+    def _head(self, corr_feat, sim_score, outbox, word_id, flang, context, embedded, flang_attn):
+        """The cross-scale tail: objectness x similarity, location module, confidence modulation
+        (:545-621).  Inputs are NHWC per-scale tensors."""
         B = flang.shape[0]
         dev = flang.device
-        _, flang_attn = self.sub_attn(context, embedded, word_id)               # :525
-        flang_attn = F.normalize(flang_attn, p=2, dim=1)                        # :526
-        corr_feat, sim_score, outbox = [], [], []
-        for s in range(3):
-            if premean is None:
-                corr, sim = NormScore.apply(corr_raw[s], flang_attn)
-            else:
-                corr = premean[s]
-                sim = torch.sum(corr * flang_attn.view(B, 1, 1, -1), dim=3)
-            h, w = corr.shape[1], corr.shape[2]
-            blk0 = self.fcn_emb[s][0]                                            # [corr | tile(flang) | coord] -> 1x1 :491-505
-            z = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, dev), blk0.conv.weight,
-                                      blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training)
-            z = self.fcn_emb[s][1](z)
-            z = self.fcn_emb[s][2](z)
-            z = self.fcn_out[s][0](z)
-            last = self.fcn_out[s][1]
-            z = ConvBias.apply(z, last.weight, last.bias)[..., :15]              # :506
-            corr_feat.append(corr); sim_score.append(sim); outbox.append(z)
-
         conf = [ob.reshape(B, ob.shape[1], ob.shape[2], 3, 5)[..., 4] for ob in outbox]   # (B,H,W,3)
         only_obj = [c.mean(dim=3) for c in conf]                                 # :551
         obj_score = [o * s for o, s in zip(only_obj, sim_score)]                 # :550
@@ -309,7 +347,7 @@ class grounding_model(nn.Module):
             c4 = ob[..., 4] * (sim_score[s] * loc_score[s]).unsqueeze(3)
             ob = torch.cat([ob[..., :4], c4.unsqueeze(4)], dim=4).reshape(B, ob.shape[1], ob.shape[2], 15)
             final.append(ToNCHW.apply(ob, 15))
-        return final, sim_score, loc_score, corr_feat, flang_attn.view(B, -1, 1, 1), only_obj
+        return final, loc_score, only_obj
 
     # ------------------------------------------------------------------------------------------
     def _presample_start(self, n, g0, top_k=30, neg_n=10, neg_c=5):
@@ -404,14 +442,17 @@ class grounding_model(nn.Module):
             word_id, flang, context, embedded = self._language(word_id)
         handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
-        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]      # :356-359
-        presampled, self._pin_event = self._presample_join(handle, image.device)
         main.wait_stream(side)
         for t_ in (flang, context, embedded):
             t_.record_stream(main)
+        _, flang_attn = self.sub_attn(context, embedded, word_id)                # :525
+        flang_attn = F.normalize(flang_attn, p=2, dim=1)                         # :526
+        res = self._run_scales(lambda s_, r_: self._scale_pairs(s_, r_, flang, flang_attn), raw, main)
+        fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
+        presampled, self._pin_event = self._presample_join(handle, image.device)
         frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
-        corr_raw = [self.corr_conv[i][0](CoAttentionPairs.apply(fv[i], self.temperature)) for i in range(3)]  # :449-468
-        outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(corr_raw, word_id, flang, context, embedded)
+        outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
+        flang_attn = flang_attn.view(N, -1, 1, 1)
         vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context, presampled)   # :625-637 (runs in eval too)
         if self.training:
             return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn,
@@ -423,23 +464,21 @@ class grounding_model(nn.Module):
         if image.size(0) % n_frame:
             raise ValueError("batch must be a multiple of n_frame (model/test_DCNet_model.py:287)")
         B = image.size(0) // n_frame
+        main = torch.cuda.current_stream()
+        side = self._side_stream(image.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            word_id, flang, context, embedded = self._language(word_id)
         raw = self.visumodel.forward_nhwc(image)
-        fv = [L2Norm.apply(self.mapping_visu[i](raw[i])) for i in range(3)]
-        ctr = n_frame // 2                                                       # :303
-        premean = []
-        for i in range(3):
-            _, h, w, e = fv[i].shape
-            clips = fv[i].view(B, n_frame, h * w, e)
-            acc = None
-            for idx in range(n_frame):                                           # :312-320
-                if idx == ctr:
-                    continue
-                cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
-                z = L2Norm.apply(self.corr_conv[i][0](cat))                      # :277-280
-                acc = z if acc is None else acc + z
-            premean.append(acc / (n_frame - 1))                                  # :324-332
-        word_id, flang, context, embedded = self._language(word_id)
-        outbox, sim, loc, corr_feat, flang_attn, only_obj = self._head(None, word_id, flang, context, embedded, premean)
+        main.wait_stream(side)
+        for t_ in (flang, context, embedded):
+            t_.record_stream(main)
+        _, flang_attn = self.sub_attn(context, embedded, word_id)
+        flang_attn = F.normalize(flang_attn, p=2, dim=1)
+        res = self._run_scales(lambda s_, r_: self._scale_nframe(s_, r_, flang, flang_attn, B, n_frame), raw, main)
+        corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
+        outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
+        flang_attn = flang_attn.view(B, -1, 1, 1)
         corr_nchw = [c.permute(0, 3, 1, 2) for c in corr_feat]
         if self.training:
             return outbox, sim, loc, corr_nchw, flang_attn

@@ -179,7 +179,9 @@ _side = {}
 
 
 def side_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index
+    """The weight-gradient companion of the current stream (one per calling stream, so the per-scale
+    head branches do not serialise on each other's weight gradients)."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _side:
         _side[key] = torch.cuda.Stream(device=device)
     return _side[key]
