@@ -95,3 +95,15 @@ def apply_bn_calibration(sd, npz_path: str):
             if k in sd and tuple(sd[k].shape) == z[k].shape:
                 sd[k] = torch.from_numpy(z[k].copy())
     return sd
+
+
+def synth_head_outputs(size: int, emb: int, seed: int):
+    """Seeded stand-ins for one clip's modulated head outputs (1,15,g,g) x3 and unit-norm correspondence
+    features (1,emb,g,g) x3, for the top-k cache / post-processing tests (numpy's legacy RandomState
+    stream is version-frozen, so fixtures need not store them)."""
+    rs = np.random.RandomState(seed)
+    grids = [size // 32, size // 16, size // 8]
+    pred = [torch.from_numpy(rs.standard_normal((1, 15, g, g)).astype(np.float32)) for g in grids]
+    feat = [torch.nn.functional.normalize(torch.from_numpy(rs.standard_normal((1, emb, g, g)).astype(np.float32)), dim=1)
+            for g in grids]
+    return pred, feat
