@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="T")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exclusive-steps", type=int, default=2,
+                    help="untimed steps after the timed region with all side streams off, for the per-kernel "
+                         "exclusive duration (0 = skip, e.g. under rocprofv3 so its averages match the timed region)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
     return ap.parse_args()
@@ -156,6 +159,30 @@ def main():
     counts = (ctypes.c_int64 * 16)(); ms = (ctypes.c_double * 16)(); work = (ctypes.c_double * 16)()
     L.prof_collect(ctypes.addressof(counts), ctypes.addressof(ms), ctypes.addressof(work))
 
+    # The timed region overlaps kernels on several streams (weight gradients beside the data-gradient chain,
+    # the three head scales beside each other), so a launch's event-to-event duration there includes the
+    # time it shared the CUs with another kernel.  A short untimed pass with every kernel alone on the GPU
+    # gives the per-launch duration that speaks about the kernel itself.
+    excl = None
+    if args.exclusive_steps > 0:
+        from dcnet_amd import ops as _ops
+        was = (_ops.WGRAD_SIDE, model.scale_streams)
+        _ops.WGRAD_SIDE = False; model.scale_streams = False
+        step(); barrier()
+        L.prof_enable(1)
+        for _ in range(args.exclusive_steps):
+            step()
+        barrier()
+        L.prof_enable(0)
+        _ops.WGRAD_SIDE, model.scale_streams = was
+        c2 = (ctypes.c_int64 * 16)(); m2 = (ctypes.c_double * 16)(); w2 = (ctypes.c_double * 16)()
+        L.prof_collect(ctypes.addressof(c2), ctypes.addressof(m2), ctypes.addressof(w2))
+        if c2[0]:
+            excl = {"achieved": w2[0] / (m2[0] * 1e-3) / 1e12, "frac": w2[0] / (m2[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "avg_launch_ms": m2[0] / c2[0], "steps": args.exclusive_steps,
+                    "note": "same kernel, same launches, weight-gradient stream switched off "
+                            "(untimed pass after the timed region)"}
+
     if rank == 0:
         clips_total = args.clips * world * args.steps
         names = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,2,0,false,32>", 1: "igemm_kernel<128,64,2,2,0>", 2: "igemm_kernel<256,32,4,1,0>",
@@ -195,6 +222,13 @@ def main():
                                          "frac": mfma_work / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if mfma_ms else None,
                                          "ms_per_step": mfma_ms / args.steps,
                                          "share_of_step": mfma_ms / args.steps / (dt / args.steps * 1e3)},
+                    "overlap": "the timed region runs the weight-gradient GEMMs on a second stream beside the data-gradient "
+                               "chain; per-launch durations above include the time a launch shared the CUs",
+                    "exclusive": excl,
+                    # every FLOP the MFMA kernels were asked for in a step over the whole step's wall time
+                    "step_mfma": {"tflop_per_step": mfma_work / args.steps / 1e12,
+                                  "achieved": mfma_work / 1e12 / dt,
+                                  "frac": mfma_work / 1e12 / dt / PEAK_FP32_MFMA_TFLOPS},
                     "hbm_scoring": {"kernel": names[8], "achieved": kern.get(names[8], {}).get("achieved"),
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": (kern[names[8]]["achieved"] / PEAK_HBM_GBS) if names[8] in kern else None},

@@ -16,6 +16,29 @@ void dcn_set_error(const char* fmt, ...) {
 extern "C" const char* dcn_last_error(void) { return g_err; }
 extern "C" int dcn_version(void) { return 100; }
 
+// ---- streams ---------------------------------------------------------------------------------
+// level: -1 = highest, 0 = normal, +1 = lowest priority the device offers.  The weight-gradient GEMMs run
+// on a lowest-priority stream: their workgroups are dispatched into whatever the data-gradient chain on
+// the caller's stream leaves idle (tile-quantisation tails) instead of competing with it.
+extern "C" void* dcn_stream_create(int level) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { dcn_set_error("stream_create: no priority range"); return nullptr; }
+  const int prio = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) { dcn_set_error("stream_create: hipStreamCreateWithPriority failed"); return nullptr; }
+  return (void*)s;
+}
+
+extern "C" int dcn_stream_destroy(void* stream) {
+  DCN_CHECK_ARG(stream, "stream_destroy: null stream");
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? DCN_OK : DCN_ERR_LAUNCH;
+}
+
+extern "C" int dcn_stream_priority_range(int* least, int* greatest) {
+  DCN_CHECK_ARG(least && greatest, "stream_priority_range: null pointer");
+  return hipDeviceGetStreamPriorityRange(least, greatest) == hipSuccess ? DCN_OK : DCN_ERR_LAUNCH;
+}
+
 // ---- profiler ---------------------------------------------------------------------------------
 namespace {
 struct Rec { hipEvent_t a, b; int tag; double work; };

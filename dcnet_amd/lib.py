@@ -56,6 +56,9 @@ SIGNATURES = {
     "dcn_lstm_cell_fwd": (I, [P, P, P, P, I, P, P, P, P, I, I, I, P]),
     "dcn_lstm_cell_bwd": (I, [P, I, P, P, P, P, P, I, P, I, P, P, I, I, P]),
     "dcn_set_tuning": (I, [c_char_p, I]),
+    "dcn_stream_create": (P, [I]),
+    "dcn_stream_destroy": (I, [P]),
+    "dcn_stream_priority_range": (I, [P, P]),
     "dcn_prof_enable": (I, [I]),
     "dcn_prof_collect": (I, [P, P, P]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),

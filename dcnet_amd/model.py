@@ -192,7 +192,9 @@ class grounding_model(nn.Module):
         self._pinned = {}
         self._pin_event = None
         self._streams = {}
-        self.scale_streams = True            # run the three per-scale branches on separate streams
+        # run the three per-scale head branches on separate streams: -1 % step time in an in-process A/B, but
+        # the HBM-bound scoring kernels then share the memory system with the other scales' GEMMs; off by default
+        self.scale_streams = False
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled

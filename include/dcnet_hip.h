@@ -205,6 +205,15 @@ int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows,
  * Used by tools/bench_convs.py for in-process A/B runs (a 128x256 tile measured 10-25 % slower and was dropped). */
 int dcn_set_tuning(const char* key, int value);
 
+/* ---- streams with a dispatch priority ------------------------------------------------------- */
+/* level -1 / 0 / +1 = highest / normal / lowest priority of the device.  Returns a hipStream_t (NULL on
+ * error).  The host side runs the weight-gradient GEMMs on a lowest-priority stream so that they fill
+ * the CUs the data-gradient chain leaves idle (replaces nothing in the reference: PyTorch autograd
+ * serialises both on one stream, train_DCNet.py:645). */
+void* dcn_stream_create(int level);
+int dcn_stream_destroy(void* stream);
+int dcn_stream_priority_range(int* least, int* greatest);
+
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
  * returns, per kernel tag (16 slots: 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
