@@ -32,6 +32,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, == fp32 vector rate
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # 256 CU x 4 SIMD x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16, 32 cycles) x 2.4 GHz
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6      # split pipe: six bf16 MFMAs per fp32 product term
 PEAK_HBM_GBS = 8000.0
 
 
@@ -156,52 +158,72 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    counts = (ctypes.c_int64 * 16)(); ms = (ctypes.c_double * 16)(); work = (ctypes.c_double * 16)()
-    L.prof_collect(ctypes.addressof(counts), ctypes.addressof(ms), ctypes.addressof(work))
+    NT = 24
 
-    # The timed region overlaps kernels on several streams (weight gradients beside the data-gradient chain,
-    # the three head scales beside each other), so a launch's event-to-event duration there includes the
-    # time it shared the CUs with another kernel.  A short untimed pass with every kernel alone on the GPU
-    # gives the per-launch duration that speaks about the kernel itself.
-    excl = None
-    if args.exclusive_steps > 0:
-        from dcnet_amd import ops as _ops
+    def collect():
+        c = (ctypes.c_int64 * NT)(); m = (ctypes.c_double * NT)(); w = (ctypes.c_double * NT)()
+        L.prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(w))
+        return list(c), list(m), list(w)
+
+    counts, ms, work = collect()
+
+    # Untimed passes after the timed region (every rank runs them, so DDP stays in step):
+    #  * "exclusive": the product configuration with the weight-gradient stream switched off.  The timed region
+    #    overlaps weight-gradient GEMMs with the data-gradient chain, so a launch's event-to-event time there
+    #    includes the time it shared the CUs; alone on the GPU the duration speaks about the kernel itself.
+    #  * "native_fp32": the same step with dcn_set_tuning("precision", 0) — every tile on v_mfma_f32_32x32x2_f32.
+    from dcnet_amd import ops as _ops
+
+    def extra_pass(precision: int):
         was = (_ops.WGRAD_SIDE, model.scale_streams)
         _ops.WGRAD_SIDE = False; model.scale_streams = False
+        L.set_tuning(b"precision", precision)
         step(); barrier()
         L.prof_enable(1)
+        t1 = time.perf_counter()
         for _ in range(args.exclusive_steps):
             step()
         barrier()
+        el = time.perf_counter() - t1
         L.prof_enable(0)
         _ops.WGRAD_SIDE, model.scale_streams = was
-        c2 = (ctypes.c_int64 * 16)(); m2 = (ctypes.c_double * 16)(); w2 = (ctypes.c_double * 16)()
-        L.prof_collect(ctypes.addressof(c2), ctypes.addressof(m2), ctypes.addressof(w2))
-        if c2[0]:
-            excl = {"achieved": w2[0] / (m2[0] * 1e-3) / 1e12, "frac": w2[0] / (m2[0] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                    "avg_launch_ms": m2[0] / c2[0], "steps": args.exclusive_steps,
-                    "note": "same kernel, same launches, weight-gradient stream switched off "
-                            "(untimed pass after the timed region)"}
+        L.set_tuning(b"precision", 1)
+        return collect() + (el / args.exclusive_steps * 1e3,)
+
+    excl = native = None
+    if args.exclusive_steps > 0:
+        excl = extra_pass(1)
+        native = extra_pass(0)
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
-        names = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,2,0,false,32>", 1: "igemm_kernel<128,64,2,2,0>", 2: "igemm_kernel<256,32,4,1,0>",
+        names = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,2,0,false,32>",
+                 1: "igemm_kernel<128,64,2,2,0>", 2: "igemm_kernel<256,32,4,1,0>",
                  3: "igemm_kernel<128,128,2,2,1>", 4: "igemm_kernel<128,64,2,2,1>", 5: "wgrad_kernel<*>",
                  6: "igemm_kernel<64,128,2,2,0>", 7: "igemm_kernel<64,128,2,2,1>",
                  8: "l2norm_score_fwd_kernel", 9: "l2norm_score_bwd_kernel", 10: "scale_act_kernel",
                  11: "bn_act_bwd_apply_kernel", 12: "exp_sums_kernel",
                  13: "igemm_kernel<...> (LSTM-step GEMMs, <1024 rows, side stream)",
-                 14: "wgrad_kernel<...> (LSTM-step GEMMs, side stream)"}
-        kern = {}
-        for t, nm in names.items():
-            if counts[t]:
-                unit = "TFLOP/s" if (t <= 7 or t >= 13) else "GB/s"
-                rate = work[t] / (ms[t] * 1e-3) / (1e12 if (t <= 7 or t >= 13) else 1e9)
-                if t == 13 or t == 14:
-                    nm = nm  # side-stream kernels overlap with the main stream: their time is not additive
-                kern[nm] = {"launches_per_step": counts[t] / args.steps, "avg_ms": ms[t] / counts[t],
-                            "ms_per_step": ms[t] / args.steps, "achieved": rate, "unit": unit}
-        dom = 0   # the 128x128 NT tile of the conv engine carries most of the FLOPs
+                 14: "wgrad_kernel<...> (LSTM-step GEMMs, side stream)",
+                 16: "igemm_kernel<128,128,2,2,0,false,16,true>",
+                 17: "wgrad_kernel<128,128,16,true>"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
+
+        def table(c, m, w, nsteps):
+            out = {}
+            for t, nm in names.items():
+                if c[t]:
+                    fl = t in flop_tags
+                    rate = w[t] / (m[t] * 1e-3) / (1e12 if fl else 1e9)
+                    out[nm] = {"launches_per_step": c[t] / nsteps, "avg_ms": m[t] / c[t], "ms_per_step": m[t] / nsteps,
+                               "achieved": rate, "unit": "TFLOP/s" if fl else "GB/s",
+                               "frac": rate / (peak_of[t] if fl else PEAK_HBM_GBS)}
+            return out
+
+        kern = table(counts, ms, work, args.steps)
+        mm_tags = sorted(flop_tags - {13, 14})
+        dom = max(mm_tags, key=lambda t: work[t])       # the kernel that carries most of the step's FLOPs
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
@@ -209,33 +231,46 @@ def main():
                 pmc = json.load(f)
             if pmc.get("kernel") == names[dom]:
                 traffic = pmc.get("hbm_bytes_per_launch")
-        conv_tags = list(range(8)) + [15]
-        mfma_ms = sum(ms[t] for t in conv_tags); mfma_work = sum(work[t] for t in conv_tags)
-        roofline = {"bound": "mfma", "kernel": names[dom],
-                    "achieved": work[dom] / (ms[dom] * 1e-3) / 1e12 if counts[dom] else None,
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": (work[dom] / (ms[dom] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if counts[dom] else None,
-                    "traffic": traffic,
-                    "avg_launch_ms": ms[dom] / counts[dom] if counts[dom] else None,
-                    "flop_per_launch": work[dom] / counts[dom] if counts[dom] else None,
-                    "all_mfma_kernels": {"achieved": mfma_work / (mfma_ms * 1e-3) / 1e12 if mfma_ms else None,
-                                         "frac": mfma_work / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS if mfma_ms else None,
-                                         "ms_per_step": mfma_ms / args.steps,
-                                         "share_of_step": mfma_ms / args.steps / (dt / args.steps * 1e3)},
+        mfma_ms = sum(ms[t] for t in mm_tags); mfma_work = sum(work[t] for t in mm_tags)
+        ach = work[dom] / (ms[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": ach, "peak": peak_of[dom], "unit": "TFLOP/s",
+                    "frac": ach / peak_of[dom], "traffic": traffic,
+                    "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
+                    "peak_note": ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
+                                  "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
+                                 if dom in (16, 17) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
                     "overlap": "the timed region runs the weight-gradient GEMMs on a second stream beside the data-gradient "
-                               "chain; per-launch durations above include the time a launch shared the CUs",
-                    "exclusive": excl,
+                               "chain; per-launch durations here include the time a launch shared the CUs",
                     # every FLOP the MFMA kernels were asked for in a step over the whole step's wall time
-                    "step_mfma": {"tflop_per_step": mfma_work / args.steps / 1e12,
-                                  "achieved": mfma_work / 1e12 / dt,
-                                  "frac": mfma_work / 1e12 / dt / PEAK_FP32_MFMA_TFLOPS},
+                    "step_mfma": {"tflop_per_step": mfma_work / args.steps / 1e12, "achieved": mfma_work / 1e12 / dt,
+                                  "frac_of_fp32_pipe": mfma_work / 1e12 / dt / PEAK_FP32_MFMA_TFLOPS},
                     "hbm_scoring": {"kernel": names[8], "achieved": kern.get(names[8], {}).get("achieved"),
                                     "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                     "frac": (kern[names[8]]["achieved"] / PEAK_HBM_GBS) if names[8] in kern else None},
                     "kernels": kern}
+        if excl is not None:
+            c2, m2, w2, ms_step = excl
+            if c2[dom]:
+                a2 = w2[dom] / (m2[dom] * 1e-3) / 1e12
+                roofline["exclusive"] = {"kernel": names[dom], "achieved": a2, "peak": peak_of[dom], "frac": a2 / peak_of[dom],
+                                         "avg_launch_ms": m2[dom] / c2[dom], "steps": args.exclusive_steps, "ms_per_step": ms_step,
+                                         "note": "same launches with the weight-gradient stream switched off (untimed pass)",
+                                         "kernels": table(c2, m2, w2, args.exclusive_steps)}
+            c3, m3, w3, ms_step3 = native
+            d3 = max(mm_tags, key=lambda t: w3[t])
+            a3 = w3[d3] / (m3[d3] * 1e-3) / 1e12
+            roofline["native_fp32"] = {"kernel": names[d3], "achieved": a3, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                       "frac": a3 / PEAK_FP32_MFMA_TFLOPS, "avg_launch_ms": m3[d3] / c3[d3],
+                                       "ms_per_step": ms_step3, "clips_per_s": args.clips * world / (ms_step3 * 1e-3),
+                                       "note": "dcn_set_tuning('precision', 0): every tile on v_mfma_f32_32x32x2_f32, "
+                                               "weight-gradient stream off (untimed pass)",
+                                       "kernels": table(c3, m3, w3, args.exclusive_steps)}
         res = {"metric": "clips/sec (T=8, 416x416, bs8) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "precision": "fp32 tensors and fp32 accumulation everywhere; the 128x128 GEMM tiles multiply on the bf16 matrix "
+                            "pipe with each operand cut into 3 exact bf16 pieces (6 cross terms >= 2^-16 kept): error vs fp64 "
+                            "<= that of the fp32 MFMA instruction (tests/test_ops_gpu.py::test_split_pipe_is_fp32_accurate)",
                "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips} clips/GPU, 20-token query, fp32, "
                                       f"pair semantics ({n_img} images/GPU/step), fwd + 5 losses + bwd + RMSprop",
                           "images_per_gpu": n_img, "parallelism": f"dp{world}"},

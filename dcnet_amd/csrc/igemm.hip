@@ -22,11 +22,13 @@
 // LeakyReLU/ReLU, the shortcut add, and accumulate-into-destination.
 #include "igemm.h"
 #include "prof.h"
+#include <type_traits>
 
 namespace {
 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr unsigned OOB = 0x80000000u;   // voffset sentinel: beyond every descriptor (num_records <= 0x7FFFFFF0) -> load returns 0
 
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -43,9 +45,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // costs ~4 VALU per activation load (add the wave-uniform tap delta, test the mask bit, select the sentinel)
 // and none per weight load (constant voffset, wave-uniform soffset).  With 64 MFMAs per K-step per wave this
 // keeps the vector ALU out of the matrix pipe's way (it was 3.4 VALU per MFMA with pointer arithmetic).
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK>
+// SP ("split"): the same tile engine on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand is cut
+// into three bf16 pieces x = h + m + l (truncation cuts, exact: 8 + 8 + 8 significant bits) when its tile
+// is written to LDS, and a product a*b is accumulated as the six cross terms of weight >= 2^-16
+// (l*h, h*l, m*m, m*h, h*m, h*h; the dropped m*l, l*m, l*l are <= 2^-23 relative, one fp32 rounding) with
+// v_mfma_f32_32x32x16_bf16: 6 instructions of 32 cycles per 16 k against 8 of 64 cycles on the fp32 pipe
+// (bf16 products are exact in the fp32 accumulator).  LDS holds three bf16 planes per operand,
+// rows padded by 16 B so the ds_read_b128 fragments (8 consecutive k per lane) are conflict-free.
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  static_assert(!SP || (BMODE == 0 && !C4), "split mode: NT operands only");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
+  constexpr int LD16 = BK + 8;             // SP: bf16 plane row in ushorts (BK*2 B + 16 B pad)
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -58,6 +69,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   float* As = smem;                      // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;    // BMODE 0: [2][BN][LDS_LD]   BMODE 1: [2][BK][BN]
   constexpr int B_TILE = BMODE == 0 ? BN * LDS_LD : BK * BN;
+  unsigned short* As16 = reinterpret_cast<unsigned short*>(smem);      // SP: [2][3][BM][LD16]
+  unsigned short* Bs16 = As16 + 2 * 3 * BM * LD16;                     // SP: [2][3][BN][LD16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -131,7 +144,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   int kbase = 0;                                        // BMODE 1: first k of the step (K tail masking)
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
-  auto load_tiles = [&](int it) {
+  f32x4 a_reg2[SP ? A_LD : 1], b_reg2[SP ? B_LD : 1];   // SP: second register stage (loads run two K-steps ahead)
+  auto load_tiles_into = [&](f32x4* a_reg, f32x4* b_reg, int it) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       unsigned v;
@@ -165,7 +179,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto split_store = [&](unsigned short* plane0, int plane_stride, int off, const f32x4 v) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e];              // (a bit_cast straight from the vector element reads element 0)
+      if (ABL == 1) { h[e] = m[e] = l[e] = __float_as_uint(x); continue; }
+      h[e] = __float_as_uint(x) & 0xFFFF0000u;
+      const float r1 = x - __uint_as_float(h[e]);
+      m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+      l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+    }
+    // pack the high halves of two dwords: bytes {lo.b2, lo.b3, hi.b2, hi.b3}
+    uint2 ph = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    uint2 pm = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    uint2 pl = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+    *reinterpret_cast<uint2*>(plane0 + off) = ph;
+    *reinterpret_cast<uint2*>(plane0 + plane_stride + off) = pm;
+    *reinterpret_cast<uint2*>(plane0 + 2 * plane_stride + off) = pl;
+  };
+  auto load_tiles = [&](int it) { load_tiles_into(a_reg, b_reg, it); };
+  auto store_tiles_from = [&](const f32x4* a_reg, const f32x4* b_reg, int buf) {
+    if constexpr (SP) {
+      unsigned short* a16 = As16 + buf * 3 * BM * LD16;
+      unsigned short* b16 = Bs16 + buf * 3 * BN * LD16;
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, (row0 + RPP * j) * LD16 + chunk * 4, a_reg[j]);
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j)
+        if (!B_PART || row0 < BN) split_store(b16, BN * LD16, (row0 + RPP * j) * LD16 + chunk * 4, b_reg[j]);
+      return;
+    }
     float* a = As + buf * BM * LDS_LD;
     float* b = Bs + buf * B_TILE;
 #pragma unroll
@@ -177,6 +221,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       else *reinterpret_cast<f32x4*>(b + (tid + 256 * j) * 4) = b_reg[j];
     }
   };
+  auto store_tiles = [&](int buf) { store_tiles_from(a_reg, b_reg, buf); };
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -190,6 +235,86 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int b_frag = BMODE == 0 ? (wn * (BN / WN) + (lane & 31)) * LDS_LD + (lane >> 5) * 4
                                 : (lane >> 5) * 4 * BN + wn * (BN / WN) + (lane & 31);
 
+  if constexpr (SP) {
+    // Two K-steps of global loads in flight (a K-step of six bf16 MFMAs per block is shorter than the
+    // L2/HBM latency): stage S of the registers holds step it+1 while stage S^1 receives step it+2.
+    // One K-step: fragments of LDS buffer `cur`, six MFMA groups (one per cross term); the split + LDS
+    // store of the NEXT step's tile (already in registers) is cut into pieces and issued between the
+    // groups, so the vector ALU and the LDS write port work in the shadow of the matrix pipe (a wave
+    // issues in order: anything placed after the last MFMA would wait for all of them).
+    auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
+      const unsigned short* a16 = As16 + cur * 3 * BM * LD16 + (wm * (BM / WM) + (lane & 31)) * LD16 + (lane >> 5) * 8;
+      const unsigned short* b16 = Bs16 + cur * 3 * BN * LD16 + (wn * (BN / WN) + (lane & 31)) * LD16 + (lane >> 5) * 8;
+      unsigned short* na = As16 + (cur ^ 1) * 3 * BM * LD16;
+      unsigned short* nb = Bs16 + (cur ^ 1) * 3 * BN * LD16;
+      constexpr int PIECES = A_LD + B_LD;
+      constexpr int GROUPS = 6 * (BK / 16);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 af[MI][3], bf[NI][3];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            af[mi][q] = *reinterpret_cast<const bf16x8*>(a16 + q * BM * LD16 + mi * 32 * LD16 + kk * 16);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            bf[ni][q] = *reinterpret_cast<const bf16x8*>(b16 + q * BN * LD16 + ni * 32 * LD16 + kk * 16);
+        // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < (ABL == 2 ? 1 : 6); ++t) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t]], bf[ni][QB[t]], acc[mi][ni], 0, 0, 0);
+          if constexpr (decltype(do_store)::value) {
+            // pieces g, g + GROUPS, ... belong to group g = kk*6 + t
+#pragma unroll
+            for (int pc = kk * 6 + t; pc < PIECES; pc += GROUPS) {
+              if (pc < A_LD) split_store(na, BM * LD16, (row0 + RPP * pc) * LD16 + chunk * 4, ar[pc]);
+              else if (!B_PART || row0 < BN) split_store(nb, BN * LD16, (row0 + RPP * (pc - A_LD)) * LD16 + chunk * 4, br[pc - A_LD]);
+            }
+          }
+        }
+      }
+      if constexpr (decltype(do_store)::value) {
+        // ask the scheduler for: 1 MFMA, then up to 5 VALU and an LDS write in its 32-cycle shadow, x24
+#pragma unroll
+        for (int g = 0; g < MI * NI * 6 * (BK / 16); ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    };
+    using T = std::true_type; using F = std::false_type;
+    load_tiles_into(a_reg, b_reg, 0);
+    if (p.kiters > 1) load_tiles_into(a_reg2, b_reg2, 1);
+    store_tiles_from(a_reg, b_reg, 0);
+    __syncthreads();
+    int it = 0;
+    for (; it + 2 < p.kiters; it += 2) {
+      // even step: LDS buffer 0 is current, stage 2 holds step it+1, stage 1 is free for step it+2
+      load_tiles_into(a_reg, b_reg, it + 2);
+      step(0, a_reg2, b_reg2, T{});
+      __syncthreads();
+      if (it + 3 < p.kiters) load_tiles_into(a_reg2, b_reg2, it + 3);
+      step(1, a_reg, b_reg, T{});
+      __syncthreads();
+    }
+    if (it + 1 < p.kiters) {      // two steps left: buffer 0 current, stage 2 holds the last step
+      step(0, a_reg2, b_reg2, T{});
+      __syncthreads();
+      step(1, a_reg, b_reg, F{});
+    } else {
+      step(0, a_reg, b_reg, F{});
+    }
+    __syncthreads();
+  } else {
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
@@ -221,6 +346,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     if (it + 1 < p.kiters) store_tiles(cur ^ 1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------
@@ -316,26 +442,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0>
 int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   IgemmParams p = p0;
   p.cpt = p.c4 ? 1 : p.Ci / BK;
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
-  const size_t lds = (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
+  const size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * (BK + 8) * sizeof(unsigned short)
+                        : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? 16 : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
@@ -345,11 +472,21 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 // ~40 KB so three workgroups share a CU — better latency hiding on the long-M layers (+3..+60 %, most on the
 // narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
 int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
+int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile onto the split-bf16 pipe (bench_convs A/B)
+int g_precision = 1;      // dcn_set_tuning("precision", 0|1): 1 = 128x128 NT tiles of >= 1024 rows use the split-bf16 pipe
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
   const long long rows = (long long)p.M * (p.batch > 0 ? p.batch : 1);       // batched GEMMs fill the chip like one long M
   const int bk = g_force_bk ? g_force_bk : (rows <= 16384 ? 32 : 16);
+  if constexpr (BMODE == 0 && !C4) {
+    // narrow tiles gain nothing from the split (its vector-ALU cost per MFMA grows as the tile shrinks:
+    // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
+    if (g_split || (g_precision == 1 && BM == 128 && BN == 128 && rows >= 1024)) {
+      if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
+      return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true>(p, stream);
+    }
+  }
   if (bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
   return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
 }
@@ -376,10 +513,15 @@ inline int tile_bm(int M, int Co) {
 
 int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
 
+void wgrad_set_split(int v);
+
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
+  if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
+  else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
   return DCN_OK;
 }

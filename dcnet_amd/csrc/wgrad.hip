@@ -12,6 +12,7 @@
 // Roofline: MFMA (same 157.3 TFLOP/s fp32 peak as the forward).
 #include "common.h"
 #include "prof.h"
+#include <type_traits>
 
 #ifndef WGRAD_KP
 #define WGRAD_KP 16          // pixels per K-step (16: ~32 KB LDS, three workgroups per CU; measured +6 % over 32)
@@ -48,8 +49,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // KP = pixels (K) per step.  Loads are raw buffer loads (out-of-range -> 0): the dY rows use a constant
 // per-thread voffset plus a wave-uniform soffset that advances by KP rows; the gathered X rows keep their
 // (n, ho, wo) coordinates and byte offset incrementally (no division, no multiply in the loop).
-template <int TM, int TN, int KP>
+// SP ("split", 128x128 tiles only): the bf16 matrix pipe at fp32 accuracy, as in igemm.hip — operands are cut
+// into three bf16 pieces when the tile goes to LDS and six cross terms are accumulated with
+// v_mfma_f32_32x32x16_bf16.  K (pixels) is the strided dimension of both operands, so the LDS planes
+// keep the HBM orientation [pixel][128 channels] (256-B rows, 16-B chunks XOR-swizzled) and the MFMA
+// operands (8 consecutive k per lane) come from the hardware transpose read ds_read_b64_tr_b16.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int sp_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// byte offset of channels c..c+3 (c % 4 == 0) of pixel row `row` inside one [16][128] bf16 plane
+__device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ sp_swz(row)) + 8 * ((c >> 2) & 1); }
+
+template <int TM, int TN, int KP, bool SP = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int MI = TM / (32 * WM), NI = TN / (32 * WN);
   constexpr int A_N = KP * TM / 4, B_N = KP * TN / 4;               // 16-B pieces per tile
@@ -113,8 +127,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
+  f32x4 a_reg2[SP ? A_LD : 1], b_reg2[SP ? B_LD : 1];    // SP: second register stage (two K-steps of loads in flight)
   unsigned a_soff = 0; int rows_left = m_end - m_begin;
-  auto load_tiles = [&]() {
+  auto load_tiles_into = [&](f32x4* a_reg, f32x4* b_reg) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
       a_reg[j] = buf_load16(a_rs, a_pix[j] < rows_left ? a_voff[j] : OOB, a_soff);
@@ -132,7 +147,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
     a_soff += (unsigned)(KP * p.lddy * 4); rows_left -= KP;
   };
+  auto load_tiles = [&]() { load_tiles_into(a_reg, b_reg); };
+  unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][3 planes][16][256 B]
+  auto split_store = [&](unsigned char* plane0, int off, const f32x4 v) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = v[e];
+      h[e] = __float_as_uint(x) & 0xFFFF0000u;
+      const float r1 = x - __uint_as_float(h[e]);
+      m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+      l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+    }
+    uint2 ph = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    uint2 pm = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    uint2 pl = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+    *reinterpret_cast<uint2*>(plane0 + off) = ph;
+    *reinterpret_cast<uint2*>(plane0 + 4096 + off) = pm;
+    *reinterpret_cast<uint2*>(plane0 + 8192 + off) = pl;
+  };
+  // SP: piece j of the A / B tile (pixel, 4 channels) -> the three planes of LDS buffer `buf`
+  auto sp_store_piece = [&](int buf, int pc, const f32x4* ar, const f32x4* br) {
+    const bool isb = pc >= A_LD;
+    const int j = isb ? pc - A_LD : pc;
+    const int idx = tid + 256 * j;
+    const int pix = idx / 32, c = (idx - pix * 32) * 4;
+    split_store(sp_base + buf * 24576 + (isb ? 12288 : 0), sp_off(pix, c), isb ? br[j] : ar[j]);
+  };
   auto store_tiles = [&](int buf) {
+    if constexpr (SP) {
+#pragma unroll
+      for (int pc = 0; pc < A_LD + B_LD; ++pc) sp_store_piece(buf, pc, a_reg, b_reg);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
       if (A_N % 256 == 0 || tid + 256 * j < A_N) *reinterpret_cast<f32x4*>(As + buf * KP * TM + (tid + 256 * j) * 4) = a_reg[j];
@@ -157,6 +204,81 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   // fragment element for k2-step ks: pixel row 2*ks + (lane>>5), channel (lane&31)
   const int a_off = (wk * KS * 2 + (lane >> 5)) * TM + wm * (TM / WM) + (lane & 31);
   const int b_off = (wk * KS * 2 + (lane >> 5)) * TN + wn * (TN / WN) + (lane & 31);
+  if constexpr (SP) {
+    // transposed-read addresses: 16-lane group g16 = (h, gg): k rows 8h + 4r + q, channels blk*32 + 16gg + 4pp
+    const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    int a_tr[MI][2], b_tr[NI][2];
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int row = 8 * hh + 4 * r2 + q;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a_tr[mi][r2] = sp_off(row, wm * 64 + mi * 32 + 16 * gg + 4 * pp);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b_tr[ni][r2] = 12288 + sp_off(row, wn * 64 + ni * 32 + 16 * gg + 4 * pp);
+    }
+    auto tr_read = [&](int byte_off) {
+      return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(sp_base + byte_off));
+    };
+    auto frag = [&](int byte0, int byte1) {
+      const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
+      bf16x8 af[MI][3], bf[NI][3];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[mi][pl] = frag(cur * 24576 + pl * 4096 + a_tr[mi][0], cur * 24576 + pl * 4096 + a_tr[mi][1]);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bf[ni][pl] = frag(cur * 24576 + pl * 4096 + b_tr[ni][0], cur * 24576 + pl * 4096 + b_tr[ni][1]);
+      constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t6]], bf[ni][QB[t6]], acc[mi][ni], 0, 0, 0);
+        if constexpr (decltype(do_store)::value)
+          if (t6 < A_LD + B_LD) sp_store_piece(cur ^ 1, t6, ar, br);
+      }
+      if constexpr (decltype(do_store)::value) {
+#pragma unroll
+        for (int g = 0; g < MI * NI * 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+    };
+    // stage 2 holds step it+1 while step it is multiplied and stage 1 receives step it+2; the split + LDS
+    // store of step it+1 rides between the MFMAs of step it
+    using T = std::true_type; using F = std::false_type;
+    if (iters > 1) load_tiles_into(a_reg2, b_reg2);
+    int it = 0;
+    for (; it + 2 < iters; it += 2) {
+      load_tiles_into(a_reg, b_reg);                       // step it+2
+      step(0, a_reg2, b_reg2, T{});
+      __syncthreads();
+      if (it + 3 < iters) load_tiles_into(a_reg2, b_reg2); // step it+3
+      step(1, a_reg, b_reg, T{});
+      __syncthreads();
+    }
+    if (it + 1 < iters) {
+      step(0, a_reg2, b_reg2, T{});
+      __syncthreads();
+      step(1, a_reg, b_reg, F{});
+    } else if (it < iters) {
+      step(0, a_reg, b_reg, F{});
+    }
+    __syncthreads();
+  } else
   for (int it = 0; it < iters; ++it) {
     const int cur = it & 1;
     if (it + 1 < iters) load_tiles();
@@ -268,29 +390,32 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   return pl;
 }
 
-template <int TM, int TN>
+int g_wsplit = 1;          // 128x128 weight-gradient / TN tiles on the split-bf16 pipe (dcn_set_tuning("precision"|"wsplit", 0) = native)
+
+template <int TM, int TN, bool SP = false>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
-  constexpr int KP = WGRAD_KP < 2 * WK ? 2 * WK : WGRAD_KP;
-  size_t lds = (size_t)2 * KP * (TM + TN) * sizeof(float);
+  constexpr int KP = SP ? 16 : (WGRAD_KP < 2 * WK ? 2 * WK : WGRAD_KP);
+  size_t lds = SP ? (size_t)2 * 24576 : (size_t)2 * KP * (TM + TN) * sizeof(float);
   const size_t red = (size_t)(WK - 1) * TM * TN * sizeof(float);
   if (red > lds) lds = red;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
-  const int pid = prof_begin(p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP>), dim3(grid, batch), dim3(256), lds, stream, p);
+  const int pid = prof_begin(SP ? 17 : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
   return DCN_OK;
 }
 
 int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream) {
-  if (tm == 128 && tn == 128) return launch_wgrad<128, 128>(p, grid, batch, stream);
+  if (tm == 128 && tn == 128) return (g_wsplit && !p.c4 && p.M >= 1024) ? launch_wgrad<128, 128, true>(p, grid, batch, stream)
+                                                         : launch_wgrad<128, 128>(p, grid, batch, stream);
   if (tm == 128 && tn == 64) return launch_wgrad<128, 64>(p, grid, batch, stream);
   if (tm == 128 && tn == 32) return launch_wgrad<128, 32>(p, grid, batch, stream);
   if (tm == 64 && tn == 128) return launch_wgrad<64, 128>(p, grid, batch, stream);
@@ -302,6 +427,8 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
 }
 
 }  // namespace
+
+void wgrad_set_split(int v) { g_wsplit = v; }
 
 // C[b][m][n] (+)= row_scale[b][m] * sum_k A[b][k][m] * B[b][k][n]   ("TN" GEMM: K is the strided dim of
 // both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.

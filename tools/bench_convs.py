@@ -85,9 +85,11 @@ def main():
             key, val = args.ab.split("=")
             lib().set_tuning(key.encode(), int(val))
             t_f2 = timeit(f_fwd); t_d2 = timeit(f_dg) if has_dg else 0.0
+            t_w2 = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
             lib().set_tuning(key.encode(), 0)
             t_f3 = timeit(f_fwd)          # default again: drift check
-            print("AB %5d %5d k%d s%d H%4d  fwd %.3f -> %.3f (recheck %.3f)  dgrad %.3f -> %.3f" % (cin, cout, k, st, h, t_f, t_f2, t_f3, t_d, t_d2))
+            print("AB %5d %5d k%d s%d H%4d  fwd %.3f -> %.3f (recheck %.3f)  dgrad %.3f -> %.3f  wgrad %.3f -> %.3f" % (cin, cout, k, st, h, t_f, t_f2, t_f3, t_d, t_d2, t_w, t_w2))
+            tot["fwd_b"] += cnt * t_f2; tot["dgrad_b"] += cnt * t_d2; tot["wgrad_b"] += cnt * t_w2
         rows.append((cin, cout, k, st, h, cnt, flop / 1e9, t_f, t_d, t_w))
         tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w
         tot["flop"] += cnt * flop
@@ -97,6 +99,8 @@ def main():
             cin, cout, k, st, h, cnt, gf, tf, gf / tf, td, gf / td if td else 0, tw, gf / tw))
     for k in ("fwd", "dgrad", "wgrad"):
         print("total %-6s %8.2f ms  -> %6.1f TF/s" % (k, tot[k], tot["flop"] / 1e9 / tot[k]))
+        if args.ab:
+            print("   with %-12s %8.2f ms  -> %6.1f TF/s" % (args.ab, tot[k + "_b"], tot["flop"] / 1e9 / tot[k + "_b"]))
 
 
 if __name__ == "__main__":
