@@ -1,0 +1,30 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root:
+#   bash tools/gpu_profile.sh <tag>
+# 1. bench.py as the driver runs it            -> gpurun_out/<tag>/bench.json
+# 2. the same command under rocprofv3 --stats  -> gpurun_out/<tag>/stats/   (kernel trace only)
+# 3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no other trace domains) -> gpurun_out/<tag>/pmc_*/
+# tools/summarize_profile.py turns 2 and 3 into the files committed under profiles/.
+set -eo pipefail
+TAG=${1:-prof}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench done"; tail -c 600 "$OUT/bench.json"; echo
+BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --exclusive-steps 0"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+echo "stats done"
+BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --exclusive-steps 0"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_fetch.err"
+echo "pmc fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_write.err"
+echo "pmc write done"
+cd "$ROOT"
+python3 tools/summarize_profile.py "$OUT" --no-copy || true
+# keep the merged-back payload small: counter_collection csv can be large, the per-kernel summaries are enough
+find "$OUT" -name '*_kernel_trace.csv' -size +20M -delete || true
+find "$OUT" -name '*counter_collection.csv' -size +20M -delete || true
+du -sh "$OUT"

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Condense what tools/gpu_profile.sh left under gpurun_out/<tag>/ into the files kept under profiles/:
+
+    python tools/summarize_profile.py gpurun_out/<tag> [--round 1] [--name bench] [--no-copy]
+
+  profiles/rNN_<name>_kernel_stats.csv       rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/rNN_<name>_under_rocprof.json     bench.py's JSON line from that same run
+  profiles/rNN_pmc_{fetch,write}_size_by_kernel.tsv   kernel, launches, sum KB, average KB per launch
+  profiles/pmc_latest.json                   HBM bytes per launch of the kernel bench.py names as dominant
+                                             (FETCH_SIZE doubled: gfx950 correction, MI355X_MICROARCH.md HBM section)
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csv.field_size_limit(1 << 30)
+
+
+def find(d, pat):
+    hits = sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+    return hits[0] if hits else None
+
+
+def pmc_by_kernel(path, counter):
+    """counter_collection.csv -> {kernel: [launches, sum]}; a dispatch may span several rows (one per counter/dimension)."""
+    per_dispatch = collections.defaultdict(float)
+    name_of = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            key = (row.get("Process_Id", ""), row.get("Dispatch_Id") or row.get("Correlation_Id"))
+            per_dispatch[key] += float(row["Counter_Value"])
+            name_of[key] = row["Kernel_Name"]
+    out = collections.defaultdict(lambda: [0, 0.0])
+    for key, v in per_dispatch.items():
+        o = out[name_of[key]]
+        o[0] += 1
+        o[1] += v
+    return out
+
+
+def norm(name):
+    return name.replace(" ", "").replace("void", "").replace("(anonymousnamespace)::", "")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--round", type=int, default=1)
+    ap.add_argument("--name", default="bench")
+    ap.add_argument("--no-copy", action="store_true", help="print only, leave profiles/ alone")
+    a = ap.parse_args()
+    prof = os.path.join(ROOT, "profiles")
+    tag = f"r{a.round:02d}"
+    stats = find(os.path.join(a.dir, "stats"), "*kernel_stats.csv")
+    bench_json = os.path.join(a.dir, "bench_under_rocprof.json")
+    dominant = None
+    if os.path.exists(bench_json) and os.path.getsize(bench_json):
+        with open(bench_json) as f:
+            line = [l for l in f if l.startswith("{")][-1]
+        dominant = json.loads(line)["roofline"]["kernel"]
+    if stats:
+        with open(stats, newline="") as f:
+            rows = list(csv.DictReader(f))
+        print(f"{'kernel':90s} {'calls':>6s} {'avg us':>10s} {'%':>6s}")
+        for r in rows[:14]:
+            print(f"{r['Name'][:90]:90s} {r['Calls']:>6s} {float(r['AverageNs']) / 1e3:10.1f} {r['Percentage']:>6s}")
+        if not a.no_copy:
+            shutil.copy(stats, os.path.join(prof, f"{tag}_{a.name}_kernel_stats.csv"))
+            if os.path.exists(bench_json):
+                shutil.copy(bench_json, os.path.join(prof, f"{tag}_{a.name}_under_rocprof.json"))
+    tables = {}
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        cc = find(os.path.join(a.dir, f"pmc_{which}"), "*counter_collection.csv")
+        if not cc:
+            continue
+        t = pmc_by_kernel(cc, counter)
+        tables[which] = t
+        lines = [f"{k[:90]}\t{n}\t{s:.3f}\t{s / n:.4f}" for k, (n, s) in sorted(t.items(), key=lambda kv: -kv[1][1])]
+        if not a.no_copy:
+            with open(os.path.join(prof, f"{tag}_pmc_{which}_size_by_kernel.tsv"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+        print(f"-- {counter} (KB): kernel, launches, sum, avg/launch")
+        print("\n".join(lines[:6]))
+    if dominant and len(tables) == 2:
+        want = norm(dominant).rstrip(">")      # rocprof prints defaulted template arguments too
+        hit = [k for k in tables["fetch"] if want in norm(k)]
+        if hit:
+            k = hit[0]
+            nf, sf = tables["fetch"][k]
+            nw, sw = tables["write"].get(k, [1, 0.0])
+            fetch_kb, write_kb = sf / nf, sw / max(nw, 1)
+            rec = {"round": a.round, "kernel": dominant, "rocprof_name": k, "launches_in_pass": nf,
+                   "FETCH_SIZE_KB_avg_per_launch": fetch_kb, "WRITE_SIZE_KB_avg_per_launch": write_kb,
+                   "gfx950_correction": "FETCH_SIZE doubled (16-B/lane coalesced reads are tallied at half their bytes, "
+                                        "MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+                   "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
+                   "command": "tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 "
+                              "bench.py --steps 1 --warmup 0 --no-cpu-baseline --exclusive-steps 0 (second pass: --pmc WRITE_SIZE)",
+                   "note": "Infinity-Cache hits are counted in FETCH_SIZE, so this is an upper bound on HBM bytes"}
+            print(json.dumps(rec, indent=1))
+            if not a.no_copy:
+                with open(os.path.join(prof, "pmc_latest.json"), "w") as f:
+                    json.dump(rec, f, indent=1)
+        else:
+            print("dominant kernel", dominant, "not found in the PMC pass", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
