@@ -56,7 +56,17 @@ template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = 
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   static_assert(!SP || (BMODE == 0 && !C4), "split mode: NT operands only");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
-  constexpr int LD16 = BK + 8;             // SP: bf16 plane row in ushorts (BK*2 B + 16 B pad)
+  // SP: bf16 plane row in ushorts.  BK = 16: unpadded 32-B rows whose two 16-B halves swap places in rows
+  // 8-15 (mod 16) — conflict-free for the ds_read_b128 fragments (16-lane groups see 16 distinct 16-B slots)
+  // AND for the ds_write_b64 of the split pieces (a 16-lane group fills four whole rows = 128 contiguous bytes;
+  // with 48-B padded rows a third of the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).  BK = 32: padded.
+  constexpr int LD16 = BK == 16 ? 16 : BK + 8;
+  auto sp_w = [](int row, int chunk) {      // ushort offset of floats 4*chunk..4*chunk+3 of `row` inside a plane
+    return BK == 16 ? row * 16 + ((((chunk >> 1) ^ (row >> 3)) & 1) << 3) + (chunk & 1) * 4 : row * LD16 + chunk * 4;
+  };
+  auto sp_r = [](int row, int half) {       // ushort offset of k = 8*half..8*half+7 (K-step slice 0) of `row`
+    return BK == 16 ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
+  };
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -204,10 +214,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       unsigned short* a16 = As16 + buf * 3 * BM * LD16;
       unsigned short* b16 = Bs16 + buf * 3 * BN * LD16;
 #pragma unroll
-      for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, (row0 + RPP * j) * LD16 + chunk * 4, a_reg[j]);
+      for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j]);
 #pragma unroll
       for (int j = 0; j < B_LD; ++j)
-        if (!B_PART || row0 < BN) split_store(b16, BN * LD16, (row0 + RPP * j) * LD16 + chunk * 4, b_reg[j]);
+        if (!B_PART || row0 < BN) split_store(b16, BN * LD16, sp_w(row0 + RPP * j, chunk), b_reg[j]);
       return;
     }
     float* a = As + buf * BM * LDS_LD;
@@ -243,8 +253,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // groups, so the vector ALU and the LDS write port work in the shadow of the matrix pipe (a wave
     // issues in order: anything placed after the last MFMA would wait for all of them).
     auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
-      const unsigned short* a16 = As16 + cur * 3 * BM * LD16 + (wm * (BM / WM) + (lane & 31)) * LD16 + (lane >> 5) * 8;
-      const unsigned short* b16 = Bs16 + cur * 3 * BN * LD16 + (wn * (BN / WN) + (lane & 31)) * LD16 + (lane >> 5) * 8;
+      const unsigned short* a16 = As16 + cur * 3 * BM * LD16 + sp_r(wm * (BM / WM) + (lane & 31), lane >> 5);
+      const unsigned short* b16 = Bs16 + cur * 3 * BN * LD16 + sp_r(wn * (BN / WN) + (lane & 31), lane >> 5);
       unsigned short* na = As16 + (cur ^ 1) * 3 * BM * LD16;
       unsigned short* nb = Bs16 + (cur ^ 1) * 3 * BN * LD16;
       constexpr int PIECES = A_LD + B_LD;
@@ -275,8 +285,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             // pieces g, g + GROUPS, ... belong to group g = kk*6 + t
 #pragma unroll
             for (int pc = kk * 6 + t; pc < PIECES; pc += GROUPS) {
-              if (pc < A_LD) split_store(na, BM * LD16, (row0 + RPP * pc) * LD16 + chunk * 4, ar[pc]);
-              else if (!B_PART || row0 < BN) split_store(nb, BN * LD16, (row0 + RPP * (pc - A_LD)) * LD16 + chunk * 4, br[pc - A_LD]);
+              if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc]);
+              else if (!B_PART || row0 < BN) split_store(nb, BN * LD16, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD]);
             }
           }
         }
@@ -449,7 +459,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
-  const size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * (BK + 8) * sizeof(unsigned short)
+  const size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * (BK == 16 ? 16 : BK + 8) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -473,6 +483,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 // narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
 int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
 int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile onto the split-bf16 pipe (bench_convs A/B)
+int g_abl = 0;            // dcn_set_tuning("abl", 1|2): timing-only ablations of the split kernel (results are wrong)
 int g_precision = 1;      // dcn_set_tuning("precision", 0|1): 1 = 128x128 NT tiles of >= 1024 rows use the split-bf16 pipe
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
@@ -484,6 +495,8 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
     if (g_split || (g_precision == 1 && BM == 128 && BN == 128 && rows >= 1024)) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
+      if (g_abl == 1) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 1>(p, stream);   // ablation: no split arithmetic (wrong results)
+      if (g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2>(p, stream);   // ablation: 1 of 6 MFMA groups (wrong results)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true>(p, stream);
     }
   }
@@ -514,6 +527,7 @@ inline int tile_bm(int M, int Co) {
 int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
 
 void wgrad_set_split(int v);
+void wgrad_set_abl(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
@@ -521,6 +535,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
+  else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
   return DCN_OK;

@@ -34,7 +34,28 @@ struct WgradParams {
   const float* row_scale;        // per output row (index batch*Co + co), may be null
   int Co_ld;                     // dy columns that may be LOADED (>= Co, zero padded by the producer)
   int accumulate;
+  const unsigned* geom;          // per output pixel: (centre input pixel << 5) | edge flags; null = identity (plain GEMM)
 };
+
+// geometry table entry flags (dcn_conv2d_geom)
+constexpr unsigned GEOM_TOP = 1, GEOM_BOTTOM = 2, GEOM_LEFT = 4, GEOM_RIGHT = 8, GEOM_INVALID = 16;
+constexpr int GEOM_SLACK = 128;  // entries past M (flagged invalid): the loader prefetches one K-step ahead
+
+__global__ __launch_bounds__(256) void geom_kernel(unsigned* __restrict__ t, int N, int H, int W, int Ho, int Wo,
+                                                   int stride, int pad, int M) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M + GEOM_SLACK) return;
+  if (m >= M) { t[m] = GEOM_INVALID; return; }
+  const int n = m / (Ho * Wo), rem = m - n * (Ho * Wo);
+  const int ho = rem / Wo, wo = rem - ho * Wo;
+  const int hy = ho * stride, wx = wo * stride;            // centre tap: always inside the image
+  unsigned f = 0;
+  if (hy - pad < 0) f |= GEOM_TOP;
+  if (hy + pad >= H) f |= GEOM_BOTTOM;
+  if (wx - pad < 0) f |= GEOM_LEFT;
+  if (wx + pad >= W) f |= GEOM_RIGHT;
+  t[m] = ((unsigned)((n * H + hy) * W + wx) << 5) | f;
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0x80000000u;
@@ -61,8 +82,8 @@ __device__ __forceinline__ int sp_swz(int row) { return ((row & 3) << 2) | ((row
 // byte offset of channels c..c+3 (c % 4 == 0) of pixel row `row` inside one [16][128] bf16 plane
 __device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ sp_swz(row)) + 8 * ((c >> 2) & 1); }
 
-template <int TM, int TN, int KP, bool SP = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+template <int TM, int TN, int KP, bool SP = false, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int MI = TM / (32 * WM), NI = TN / (32 * WN);
@@ -77,8 +98,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
 
-  int b = blockIdx.x;
-  const int split = b % p.splits; b /= p.splits;
+  // Block order: split-major, and each XCD gets a contiguous run of it (xcd_remap).  The tiles_co x tiles_ci x T
+  // workgroups of one split walk the SAME pixel range at the same pace, so they are served from one XCD's L2
+  // (with the split index fastest, the sharers sat 'splits' blocks apart, i.e. on all eight XCDs).
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = p.tiles_ci * p.tiles_co * p.T;
+  const int split = b / per_split; b -= split * per_split;
   const int tci = b % p.tiles_ci; b /= p.tiles_ci;
   const int tco = b % p.tiles_co; b /= p.tiles_co;
   const int t = b;                                   // tap (c4: always 0)
@@ -105,26 +130,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     a_pix[j] = pix;
     a_voff[j] = (idx < A_N && co0 + c < p.Co_ld) ? (unsigned)((pix * p.lddy + co0 + c) * 4) : OOB;
   }
-  // gathered operand: per staged pixel slot (n, hy = ho*stride + r - pad, wx = wo*stride + s - pad, byte offset)
-  int b_hy[B_LD], b_wx[B_LD], b_ho[B_LD], b_wo[B_LD], b_pix[B_LD]; unsigned b_voff[B_LD]; bool b_ok[B_LD];
-  const int step_w = p.stride * p.ldx * 4;                          // bytes per +1 in wo
-  const int step_h = p.stride * p.W * p.ldx * 4;                    // bytes per +1 in ho
-  const int step_n = (int)(ximg * 4) - p.Ho * step_h;               // bytes per image wrap (after ho -= Ho)
+  // gathered operand: the (n, ho, wo) decomposition of an output pixel never happens in this kernel — the
+  // geometry table (dcn_conv2d_geom, built once per conv geometry) holds per output pixel m the index of its
+  // centre input pixel and four edge flags; a tap is a wave-uniform pixel delta plus a flag mask.  The entry
+  // for the next K-step is fetched while the current one is consumed (one 4-B load per slot, L1/L2 resident).
+  int b_pix[B_LD], b_tdelta[B_LD]; unsigned b_ent[B_LD], b_tmask[B_LD], b_coff[B_LD]; bool b_ok[B_LD];
+  const int ldx4 = p.ldx * 4;
+  const int pixbase = n_first * p.H * p.W;
+  auto entry = [&](int m) -> unsigned { return p.geom ? p.geom[m] : (unsigned)m << 5; };
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int idx = tid + 256 * j;
     const int pix = idx / (TN / 4), c = (idx - pix * (TN / 4)) * 4;
     b_pix[j] = pix;
-    const int m = m_begin + pix;
-    const int n = m / howo, rem = m - n * howo;
-    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     int rr = r, ss = s, ci = ci0 + c;
     bool ok = idx < B_N && ci < p.Ci;
     if (p.c4) { const int tap = c >> 2; rr = tap / 3; ss = tap - 3 * rr; ci = 0; ok = idx < B_N && tap < 9; }
-    b_ok[j] = ok; b_ho[j] = ho; b_wo[j] = wo;
-    b_hy[j] = ho * p.stride + rr - p.pad; b_wx[j] = wo * p.stride + ss - p.pad;
-    b_voff[j] = (unsigned)((((n - n_first) * p.H + b_hy[j]) * p.W + b_wx[j]) * p.ldx * 4 + ci * 4);
+    b_ok[j] = ok;
+    b_tdelta[j] = (rr - p.pad) * p.W + (ss - p.pad) - pixbase;
+    b_tmask[j] = (rr < p.pad ? GEOM_TOP : 0u) | (rr > p.pad ? GEOM_BOTTOM : 0u) | (ss < p.pad ? GEOM_LEFT : 0u) |
+                 (ss > p.pad ? GEOM_RIGHT : 0u) | GEOM_INVALID;
+    b_coff[j] = (unsigned)ci * 4u;
+    b_ent[j] = entry(m_begin + pix);
   }
+  int m_cur = m_begin;
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
   f32x4 a_reg2[SP ? A_LD : 1], b_reg2[SP ? B_LD : 1];    // SP: second register stage (two K-steps of loads in flight)
@@ -133,17 +162,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
       a_reg[j] = buf_load16(a_rs, a_pix[j] < rows_left ? a_voff[j] : OOB, a_soff);
+    m_cur += KP;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const bool ok = b_ok[j] && b_pix[j] < rows_left && (unsigned)b_hy[j] < (unsigned)p.H && (unsigned)b_wx[j] < (unsigned)p.W;
-      b_reg[j] = buf_load16(b_rs, ok ? b_voff[j] : OOB, 0);
-      // advance this slot by KP pixels
-      b_wo[j] += KP; b_wx[j] += KP * p.stride; b_voff[j] += (unsigned)(KP * step_w);
-      while (b_wo[j] >= p.Wo) {
-        b_wo[j] -= p.Wo; b_wx[j] -= p.Wo * p.stride; b_voff[j] += (unsigned)(step_h - p.Wo * step_w);
-        ++b_ho[j]; b_hy[j] += p.stride;
-        if (b_ho[j] >= p.Ho) { b_ho[j] -= p.Ho; b_hy[j] -= p.Ho * p.stride; b_voff[j] += (unsigned)step_n; }
-      }
+      const unsigned e = b_ent[j];
+      const bool ok = b_ok[j] && b_pix[j] < rows_left && !(e & b_tmask[j]);
+      const unsigned voff = (unsigned)(((int)(e >> 5) + b_tdelta[j]) * ldx4) + b_coff[j];
+      b_reg[j] = buf_load16(b_rs, ok ? voff : OOB, 0);
+      b_ent[j] = entry(m_cur + b_pix[j]);          // next K-step's pixel (the table is padded past M)
     }
     a_soff += (unsigned)(KP * p.lddy * 4); rows_left -= KP;
   };
@@ -154,6 +180,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float x = v[e];
+      if (ABL == 1) { h[e] = m[e] = l[e] = __float_as_uint(x); continue; }   // timing ablation: no split arithmetic
       h[e] = __float_as_uint(x) & 0xFFFF0000u;
       const float r1 = x - __uint_as_float(h[e]);
       m[e] = __float_as_uint(r1) & 0xFFFF0000u;
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int t6 = 0; t6 < 6; ++t6) {
+        if (ABL != 2 || t6 == 5)        // timing ablation 2: one of the six MFMA groups
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -349,11 +377,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// Sums the split-K slabs in a fixed order (bitwise reproducible).  Eight independent 16-B loads are in
+// flight per thread: with one dependent load per split the pass ran at a fifth of the HBM rate.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int64_t n4, int splits) {
+  const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(ws);
   for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 s = reinterpret_cast<const f32x4*>(ws)[i];
-    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(ws)[i + (int64_t)k * n4];
+    f32x4 s = w[i];
+    int k = 1;
+    for (; k + 8 <= splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = w[i + (int64_t)(k + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += w[i + (int64_t)k * n4];
     reinterpret_cast<f32x4*>(out)[i] = s;
   }
 }
@@ -390,9 +429,10 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   return pl;
 }
 
+int g_wabl = 0;            // timing-only ablations of the split kernel (wrong results): dcn_set_tuning("abl", v)
 int g_wsplit = 1;          // 128x128 weight-gradient / TN tiles on the split-bf16 pipe (dcn_set_tuning("precision"|"wsplit", 0) = native)
 
-template <int TM, int TN, bool SP = false>
+template <int TM, int TN, bool SP = false, int ABL = 0>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int KP = SP ? 16 : (WGRAD_KP < 2 * WK ? 2 * WK : WGRAD_KP);
@@ -401,19 +441,22 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
   if (red > lds) lds = red;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
   const int pid = prof_begin(SP ? 17 : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP>), dim3(grid, batch), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
   return DCN_OK;
 }
 
 int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream) {
+  if (tm == 128 && tn == 128 && g_wabl && g_wsplit && !p.c4 && p.M >= 1024)
+    return g_wabl == 1 ? launch_wgrad<128, 128, true, 1>(p, grid, batch, stream)
+         : launch_wgrad<128, 128, true, 2>(p, grid, batch, stream);
   if (tm == 128 && tn == 128) return (g_wsplit && !p.c4 && p.M >= 1024) ? launch_wgrad<128, 128, true>(p, grid, batch, stream)
                                                          : launch_wgrad<128, 128>(p, grid, batch, stream);
   if (tm == 128 && tn == 64) return launch_wgrad<128, 64>(p, grid, batch, stream);
@@ -429,6 +472,7 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
 }  // namespace
 
 void wgrad_set_split(int v) { g_wsplit = v; }
+void wgrad_set_abl(int v) { g_wabl = v; }
 
 // C[b][m][n] (+)= row_scale[b][m] * sum_k A[b][k][m] * B[b][k][n]   ("TN" GEMM: K is the strided dim of
 // both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.
@@ -454,7 +498,27 @@ extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int c
   return pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
 }
 
+extern "C" int64_t dcn_conv2d_geom_size(int n, int h, int wd, int ksize, int stride) {
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  return (int64_t)n * ho * wo + GEOM_SLACK;
+}
+
+extern "C" int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize, int stride, void* stream_) {
+  DCN_CHECK_ARG(table && n > 0 && h > 0 && wd > 0, "conv2d_geom: bad argument");
+  DCN_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_geom: ksize=%d stride=%d", ksize, stride);
+  DCN_CHECK_ARG((int64_t)n * h * wd < (1LL << 27), "conv2d_geom: %lld input pixels exceed the 27-bit index", (long long)n * h * wd);
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  const int M = n * ho * wo;
+  hipLaunchKernelGGL(geom_kernel, dim3(cdiv(M + GEOM_SLACK, 256)), dim3(256), 0, (hipStream_t)stream_,
+                     table, n, h, wd, ho, wo, stride, pad, M);
+  DCN_CHECK_LAUNCH("conv2d_geom");
+  return DCN_OK;
+}
+
 extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                                     const uint32_t* geom,
                                      int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_weight: ksize=%d", ksize);
@@ -462,7 +526,7 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   DCN_CHECK_ARG(cin == 4 || cin % 4 == 0, "conv2d_bwd_weight: cin=%d must be a multiple of 4", cin);
   DCN_CHECK_ARG(cin != 4 || (ksize == 3 && stride == 1), "conv2d_bwd_weight: cin=4 path is the 3x3 stride-1 stem only");
   DCN_CHECK_ARG(cout % 4 == 0, "conv2d_bwd_weight: cout=%d must be a multiple of 4", cout);
-  DCN_CHECK_ARG(x && dy && dw, "conv2d_bwd_weight: null pointer");
+  DCN_CHECK_ARG(x && dy && dw && geom, "conv2d_bwd_weight: null pointer (geom = table of dcn_conv2d_geom for this geometry)");
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
   WgradParams p{};
@@ -473,13 +537,13 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   p.Co = cout; p.lddy = lddy > 0 ? lddy : cout;
   p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = cin == 4; p.ld_out = pl.ld_out;
-  p.Co_ld = cout;
+  p.Co_ld = cout; p.geom = geom;
   const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
   int rc = dispatch_wgrad(p, pl.tm, pl.tn, grid, 1, stream);
   if (rc != DCN_OK) return rc;
   if (pl.splits > 1) {
     const int64_t n4 = (int64_t)cout * pl.ld_out / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, pl.splits);
     DCN_CHECK_LAUNCH("reduce_slabs");
   }

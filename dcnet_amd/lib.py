@@ -25,7 +25,9 @@ SIGNATURES = {
     "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P]),
     "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),
     "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
+    "dcn_conv2d_geom": (I, [P, I, I, I, I, I, P]),
+    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
     "dcn_bn_ws": (L, [I]),
     "dcn_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),

@@ -159,6 +159,21 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     return out
 
 
+_geom = {}
+
+
+def conv_geom(device, n: int, h: int, wd: int, ksize: int, stride: int) -> torch.Tensor:
+    """The gather table of a conv geometry (dcn_conv2d_geom), built on first use and kept per device."""
+    key = (torch.device(device).index, n, h, wd, ksize, stride)
+    t = _geom.get(key)
+    if t is None:
+        t = torch.empty(lib().conv2d_geom_size(n, h, wd, ksize, stride), dtype=torch.int32, device=device)
+        lib().conv2d_geom(t.data_ptr(), n, h, wd, ksize, stride, _s())
+        torch.cuda.current_stream().synchronize()      # once per geometry: other streams may use it right away
+        _geom[key] = t
+    return t
+
+
 def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0):
     """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
     ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0)."""
@@ -167,7 +182,8 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0):
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
-    lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws),
+    geom = conv_geom(x.device, n, h, wd, ksize, stride)
+    lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
                             n, h, wd, cin, cout, ksize, stride, _s())
     return dw
 

@@ -76,10 +76,18 @@ int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, fl
                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
                         int accumulate, void* stream);
 
+/* Geometry table of a convolution (depends on n, h, wd, ksize, stride only; build once, reuse every step):
+ * dcn_conv2d_geom_size entries of uint32, entry m = (index of the input pixel under the centre tap of
+ * output pixel m) << 5 | edge flags.  The weight-gradient kernel walks K = output pixels and reads its
+ * gather addresses from this table instead of dividing by Wo / Ho per pixel. */
+int64_t dcn_conv2d_geom_size(int n, int h, int wd, int ksize, int stride);
+int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize, int stride, void* stream);
+
 /* dw[co,r,s,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*stride+r-pad,wo*stride+s-pad,ci]
  * (OHWI).  x has pixel stride ldx.  ws = caller scratch of dcn_conv2d_bwd_weight_ws(...) floats
- * (split-K partial slabs, reduced deterministically). */
+ * (split-K partial slabs, reduced deterministically).  geom = dcn_conv2d_geom table of this geometry. */
 int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                          const uint32_t* geom,
                           int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
 int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 
