@@ -35,7 +35,7 @@ void base_params(IgemmParams& p) {
 extern "C" int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride) {
   const int pad = (ksize - 1) / 2;
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
-  return igemm_grid_m(n * ho * wo, cout);
+  return igemm_grid_m(n * ho * wo, cout, ksize * ksize);
 }
 
 extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,

@@ -40,5 +40,5 @@ struct IgemmParams {
 };
 
 // rows of the stats partial buffer (= number of M-blocks) the launch will use
-int igemm_grid_m(int M, int Co);
+int igemm_grid_m(int M, int Co, int ntaps);
 int igemm_launch(const IgemmParams& p, hipStream_t stream);

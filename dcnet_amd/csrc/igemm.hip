@@ -469,7 +469,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = SP ? 16 : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? (BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
@@ -493,7 +493,8 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
   if constexpr (BMODE == 0 && !C4) {
     // narrow tiles gain nothing from the split (its vector-ALU cost per MFMA grows as the tile shrinks:
     // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
-    if (g_split || (g_precision == 1 && BM == 128 && BN == 128 && rows >= 1024)) {
+    // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
+    if (g_split || (g_precision == 1 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
       if (g_abl == 1) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 1>(p, stream);   // ablation: no split arithmetic (wrong results)
       if (g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2>(p, stream);   // ablation: 1 of 6 MFMA groups (wrong results)
@@ -510,10 +511,13 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
 // 64x128 tile (measured ~0.9x the per-tile efficiency) doubles the workgroup count.
 inline double fill(long long blocks, long long slots) { return (double)blocks / (double)(((blocks + slots - 1) / slots) * slots); }
 int g_force_bm = 0;       // experiment knob, set through dcn_set_tuning (tools/bench_convs.py)
+int g_tile64 = 1;         // dcn_set_tuning("tile64", 0): 64-channel layers back on the fp32-pipe 128x64 tile
 
-inline int tile_bm(int M, int Co) {
+// (A/B per layer, tools/bench_convs.py --ab tile64=0: the 256x64 split tile wins 10-30 % where the K loop is long —
+//  3x3 layers and their data gradients — and loses on 1-tap problems with K <= 128, which stay on the fp32 pipe.)
+inline int tile_bm(int M, int Co, int ntaps, int Ci) {
   if (Co <= 32) return 256;
-  if (Co <= 64) return 128;
+  if (Co <= 64) return (g_tile64 && g_precision == 1 && !g_force_bm && ntaps >= 2 && ntaps * Ci >= 256) ? 256 : 128;
   if (g_force_bm) return g_force_bm;
   // In-process A/B (tools/bench_convs.py --ab bm=64 / bm=128): with the current K-steps the 64-row tile only
   // wins by 3-4 % on the 3x3 layers of the 13x13 maps and loses 10-70 % everywhere else, so it is kept as a
@@ -524,7 +528,7 @@ inline int tile_bm(int M, int Co) {
 
 }  // namespace
 
-int igemm_grid_m(int M, int Co) { return cdiv(M, tile_bm(M, Co)); }
+int igemm_grid_m(int M, int Co, int ntaps) { return cdiv(M, tile_bm(M, Co, ntaps, 32)); }   // Ci >= 32 on every multi-tap path
 
 void wgrad_set_split(int v);
 void wgrad_set_abl(int v);
@@ -535,6 +539,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
+  else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
@@ -559,7 +564,7 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);
     if (p.Co <= 64) return launch_variant<128, 64, 2, 2, 1>(p, stream);
-    if (tile_bm(p.M, p.Co) == 64) return launch_variant<64, 128, 2, 2, 1>(p, stream);
+    if (tile_bm(p.M, p.Co, p.ntaps, p.Ci) == 64) return launch_variant<64, 128, 2, 2, 1>(p, stream);
     return launch_variant<128, 128, 2, 2, 1>(p, stream);
   }
   if (p.c4) {
@@ -567,7 +572,11 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
     return launch_variant<256, 32, 4, 1, 0, true>(p, stream);
   }
   if (p.Co <= 32) return launch_variant<256, 32, 4, 1, 0>(p, stream);
-  if (p.Co <= 64) return launch_variant<128, 64, 2, 2, 0>(p, stream);
-  if (tile_bm(p.M, p.Co) == 64) return launch_variant<64, 128, 2, 2, 0>(p, stream);
+  if (p.Co <= 64) {
+    // 64 output channels: four waves stacked along M (each 64x64) on the split pipe; fp32-pipe 128x64 tile otherwise
+    if (tile_bm(p.M, p.Co, p.ntaps, p.Ci) == 256) return launch_variant<256, 64, 4, 1, 0>(p, stream);
+    return launch_variant<128, 64, 2, 2, 0>(p, stream);
+  }
+  if (tile_bm(p.M, p.Co, p.ntaps, p.Ci) == 64) return launch_variant<64, 128, 2, 2, 0>(p, stream);
   return launch_variant<128, 128, 2, 2, 0>(p, stream);
 }

@@ -320,10 +320,13 @@ class grounding_model(nn.Module):
         cnt = float(B * P)
         if self.training:
             Ed, Md, bd = E8.double(), M.double(), lt.bias.double()
-            s1 = Ed.sum(0); S2 = Ed.t() @ Ed
-            t1 = torch.einsum("k,nkc->c", s1, Md)
+            # (broadcast products, not matmul/einsum: rocBLAS runs these 8-wide fp64 shapes on a 128x128 DGEMM
+            #  tile — one of them took 3.5 ms — while the tensors here are a few MB)
+            s1 = Ed.sum(0); S2 = (Ed.unsqueeze(2) * Ed.unsqueeze(1)).sum(0)                  # (8,), (8,8)
+            t1 = (s1.view(1, 8, 1) * Md).sum((0, 1))
             mean = t1 / cnt + bd
-            ex2 = ((Md * torch.matmul(S2, Md)).sum((0, 1)) + 2 * bd * t1) / cnt + bd * bd     # M_n^T S2 M_n per channel
+            S2M = (S2.view(1, 8, 8, 1) * Md.unsqueeze(1)).sum(2)                              # (B,8,512)
+            ex2 = ((Md * S2M).sum((0, 1)) + 2 * bd * t1) / cnt + bd * bd                      # M_n^T S2 M_n per channel
             var = torch.clamp(ex2 - mean * mean, min=0)
             with torch.no_grad():
                 bn2.running_mean.mul_(1 - bn2.momentum).add_(bn2.momentum * mean.float())

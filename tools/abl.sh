@@ -1,4 +1,3 @@
 set -e
-for L in 256,512,3,1,52 512,256,1,1,52 512,1024,3,1,26 128,256,3,1,52 256,512,3,1,26; do
-  python tools/bench_convs.py --only $L --ab abl=2 --iters 10 2>&1 | grep "^AB"
-done
+python tools/bench_convs.py --ab tile64=0 --ab-default 1 --iters 5 > gpurun_out/ab_tile64.txt 2>&1
+grep "^AB\|^total\|with" gpurun_out/ab_tile64.txt

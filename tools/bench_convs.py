@@ -57,6 +57,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--only", type=str, default="", help="cin,cout,k,stride,h: benchmark a single shape")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ab-default", type=int, default=0, help="the knob's default value (restored for the A arm)")
     ap.add_argument("--ab", type=str, default="", help="key=value tuning knob (dcn_set_tuning) measured against the default, same process")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -81,14 +82,20 @@ def main():
         t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
         t_d = timeit(f_dg) if has_dg else 0.0
         if args.ab:
+            # interleaved rounds in one process (default, knob, default, knob, ...), minimum per arm
             from dcnet_amd.lib import lib
             key, val = args.ab.split("=")
-            lib().set_tuning(key.encode(), int(val))
-            t_f2 = timeit(f_fwd); t_d2 = timeit(f_dg) if has_dg else 0.0
-            t_w2 = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
-            lib().set_tuning(key.encode(), 0)
-            t_f3 = timeit(f_fwd)          # default again: drift check
-            print("AB %5d %5d k%d s%d H%4d  fwd %.3f -> %.3f (recheck %.3f)  dgrad %.3f -> %.3f  wgrad %.3f -> %.3f" % (cin, cout, k, st, h, t_f, t_f2, t_f3, t_d, t_d2, t_w, t_w2))
+            f_w = lambda: ops.conv2d_bwd_weight(x, dy, k, st)
+            arms = {0: [[], [], []], 1: [[], [], []]}
+            for rnd in range(4):
+                for arm in (0, 1):
+                    lib().set_tuning(key.encode(), int(val) if arm else args.ab_default)
+                    arms[arm][0].append(timeit(f_fwd)); arms[arm][1].append(timeit(f_dg) if has_dg else 0.0)
+                    arms[arm][2].append(timeit(f_w))
+            lib().set_tuning(key.encode(), args.ab_default)
+            t_f, t_d, t_w = (min(v) for v in arms[0])
+            t_f2, t_d2, t_w2 = (min(v) for v in arms[1])
+            print("AB %5d %5d k%d s%d H%4d  fwd %.3f -> %.3f  dgrad %.3f -> %.3f  wgrad %.3f -> %.3f" % (cin, cout, k, st, h, t_f, t_f2, t_d, t_d2, t_w, t_w2))
             tot["fwd_b"] += cnt * t_f2; tot["dgrad_b"] += cnt * t_d2; tot["wgrad_b"] += cnt * t_w2
         rows.append((cin, cout, k, st, h, cnt, flop / 1e9, t_f, t_d, t_w))
         tot["fwd"] += cnt * t_f; tot["dgrad"] += cnt * t_d; tot["wgrad"] += cnt * t_w
