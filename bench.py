@@ -190,10 +190,11 @@ def main():
         L.set_tuning(b"precision", 1)
         return collect() + (el / args.exclusive_steps * 1e3,)
 
-    excl = native = None
+    excl = native = bf16 = None
     if args.exclusive_steps > 0:
         excl = extra_pass(1)
         native = extra_pass(0)
+        bf16 = extra_pass(2)
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
@@ -206,9 +207,13 @@ def main():
                  13: "igemm_kernel<...> (LSTM-step GEMMs, <1024 rows, side stream)",
                  14: "wgrad_kernel<...> (LSTM-step GEMMs, side stream)",
                  16: "igemm_kernel<128,128,2,2,0,false,16,true>",
-                 17: "wgrad_kernel<128,128,16,true>"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
+                 17: "wgrad_kernel<128,128,16,true>",
+                 18: "igemm_kernel<256,64,4,1,0,false,16,true>",
+                 19: "igemm_kernel<*,*,*,*,0,false,32,true,0,1> (bf16 operands)",
+                 20: "wgrad_kernel<128,128,16,true,0,1> (bf16 operands)"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20)
+                       else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
             out = {}
@@ -238,7 +243,7 @@ def main():
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
                     "peak_note": ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
                                   "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
-                                 if dom in (16, 17) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
+                                 if dom in (16, 17, 18) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
                     "overlap": "the timed region runs the weight-gradient GEMMs on a second stream beside the data-gradient "
                                "chain; per-launch durations here include the time a launch shared the CUs",
                     # every FLOP the MFMA kernels were asked for in a step over the whole step's wall time
@@ -265,6 +270,17 @@ def main():
                                        "note": "dcn_set_tuning('precision', 0): every tile on v_mfma_f32_32x32x2_f32, "
                                                "weight-gradient stream off (untimed pass)",
                                        "kernels": table(c3, m3, w3, args.exclusive_steps)}
+            c4, m4, w4, ms_step4 = bf16
+            d4 = max(mm_tags, key=lambda t: w4[t])
+            a4 = w4[d4] / (m4[d4] * 1e-3) / 1e12
+            roofline["bf16_operands"] = {"kernel": names[d4], "achieved": a4, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                         "frac": a4 / PEAK_BF16_MFMA_TFLOPS, "avg_launch_ms": m4[d4] / c4[d4],
+                                         "ms_per_step": ms_step4, "clips_per_s": args.clips * world / (ms_step4 * 1e-3),
+                                         "note": "dcn_set_tuning('precision', 2) = BASELINE.json configs[2] on one GPU: bf16 operands "
+                                                 "(RNE), one MFMA per product, fp32 accumulate, fp32 tensors; REDUCED precision, "
+                                                 "reported beside the fp32 headline, never as `value` (untimed pass, weight-gradient "
+                                                 "stream off)",
+                                         "kernels": table(c4, m4, w4, args.exclusive_steps)}
         res = {"metric": "clips/sec (T=8, 416x416, bs8) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -52,7 +52,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // v_mfma_f32_32x32x16_bf16: 6 instructions of 32 cycles per 16 k against 8 of 64 cycles on the fp32 pipe
 // (bf16 products are exact in the fp32 accumulator).  LDS holds three bf16 planes per operand,
 // rows padded by 16 B so the ds_read_b128 fragments (8 consecutive k per lane) are conflict-free.
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0>
+// NP = number of bf16 pieces per operand: 3 = fp32-accurate split (six cross terms); 1 = plain bf16 operands
+// (round-to-nearest-even, one MFMA per product, fp32 accumulate): the builder-defined bf16 mode of
+// BASELINE.json configs[2] (dcn_set_tuning("precision", 2)); tensors in HBM stay fp32.
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   static_assert(!SP || (BMODE == 0 && !C4), "split mode: NT operands only");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   float* As = smem;                      // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;    // BMODE 0: [2][BN][LDS_LD]   BMODE 1: [2][BK][BN]
   constexpr int B_TILE = BMODE == 0 ? BN * LDS_LD : BK * BN;
-  unsigned short* As16 = reinterpret_cast<unsigned short*>(smem);      // SP: [2][3][BM][LD16]
-  unsigned short* Bs16 = As16 + 2 * 3 * BM * LD16;                     // SP: [2][3][BN][LD16]
+  unsigned short* As16 = reinterpret_cast<unsigned short*>(smem);      // SP: [2][NP][BM][LD16]
+  unsigned short* Bs16 = As16 + 2 * NP * BM * LD16;                    // SP: [2][NP][BN][LD16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -190,6 +193,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   };
   auto split_store = [&](unsigned short* plane0, int plane_stride, int off, const f32x4 v) {
+    if constexpr (NP == 1) {             // plain bf16 operands: v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, b);
+      return;
+    }
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -211,8 +220,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   auto load_tiles = [&](int it) { load_tiles_into(a_reg, b_reg, it); };
   auto store_tiles_from = [&](const f32x4* a_reg, const f32x4* b_reg, int buf) {
     if constexpr (SP) {
-      unsigned short* a16 = As16 + buf * 3 * BM * LD16;
-      unsigned short* b16 = Bs16 + buf * 3 * BN * LD16;
+      unsigned short* a16 = As16 + buf * NP * BM * LD16;
+      unsigned short* b16 = Bs16 + buf * NP * BN * LD16;
 #pragma unroll
       for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j]);
 #pragma unroll
@@ -253,29 +262,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // groups, so the vector ALU and the LDS write port work in the shadow of the matrix pipe (a wave
     // issues in order: anything placed after the last MFMA would wait for all of them).
     auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
-      const unsigned short* a16 = As16 + cur * 3 * BM * LD16 + sp_r(wm * (BM / WM) + (lane & 31), lane >> 5);
-      const unsigned short* b16 = Bs16 + cur * 3 * BN * LD16 + sp_r(wn * (BN / WN) + (lane & 31), lane >> 5);
-      unsigned short* na = As16 + (cur ^ 1) * 3 * BM * LD16;
-      unsigned short* nb = Bs16 + (cur ^ 1) * 3 * BN * LD16;
+      const unsigned short* a16 = As16 + cur * NP * BM * LD16 + sp_r(wm * (BM / WM) + (lane & 31), lane >> 5);
+      const unsigned short* b16 = Bs16 + cur * NP * BN * LD16 + sp_r(wn * (BN / WN) + (lane & 31), lane >> 5);
+      unsigned short* na = As16 + (cur ^ 1) * NP * BM * LD16;
+      unsigned short* nb = Bs16 + (cur ^ 1) * NP * BN * LD16;
       constexpr int PIECES = A_LD + B_LD;
-      constexpr int GROUPS = 6 * (BK / 16);
+      constexpr int TERMS = NP == 3 ? 6 : 1;
+      constexpr int GROUPS = TERMS * (BK / 16);
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
-        bf16x8 af[MI][3], bf[NI][3];
+        bf16x8 af[MI][NP], bf[NI][NP];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
+          for (int q = 0; q < NP; ++q)
             af[mi][q] = *reinterpret_cast<const bf16x8*>(a16 + q * BM * LD16 + mi * 32 * LD16 + kk * 16);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int q = 0; q < 3; ++q)
+          for (int q = 0; q < NP; ++q)
             bf[ni][q] = *reinterpret_cast<const bf16x8*>(b16 + q * BN * LD16 + ni * 32 * LD16 + kk * 16);
         // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-        constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int QA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < (ABL == 2 ? 1 : 6); ++t) {
+        for (int t = 0; t < (ABL == 2 ? 1 : TERMS); ++t) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -284,14 +294,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           if constexpr (decltype(do_store)::value) {
             // pieces g, g + GROUPS, ... belong to group g = kk*6 + t
 #pragma unroll
-            for (int pc = kk * 6 + t; pc < PIECES; pc += GROUPS) {
+            for (int pc = kk * TERMS + t; pc < PIECES; pc += GROUPS) {
               if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc]);
               else if (!B_PART || row0 < BN) split_store(nb, BN * LD16, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD]);
             }
           }
         }
       }
-      if constexpr (decltype(do_store)::value) {
+      if constexpr (decltype(do_store)::value && NP == 3) {
         // ask the scheduler for: 1 MFMA, then up to 5 VALU and an LDS write in its 32-cycle shadow, x24
 #pragma unroll
         for (int g = 0; g < MI * NI * 6 * (BK / 16); ++g) {
@@ -452,27 +462,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3>
 int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   IgemmParams p = p0;
   p.cpt = p.c4 ? 1 : p.Ci / BK;
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
-  const size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * (BK == 16 ? 16 : BK + 8) * sizeof(unsigned short)
+  const size_t lds = SP ? (size_t)2 * NP * (BM + BN) * (BK == 16 ? 16 : BK + 8) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = SP ? (BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? (NP == 1 ? 19 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
@@ -484,7 +494,8 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
 int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile onto the split-bf16 pipe (bench_convs A/B)
 int g_abl = 0;            // dcn_set_tuning("abl", 1|2): timing-only ablations of the split kernel (results are wrong)
-int g_precision = 1;      // dcn_set_tuning("precision", 0|1): 1 = 128x128 NT tiles of >= 1024 rows use the split-bf16 pipe
+int g_precision = 1;      // dcn_set_tuning("precision", 0|1|2): 0 = fp32 MFMA everywhere; 1 = wide NT tiles of >= 1024 rows on the
+                          // split-bf16 pipe (fp32 accuracy); 2 = those tiles with plain bf16 operands (configs[2], reduced precision)
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
@@ -494,6 +505,8 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // narrow tiles gain nothing from the split (its vector-ALU cost per MFMA grows as the tile shrinks:
     // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
+    if (g_precision == 2 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
+      return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1>(p, stream);     // bf16 operands: 8 MFMAs per 32-wide K-step
     if (g_split || (g_precision == 1 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
       if (g_abl == 1) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 1>(p, stream);   // ablation: no split arithmetic (wrong results)
@@ -517,7 +530,7 @@ int g_tile64 = 1;         // dcn_set_tuning("tile64", 0): 64-channel layers back
 //  3x3 layers and their data gradients — and loses on 1-tap problems with K <= 128, which stay on the fp32 pipe.)
 inline int tile_bm(int M, int Co, int ntaps, int Ci) {
   if (Co <= 32) return 256;
-  if (Co <= 64) return (g_tile64 && g_precision == 1 && !g_force_bm && ntaps >= 2 && ntaps * Ci >= 256) ? 256 : 128;
+  if (Co <= 64) return (g_tile64 && g_precision >= 1 && !g_force_bm && ntaps >= 2 && ntaps * Ci >= 256) ? 256 : 128;
   if (g_force_bm) return g_force_bm;
   // In-process A/B (tools/bench_convs.py --ab bm=64 / bm=128): with the current K-steps the 64-row tile only
   // wins by 3-4 % on the 3x3 layers of the 13x13 maps and loses 10-70 % everywhere else, so it is kept as a

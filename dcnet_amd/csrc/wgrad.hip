@@ -82,7 +82,8 @@ __device__ __forceinline__ int sp_swz(int row) { return ((row & 3) << 2) | ((row
 // byte offset of channels c..c+3 (c % 4 == 0) of pixel row `row` inside one [16][128] bf16 plane
 __device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ sp_swz(row)) + 8 * ((c >> 2) & 1); }
 
-template <int TM, int TN, int KP, bool SP = false, int ABL = 0>
+// NP: bf16 pieces per operand (3 = fp32-accurate split, 1 = plain bf16 operands; igemm.hip)
+template <int TM, int TN, int KP, bool SP = false, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
@@ -174,8 +175,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     a_soff += (unsigned)(KP * p.lddy * 4); rows_left -= KP;
   };
   auto load_tiles = [&]() { load_tiles_into(a_reg, b_reg); };
-  unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][3 planes][16][256 B]
+  unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][NP planes][16][256 B]
+  constexpr int SP_OPND = NP * 4096, SP_BUF = 2 * SP_OPND;
   auto split_store = [&](unsigned char* plane0, int off, const f32x4 v) {
+    if constexpr (NP == 1) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, b);
+      return;
+    }
     unsigned h[4], m[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const int j = isb ? pc - A_LD : pc;
     const int idx = tid + 256 * j;
     const int pix = idx / 32, c = (idx - pix * 32) * 4;
-    split_store(sp_base + buf * 24576 + (isb ? 12288 : 0), sp_off(pix, c), isb ? br[j] : ar[j]);
+    split_store(sp_base + buf * SP_BUF + (isb ? SP_OPND : 0), sp_off(pix, c), isb ? br[j] : ar[j]);
   };
   auto store_tiles = [&](int buf) {
     if constexpr (SP) {
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) a_tr[mi][r2] = sp_off(row, wm * 64 + mi * 32 + 16 * gg + 4 * pp);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b_tr[ni][r2] = 12288 + sp_off(row, wn * 64 + ni * 32 + 16 * gg + 4 * pp);
+      for (int ni = 0; ni < NI; ++ni) b_tr[ni][r2] = SP_OPND + sp_off(row, wn * 64 + ni * 32 + 16 * gg + 4 * pp);
     }
     auto tr_read = [&](int byte_off) {
       return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -253,30 +261,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       return __builtin_bit_cast(bf16x8, v);
     };
     auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
-      bf16x8 af[MI][3], bf[NI][3];
+      bf16x8 af[MI][NP], bf[NI][NP];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          af[mi][pl] = frag(cur * 24576 + pl * 4096 + a_tr[mi][0], cur * 24576 + pl * 4096 + a_tr[mi][1]);
+        for (int pl = 0; pl < NP; ++pl)
+          af[mi][pl] = frag(cur * SP_BUF + pl * 4096 + a_tr[mi][0], cur * SP_BUF + pl * 4096 + a_tr[mi][1]);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bf[ni][pl] = frag(cur * 24576 + pl * 4096 + b_tr[ni][0], cur * 24576 + pl * 4096 + b_tr[ni][1]);
-      constexpr int QA[6] = {2, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+        for (int pl = 0; pl < NP; ++pl)
+          bf[ni][pl] = frag(cur * SP_BUF + pl * 4096 + b_tr[ni][0], cur * SP_BUF + pl * 4096 + b_tr[ni][1]);
+      constexpr int TERMS = NP == 3 ? 6 : 1;
+      constexpr int QA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int t6 = 0; t6 < 6; ++t6) {
+      for (int t6 = 0; t6 < TERMS; ++t6) {
         if (ABL != 2 || t6 == 5)        // timing ablation 2: one of the six MFMA groups
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t6]], bf[ni][QB[t6]], acc[mi][ni], 0, 0, 0);
-        if constexpr (decltype(do_store)::value)
-          if (t6 < A_LD + B_LD) sp_store_piece(cur ^ 1, t6, ar, br);
+        if constexpr (decltype(do_store)::value) {
+          if constexpr (NP == 3) { if (t6 < A_LD + B_LD) sp_store_piece(cur ^ 1, t6, ar, br); }
+          else {
+#pragma unroll
+            for (int pc = 0; pc < A_LD + B_LD; ++pc) sp_store_piece(cur ^ 1, pc, ar, br);
+          }
+        }
       }
-      if constexpr (decltype(do_store)::value) {
+      if constexpr (decltype(do_store)::value && NP == 3) {
 #pragma unroll
         for (int g = 0; g < MI * NI * 6; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -432,22 +446,22 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
 int g_wabl = 0;            // timing-only ablations of the split kernel (wrong results): dcn_set_tuning("abl", v)
 int g_wsplit = 1;          // 128x128 weight-gradient / TN tiles on the split-bf16 pipe (dcn_set_tuning("precision"|"wsplit", 0) = native)
 
-template <int TM, int TN, bool SP = false, int ABL = 0>
+template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int KP = SP ? 16 : (WGRAD_KP < 2 * WK ? 2 * WK : WGRAD_KP);
-  size_t lds = SP ? (size_t)2 * 24576 : (size_t)2 * KP * (TM + TN) * sizeof(float);
+  size_t lds = SP ? (size_t)2 * 2 * NP * 4096 : (size_t)2 * KP * (TM + TN) * sizeof(float);
   const size_t red = (size_t)(WK - 1) * TM * TN * sizeof(float);
   if (red > lds) lds = red;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL, NP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
-  const int pid = prof_begin(SP ? 17 : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL>), dim3(grid, batch), dim3(256), lds, stream, p);
+  const int pid = prof_begin(SP ? (NP == 1 ? 20 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL, NP>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
   return DCN_OK;
@@ -457,6 +471,7 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
   if (tm == 128 && tn == 128 && g_wabl && g_wsplit && !p.c4 && p.M >= 1024)
     return g_wabl == 1 ? launch_wgrad<128, 128, true, 1>(p, grid, batch, stream)
          : launch_wgrad<128, 128, true, 2>(p, grid, batch, stream);
+  if (tm == 128 && tn == 128 && g_wsplit == 2 && !p.c4 && p.M >= 1024) return launch_wgrad<128, 128, true, 0, 1>(p, grid, batch, stream);
   if (tm == 128 && tn == 128) return (g_wsplit && !p.c4 && p.M >= 1024) ? launch_wgrad<128, 128, true>(p, grid, batch, stream)
                                                          : launch_wgrad<128, 128>(p, grid, batch, stream);
   if (tm == 128 && tn == 64) return launch_wgrad<128, 64>(p, grid, batch, stream);

@@ -14,6 +14,26 @@ from .lib import lib
 
 ACT_NONE, ACT_LEAKY = 0, 1
 
+# Matrix-pipe precision of the wide GEMM tiles (conv forward / data gradient / weight gradient, co-attention GEMMs):
+#   "fp32"      fp32 accuracy on the bf16 matrix pipe (3 exact bf16 pieces per operand, 6 cross terms) — the default
+#   "fp32_mfma" the native fp32 MFMA instruction on every tile
+#   "bf16"      bf16 operands (round to nearest even), fp32 accumulate: BASELINE.json configs[2]; reduced precision,
+#               builder-defined (the reference has no bf16 semantics); tensors in HBM stay fp32
+PRECISIONS = {"fp32_mfma": 0, "fp32": 1, "bf16": 2}
+_precision = "fp32"
+
+
+def set_precision(mode: str) -> None:
+    global _precision
+    if mode not in PRECISIONS:
+        raise ValueError(f"precision {mode!r}: expected one of {sorted(PRECISIONS)}")
+    lib().set_tuning(b"precision", PRECISIONS[mode])
+    _precision = mode
+
+
+def get_precision() -> str:
+    return _precision
+
 
 def _s() -> int:
     return torch.cuda.current_stream().cuda_stream

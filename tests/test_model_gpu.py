@@ -282,3 +282,41 @@ def test_eval_mode_backward_and_argument_errors(dev):
     from model.DCNet_model import grounding_model
     with pytest.raises(NotImplementedError):
         grounding_model(corpus=None)                                        # BERT encoder is out of scope
+
+
+def test_bf16_operand_mode_end_to_end(dev):
+    """configs[2] (bf16 operands on the matrix pipe, fp32 accumulate and fp32 tensors): the kernels are checked
+    against their exact model in test_ops_gpu.py; here the whole model runs in that mode.  The reference has no
+    bf16 semantics and the synthetic random-init network amplifies a 2^-9 operand rounding over ~75 layers
+    (measured at 256^2: outbox differs from fp32 by up to 1.0 on a scale of 5.3, loss terms by 0.5-14 %), so
+    the bounds below are sanity limits, not parity: the fp32 mode is the parity path."""
+    from dcnet_amd import losses, ops
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n = 256, 4
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=11)
+    bbox = synth_boxes(n, size, seed=11).to(dev)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_precision(mode)
+            m = build_product(size, sd, dev).eval()
+            with torch.no_grad():
+                outbox = m(image.to(dev), word_id.to(dev), word_mask.to(dev))[0]
+            m.train()
+            random.seed(13)
+            out = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+            loss, parts = losses.total_loss(out, bbox, size)
+            loss.backward()
+            g = m.fcn_out[0][1].weight.grad
+            assert torch.isfinite(loss) and g is not None and torch.isfinite(g).all()
+            res[mode] = ([o.detach().cpu() for o in outbox], {k: float(v.detach()) for k, v in parts.items()}, g.detach().cpu())
+    finally:
+        ops.set_precision("fp32")
+    for a, b in zip(res["fp32"][0], res["bf16"][0]):
+        d = maxdiff(a, b)
+        assert 1e-4 < d < 0.35 * float(a.abs().max()), d          # the mode is live (not bit-identical to fp32) and bounded
+    for k, v in res["fp32"][1].items():
+        assert abs(res["bf16"][1][k] - v) <= 0.25 * max(abs(v), 1e-3), (k, v, res["bf16"][1][k])
+    cos = torch.nn.functional.cosine_similarity(res["fp32"][2].flatten().double(), res["bf16"][2].flatten().double(), dim=0)
+    assert float(cos) > 0.8, float(cos)

@@ -394,3 +394,49 @@ def test_split_pipe_forced_on_every_nt_tile(dev):
                 _close(y, ref, 1e-5, f"cout {cout} split {mode}")
     finally:
         lib().set_tuning(b"split", 0)
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_bf16_operand_mode_matches_its_exact_model(dev, case):
+    """precision "bf16" (BASELINE.json configs[2]; builder-defined): operands rounded to bf16
+    (nearest even), products exact, fp32 accumulation.  Its exact model is the same convolution on the
+    bf16-rounded operands, so the kernels must match THAT to accumulation-order accuracy (3e-5), and differ from
+    the unrounded fp64 result by about 2^-9 relative, not more (tolerance 1e-2 of the output scale)."""
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k, st = case
+    x = _rand(n, h, w, cin, seed=1).to(dev)
+    wt = (_rand(cout, k, k, cin, seed=2) / (cin * k * k) ** 0.5).to(dev)
+    rb = lambda t: t.bfloat16().double()                        # round to nearest even, as v_cvt_pk_bf16_f32
+    dy = None
+    refs = {}
+    for tag, f in (("model", rb), ("exact", lambda t: t.double())):
+        xd = f(x.cpu()).permute(0, 3, 1, 2).requires_grad_(True)
+        wd = f(wt.cpu()).permute(0, 3, 1, 2).requires_grad_(True)
+        yd = F.conv2d(xd, wd, stride=st, padding=(k - 1) // 2)
+        if dy is None:
+            dy = (_rand(*yd.shape, seed=3) / 8).permute(0, 2, 3, 1).contiguous().to(dev)
+        yd.backward(f(dy.cpu()).permute(0, 3, 1, 2))
+        refs[tag] = {"fwd": yd.detach().permute(0, 2, 3, 1), "dgrad": xd.grad.permute(0, 2, 3, 1), "wgrad": wd.grad.permute(0, 2, 3, 1)}
+    cout_p = (cout + 31) // 32 * 32
+    wt_p = torch.zeros(cout_p, k, k, cin, device=dev); wt_p[:cout] = wt
+    dy_p = torch.zeros(*dy.shape[:3], cout_p, device=dev); dy_p[..., :cout] = dy
+    try:
+        ops.set_precision("bf16")
+        got = {"fwd": ops.conv2d_fwd(x, wt, k, st)[0],
+               "dgrad": ops.conv2d_bwd_data(dy_p, wt_p, (h, w), k, st),
+               "wgrad": ops.conv2d_bwd_weight(x, dy, k, st)}
+    finally:
+        ops.set_precision("fp32")
+    modes = {}
+    for name, t in got.items():
+        t = t.double().cpu().reshape(refs["model"][name].shape)
+        scale = max(1.0, float(refs["exact"][name].abs().max()))
+        e_model = float((t - refs["model"][name]).abs().max())
+        e_exact = float((t - refs["exact"][name]).abs().max())
+        # tiles the dispatcher keeps on the fp32 pipe (narrow N, short grids) stay exact: every launch is one or the other
+        assert min(e_model, e_exact) <= 3e-5 * scale, (name, e_model, e_exact, scale)
+        modes[name] = "bf16" if e_model < e_exact else "fp32"
+        if modes[name] == "bf16":
+            assert 1e-5 * scale < e_exact <= 1e-2 * scale, (name, e_exact, scale)  # it IS reduced precision, by about 2^-9
+    if cout >= 128 and n * (h // st) * (w // st) >= 1024:
+        assert modes["fwd"] == "bf16", modes                     # the wide forward tile runs with bf16 operands
