@@ -98,6 +98,7 @@ def main():
     use_ddp = world > 1 or args.force_ddp
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"       # keep RCCL's version banner out of stdout (one JSON line only)
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")     # RCCL prints its warnings on stdout by default
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
