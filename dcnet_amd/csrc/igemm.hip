@@ -55,8 +55,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // NP = number of bf16 pieces per operand: 3 = fp32-accurate split (six cross terms); 1 = plain bf16 operands
 // (round-to-nearest-even, one MFMA per product, fp32 accumulate): the builder-defined bf16 mode of
 // BASELINE.json configs[2] (dcn_set_tuning("precision", 2)); tensors in HBM stay fp32.
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+// OCC = waves per SIMD the register allocation must allow (__launch_bounds__): the split kernel needs 206 registers
+// (2 waves/SIMD); forced to 168 (3 waves/SIMD, some loop-invariant state in scratch) it is 8-19 % faster on short-K
+// launches (1x1 layers: more waves cover the prologue/epilogue and the barrier) and 2-5 % on the 3x3 layers
+// (tools/bench_convs.py --ab occ3=0 --ab-default 1073741824: forward 34.4 -> 32.8 ms, data gradient 37.5 -> 35.7 ms).
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   static_assert(!SP || (BMODE == 0 && !C4), "split mode: NT operands only");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
   // SP: bf16 plane row in ushorts.  BK = 16: unpadded 32-B rows whose two 16-B halves swap places in rows
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1>
 int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   IgemmParams p = p0;
   p.cpt = p.c4 ? 1 : p.Ci / BK;
@@ -473,7 +477,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
@@ -482,7 +486,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   const int tag = SP ? (NP == 1 ? 19 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
@@ -493,6 +497,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 // narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
 int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
 int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile onto the split-bf16 pipe (bench_convs A/B)
+int g_occ3 = 1 << 30;     // dcn_set_tuning("occ3", n): split launches of <= n K-steps use the 3-waves/SIMD build (A/B: 0 = never)
 int g_abl = 0;            // dcn_set_tuning("abl", 1|2): timing-only ablations of the split kernel (results are wrong)
 int g_precision = 1;      // dcn_set_tuning("precision", 0|1|2): 0 = fp32 MFMA everywhere; 1 = wide NT tiles of >= 1024 rows on the
                           // split-bf16 pipe (fp32 accuracy); 2 = those tiles with plain bf16 operands (configs[2], reduced precision)
@@ -511,6 +516,8 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
       if (g_abl == 1) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 1>(p, stream);   // ablation: no split arithmetic (wrong results)
       if (g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2>(p, stream);   // ablation: 1 of 6 MFMA groups (wrong results)
+      if (BM == 128 && BN == 128 && (p.c4 ? 4 : p.ntaps * (p.Ci / 16)) <= g_occ3)     // (256x64 tile: 10-25 % slower at 3)
+        return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 3, 3>(p, stream);
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true>(p, stream);
     }
   }
@@ -552,6 +559,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
+  else if (k == 'o') g_occ3 = value;         // "occ3"
   else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step

@@ -14,6 +14,9 @@
 #include "prof.h"
 #include <type_traits>
 
+#ifndef WG_OCC
+#define WG_OCC 2            // waves/SIMD the split weight-gradient kernel must fit (2: 205 registers; 3: 168 + 312 B scratch, measured 1.5x slower)
+#endif
 #ifndef WGRAD_KP
 #define WGRAD_KP 16          // pixels per K-step (16: ~32 KB LDS, three workgroups per CU; measured +6 % over 32)
 #endif
@@ -84,7 +87,7 @@ __device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * 
 
 // NP: bf16 pieces per operand (3 = fp32-accurate split, 1 = plain bf16 operands; igemm.hip)
 template <int TM, int TN, int KP, bool SP = false, int ABL = 0, int NP = 3>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kernel(const WgradParams p) {
   static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int MI = TM / (32 * WM), NI = TN / (32 * WN);

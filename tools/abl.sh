@@ -1,3 +1,4 @@
 set -e
-python tools/bench_convs.py --ab tile64=0 --ab-default 1 --iters 5 > gpurun_out/ab_tile64.txt 2>&1
-grep "^AB\|^total\|with" gpurun_out/ab_tile64.txt
+python tools/bench_convs.py --iters 5 > gpurun_out/convs_occ3.txt 2>&1
+tail -42 gpurun_out/convs_occ3.txt
+python -m pytest tests/test_ops_gpu.py -x -q 2>&1 | tail -2
