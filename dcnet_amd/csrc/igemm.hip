@@ -52,6 +52,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // v_mfma_f32_32x32x16_bf16: 6 instructions of 32 cycles per 16 k against 8 of 64 cycles on the fp32 pipe
 // (bf16 products are exact in the fp32 accumulator).  LDS holds three bf16 planes per operand,
 // rows padded by 16 B so the ds_read_b128 fragments (8 consecutive k per lane) are conflict-free.
+// NN split mode: the B tile keeps its HBM orientation [16 k][128 n] per bf16 plane (256-B rows, 16-B chunks
+// XOR-swizzled) and the k-contiguous MFMA fragments come from the hardware transpose read (as in wgrad.hip).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int nn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int nn_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ nn_swz(row)) + 8 * ((c >> 2) & 1); }
+__device__ __forceinline__ bf16x8 nn_frag(const unsigned char* base, int byte0, int byte1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + byte0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + byte1));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // NP = number of bf16 pieces per operand: 3 = fp32-accurate split (six cross terms); 1 = plain bf16 operands
 // (round-to-nearest-even, one MFMA per product, fp32 accumulate): the builder-defined bf16 mode of
 // BASELINE.json configs[2] (dcn_set_tuning("precision", 2)); tensors in HBM stay fp32.
@@ -61,7 +74,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // (tools/bench_convs.py --ab occ3=0 --ab-default 1073741824: forward 34.4 -> 32.8 ms, data gradient 37.5 -> 35.7 ms).
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
-  static_assert(!SP || (BMODE == 0 && !C4), "split mode: NT operands only");
+  static_assert(!SP || !C4, "split mode: no stem path");
+  static_assert(!SP || BMODE == 0 || (BN == 128 && BK == 16 && NP == 3), "split NN mode: 128-wide tile, 16-deep K-step");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
   // SP: bf16 plane row in ushorts.  BK = 16: unpadded 32-B rows whose two 16-B halves swap places in rows
   // 8-15 (mod 16) — conflict-free for the ds_read_b128 fragments (16-lane groups see 16 distinct 16-B slots)
@@ -87,7 +101,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   float* Bs = smem + 2 * BM * LDS_LD;    // BMODE 0: [2][BN][LDS_LD]   BMODE 1: [2][BK][BN]
   constexpr int B_TILE = BMODE == 0 ? BN * LDS_LD : BK * BN;
   unsigned short* As16 = reinterpret_cast<unsigned short*>(smem);      // SP: [2][NP][BM][LD16]
-  unsigned short* Bs16 = As16 + 2 * NP * BM * LD16;                    // SP: [2][NP][BN][LD16]
+  unsigned short* Bs16 = As16 + 2 * NP * BM * LD16;                    // SP: [2][NP][BN][LD16]   (NN: [2][NP][16][128])
+  constexpr int B_PLANE = BMODE == 0 ? BN * LD16 : 2048;               // ushorts per B plane
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -225,12 +240,14 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   auto store_tiles_from = [&](const f32x4* a_reg, const f32x4* b_reg, int buf) {
     if constexpr (SP) {
       unsigned short* a16 = As16 + buf * NP * BM * LD16;
-      unsigned short* b16 = Bs16 + buf * NP * BN * LD16;
+      unsigned short* b16 = Bs16 + buf * NP * B_PLANE;
 #pragma unroll
       for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j]);
 #pragma unroll
-      for (int j = 0; j < B_LD; ++j)
-        if (!B_PART || row0 < BN) split_store(b16, BN * LD16, sp_w(row0 + RPP * j, chunk), b_reg[j]);
+      for (int j = 0; j < B_LD; ++j) {
+        if constexpr (BMODE == 0) { if (!B_PART || row0 < BN) split_store(b16, B_PLANE, sp_w(row0 + RPP * j, chunk), b_reg[j]); }
+        else split_store(b16, B_PLANE, nn_off((tid + 256 * j) >> 5, ((tid + 256 * j) & 31) * 4) >> 1, b_reg[j]);
+      }
       return;
     }
     float* a = As + buf * BM * LDS_LD;
@@ -258,6 +275,15 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   const int b_frag = BMODE == 0 ? (wn * (BN / WN) + (lane & 31)) * LDS_LD + (lane >> 5) * 4
                                 : (lane >> 5) * 4 * BN + wn * (BN / WN) + (lane & 31);
 
+  int nn_tr[NI][2];
+  if constexpr (SP && BMODE == 1) {
+    // transposed-read addresses (wgrad.hip): 16-lane group (h, gg): k rows 8h + 4r + q, columns blk*32 + 16gg + 4pp
+    const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) nn_tr[ni][r2] = nn_off(8 * hh + 4 * r2 + q, wn * (BN / WN) + ni * 32 + 16 * gg + 4 * pp);
+  }
   if constexpr (SP) {
     // Two K-steps of global loads in flight (a K-step of six bf16 MFMAs per block is shorter than the
     // L2/HBM latency): stage S of the registers holds step it+1 while stage S^1 receives step it+2.
@@ -267,9 +293,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     // issues in order: anything placed after the last MFMA would wait for all of them).
     auto step = [&](int cur, const f32x4* ar, const f32x4* br, auto do_store) {
       const unsigned short* a16 = As16 + cur * NP * BM * LD16 + sp_r(wm * (BM / WM) + (lane & 31), lane >> 5);
-      const unsigned short* b16 = Bs16 + cur * NP * BN * LD16 + sp_r(wn * (BN / WN) + (lane & 31), lane >> 5);
+      const unsigned short* b16 = Bs16 + cur * NP * B_PLANE + (BMODE == 0 ? sp_r(wn * (BN / WN) + (lane & 31), lane >> 5) : 0);
       unsigned short* na = As16 + (cur ^ 1) * NP * BM * LD16;
-      unsigned short* nb = Bs16 + (cur ^ 1) * NP * BN * LD16;
+      unsigned short* nb = Bs16 + (cur ^ 1) * NP * B_PLANE;
       constexpr int PIECES = A_LD + B_LD;
       constexpr int TERMS = NP == 3 ? 6 : 1;
       constexpr int GROUPS = TERMS * (BK / 16);
@@ -284,8 +310,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int q = 0; q < NP; ++q)
-            bf[ni][q] = *reinterpret_cast<const bf16x8*>(b16 + q * BN * LD16 + ni * 32 * LD16 + kk * 16);
+          for (int q = 0; q < NP; ++q) {
+            if constexpr (BMODE == 0) bf[ni][q] = *reinterpret_cast<const bf16x8*>(b16 + q * B_PLANE + ni * 32 * LD16 + kk * 16);
+            else bf[ni][q] = nn_frag(reinterpret_cast<const unsigned char*>(b16 + q * B_PLANE), nn_tr[ni][0], nn_tr[ni][1]);
+          }
         // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
         constexpr int QA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -300,7 +328,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int pc = kk * TERMS + t; pc < PIECES; pc += GROUPS) {
               if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc]);
-              else if (!B_PART || row0 < BN) split_store(nb, BN * LD16, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD]);
+              else if constexpr (BMODE == 1)
+                split_store(nb, B_PLANE, nn_off((tid + 256 * (pc - A_LD)) >> 5, ((tid + 256 * (pc - A_LD)) & 31) * 4) >> 1, br[pc - A_LD]);
+              else if (!B_PART || row0 < BN) split_store(nb, B_PLANE, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD]);
             }
           }
         }
@@ -473,7 +503,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
-  const size_t lds = SP ? (size_t)2 * NP * (BM + BN) * (BK == 16 ? 16 : BK + 8) * sizeof(unsigned short)
+  const size_t lds = SP ? (size_t)2 * NP * (BM * (BK == 16 ? 16 : BK + 8) + (BMODE == 0 ? BN * (BK == 16 ? 16 : BK + 8) : 2048)) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -483,7 +513,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = SP ? (NP == 1 ? 19 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? (NP == 1 ? 19 : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
@@ -497,6 +527,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
 // narrow early layers) — while the short grids of the 13x13 maps (M <= 16 K rows) prefer fewer, longer steps.
 int g_force_bk = 0;       // experiment knob (dcn_set_tuning("k", 16|32))
 int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile onto the split-bf16 pipe (bench_convs A/B)
+int g_nn_split = 1;       // dcn_set_tuning("nnsplit", 0): NN products back on the fp32 MFMA
 int g_occ3 = 1 << 30;     // dcn_set_tuning("occ3", n): split launches of <= n K-steps use the 3-waves/SIMD build (A/B: 0 = never)
 int g_abl = 0;            // dcn_set_tuning("abl", 1|2): timing-only ablations of the split kernel (results are wrong)
 int g_precision = 1;      // dcn_set_tuning("precision", 0|1|2): 0 = fp32 MFMA everywhere; 1 = wide NT tiles of >= 1024 rows on the
@@ -520,6 +551,10 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
         return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 3, 3>(p, stream);
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true>(p, stream);
     }
+  }
+  if constexpr (BMODE == 1 && BM == 128 && BN == 128) {
+    // NN products of the co-attention (E.f2, dA.f2): the same split body with transposed B fragments
+    if (g_precision == 1 && g_nn_split && rows >= 1024) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 3, 3>(p, stream);
   }
   if (bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
   return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
@@ -559,6 +594,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
+  else if (k == 'n') g_nn_split = value;     // "nnsplit"
   else if (k == 'o') g_occ3 = value;         // "occ3"
   else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"

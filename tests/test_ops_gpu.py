@@ -440,3 +440,24 @@ def test_bf16_operand_mode_matches_its_exact_model(dev, case):
             assert 1e-5 * scale < e_exact <= 1e-2 * scale, (name, e_exact, scale)  # it IS reduced precision, by about 2^-9
     if cout >= 128 and n * (h // st) * (w // st) >= 1024:
         assert modes["fwd"] == "bf16", modes                     # the wide forward tile runs with bf16 operands
+
+
+@pytest.mark.parametrize("m,n,k,kvalid", [(2048, 384, 256, 0), (1500, 132, 320, 300), (2704, 512, 2720, 2704)])
+def test_gemm_nn_split_pipe(dev, m, n, k, kvalid):
+    """out = a[M,K] @ b[K,N] with the B operand N-contiguous (the co-attention's E.f2 products): >= 1024 rows run on the
+    split-bf16 pipe with transposed LDS fragments; must match fp64 like the fp32 MFMA kernel does (K tail via kvalid)."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    a = _rand(m, k, seed=1).to(dev); b = (_rand(k, n, seed=2) / k ** 0.5).to(dev)
+    kv = kvalid or k
+    ref = a.double().cpu()[:, :kv] @ b.double().cpu()[:kv]
+    err = {}
+    try:
+        for mode in (0, 1):
+            lib().set_tuning(b"nnsplit", mode)
+            out = ops.gemm_nn(a, b, kvalid=kvalid)
+            err[mode] = float((out.double().cpu() - ref).abs().max())
+    finally:
+        lib().set_tuning(b"nnsplit", 1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert err[1] <= 2 * err[0] + 1e-6 * scale and err[1] <= 3e-5 * scale, err
