@@ -320,3 +320,50 @@ def test_bf16_operand_mode_end_to_end(dev):
         assert abs(res["bf16"][1][k] - v) <= 0.25 * max(abs(v), 1e-3), (k, v, res["bf16"][1][k])
     cos = torch.nn.functional.cosine_similarity(res["fp32"][2].flatten().double(), res["bf16"][2].flatten().double(), dim=0)
     assert float(cos) > 0.8, float(cos)
+
+
+def test_full_size_c2_batch_invariance_and_determinism(dev):
+    """BASELINE configs[1] at its full size (64 images of 416x416 = 8 clips x T 8), where the CPU oracle cannot run
+    (~80 GB of host memory).  Size-independent properties instead:
+      * eval mode is per-pair independent (frozen BatchNorm): pairs taken out of the 64-image batch and run alone —
+        at a size the oracle DOES check in test_eval_forward_matches_oracle_and_golden — must give the same outputs
+        (different tile/grid shapes, so equal to accumulation-order accuracy, 1e-4);
+      * the oracle itself, on one of those pairs, agrees with the slice of the full-size run to 1e-3;
+      * a training step (forward, five losses, backward) is bitwise reproducible: split-K slabs and BatchNorm partials
+        are reduced in a fixed order, there are no float atomics, side streams join before results are read."""
+    from dcnet_amd import losses
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    from oracle import dcnet_oracle as O
+    size, n = 416, 64
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=64)
+    m = build_product(size, sd, dev).eval()
+    with torch.no_grad():
+        full = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        for lo in (0, 30, 62):
+            part = m(image[lo:lo + 2].to(dev), word_id[lo:lo + 2].to(dev), word_mask[lo:lo + 2].to(dev))
+            for k in range(3):                                   # outbox, sim_score, loc_score
+                for s in range(3):
+                    assert maxdiff(full[k][s][lo:lo + 2], part[k][s]) < 1e-4, (lo, k, s)
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image[30:32], word_id[30:32], training=False, sample=False)
+    for s in range(3):
+        assert maxdiff(full[0][s][30:32], o["outbox"][s]) < TOL and maxdiff(full[1][s][30:32], o["sim_score"][s]) < TOL
+        assert maxdiff(full[2][s][30:32], o["loc_score"][s]) < TOL
+    del full, part
+    bbox = synth_boxes(n, size, seed=64).to(dev)
+    m.train()
+    runs = []
+    for _ in range(2):
+        m.load_state_dict(sd, strict=True)                       # running statistics back to the start
+        m.zero_grad(set_to_none=True)
+        random.seed(13)
+        out = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        loss, parts = losses.total_loss(out, bbox, size)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), m.visumodel.module_list[0][0].weight.grad.clone(),
+                     m.fcn_out[2][1].weight.grad.clone(), out[0][2].detach().clone()))
+        del out, loss
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(runs[0][0])
