@@ -282,7 +282,7 @@ def main():
                                                  "reported beside the fp32 headline, never as `value` (untimed pass, weight-gradient "
                                                  "stream off)",
                                          "kernels": table(c4, m4, w4, args.exclusive_steps)}
-        res = {"metric": "clips/sec (T=8, 416x416, bs8) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
+        res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "precision": "fp32 tensors and fp32 accumulation everywhere; the 128x128 GEMM tiles multiply on the bf16 matrix "
