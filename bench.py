@@ -211,9 +211,11 @@ def main():
                  17: "wgrad_kernel<128,128,16,true>",
                  18: "igemm_kernel<256,64,4,1,0,false,16,true>",
                  19: "igemm_kernel<*,*,*,*,0,false,32,true,0,1> (bf16 operands)",
-                 20: "wgrad_kernel<128,128,16,true,0,1> (bf16 operands)"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20)
+                 20: "wgrad_kernel<128,128,16,true,0,1> (bf16 operands)",
+                 21: "igemm_kernel<128,128,2,2,1,false,16,true> (NN)",
+                 22: "channel_partials_kernel<1>"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20)
                        else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
@@ -244,7 +246,7 @@ def main():
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
                     "peak_note": ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
                                   "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
-                                 if dom in (16, 17, 18) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
+                                 if dom in (16, 17, 18, 21) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
                     "overlap": "the timed region runs the weight-gradient GEMMs on a second stream beside the data-gradient "
                                "chain; per-launch durations here include the time a launch shared the CUs",
                     # every FLOP the MFMA kernels were asked for in a step over the whole step's wall time

@@ -262,8 +262,10 @@ extern "C" int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo
   DCN_CHECK_ARG(y && dout && mean && invstd && stats && rows > 0 && c > 0, "bn_act_bwd_reduce: bad argument");
   DCN_CHECK_ARG(c % 4 == 0 && (lddo <= 0 || lddo % 4 == 0) && (((uintptr_t)y | (uintptr_t)dout | (uintptr_t)mean | (uintptr_t)invstd) & 15) == 0,
                 "bn_act_bwd_reduce: c=%d / lddo=%d must be multiples of 4 floats, pointers 16-byte aligned", c, lddo);
+  const int pid = prof_begin(22, 8.0 * (double)rows * c, (hipStream_t)stream);
   hipLaunchKernelGGL((channel_partials_kernel<1>), dim3(cdiv(rows, 128), cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream,
                      y, c, dout, lddo > 0 ? lddo : c, mean, invstd, gamma, beta, act, slope, rows, c, stats);
+  prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_reduce");
   return DCN_OK;
 }

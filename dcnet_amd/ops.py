@@ -118,6 +118,8 @@ def weight_to_ohwi(w: torch.Tensor, ci_pad: Optional[int] = None, co_pad: Option
         return out
     ci_pad = pad32(ci) if ci_pad is None else ci_pad
     co_pad = co if co_pad is None else co_pad
+    if kh == 1 and kw == 1 and ci_pad == ci and co_pad == co:
+        return w.view(co, 1, 1, ci)            # a 1x1 filter bank is the same bytes in OIHW and OHWI: no kernel
     alloc = torch.zeros if co_pad != co else torch.empty
     out = alloc((co_pad, kh, kw, ci_pad), dtype=torch.float32, device=w.device)
     lib().oihw_to_ohwi(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, ci_pad, _s())
@@ -134,6 +136,8 @@ def weight_grad_to_oihw(dw: torch.Tensor, shape: Tuple[int, int, int, int]) -> t
         return out
     _chk(dw, "weight_grad_to_oihw")
     ci_pad = dw.shape[3]
+    if kh == 1 and kw == 1 and ci_pad == ci and dw.shape[0] == co:
+        return dw.view(co, ci, 1, 1)
     out = torch.empty(shape, dtype=torch.float32, device=dw.device)
     lib().ohwi_to_oihw(dw.data_ptr(), out.data_ptr(), co, ci, kh, kw, ci_pad, _s())
     return out

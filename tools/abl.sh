@@ -1,22 +1,4 @@
 set -e
-python -m pytest tests/test_ops_gpu.py -x -q 2>&1 | tail -3
-python - <<'PY'
-import torch, sys, os
-sys.path.insert(0, os.getcwd())
-from dcnet_amd import ops
-from dcnet_amd.lib import lib
-dev = torch.device("cuda:0")
-a = torch.randn(32, 2704, 2720, device=dev); b = torch.randn(32, 2720, 512, device=dev)
-def run():
-    # batched NN through coattn is internal; time the plain 2D gemm_nn on one big problem instead
-    ops.gemm_nn(a.view(-1, 2720)[:86528], b[0], kvalid=2704)
-for mode in (0, 1, 0, 1):
-    lib().set_tuning(b"nnsplit", mode)
-    run(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): run()
-    e1.record(); torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / 5
-    print("nnsplit", mode, "%.3f ms" % t, "%.1f TF/s" % (2 * 86528 * 512 * 2704 / t / 1e9))
-PY
+for L in 32,64,3,2,416 32,64,3,1,208 64,32,1,1,208 256,32,1,1,52; do
+  python tools/bench_convs.py --only $L --ab split=16 --iters 10 2>&1 | grep "^AB"
+done
