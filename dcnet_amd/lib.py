@@ -66,7 +66,7 @@ SIGNATURES = {
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
-_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows"}
+_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows"}      # int-returning value functions
 
 
 class DcnError(RuntimeError):

@@ -30,6 +30,8 @@ def test_header_symbols_are_exported_and_bound():
     assert L.version() >= 100
     assert L.conv2d_stats_rows(2, 13, 13, 128, 3, 1) in (3, 6)     # 338 rows in 128- or 64-row tiles: pure host arithmetic
     assert L.channel_stats_rows(1000) == 8
+    assert L.conv2d_geom_size(2, 13, 13, 3, 1) == 2 * 13 * 13 + 128          # one entry per output pixel + prefetch slack
+    assert L.conv2d_geom_size(1, 416, 416, 3, 2) == 208 * 208 + 128
     assert L.coattn_e_size(2, 169) == 2 * 169 * 192
 
 
