@@ -57,10 +57,16 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--n", type=int, default=64); ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--only", type=str, default="", help="cin,cout,k,stride,h: benchmark a single shape")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--set", type=str, default="", help="key=value[,key=value] tuning knobs applied to both arms")
     ap.add_argument("--ab-default", type=int, default=0, help="the knob's default value (restored for the A arm)")
     ap.add_argument("--ab", type=str, default="", help="key=value tuning knob (dcn_set_tuning) measured against the default, same process")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.set:
+        from dcnet_amd.lib import lib as _lib
+        for kv in args.set.split(","):
+            kk, vv = kv.split("=")
+            _lib().set_tuning(kk.encode(), int(vv))
     tot = collections.Counter()
     rows = []
     table = shapes(args.size)
