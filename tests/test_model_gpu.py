@@ -367,3 +367,25 @@ def test_full_size_c2_batch_invariance_and_determinism(dev):
     for a, b in zip(*runs):
         assert torch.equal(a, b)
     assert torch.isfinite(runs[0][0])
+
+
+def test_full_size_c4_nframe_clip_invariance(dev):
+    """BASELINE configs[3] at its full size: 4 clips x T 16 frames of 608x608 through the n_frame inference model
+    (15 frame-to-centre co-attention pairs per clip over 76x76 = 5776 positions).  The oracle checks this geometry at
+    T = 4 (test_large_input_608_nframe_and_pairs); at full size the property is clip independence: a clip taken out of
+    the batch and run alone gives the same outputs (eval mode), and the run is bitwise repeatable."""
+    from dcnet_amd.utils.synth import synth_inputs
+    size, b, t = 608, 4, 16
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(b * t, size, n_queries=b, seed=1608)
+    m = build_product(size, sd, dev, test_model=True).eval()
+    with torch.no_grad():
+        full = m(image.to(dev), word_id.to(dev), word_mask.to(dev), t)
+        again = m(image.to(dev), word_id.to(dev), word_mask.to(dev), t)
+        one = m(image[2 * t:3 * t].to(dev), word_id[2:3].to(dev), word_mask[2:3].to(dev), t)
+    assert full[0][2].shape == (b, 15, 76, 76)
+    for k in range(4):                               # outbox, sim_score, loc_score, corr_feat
+        for s in range(3):
+            assert torch.equal(full[k][s], again[k][s])
+            assert maxdiff(full[k][s][2:3], one[k][s]) < 1e-4, (k, s)
+            assert torch.isfinite(full[k][s]).all()
