@@ -191,11 +191,14 @@ def main():
         L.set_tuning(b"precision", 1)
         return collect() + (el / args.exclusive_steps * 1e3,)
 
-    excl = native = bf16 = None
+    excl = native = bf16 = fp8 = None
     if args.exclusive_steps > 0:
         excl = extra_pass(1)
         native = extra_pass(0)
         bf16 = extra_pass(2)
+        _ops._precision = "fp8"            # conv wrappers compute the operand scales in this mode
+        fp8 = extra_pass(3)
+        _ops._precision = "fp32"
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
@@ -213,9 +216,10 @@ def main():
                  19: "igemm_kernel<*,*,*,*,0,false,32,true,0,1> (bf16 operands)",
                  20: "wgrad_kernel<128,128,16,true,0,1> (bf16 operands)",
                  21: "igemm_kernel<128,128,2,2,1,false,16,true> (NN)",
-                 22: "channel_partials_kernel<1>"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20)
+                 22: "channel_partials_kernel<1>",
+                 23: "igemm_kernel<*,*,*,*,0,false,32,true,0,1,1,true> (fp8 operands)"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23)
                        else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
@@ -284,6 +288,17 @@ def main():
                                                  "reported beside the fp32 headline, never as `value` (untimed pass, weight-gradient "
                                                  "stream off)",
                                          "kernels": table(c4, m4, w4, args.exclusive_steps)}
+            c5, m5, w5, ms_step5 = fp8
+            d5 = max(mm_tags, key=lambda t: w5[t])
+            a5 = w5[d5] / (m5[d5] * 1e-3) / 1e12
+            roofline["fp8_operands"] = {"kernel": names[d5], "achieved": a5, "peak": PEAK_BF16_MFMA_TFLOPS,
+                                        "frac": a5 / PEAK_BF16_MFMA_TFLOPS, "avg_launch_ms": m5[d5] / c5[d5],
+                                        "ms_per_step": ms_step5, "clips_per_s": args.clips * world / (ms_step5 * 1e-3),
+                                        "note": "ops.set_precision('fp8') = BASELINE.json configs[4] at batch 8: fp8 e4m3 operands with "
+                                                "per-tensor power-of-two scales (non-scaled fp8 MFMA: bf16 rate) in forward and data "
+                                                "gradient, bf16 operands in the weight gradient, fp32 accumulate and tensors; REDUCED "
+                                                "precision, reported beside the fp32 headline, never as `value` (untimed pass)",
+                                        "kernels": table(c5, m5, w5, args.exclusive_steps)}
         res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

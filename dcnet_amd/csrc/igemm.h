@@ -15,6 +15,7 @@
 struct IgemmParams {
   const float* in;        // gathered tensor, NHWC, pixel stride ldi
   const float* wt;        // [Co][ldw] K-contiguous rows
+  const float* f8;        // optional device {sA, sB}: power-of-two operand scales of the fp8 path (dcn_f8_scale); null = off
   float* out;             // NHWC, pixel stride ldo
   const float* scale;     // per-Co, may be null
   const float* shift;     // per-Co, may be null

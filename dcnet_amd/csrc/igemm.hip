@@ -72,8 +72,14 @@ __device__ __forceinline__ bf16x8 nn_frag(const unsigned char* base, int byte0, 
 // (2 waves/SIMD); forced to 168 (3 waves/SIMD, some loop-invariant state in scratch) it is 8-19 % faster on short-K
 // launches (1x1 layers: more waves cover the prologue/epilogue and the barrier) and 2-5 % on the 3x3 layers
 // (tools/bench_convs.py --ab occ3=0 --ab-default 1073741824: forward 34.4 -> 32.8 ms, data gradient 37.5 -> 35.7 ms).
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1>
+// F8 (with NP = 1, BK = 32): operands scaled by a per-tensor power of two (IgemmParams::f8 = {sA, sB}, dcn_f8_scale),
+// rounded to OCP fp8 e4m3 (v_cvt_pk_fp8_f32) when the tile is staged, multiplied by v_mfma_f32_32x32x16_fp8_fp8 (one
+// 16-B LDS fragment = 16 fp8 feeds two MFMAs), accumulated in fp32 and rescaled by 1/(sA*sB) before the epilogue:
+// the builder-defined fp8 conv path of BASELINE.json configs[4] (ops.set_precision("fp8")).
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1,
+          bool F8 = false>
 __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
+  static_assert(!F8 || (SP && NP == 1 && BK == 32 && BMODE == 0), "fp8 operands: NT tiles, 32-deep K-step");
   static_assert(!SP || !C4, "split mode: no stem path");
   static_assert(!SP || BMODE == 0 || (BN == 128 && BK == 16 && NP == 3), "split NN mode: 128-wide tile, 16-deep K-step");
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
@@ -81,13 +87,15 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   // 8-15 (mod 16) — conflict-free for the ds_read_b128 fragments (16-lane groups see 16 distinct 16-B slots)
   // AND for the ds_write_b64 of the split pieces (a 16-lane group fills four whole rows = 128 contiguous bytes;
   // with 48-B padded rows a third of the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).  BK = 32: padded.
-  constexpr int LD16 = BK == 16 ? 16 : BK + 8;
+  constexpr int LD16 = (BK == 16 || F8) ? 16 : BK + 8;      // (fp8, BK = 32: the same 32-B rows, 32 one-byte k)
   auto sp_w = [](int row, int chunk) {      // ushort offset of floats 4*chunk..4*chunk+3 of `row` inside a plane
+    if (F8) return row * 16 + ((((chunk >> 2) ^ (row >> 3)) & 1) << 3) + (chunk & 3) * 2;
     return BK == 16 ? row * 16 + ((((chunk >> 1) ^ (row >> 3)) & 1) << 3) + (chunk & 1) * 4 : row * LD16 + chunk * 4;
   };
-  auto sp_r = [](int row, int half) {       // ushort offset of k = 8*half..8*half+7 (K-step slice 0) of `row`
-    return BK == 16 ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
+  auto sp_r = [](int row, int half) {       // ushort offset of the 16-B half `half` (K-step slice 0) of `row`
+    return (BK == 16 || F8) ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
   };
+  const float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -211,7 +219,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       }
     }
   };
-  auto split_store = [&](unsigned short* plane0, int plane_stride, int off, const f32x4 v) {
+  auto split_store = [&](unsigned short* plane0, int plane_stride, int off, const f32x4 v, const float sc = 1.f) {
+    if constexpr (F8) {                  // 4 floats -> 4 e4m3 bytes (scaled, clamped to the finite range, nearest even)
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = fminf(fmaxf(v[e] * sc, -448.f), 448.f);
+      int w = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], w, true);
+      *reinterpret_cast<int*>(plane0 + off) = w;
+      return;
+    }
     if constexpr (NP == 1) {             // plain bf16 operands: v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
       typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
       const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -242,10 +259,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       unsigned short* a16 = As16 + buf * NP * BM * LD16;
       unsigned short* b16 = Bs16 + buf * NP * B_PLANE;
 #pragma unroll
-      for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j]);
+      for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j], f8_sa);
 #pragma unroll
       for (int j = 0; j < B_LD; ++j) {
-        if constexpr (BMODE == 0) { if (!B_PART || row0 < BN) split_store(b16, B_PLANE, sp_w(row0 + RPP * j, chunk), b_reg[j]); }
+        if constexpr (BMODE == 0) { if (!B_PART || row0 < BN) split_store(b16, B_PLANE, sp_w(row0 + RPP * j, chunk), b_reg[j], f8_sb); }
         else split_store(b16, B_PLANE, nn_off((tid + 256 * j) >> 5, ((tid + 256 * j) & 31) * 4) >> 1, b_reg[j]);
       }
       return;
@@ -298,9 +315,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       unsigned short* nb = Bs16 + (cur ^ 1) * NP * B_PLANE;
       constexpr int PIECES = A_LD + B_LD;
       constexpr int TERMS = NP == 3 ? 6 : 1;
-      constexpr int GROUPS = TERMS * (BK / 16);
+      constexpr int KK = F8 ? 1 : BK / 16;          // fragment reads per K-step (fp8: one 16-B read covers 16 k)
+      constexpr int GROUPS = TERMS * KK;
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
+      for (int kk = 0; kk < KK; ++kk) {
         bf16x8 af[MI][NP], bf[NI][NP];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -321,16 +339,23 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni) {
+              if constexpr (F8) {
+                typedef long l64x2 __attribute__((ext_vector_type(2)));
+                const l64x2 a2 = __builtin_bit_cast(l64x2, af[mi][0]), b2 = __builtin_bit_cast(l64x2, bf[ni][0]);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[0], b2[0], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[1], b2[1], acc[mi][ni], 0, 0, 0);
+              } else
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t]], bf[ni][QB[t]], acc[mi][ni], 0, 0, 0);
+            }
           if constexpr (decltype(do_store)::value) {
             // pieces g, g + GROUPS, ... belong to group g = kk*6 + t
 #pragma unroll
             for (int pc = kk * TERMS + t; pc < PIECES; pc += GROUPS) {
-              if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc]);
+              if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc], f8_sa);
               else if constexpr (BMODE == 1)
                 split_store(nb, B_PLANE, nn_off((tid + 256 * (pc - A_LD)) >> 5, ((tid + 256 * (pc - A_LD)) & 31) * 4) >> 1, br[pc - A_LD]);
-              else if (!B_PART || row0 < BN) split_store(nb, B_PLANE, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD]);
+              else if (!B_PART || row0 < BN) split_store(nb, B_PLANE, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD], f8_sb);
             }
           }
         }
@@ -403,6 +428,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   }
   }
 
+  if constexpr (F8) {
+    const float dq = 1.f / (f8_sa * f8_sb);          // powers of two: exact
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= dq;
+  }
   // ---- epilogue ----------------------------------------------------------------------------
   // (0) accumulate: the destination's current content joins the RAW accumulator, i.e. before the
   //     statistics and before scale/shift/activation (dX += ..., or a pre-filled per-image/per-position
@@ -496,27 +528,28 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1, bool F8 = false>
 int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   IgemmParams p = p0;
   p.cpt = p.c4 ? 1 : p.Ci / BK;
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
-  const size_t lds = SP ? (size_t)2 * NP * (BM * (BK == 16 ? 16 : BK + 8) + (BMODE == 0 ? BN * (BK == 16 ? 16 : BK + 8) : 2048)) * sizeof(unsigned short)
+  constexpr int LD16 = (BK == 16 || F8) ? 16 : BK + 8;
+  const size_t lds = SP ? (size_t)2 * NP * (BM * LD16 + (BMODE == 0 ? BN * LD16 : 2048)) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = SP ? (NP == 1 ? 19 : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
@@ -541,7 +574,9 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // narrow tiles gain nothing from the split (its vector-ALU cost per MFMA grows as the tile shrinks:
     // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
-    if (g_precision == 2 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
+    if (p.f8 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
+      return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
+    if (g_precision >= 2 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1>(p, stream);     // bf16 operands: 8 MFMAs per 32-wide K-step
     if (g_split || (g_precision == 1 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
@@ -591,7 +626,7 @@ void wgrad_set_abl(int v);
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
-  if (k == 'p') { g_precision = value; wgrad_set_split(value); return DCN_OK; }   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
+  if (k == 'p') { g_precision = value; wgrad_set_split(value > 2 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
   else if (k == 'n') g_nn_split = value;     // "nnsplit"

@@ -98,6 +98,44 @@ extern "C" int dcn_nhwc_to_nchw(const float* src, float* dst, int n, int c, int 
   return DCN_OK;
 }
 
+// ---- fp8 path: per-tensor power-of-two scale ------------------------------------------------------------------
+// scale = 2^floor(log2(448 / max|x|)) (1 for an all-zero tensor): x*scale fits the finite e4m3 range and the scaling is
+// exact.  max is order-independent, so the atomic (on the bits of a non-negative float) keeps results reproducible.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int c4, int ld, unsigned* __restrict__ out) {
+  const int64_t total = rows * c4;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c4; const int c = (int)(i - r * c4) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + c);
+    m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+__global__ void f8_scale_finish_kernel(unsigned* bits, float* scale) {
+  const float amax = __uint_as_float(*bits);
+  float s = 1.f;
+  if (amax > 0.f && amax < 3.0e38f) {
+    int e; (void)frexpf(448.f / amax, &e);          // 448/amax = f * 2^e, f in [0.5, 1)  ->  floor(log2) = e - 1
+    e = e - 1; e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    s = ldexpf(1.f, e);
+  }
+  *scale = s;
+}
+
+extern "C" int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* scale, void* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(x && scale && ws && rows > 0 && c > 0 && c % 4 == 0 && ld % 4 == 0 && ld >= c, "f8_scale: bad argument (c=%d ld=%d)", c, ld);
+  DCN_CHECK_ARG(((uintptr_t)x & 15) == 0, "f8_scale: x must be 16-byte aligned");
+  if (hipMemsetAsync(ws, 0, 4, stream) != hipSuccess) { dcn_set_error("f8_scale: memset failed"); return DCN_ERR_LAUNCH; }
+  const int64_t total = rows * (c / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)ws);
+  hipLaunchKernelGGL(f8_scale_finish_kernel, dim3(1), dim3(1), 0, stream, (unsigned*)ws, scale);
+  DCN_CHECK_LAUNCH("f8_scale");
+  return DCN_OK;
+}
+
 extern "C" int dcn_oihw_to_ohwi(const float* src, float* dst, int co, int ci, int kh, int kw, int ci_pad, void* stream) {
   DCN_CHECK_ARG(src && dst && co > 0 && ci > 0 && kh > 0 && kw > 0 && ci_pad >= ci, "oihw_to_ohwi: bad argument");
   // per output channel: [Ci][T] -> [T][ci_pad]

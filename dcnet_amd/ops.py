@@ -19,7 +19,9 @@ ACT_NONE, ACT_LEAKY = 0, 1
 #   "fp32_mfma" the native fp32 MFMA instruction on every tile
 #   "bf16"      bf16 operands (round to nearest even), fp32 accumulate: BASELINE.json configs[2]; reduced precision,
 #               builder-defined (the reference has no bf16 semantics); tensors in HBM stay fp32
-PRECISIONS = {"fp32_mfma": 0, "fp32": 1, "bf16": 2}
+#   "fp8"       forward and data-gradient tiles with OCP fp8 e4m3 operands (per-tensor power-of-two scales from an abs-max
+#               pass, fp32 accumulate), weight gradient with bf16 operands: BASELINE.json configs[4]; reduced precision
+PRECISIONS = {"fp32_mfma": 0, "fp32": 1, "bf16": 2, "fp8": 3}
 _precision = "fp32"
 
 
@@ -149,6 +151,16 @@ def conv_out_hw(h: int, w: int, k: int, stride: int) -> Tuple[int, int]:
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
+def f8_scales(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Device tensor {s_a, s_w}: power-of-two scales that map max|a| and max|w| into the fp8 e4m3 range (dcn_f8_scale)."""
+    out = torch.empty(4, dtype=torch.float32, device=a.device)          # [s_a, s_w, scratch, scratch]
+    for i, t in enumerate((a, w)):
+        c = t.shape[-1]
+        lib().f8_scale(t.data_ptr(), t.numel() // c if t.is_contiguous() else t.numel() // c, c,
+                       c if t.is_contiguous() else t.stride(-2), out[i:].data_ptr(), out[2 + i:].data_ptr(), _s())
+    return out
+
+
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
                residual=None, out=None, want_stats=False, accumulate=False):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
@@ -164,9 +176,10 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
     if want_stats:
         rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
+    f8 = f8_scales(x, w_ohwi) if (_precision == "fp8" and cin != 4) else None
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
-                     0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _s())
+                     0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8), _s())
     return out, stats
 
 
@@ -178,8 +191,9 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     if out is None:
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     wt = scratch(w_ohwi.numel(), dy.device, slot=1)
+    f8 = f8_scales(dy, w_ohwi) if _precision == "fp8" else None
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
-                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _s())
+                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _s())
     return out
 
 

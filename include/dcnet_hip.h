@@ -64,8 +64,13 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
                    const float* scale, const float* shift, int act, float slope,
                    const float* residual, int ldr, int ldy,
-                   float* stats, int accumulate, void* stream);
+                   float* stats, int accumulate, const float* f8_scales, void* stream);
 int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride);
+/* f8_scales (dcn_conv2d_fwd / dcn_conv2d_bwd_data; NULL = off): device pointer to {s_activation, s_weight}, the
+ * power-of-two operand scales of the builder-defined fp8 e4m3 conv path (BASELINE.json configs[4]): the wide tiles
+ * round s*x to fp8, multiply with v_mfma_f32_32x32x16_fp8_fp8, accumulate in fp32 and rescale.  dcn_f8_scale writes
+ * 2^floor(log2(448 / max|x|)) for a [rows][c] tensor (row stride ld) into *scale; ws = 4 bytes of device scratch. */
+int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* scale, void* ws, void* stream);
 
 /* dx = conv_transpose(dy, w): gradient w.r.t. the conv input (autograd of nn.Conv2d,
  * reached from loss.backward() at train_DCNet.py:645).  dy NHWC (n,ho,wo,cout) with pixel
@@ -74,7 +79,7 @@ int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride)
  * accumulate != 0: dx += result (used where a tensor feeds two consumers). */
 int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                        int accumulate, void* stream);
+                        int accumulate, const float* f8_scales, void* stream);
 
 /* Geometry table of a convolution (depends on n, h, wd, ksize, stride only; build once, reuse every step):
  * dcn_conv2d_geom_size entries of uint32, entry m = (index of the input pixel under the centre tap of
