@@ -54,6 +54,28 @@ def parse():
     return ap.parse_args()
 
 
+def parity_check(size: int = 256, n: int = 4):
+    """The metric's second half (Acc@0.5 IoU), as agreement with the oracle: decoded boxes of the HIP model vs the CPU
+    oracle on a small seeded eval batch (the oracle is the checker here, as in smoke()); part of the cpu_baseline leg."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import build_product, maxdiff, synth_sd
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=77)
+    m = build_product(size, sd, dev).eval()
+    with torch.no_grad():
+        outbox = m(image.to(dev), word_id.to(dev), word_mask.to(dev))[0]
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image, word_id, training=False, sample=False)
+    boxes = O.decode_boxes([x.cpu() for x in outbox], size)
+    ref = O.decode_boxes(o["outbox"], size)
+    iou = O.bbox_iou_xyxy(boxes, ref)
+    return {"images": n, "size": size, "acc_at_iou_0.5_vs_oracle_boxes": float((iou > 0.5).float().mean()),
+            "min_iou_vs_oracle_boxes": float(iou.min()),
+            "max_abs_err_outbox": max(maxdiff(a, b) for a, b in zip(outbox, o["outbox"]))}
+
+
 def cpu_baseline(size: int, frames: int, steps: int):
     """Oracle forward+backward on the host cores, 1 clip (bs 8 would need ~80 GB of host RAM)."""
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs, synth_state_dict
@@ -81,6 +103,7 @@ def cpu_baseline(size: int, frames: int, steps: int):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
     return {"value": 1.0 / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "parity": parity_check(),
             "sample": f"oracle/ (CPU restatement pinned to the reference) fwd+5 losses+bwd on 1 clip T={frames} "
                       f"{size}x{size}, {steps} timed steps after 1 warm-up, median; host has {os.cpu_count()} cpus"}
 
