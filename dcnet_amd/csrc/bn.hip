@@ -61,6 +61,48 @@ __global__ __launch_bounds__(256) void sums_finalize_kernel(const double* __rest
   out[col] = (float)s;
 }
 
+// ---- one-launch reduce + finalize for short partial lists -------------------------------------------------------
+// Most layers hand over <= 4096 partial rows (one per 128-row tile): one block per 32 channels sums them in a fixed
+// order (1024 threads = 32 row lanes x 32 channels, doubles) and finalises its channels itself — one launch instead of
+// the two-stage pair, on the critical path between every conv and its BatchNorm apply.  MODE 0: BatchNorm statistics
+// (same arithmetic as bn_finalize_kernel); MODE 1: the two backward sums.
+constexpr int FUSED_ROWS_MAX = 4096;
+template <int MODE>
+__global__ __launch_bounds__(1024) void reduce_finalize_kernel(const float* __restrict__ stats, int rows, int c, double inv_count,
+                                                               double unbias, const float* gamma, const float* beta, float eps,
+                                                               float momentum, float* running_mean, float* running_var,
+                                                               float* mean, float* invstd, float* scale, float* shift,
+                                                               float* sums) {
+  __shared__ double red[2][32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + tx;
+  double s = 0.0, ss = 0.0;
+  if (ch < c)
+    for (int r = ty; r < rows; r += 32) {
+      s += (double)stats[((size_t)r * 2 + 0) * c + ch];
+      ss += (double)stats[((size_t)r * 2 + 1) * c + ch];
+    }
+  red[0][ty][tx] = s; red[1][ty][tx] = ss;
+  __syncthreads();
+  if (ty != 0 || ch >= c) return;
+  s = 0.0; ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) { s += red[0][k][tx]; ss += red[1][k][tx]; }
+  if (MODE == 1) { sums[ch] = (float)s; sums[c + ch] = (float)ss; return; }
+  const double m = s * inv_count;
+  double var = ss * inv_count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)m; invstd[ch] = is;
+  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  const float sc = g * is;
+  scale[ch] = sc; shift[ch] = b - (float)m * sc;
+  if (running_mean) {
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)(var * unbias);
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                                       float eps, int c, float* scale, float* shift) {
   const int ch = blockIdx.x * 256 + threadIdx.x;
@@ -212,10 +254,16 @@ extern "C" int dcn_bn_finalize(const float* stats, int rows, int c, int64_t coun
   DCN_CHECK_ARG(stats && mean && invstd && scale && shift && ws, "bn_finalize: null pointer");
   DCN_CHECK_ARG(rows > 0 && c > 0 && count > 0, "bn_finalize: bad shape");
   DCN_CHECK_ARG(((uintptr_t)ws & 7) == 0, "bn_finalize: ws must be 8-byte aligned");
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  if (rows <= FUSED_ROWS_MAX) {
+    hipLaunchKernelGGL((reduce_finalize_kernel<0>), dim3(cdiv(c, 32)), dim3(1024), 0, stream, stats, rows, c, 1.0 / (double)count,
+                       unbias, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, (float*)nullptr);
+    DCN_CHECK_LAUNCH("bn_reduce_finalize");
+    return DCN_OK;
+  }
   const int rs = row_slices(rows);
   hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(2 * c, 32), rs), dim3(256), 0, stream, stats, rows, 2 * c, rs, (double*)ws);
   DCN_CHECK_LAUNCH("colsum_stage1");
-  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 256)), dim3(256), 0, stream, (const double*)ws, rs, c,
                      1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var,
                      mean, invstd, scale, shift);
@@ -273,6 +321,13 @@ extern "C" int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo
 extern "C" int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums, float* ws, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(stats && sums && ws && rows > 0 && c > 0, "bn_bwd_sums: bad argument");
+  if (rows <= FUSED_ROWS_MAX) {
+    hipLaunchKernelGGL((reduce_finalize_kernel<1>), dim3(cdiv(c, 32)), dim3(1024), 0, stream, stats, rows, c, 0.0, 0.0,
+                       (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, sums);
+    DCN_CHECK_LAUNCH("bn_reduce_sums");
+    return DCN_OK;
+  }
   const int rs = row_slices(rows);
   hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(2 * c, 32), rs), dim3(256), 0, stream, stats, rows, 2 * c, rs, (double*)ws);
   DCN_CHECK_LAUNCH("colsum_stage1");
