@@ -145,7 +145,8 @@ def main():
     visu = [p for p in model.visumodel.parameters() if p.requires_grad]
     vis_ids = {id(p) for p in visu}
     rest = [p for p in model.parameters() if p.requires_grad and id(p) not in vis_ids]
-    opt = torch.optim.RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)  # :533
+    from dcnet_amd.optim import RMSprop     # torch.optim.RMSprop's update (train_DCNet.py:533) as one fused HIP pass
+    opt = RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)
 
     n_img = args.clips * args.frames
     image, word_id, word_mask = synth_inputs(n_img, args.size, seed=100 + rank)

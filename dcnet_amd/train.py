@@ -34,7 +34,8 @@ def make_optimizer(model, lr: float = 1e-4, optimizer: str = "RMSprop"):
         return torch.optim.Adam([p for p in core.parameters() if p.requires_grad], lr=lr, weight_decay=0.0005)
     if optimizer.lower() == "sgd":
         return torch.optim.SGD([p for p in core.parameters() if p.requires_grad], lr=lr, momentum=0.99)
-    return torch.optim.RMSprop([{"params": rest}, {"params": visu, "lr": lr / 10.}], lr=lr, weight_decay=0.0005)
+    from .optim import RMSprop          # torch.optim.RMSprop's update as one fused HIP pass (same state_dict layout)
+    return RMSprop([{"params": rest}, {"params": visu, "lr": lr / 10.}], lr=lr, weight_decay=0.0005)
 
 
 def lr_poly(base_lr: float, it: int, max_iter: int, power: float) -> float:

@@ -217,6 +217,13 @@ int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows,
 /* Experiment knob of the conv engine's tile heuristic ("bm": force the M tile to 64 or 128, 0 = automatic).
  * Used by tools/bench_convs.py for in-process A/B runs (a 128x256 tile measured 10-25 % slower and was dropped). */
 int dcn_set_tuning(const char* key, int value);
+
+/* ---- optimiser ---------------------------------------------------------------------------------
+ * One fused RMSprop step over `count` fp32 tensors (host arrays of device pointers and element counts):
+ * g += weight_decay*p;  v = alpha*v + (1-alpha)*g*g;  p -= lr*g/(sqrt(v)+eps)   — torch.optim.RMSprop with
+ * momentum = 0, centered = False (train_DCNet.py:528-534), which the reference steps at train_DCNet.py:646. */
+int dcn_rmsprop_step(float* const* params, const float* const* grads, float* const* square_avgs, const int64_t* numel,
+                     int count, float lr, float alpha, float eps, float weight_decay, void* stream);
 /* Keys: "precision" 1 (default): the 128x128 tiles of the conv engine and of the weight-gradient / TN GEMM run on
  *         the bf16 matrix pipe with every fp32 operand cut into three bf16 pieces (exact) and the six cross terms
  *         >= 2^-16 accumulated in fp32 — measured error against fp64 is at or below that of v_mfma_f32_32x32x2_f32;

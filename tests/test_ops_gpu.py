@@ -507,3 +507,28 @@ def test_fp8_operand_mode_matches_its_exact_model(dev, case):
             assert 1e-4 * scale < e_exact <= 0.2 * scale, (name, e_exact, scale)      # 3 mantissa bits: a few per cent
     if cout >= 128 and n * ho * wo >= 1024:
         assert modes["fwd"] == "fp8", modes
+
+
+def test_fused_rmsprop_matches_torch(dev):
+    """dcnet_amd.optim.RMSprop (one fused pass, dcn_rmsprop_step) against torch.optim.RMSprop on the same parameters and
+    gradients: ragged sizes (vector body + scalar tail), two groups with different rates, weight decay, 3 steps;
+    the state_dict loads into torch's optimiser and back."""
+    from dcnet_amd.optim import RMSprop
+    shapes = [(7,), (64, 33), (3, 3, 16, 5), (1,), (1024, 257), (40, 8, 3, 3)] * 8        # 48 tensors: two launches
+    g = torch.Generator().manual_seed(5)
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    mk = lambda: [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pa, pb = mk(), mk()
+    groups = lambda ps: [{"params": ps[:20]}, {"params": ps[20:], "lr": 1e-3}]
+    oa = RMSprop(groups(pa), lr=1e-2, weight_decay=5e-4)
+    ob = torch.optim.RMSprop(groups(pb), lr=1e-2, weight_decay=5e-4)
+    for it in range(3):
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, generator=g).to(dev) * (it + 1)
+            x.grad = gr.clone(); y.grad = gr.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        _close(x, y, 2e-6, "param")
+    for x, y in zip(pa, pb):
+        _close(oa.state[x]["square_avg"], ob.state[y]["square_avg"], 2e-6, "square_avg")
+    ob.load_state_dict(oa.state_dict()); oa.load_state_dict(ob.state_dict())             # interchangeable layout
