@@ -102,6 +102,12 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
       }
     return igemm_launch(p, stream);
   }
+  // 1x1 stride 2: only the even-even pixels receive a gradient; the other three parity classes have no tap and are
+  // never visited below, so they must be zeroed here (not a DCNet layer shape, but the entry point is general).
+  if (ksize == 1 && !accumulate &&
+      hipMemsetAsync(dx, 0, (size_t)n * h * wd * cin * sizeof(float), stream) != hipSuccess) {
+    dcn_set_error("conv2d_bwd_data: memset failed"); return DCN_ERR_LAUNCH;
+  }
   // stride 2: output pixels of parity class (a,b) only see taps with (a+pad-r), (b+pad-s) even.
   // Four dense sub-problems with 1/2/2/4 taps (3x3) instead of one 9-tap problem that is 3/4 zeros.
   for (int a = 0; a < 2; ++a)

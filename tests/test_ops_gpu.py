@@ -532,3 +532,35 @@ def test_fused_rmsprop_matches_torch(dev):
     for x, y in zip(pa, pb):
         _close(oa.state[x]["square_avg"], ob.state[y]["square_avg"], 2e-6, "square_avg")
     ob.load_state_dict(oa.state_dict()); oa.load_state_dict(ob.state_dict())             # interchangeable layout
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_conv_engines_random_shapes(dev, seed):
+    """Seeded random conv geometries that reach the wide split-pipe tiles (>= 1024 output rows) with ragged everything:
+    M and Cout tails, odd spatial sizes, stride 2, 1x1 and 3x3, 64-channel (256x64 tile) and 128+ channel layers —
+    forward (with BatchNorm partial sums), data gradient and weight gradient against fp64."""
+    import random as _r
+    from dcnet_amd import ops
+    rng = _r.Random(1000 + seed)
+    k = rng.choice([1, 3]); st = rng.choice([1, 1, 2])
+    cin = rng.choice([32, 64, 96, 128, 160, 256])
+    cout = rng.choice([64, 96, 128, 136, 192, 256, 320])
+    h = rng.randint(17, 45); w = rng.randint(17, 45); n = rng.randint(2, 4)
+    x = _rand(n, h, w, cin, seed=seed).to(dev)
+    wt = (_rand(cout, k, k, cin, seed=seed + 100) / (cin * k * k) ** 0.5).to(dev)
+    xd = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wd = wt.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    yd = F.conv2d(xd, wd, stride=st, padding=(k - 1) // 2)
+    dy = (_rand(*yd.shape, seed=seed + 200) / 8).permute(0, 2, 3, 1).contiguous().to(dev)
+    yd.backward(dy.permute(0, 3, 1, 2).double().cpu())
+    y, stats = ops.conv2d_fwd(x, wt, k, st, want_stats=True)
+    _close(y, yd.detach().permute(0, 2, 3, 1), 3e-5, "fwd")
+    ref_s = yd.detach().permute(0, 2, 3, 1).reshape(-1, cout)
+    _close(stats[:, 0].double().sum(0), ref_s.sum(0), 1e-4, "stats sum")
+    _close(stats[:, 1].double().sum(0), (ref_s * ref_s).sum(0), 1e-4, "stats sumsq")
+    cout_p = (cout + 31) // 32 * 32
+    wt_p = torch.zeros(cout_p, k, k, cin, device=dev); wt_p[:cout] = wt
+    dy_p = torch.zeros(*dy.shape[:3], cout_p, device=dev); dy_p[..., :cout] = dy
+    _close(ops.conv2d_bwd_data(dy_p, wt_p, (h, w), k, st), xd.grad.permute(0, 2, 3, 1), 3e-5, "dgrad")
+    dw = ops.conv2d_bwd_weight(x, dy_p[..., :cout_p], k, st)[:cout] if cout % 4 else ops.conv2d_bwd_weight(x, dy, k, st)
+    _close(dw, wd.grad.permute(0, 2, 3, 1), 3e-5, "wgrad")
