@@ -393,3 +393,27 @@ def test_full_size_c4_nframe_clip_invariance(dev):
             assert torch.equal(full[k][s], again[k][s])
             assert maxdiff(full[k][s][2:3], one[k][s]) < 1e-4, (k, s)
             assert torch.isfinite(full[k][s]).all()
+
+
+def test_eval_forward_at_an_unlisted_size(dev):
+    """320x320 (grids 10/20/40: ragged tiles everywhere, none of the sizes the kernels were tuned on): pair model and
+    n_frame model against the oracle."""
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    size = 320
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(2, size, seed=322)
+    m = build_product(size, sd, dev).eval()
+    with torch.no_grad():
+        outbox, sim, loc, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image, word_id, training=False, sample=False)
+    for s in range(3):
+        assert maxdiff(outbox[s], o["outbox"][s]) < TOL and maxdiff(sim[s], o["sim_score"][s]) < TOL
+        assert maxdiff(loc[s], o["loc_score"][s]) < TOL and maxdiff(only_obj[s], o["only_obj"][s]) < TOL
+    mt = build_product(size, sd, dev, test_model=True).eval()
+    image, word_id, word_mask = synth_inputs(3, size, n_queries=1, seed=320)
+    with torch.no_grad():
+        ob, sm, lc, cf, oo = mt(image.to(dev), word_id.to(dev), word_mask.to(dev), 3)
+        o = O.grounding_forward_nframe({k: v.clone() for k, v in sd.items()}, image, word_id, 3)
+    for s in range(3):
+        assert maxdiff(ob[s], o["outbox"][s]) < TOL and maxdiff(lc[s], o["loc_score"][s]) < TOL and maxdiff(cf[s], o["corr_feat"][s]) < TOL
