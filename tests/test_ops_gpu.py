@@ -118,9 +118,11 @@ def test_conv2d_bwd_weight(dev, case):
     _close(got, wt.grad.float(), 3e-5, "wgrad")
 
 
-def test_batchnorm_train_fwd_bwd(dev):
+@pytest.mark.parametrize("n,h,w,c", [(3, 9, 7, 96), (2, 5, 5, 4), (1, 33, 31, 68), (4, 64, 64, 32), (2, 416, 416, 8), (4, 416, 416, 8), (5, 13, 13, 1024)])
+def test_batchnorm_train_fwd_bwd(dev, n, h, w, c):
+    """(2,416,416,8): 2704 partial rows -> the one-launch reduce; (4,416,416,8): 5408 partial rows -> the two-stage
+    reduce; the others: ragged channel blocks and tiny / wide channel counts."""
     from dcnet_amd import ops
-    n, h, w, c = 3, 9, 7, 96
     y = (_rand(n, c, h, w, seed=20) * 2 + 0.5)
     gamma = _rand(c, seed=21).abs() + 0.5; beta = _rand(c, seed=22)
     rm = _rand(c, seed=23); rv = _rand(c, seed=24).abs() + 0.5
