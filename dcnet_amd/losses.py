@@ -19,6 +19,11 @@ ANCHORS_FULL = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119),
 _const_cache = {}
 
 
+# Set by grounding_model.forward (train mode): the stream its sampling heads ran on, or None.  total_loss evaluates the
+# two contrastive losses there; every consumer on the current stream is ordered behind it by an explicit wait.
+CONTRASTIVE_STREAM = None
+
+
 def _const(key, device, builder):
     """Small constant tensors, uploaded once per (key, device): a ``torch.tensor(list, device=...)`` in the
     step would be a pageable H2D copy that blocks the host until the queued forward kernels have drained."""
@@ -159,10 +164,23 @@ def total_loss(outputs, bbox: torch.Tensor, size: int):
     gt_param, gi, gj, best_n, gt_center = build_target(bbox, size)
     pred5 = [p.view(p.size(0), 3, 5, p.size(2), p.size(3)) for p in pred]
     neg_sim = [torch.sum(flang_attn.flip(0) * cf[:, :512], dim=1) for cf in corr_feat]      # :623-627
+    cs = CONTRASTIVE_STREAM if frame_f[0].is_cuda else None
+    if cs is not None:
+        # the sampled lists were produced on the model's sampling stream: evaluate their two losses there as well, so
+        # that autograd replays this whole branch (gathers, top-k bookkeeping, normalisations) beside the heads' backward
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(cs):
+            inter = interframe_contrastive_loss(frame_f, corr_f, neg_f)
+            cross = crossmodal_contrastive_loss(vit_p, lag_p, neg_c)
+        main.wait_stream(cs)
+        inter.record_stream(main); cross.record_stream(main)
+    else:
+        inter = interframe_contrastive_loss(frame_f, corr_f, neg_f)
+        cross = crossmodal_contrastive_loss(vit_p, lag_p, neg_c)
     parts = dict(yolo=yolo_loss(pred5, gt_param, gi, gj, best_n),
                  rank=rank_loss(sim, neg_sim, gt_center),
-                 interframe=interframe_contrastive_loss(frame_f, corr_f, neg_f),
-                 cross=crossmodal_contrastive_loss(vit_p, lag_p, neg_c),
+                 interframe=inter,
+                 cross=cross,
                  loc=loc_loss(loc, best_n, gi, gj))
     loss = parts["yolo"] + 100 * parts["rank"] + parts["loc"] + 100 * parts["interframe"] + parts["cross"]   # :642
     return loss, parts

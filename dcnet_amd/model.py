@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import losses as losses_mod
 from . import ops
 from .darknet import Darknet
 from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, FusionConvBNAct,
@@ -195,6 +196,9 @@ class grounding_model(nn.Module):
         # run the three per-scale head branches on separate streams: -1 % step time in an in-process A/B, but
         # the HBM-bound scoring kernels then share the memory system with the other scales' GEMMs; off by default
         self.scale_streams = False
+        # the two sampling heads (K9, K14) on their own stream under the head convs of scales 1 and 2 (forward()), and
+        # their contrastive losses on that stream too (losses.total_loss), so that their backward overlaps as well
+        self.sampling_stream = True
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
@@ -452,13 +456,37 @@ class grounding_model(nn.Module):
             t_.record_stream(main)
         _, flang_attn = self.sub_attn(context, embedded, word_id)                # :525
         flang_attn = F.normalize(flang_attn, p=2, dim=1)                         # :526
-        res = self._run_scales(lambda s_, r_: self._scale_pairs(s_, r_, flang, flang_attn), raw, main)
-        fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
-        presampled, self._pin_event = self._presample_join(handle, image.device)
-        frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
-        outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
-        flang_attn = flang_attn.view(N, -1, 1, 1)
-        vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context, presampled)   # :625-637 (runs in eval too)
+        if self.sampling_stream and not self.scale_streams:
+            # The two correspondence-sampling heads read only the scale-0 features: a few hundred tiny launches (top-k,
+            # gathers, normalisations) that otherwise sit between the last head conv and the first backward kernel with
+            # nothing to overlap.  They go on their own stream as soon as scale 0 is queued and run under the head convs
+            # of scales 1 and 2; autograd replays their backward on the same stream, beside the heads' backward.
+            r0 = self._scale_pairs(0, raw[0], flang, flang_attn)
+            presampled, self._pin_event = self._presample_join(handle, image.device)
+            samp = self._side_stream(image.device, "samp")
+            samp.wait_stream(main)
+            with torch.cuda.stream(samp):
+                frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(r0[0], presampled)   # :381-430
+                vit_posit, lag_posit, neg_cross = self._crossmodal(r0[0], context, presampled)                      # :625-637
+            for t_ in (r0[0], context, presampled["k9"], presampled["k14"]):
+                t_.record_stream(samp)
+            res = [r0, self._scale_pairs(1, raw[1], flang, flang_attn), self._scale_pairs(2, raw[2], flang, flang_attn)]
+            fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
+            outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
+            flang_attn = flang_attn.view(N, -1, 1, 1)
+            main.wait_stream(samp)               # callers read the sampled lists on the current stream
+            for t_ in frame_feature + corrspendence_feature + neg_feature + vit_posit + lag_posit + neg_cross:
+                t_.record_stream(main)
+            losses_mod.CONTRASTIVE_STREAM = samp if (self.training and torch.is_grad_enabled()) else None
+        else:
+            losses_mod.CONTRASTIVE_STREAM = None
+            res = self._run_scales(lambda s_, r_: self._scale_pairs(s_, r_, flang, flang_attn), raw, main)
+            fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
+            presampled, self._pin_event = self._presample_join(handle, image.device)
+            frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
+            outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
+            flang_attn = flang_attn.view(N, -1, 1, 1)
+            vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context, presampled)   # :625-637 (runs in eval too)
         if self.training:
             return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn,
                     frame_feature, corrspendence_feature, neg_feature, vit_posit, lag_posit, neg_cross)
