@@ -1,8 +1,7 @@
-#!/usr/bin/env python
 """DCNet hot-path benchmark: clips/s, forward + backward (+ optimizer step), T=8 frames of
 416x416, batch 8 clips per GPU (BASELINE.json configs[1]: fp32, synthetic data, random init).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 5 --warmup 2        (always through the interpreter — under rocprofv3: `-- python3 bench.py`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -142,11 +141,8 @@ def main():
     from dcnet_amd.parallel import freeze_gradless, wrap_ddp
     freeze_gradless(model)
     net = wrap_ddp(model, local_rank) if use_ddp else model
-    visu = [p for p in model.visumodel.parameters() if p.requires_grad]
-    vis_ids = {id(p) for p in visu}
-    rest = [p for p in model.parameters() if p.requires_grad and id(p) not in vis_ids]
-    from dcnet_amd.optim import RMSprop     # torch.optim.RMSprop's update (train_DCNet.py:533) as one fused HIP pass
-    opt = RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)
+    from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
+    opt = make_optimizer(model, 1e-4)
 
     n_img = args.clips * args.frames
     image, word_id, word_mask = synth_inputs(n_img, args.size, seed=100 + rank)
@@ -200,8 +196,8 @@ def main():
     from dcnet_amd import ops as _ops
 
     def extra_pass(precision: int):
-        was = (_ops.WGRAD_SIDE, model.scale_streams)
-        _ops.WGRAD_SIDE = False; model.scale_streams = False
+        was = (_ops.WGRAD_SIDE, model.scale_streams, model.sampling_stream)
+        _ops.WGRAD_SIDE = False; model.scale_streams = False; model.sampling_stream = False
         L.set_tuning(b"precision", precision)
         step(); barrier()
         L.prof_enable(1)
@@ -211,7 +207,7 @@ def main():
         barrier()
         el = time.perf_counter() - t1
         L.prof_enable(0)
-        _ops.WGRAD_SIDE, model.scale_streams = was
+        _ops.WGRAD_SIDE, model.scale_streams, model.sampling_stream = was
         L.set_tuning(b"precision", 1)
         return collect() + (el / args.exclusive_steps * 1e3,)
 

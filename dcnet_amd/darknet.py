@@ -526,17 +526,21 @@ class Darknet(nn.Module):
                     take(conv.bias)
                 take(conv.weight)
 
-    def save_weights(self, path: str, cutoff: int = -1) -> None:
-        """Writes every conv slot (the reference's writer skips ``yoloconvolutional`` slots,
-        model/darknet.py:498, which makes its own files unreadable by its loader; we write the
-        loader's format)."""
+    def save_weights(self, path: str, cutoff: int = -1, reference_layout: bool = False) -> None:
+        """Writes every conv slot, i.e. the format ``load_weights`` (here and in the reference, model/darknet.py:433-483)
+        reads.  The reference's own writer (model/darknet.py:490-513) skips the three ``yoloconvolutional`` slots, so its
+        files cannot be read back by its loader; ``reference_layout=True`` reproduces that file byte for byte
+        (pinned by oracle/make_format_goldens.py)."""
         hdr = np.array(self.header_info, dtype=np.int32).copy()
         hdr[3] = self.seen
         defs = self.module_defs if cutoff == -1 else self.module_defs[:cutoff]
+        if reference_layout and cutoff == -1:
+            defs = self.module_defs[:-1]                     # the reference slices [:cutoff] with cutoff = -1 (:498)
+        kinds = ("convolutional",) if reference_layout else ("convolutional", "yoloconvolutional")
         with open(path, "wb") as fp:
             hdr.tofile(fp)
             for d, seq in zip(defs, self.module_list):
-                if d["type"] in ("convolutional", "yoloconvolutional"):
+                if d["type"] in kinds:
                     conv = seq[0]
                     if int(d["batch_normalize"]):
                         bn = seq[1]

@@ -364,6 +364,10 @@ class grounding_model(nn.Module):
         reference's order (K9 then K14), natively and on a worker thread (ctypes drops the GIL inside the
         call): the draws depend only on shapes, so they overlap with queueing and running the backbone."""
         hw = g0 * g0
+        # random.sample raises ValueError for these in the reference (model/DCNet_model.py:412,88); so do we, up front
+        if n < 2 or hw - 1 < neg_n or hw - 1 < neg_c or hw * hw < top_k:
+            raise ValueError(f"correspondence sampling needs >= 2 images and a coarsest grid of more than {max(neg_n, neg_c)} "
+                             f"cells with >= {top_k} cell pairs (got {n} images, {g0}x{g0})")
         key = (n, hw, top_k, neg_n, neg_c)
         if key not in self._pinned:
             # page-locked staging so the upload is a true async copy (a pageable H2D would block the host
@@ -376,18 +380,32 @@ class grounding_model(nn.Module):
             self._pin_event.synchronize()        # the previous forward's upload of these buffers has completed
         st, arr = _mt_state()
         L = lib()
+        box = {"err": None, "shape": (n, top_k, hw, neg_n, neg_c)}
 
         def work():
-            L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
-            L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+            try:
+                L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
+                L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+            except BaseException as e:       # re-raised on the caller's thread by _presample_join
+                box["err"] = e
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        return th, st, arr, k9, k14
+        return th, st, arr, k9, k14, box
 
     def _presample_join(self, handle, device):
-        th, st, arr, k9, k14 = handle
+        th, st, arr, k9, k14, box = handle
         th.join()
+        if box["err"] is not None:
+            raise box["err"]
+        if random.getstate() != st:
+            # someone drew from the global stream while the worker was running (another thread: forward itself draws
+            # nothing else).  The worker started from a stale state: redo the draws from the current one, synchronously.
+            st, arr = _mt_state()
+            n, top_k, hw, neg_n, neg_c = box["shape"]
+            L = lib()
+            L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
+            L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
         _mt_restore(st, arr)
         out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
         ev = torch.cuda.Event(); ev.record()

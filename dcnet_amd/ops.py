@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .lib import lib
+from .lib import DcnError, lib
 
 ACT_NONE, ACT_LEAKY = 0, 1
 

@@ -25,15 +25,20 @@ from . import losses
 
 def make_optimizer(model, lr: float = 1e-4, optimizer: str = "RMSprop"):
     """Two groups like the reference: everything except the backbone at ``lr``, the Darknet backbone at
-    ``lr / 10``; weight decay 5e-4 (train_DCNet.py:519-534).  ``model`` may be DDP-wrapped."""
+    ``lr / 10``; weight decay 5e-4 (train_DCNet.py:519-534).  ``model`` may be DDP-wrapped.
+
+    Every parameter is listed, in ``model.parameters()`` order, whether or not it is trainable — the reference's
+    groups hold [93, 222] tensors including the dead YOLO heads and ``feature_map`` — so that the ``optimizer`` entry
+    of a ``.pth.tar`` checkpoint moves between the reference and this harness in both directions even after
+    ``parallel.freeze_gradless`` has run.  Parameters without a gradient are skipped by the step, as in torch."""
     core = model.module if hasattr(model, "module") else model
-    visu = [p for p in core.visumodel.parameters() if p.requires_grad]
+    visu = list(core.visumodel.parameters())
     ids = {id(p) for p in visu}
-    rest = [p for p in core.parameters() if p.requires_grad and id(p) not in ids]
+    rest = [p for p in core.parameters() if id(p) not in ids]
     if optimizer.lower() == "adam":
-        return torch.optim.Adam([p for p in core.parameters() if p.requires_grad], lr=lr, weight_decay=0.0005)
+        return torch.optim.Adam(list(core.parameters()), lr=lr, weight_decay=0.0005)
     if optimizer.lower() == "sgd":
-        return torch.optim.SGD([p for p in core.parameters() if p.requires_grad], lr=lr, momentum=0.99)
+        return torch.optim.SGD(list(core.parameters()), lr=lr, momentum=0.99)
     from .optim import RMSprop          # torch.optim.RMSprop's update as one fused HIP pass (same state_dict layout)
     return RMSprop([{"params": rest}, {"params": visu, "lr": lr / 10.}], lr=lr, weight_decay=0.0005)
 

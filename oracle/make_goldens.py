@@ -70,6 +70,7 @@ def _import_reference():
     sys.modules["model"] = pkg
     import model.darknet as rdark
     assert rdark.__file__.startswith(REF), rdark.__file__
+    rdark.Darknet._real_load_weights = rdark.Darknet.load_weights   # kept for oracle/make_format_goldens.py
     rdark.Darknet.load_weights = lambda self, p: None        # saved_models is a dangling symlink (F6)
     return rdark
 

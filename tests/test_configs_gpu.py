@@ -1,0 +1,102 @@
+"""BASELINE.json configs[2] (bf16) and configs[4] (fp8 conv path) AT THEIR WORKLOAD: 64 images of 416x416 in bf16 and
+256 images of 416x416 (batch 32 clips x T 8) in fp8, through a full training step.  The CPU oracle cannot run these sizes
+and the reference has no reduced-precision semantics, so the tests use what is size independent:
+
+  * every output and gradient is finite and a whole step (forward, five losses, backward) is bitwise repeatable;
+  * at this very batch size the kernels agree with the mode's EXACT MODEL — the same convolution on operands that were
+    rounded beforehand (bf16 nearest-even / scaled e4m3), evaluated by the fp32-exact split pipe, which
+    tests/test_ops_gpu.py pins against fp64 — forward, data gradient and weight gradient, on the layer shapes that carry
+    most of the step;
+  * bf16, eval mode: a clip taken out of the batch and run alone sees the same per-element operand rounding, so it must
+    agree with its slice of the full batch far better than the mode differs from fp32.
+"""
+import random
+
+import pytest
+import torch
+
+from util import build_product, maxdiff, synth_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def _train_step(m, sd, image, word_id, word_mask, bbox, size):
+    from dcnet_amd import losses
+    m.load_state_dict(sd, strict=True)
+    m.zero_grad(set_to_none=True)
+    random.seed(13)
+    out = m(image, word_id, word_mask)
+    loss, parts = losses.total_loss(out, bbox, size)
+    loss.backward()
+    torch.cuda.synchronize()
+    res = (loss.detach().clone(), m.visumodel.module_list[0][0].weight.grad.clone(), m.fcn_out[2][1].weight.grad.clone(),
+           m.textmodel.rnn.weight_hh_l0.grad.clone(), out[0][2].detach().clone())
+    finite = all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    return res, finite, {k: float(v) for k, v in parts.items()}
+
+
+def _round_operand(t, mode):
+    if mode == "bf16":
+        return t.bfloat16().float(), 1.0
+    amax = float(t.abs().max())
+    s = 2.0 ** torch.floor(torch.log2(torch.tensor(448.0 / amax))).item()
+    return (t * s).clamp(-448, 448).to(torch.float8_e4m3fn).float(), s
+
+
+@pytest.mark.parametrize("mode,n_img", [("bf16", 64), ("fp8", 256)])
+def test_reduced_precision_config_at_full_workload(dev, mode, n_img):
+    from dcnet_amd import ops
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size = 416
+    sd = synth_sd(size)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n_img, size, seed=n_img))
+    bbox = synth_boxes(n_img, size, seed=n_img).to(dev)
+    try:
+        # ---- layer-level exact model at this batch size ------------------------------------------------------------
+        g = torch.Generator().manual_seed(1)
+        for (h, cin, cout, k, st) in ((52, 128, 256, 3, 1), (26, 512, 256, 1, 1), (104, 128, 256, 3, 2)):
+            x = torch.randn(n_img, h, h, cin, generator=g).to(dev)
+            w = (torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).to(dev)
+            ho = h // st
+            dy = (torch.randn(n_img, ho, ho, cout, generator=g) / 8).to(dev)
+            xr, sx = _round_operand(x, mode); wr, sw = _round_operand(w, mode); dyr, sdy = _round_operand(dy, mode)
+            ops.set_precision("fp32")
+            ref_fwd = ops.conv2d_fwd(xr, wr, k, st)[0] / (sx * sw)
+            ref_dx = ops.conv2d_bwd_data(dyr, wr, (h, h), k, st) / (sdy * sw)
+            wg_mode = "bf16"                                   # the fp8 path keeps its weight gradient on bf16 operands
+            xb, _ = _round_operand(x, wg_mode); dyb, _ = _round_operand(dy, wg_mode)
+            ref_dw = ops.conv2d_bwd_weight(xb, dyb, k, st)
+            ops.set_precision(mode)
+            got_fwd = ops.conv2d_fwd(x, w, k, st)[0]
+            got_dx = ops.conv2d_bwd_data(dy, w, (h, h), k, st)
+            got_dw = ops.conv2d_bwd_weight(x, dy, k, st)
+            for name, a, b in (("fwd", got_fwd, ref_fwd), ("dgrad", got_dx, ref_dx), ("wgrad", got_dw, ref_dw)):
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 1e-4 * scale, (mode, name, (h, cin, cout, k, st), float((a - b).abs().max()), scale)
+            # ... and it IS the reduced-precision path (differs from the unrounded fp32 result)
+            ops.set_precision("fp32")
+            full = ops.conv2d_fwd(x, w, k, st)[0]
+            assert float((got_fwd - full).abs().max()) > 1e-4 * float(full.abs().max())
+            del x, w, dy, xr, wr, dyr, xb, dyb, ref_fwd, ref_dx, ref_dw, got_fwd, got_dx, got_dw, full
+        # ---- the whole step at the config's workload ---------------------------------------------------------------
+        ops.set_precision(mode)
+        m = build_product(size, sd, dev).train()
+        a, finite_a, parts = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        b, finite_b, _ = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        assert finite_a and finite_b and all(v == v and abs(v) < 1e6 for v in parts.values()), parts
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+        del a, b
+        if mode == "bf16":
+            m.eval()
+            with torch.no_grad():
+                full = m(image, word_id, word_mask)
+                one = m(image[24:32], word_id[24:32], word_mask[24:32])
+                ops.set_precision("fp32")
+                ref = m(image[24:32], word_id[24:32], word_mask[24:32])
+            for s in range(3):
+                d_mode = maxdiff(one[0][s], ref[0][s])                 # what bf16 operands cost on this network
+                d_inv = maxdiff(full[0][s][24:32], one[0][s])          # batch invariance of the bf16 path itself
+                assert d_mode > 1e-3 and d_inv < 0.25 * d_mode, (s, d_inv, d_mode)
+    finally:
+        ops.set_precision("fp32")

@@ -133,9 +133,12 @@ def test_lr_schedule_and_optimizer_groups():
     freeze_gradless(m)
     opt = T.make_optimizer(m, 1e-4)
     assert len(opt.param_groups) == 2 and opt.param_groups[1]["lr"] == 1e-5 and opt.param_groups[0]["weight_decay"] == 0.0005
+    # the reference's groups hold every parameter, trainable or not ([93, 222] tensors: oracle/make_format_goldens.py)
+    assert [len(g["params"]) for g in opt.param_groups] == [93, 222]
     n_visu = sum(p.numel() for p in opt.param_groups[1]["params"]); n_rest = sum(p.numel() for p in opt.param_groups[0]["params"])
-    assert n_visu + n_rest == sum(p.numel() for p in m.parameters() if p.requires_grad)
-    assert n_visu == 61949149 - 6687485                     # backbone minus the dead YOLO heads
+    assert n_visu + n_rest == sum(p.numel() for p in m.parameters())
+    assert n_visu == 61949149                               # the whole backbone incl. the dead YOLO heads
+    assert sum(p.numel() for p in opt.param_groups[1]["params"] if p.requires_grad) == 61949149 - 6687485
     lr = T.adjust_learning_rate(opt, 30, 1e-4, 100, 0.9)
     assert abs(lr - 1e-4 * 0.7 ** 0.9) < 1e-12 and opt.param_groups[1]["lr"] == lr / 10
     assert T.lr_poly(1.0, 0, 10, 0.9) == 1.0
@@ -159,3 +162,105 @@ def test_checkpoint_roundtrip_with_module_prefix(tmp_path):
         assert torch.equal(va, vb), k
     c = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(5))  # shape mismatch on the BN: skipped
     assert T.load_pretrain(c, path) == 3                     # Linear weight + bias + the shape-less num_batches_tracked
+
+
+def _sha(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def test_darknet_weights_file_pinned_to_the_reference(tmp_path):
+    """tests/golden/formats_ref.json (oracle/make_format_goldens.py): the file ``save_weights`` writes from the synthetic
+    state_dict was read back, tensor for tensor, by the REFERENCE's ``Darknet.load_weights``; and the reference's own
+    ``save_weights`` output equals ``save_weights(reference_layout=True)`` byte for byte.  Here: the same files again."""
+    from dcnet_amd.darknet import Darknet
+    from dcnet_amd.utils.synth import synth_state_dict
+    with open(os.path.join(GOLD, "formats_ref.json")) as f:
+        pin = json.load(f)
+    sd = synth_state_dict(ref_shapes(256), seed=0)
+    a = Darknet(config_path=os.path.join(ROOT, "model", "yolov3.cfg"))
+    a.load_state_dict({k[len("visumodel."):]: v for k, v in sd.items() if k.startswith("visumodel.")}, strict=True)
+    a.seen = pin["weights_product_file_read_by_reference"]["seen"]
+    p1, p2 = str(tmp_path / "all.weights"), str(tmp_path / "ref.weights")
+    a.save_weights(p1); a.save_weights(p2, reference_layout=True)
+    assert os.path.getsize(p1) == pin["weights_product_file_read_by_reference"]["bytes"] == 248007048
+    assert _sha(p1) == pin["weights_product_file_read_by_reference"]["sha256"]
+    assert os.path.getsize(p2) == pin["weights_reference_writer_file"]["bytes"]
+    assert _sha(p2) == pin["weights_reference_writer_file"]["sha256"]
+    b = Darknet(config_path="")
+    b.load_weights(p1)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        if "num_batches_tracked" not in k:
+            assert torch.equal(va, vb), k
+
+
+def test_checkpoint_in_the_reference_layout_loads_with_its_optimizer(tmp_path):
+    """A ``.pth.tar`` as the reference writes it (train_DCNet.py:552-557: 'module.'-prefixed keys, torch.optim.RMSprop over
+    ALL parameters in two groups) resumes into the product model + fused optimizer after freeze_gradless, and the product's
+    optimizer state goes back into an all-parameter torch.optim.RMSprop.  Layout facts (key list digest, group
+    sizes, tensor checksums) are those of a checkpoint the real reference wrote (tests/golden/formats_ref.json)."""
+    import hashlib
+    import zlib
+    from dcnet_amd import train as T
+    from dcnet_amd.parallel import freeze_gradless
+    from dcnet_amd.utils.synth import synth_state_dict
+    from model.DCNet_model import grounding_model
+    with open(os.path.join(GOLD, "formats_ref.json")) as f:
+        pin = json.load(f)["checkpoint_reference_writer"]
+    mk = lambda: grounding_model(corpus=list(range(1000)), emb_size=512, img_size=256, weights_path=None,
+                                 config_path=os.path.join(ROOT, "model", "yolov3.cfg"))
+    src = mk()
+    src.load_state_dict(synth_state_dict(ref_shapes(256), seed=0), strict=True)
+    wrapped = torch.nn.Sequential(); wrapped.add_module("module", src)
+    keys = list(wrapped.state_dict().keys())
+    assert len(keys) == pin["n_keys"] and hashlib.sha256("\n".join(keys).encode()).hexdigest() == pin["keys_sha256"]
+    for k, c in pin["crc32"].items():
+        assert zlib.crc32(wrapped.state_dict()[k].contiguous().numpy().tobytes()) == c, k
+    visu = list(src.visumodel.parameters()); ids = {id(p) for p in visu}
+    rest = [p for p in wrapped.parameters() if id(p) not in ids]
+    ref_opt = torch.optim.RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)
+    assert [len(g["params"]) for g in ref_opt.param_groups] == pin["optimizer_group_sizes"] == [93, 222]
+    nograd = {"module." + str(k) for k in np.load(os.path.join(GOLD, "train_S256_N4.npz"), allow_pickle=True)["nograd"]}
+    g = torch.Generator().manual_seed(5)
+    for k, p in wrapped.named_parameters():
+        if k not in nograd:
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    for g_ in ref_opt.param_groups:
+        g_["lr"] = 0.0                                      # fill the state, keep the weights (as the fixture's writer did)
+    ref_opt.step()
+    ref_opt.param_groups[0]["lr"], ref_opt.param_groups[1]["lr"] = 1e-4, 1e-5
+    assert len(ref_opt.state_dict()["state"]) == pin["optimizer_state_entries"]
+    for i, c in pin["square_avg_crc32"].items():      # the reference's RMSprop wrote exactly these buffers
+        assert zlib.crc32(ref_opt.state_dict()["state"][int(i)]["square_avg"].contiguous().numpy().tobytes()) == c, i
+    path = T.save_checkpoint({"epoch": 7, "state_dict": wrapped.state_dict(), "best_loss": 0.125, "optimizer": ref_opt.state_dict()},
+                             False, "pin", str(tmp_path))
+    dst = mk()
+    freeze_gradless(dst)
+    opt = T.make_optimizer(dst, 1e-4)
+    assert T.load_checkpoint(dst, path, opt) == (7, 0.125)
+    for k, v in wrapped.state_dict().items():
+        assert torch.equal(dst.state_dict()[k[7:]], v), k
+    st = opt.state_dict()
+    assert [len(g_["params"]) for g_ in st["param_groups"]] == [93, 222] and len(st["state"]) == pin["optimizer_state_entries"]
+    # and back: the product's optimizer entry loads into the reference's optimizer class
+    back = torch.optim.RMSprop([{"params": rest}, {"params": visu, "lr": 1e-5}], lr=1e-4, weight_decay=0.0005)
+    back.load_state_dict(st)
+    for i, e in ref_opt.state_dict()["state"].items():
+        assert torch.equal(back.state_dict()["state"][i]["square_avg"], e["square_avg"])
+
+
+def test_oracle_decode_matches_the_reference_fixture():
+    """tests/golden/decode_ref.npz holds what the reference's validate_epoch (train_DCNet.py:764-816) decoded."""
+    from oracle import dcnet_oracle as O
+    g = np.load(os.path.join(GOLD, "decode_ref.npz"))
+    for tag in ("256", "416"):
+        outbox = [torch.from_numpy(g[f"outbox{s}_{tag}"]) for s in range(3)]
+        boxes = O.decode_boxes(outbox, int(tag))
+        assert float((boxes - torch.from_numpy(g[f"pred_bbox_{tag}"])).abs().max()) < 1e-4
+        iou = O.bbox_iou_xyxy(boxes, torch.from_numpy(g[f"gt_bbox_{tag}"]))
+        assert torch.allclose(iou, torch.from_numpy(g[f"iou_{tag}"]), atol=1e-6)
+        assert abs(float((iou > 0.5).float().mean()) - float(g[f"accu_{tag}"])) < 1e-6

@@ -99,7 +99,8 @@ def test_train_forward_backward_matches_oracle(dev):
     names = ["outbox", "sim_score", "loc_score", "corr_feat", "flang_attn", "frame_feature", "corrspendence_feature",
              "neg_feature", "vit_posit", "lag_posit", "neg_cross"]
     out = dict(zip(names, outs))
-    loss, parts = TO.total_loss(out, bbox.to(dev), size)
+    from dcnet_amd import losses
+    loss, parts = losses.total_loss(outs, bbox.to(dev), size)      # the PRODUCT's loss heads on the product's outputs
     loss.backward()
 
     sdo = {k: v.clone() for k, v in sd.items()}
