@@ -196,8 +196,8 @@ def main():
     from dcnet_amd import ops as _ops
 
     def extra_pass(precision: int):
-        was = (_ops.WGRAD_SIDE, model.scale_streams, model.sampling_stream)
-        _ops.WGRAD_SIDE = False; model.scale_streams = False; model.sampling_stream = False
+        was = (_ops.WGRAD_SIDE, model.language_stream, model.sampling_stream)
+        _ops.WGRAD_SIDE = False; model.language_stream = False; model.sampling_stream = False
         L.set_tuning(b"precision", precision)
         step(); barrier()
         L.prof_enable(1)
@@ -207,7 +207,7 @@ def main():
         barrier()
         el = time.perf_counter() - t1
         L.prof_enable(0)
-        _ops.WGRAD_SIDE, model.scale_streams, model.sampling_stream = was
+        _ops.WGRAD_SIDE, model.language_stream, model.sampling_stream = was
         L.set_tuning(b"precision", 1)
         return collect() + (el / args.exclusive_steps * 1e3,)
 

@@ -117,3 +117,13 @@ extern "C" int dcn_lstm_cell_bwd(const float* dy, int lddy, const float* dh_rec,
   DCN_CHECK_LAUNCH("lstm_cell_bwd");
   return DCN_OK;
 }
+
+// C[b][M][N] = A[b][M][K] . B[b][N][K]^T, `batch` independent problems (grid.y)
+extern "C" int dcn_gemm_nt_batched(const float* A, int lda, int64_t a_bs, const float* B, int ldb, int64_t b_bs, float* C, int ldc,
+                                   int64_t c_bs, int M, int N, int K, int batch, void* stream) {
+  DCN_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && K % 32 == 0 && batch > 0, "gemm_nt_batched: bad argument (K=%d must be a multiple of 32)", K);
+  DCN_CHECK_ARG(ldc >= N, "gemm_nt_batched: ldc=%d < N=%d", ldc, N);
+  IgemmParams p; gemm_params(p, A, lda, B, ldb, C, ldc, M, N, K);
+  p.batch = batch; p.in_bs = a_bs; p.wt_bs = b_bs; p.out_bs = c_bs;
+  return igemm_launch(p, (hipStream_t)stream);
+}

@@ -112,3 +112,21 @@ extern "C" int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int ne
     }
   return DCN_OK;
 }
+
+// Counting sort of the (ii, jj, m) -> position table by position: csr_src lists, for every position of the last image,
+// the flat indices (ii*rows + jj)*neg_n + m that drew it, in ascending order (a deterministic backward of the gather).
+extern "C" int dcn_mt_sample_crossmodal_csr(const int64_t* out, int n, int rows, int neg_n, int32_t* csr_off, int32_t* csr_src) {
+  DCN_CHECK_ARG(out && csr_off && csr_src && n > 0 && rows > 0 && neg_n > 0, "mt_sample_crossmodal_csr: bad argument");
+  const int64_t total = (int64_t)n * rows * neg_n;
+  DCN_CHECK_ARG(total < (1LL << 31), "mt_sample_crossmodal_csr: %lld entries exceed 31 bits", (long long)total);
+  for (int p = 0; p <= rows; ++p) csr_off[p] = 0;
+  for (int64_t i = 0; i < total; ++i) {
+    const int64_t p = out[i];
+    DCN_CHECK_ARG(p >= 0 && p < rows, "mt_sample_crossmodal_csr: position out of range");
+    ++csr_off[p + 1];
+  }
+  for (int p = 0; p < rows; ++p) csr_off[p + 1] += csr_off[p];
+  std::vector<int32_t> cur(csr_off, csr_off + rows);
+  for (int64_t i = 0; i < total; ++i) csr_src[cur[out[i]]++] = (int32_t)i;
+  return DCN_OK;
+}

@@ -87,7 +87,7 @@ class L2Norm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        out, norm, _ = ops.l2norm_score_fwd(x)
+        out, norm, _, _ = ops.l2norm_score_fwd(x)
         ctx.save_for_backward(out, norm)
         return out
 
@@ -99,26 +99,262 @@ class L2Norm(torch.autograd.Function):
 
 
 class NormScore(torch.autograd.Function):
-    """One pass over the corr_conv output x (N,H,W,E):  corr = x / ||x||  (model/DCNet_model.py:469) and
-    sim = <corr, q>  (:530-535, q = flang_attn).  Returns (corr (N,H,W,E), sim (N,H,W))."""
+    """One pass over the corr_conv output x (N,H,W,E):  corr = x / ||x||  (model/DCNet_model.py:469), sim = <corr, q>
+    (:530-535, q = flang_attn) and, with ``want_neg``, neg_sim = <corr, q reversed along the batch> — the caller's
+    neg_sim_score (train_DCNet.py:623-627) from the same read.  Returns (corr (N,H,W,E), sim (N,H,W), neg_sim|None)."""
 
     @staticmethod
-    def forward(ctx, x, q):
+    def forward(ctx, x, q, want_neg: bool):
         n, h, w, e = x.shape
         q = q.contiguous()
-        corr, norm, score = ops.l2norm_score_fwd(x, q, h * w)
+        corr, norm, score, flip = ops.l2norm_score_fwd(x, q, h * w, want_flip=want_neg)
         ctx.save_for_backward(corr, norm, q)
-        return corr, score.view(n, h, w)
+        if not want_neg:
+            return corr, score.view(n, h, w), None
+        return corr, score.view(n, h, w), flip.view(n, h, w)
 
     @staticmethod
-    def backward(ctx, dcorr, dscore):
+    def backward(ctx, dcorr, dscore, dneg):
         corr, norm, q = ctx.saved_tensors
         q = q.detach()
         n, h, w, _ = corr.shape
         dout = dcorr.contiguous() if dcorr is not None else None
         ds = dscore.contiguous().view(-1) if dscore is not None else None
-        dx, dq = ops.l2norm_score_bwd(corr, norm, dout, q if ds is not None else None, ds, h * w)
-        return dx, dq
+        dn = dneg.contiguous().view(-1) if dneg is not None else None
+        use_q = q if (ds is not None or dn is not None) else None
+        dx, dq = ops.l2norm_score_bwd(corr, norm, dout, use_q, ds, h * w, dscore_flip=dn)
+        return dx, dq, None
+
+
+class RowDot(torch.autograd.Function):
+    """score (N,H,W) = <x[n,h,w,:], q[n]> (flip: q[N-1-n]) on a map that is NOT normalised here: sim_score of the n_frame
+    model (model/test_DCNet_model.py:386-391) and neg_sim_score on plain tensors (train_DCNet.py:623-627)."""
+
+    @staticmethod
+    def forward(ctx, x, q, flip: bool):
+        n, h, w, e = x.shape
+        x = x.contiguous(); q = q.contiguous()
+        ctx.save_for_backward(x, q)
+        ctx.flip = flip
+        return ops.rowdot_fwd(x, q, h * w, flip).view(n, h, w)
+
+    @staticmethod
+    def backward(ctx, ds):
+        x, q = ctx.saved_tensors
+        n, h, w, e = x.shape
+        dx, dq = ops.rowdot_bwd(x, q.detach(), ds.contiguous().view(-1), h * w, ctx.flip, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dq, None
+
+
+class NormAccumulate(torch.autograd.Function):
+    """acc (+)= scale * normalize(x) — the mean over the T-1 normalised correspondence features of the inference model
+    (model/test_DCNet_model.py:277-280,324-332).  Forward only, like the rest of the n_frame path."""
+
+    @staticmethod
+    def forward(ctx, x, acc: Optional[torch.Tensor], scale: float):
+        out, _, _, _ = ops.l2norm_score_fwd(x, out=acc, out_scale=scale, accumulate=acc is not None)
+        ctx.mark_dirty(*([acc] if acc is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("the n_frame (inference) model has no backward; train with pair semantics")
+
+
+class PhraseAttn(torch.autograd.Function):
+    """PhraseAttention (model/DCNet_model.py:190-219) for one or two heads over the same (context, embedded, ids), each
+    followed by F.normalize when ``normalize`` (:526,:557).  Returns (out_0, out_1|None, attn (H,N,L))."""
+
+    @staticmethod
+    def forward(ctx, context, embedded, ids, w0, b0, w1, b1, normalize: bool):
+        context = context.contiguous(); embedded = embedded.contiguous(); ids = ids.contiguous()
+        d = context.shape[2]
+        wa = w0.detach().reshape(-1).contiguous(); wb = None if w1 is None else w1.detach().reshape(-1).contiguous()
+        attn, out, vnorm = ops.phrase_attn_fwd(context, embedded, ids, wa, b0.detach(), wb, None if b1 is None else b1.detach(), normalize)
+        ctx.save_for_backward(context, embedded, wa, wb if wb is not None else wa.new_empty(0), attn, out,
+                              vnorm if vnorm is not None else wa.new_empty(0))
+        ctx.meta = (normalize, w1 is not None, tuple(w0.shape), d)
+        ctx.mark_non_differentiable(attn)
+        return out[0], (out[1] if w1 is not None else None), attn
+
+    @staticmethod
+    def backward(ctx, g0, g1, _gattn):
+        context, embedded, wa, wb, attn, out, vnorm = ctx.saved_tensors
+        normalize, two, wshape, d = ctx.meta
+        dout = torch.zeros_like(out) if (g0 is None or (two and g1 is None)) else torch.empty_like(out)
+        if g0 is not None:
+            ops.copy_slice(g0.contiguous(), dout[0])
+        if two and g1 is not None:
+            ops.copy_slice(g1.contiguous(), dout[1])
+        dctx, demb, dwb = ops.phrase_attn_bwd(context, embedded, wa, wb if two else None, attn, out, vnorm if normalize else None, dout, normalize)
+        h = 2 if two else 1
+        dw0 = dwb[:d].view(wshape); db0 = dwb[h * d:h * d + 1]
+        dw1 = dwb[d:2 * d].view(wshape) if two else None
+        db1 = dwb[2 * d + 1:2 * d + 2] if two else None
+        return dctx, demb, None, dw0, db0, dw1, db1, None
+
+
+class HeadTail(torch.autograd.Function):
+    """The cross-scale tail (model/DCNet_model.py:545-621): only_obj, the location module in its rank-8 form
+    (csrc/head.hip, csrc/locmod.hip), min-max normalisation, confidence modulation, NCHW outbox.
+
+    Inputs: logits[3] (B,H,W,32) NHWC from fcn_out, sim[3] (B,H,W), q_loc (B,512) the normalised loc_attn phrase vector,
+    coord (P,8) the concatenated coordinate rows, then the parameters of loc_embedding and loc_text_embedding.
+    Returns outbox[3] (B,15,H,W), loc_score[3] (B,H,W), only_obj[3] (B,H,W)."""
+
+    @staticmethod
+    def forward(ctx, l0, l1, l2, s0, s1, s2, q_loc, coord, w_le, b_le, g_le, be_le, w_lt, b_lt, g_lt, be_lt, bn_le, bn_lt, training: bool):
+        logits = [l0.contiguous(), l1.contiguous(), l2.contiguous()]
+        B = logits[0].shape[0]
+        sims = [s.contiguous().view(B, -1) for s in (s0, s1, s2)]
+        P = coord.shape[0]
+        cnt = B * P
+        det = lambda t: t.detach().contiguous()
+        w_le, b_le, g_le, be_le, w_lt, b_lt, g_lt, be_lt = map(det, (w_le, b_le, g_le, be_le, w_lt, b_lt, g_lt, be_lt))
+        q_loc = q_loc.contiguous()
+        e8, xh, stat, mom = ops.locemb_fwd(coord, w_le, b_le, g_le, be_le, bn_le, training, cnt)          # :572-578
+        only, obj_map, objn, X = ops.head_obj(logits, sims, e8)                                           # :545-569
+        wp = ops.pad_rows(w_lt, X.shape[1])                                                               # (512, Ppad)
+        M = ops.gemm_nt(X, wp).view(B, 8, -1)                                                             # :581-585, rank-8
+        Mp, bp, saved = ops.locbn_fwd(M, mom, b_lt, g_lt, be_lt, bn_lt, training, cnt)
+        loc_map = ops.locmod_fwd(e8, Mp, bp, q_loc)                                                       # :585-594
+        outbox, loc, mm = ops.head_final_fwd(logits, sims, loc_map)                                       # :597-621
+        if training:
+            bn_le.num_batches_tracked += 1; bn_lt.num_batches_tracked += 1
+        ctx.save_for_backward(*logits, *sims, *loc, *only, q_loc, coord, w_le, g_le, be_le, b_lt, g_lt, e8, xh, stat, mom, obj_map, objn, X,
+                              wp, M, Mp, bp, saved, mm, bn_lt.running_mean)
+        ctx.training = training
+        ctx.wshape = tuple(w_lt.shape)
+        return (*outbox, *loc, *only)
+
+    @staticmethod
+    def backward(ctx, do0, do1, do2, dl0, dl1, dl2, dn0, dn1, dn2):
+        sv = ctx.saved_tensors
+        logits, sims, loc, only = list(sv[0:3]), list(sv[3:6]), list(sv[6:9]), list(sv[9:12])
+        (q_loc, coord, w_le, g_le, be_le, b_lt, g_lt, e8, xh, stat, mom, obj_map, objn, X, wp, M, Mp, bp, saved, mm, rmean_lt) = sv[12:]
+        B, P = obj_map.shape
+        cnt = B * P
+        training = ctx.training
+        cg = lambda t: None if t is None else t.contiguous()
+        d_out = [cg(do0), cg(do1), cg(do2)]; d_loc = [cg(dl0), cg(dl1), cg(dl2)]; d_only = [cg(dn0), cg(dn1), cg(dn2)]
+        dloc_map = ops.head_dloc(logits, sims, loc, d_out, d_loc, mm)
+        dE_part, dsum = ops.locmod_bwd(e8, Mp, bp, q_loc, dloc_map)          # dE_part (B,P,8); dsum (B,10,512): dMp | dbp_n | dq
+        dE_a = ops.colsum(dE_part.view(B, P * 8)).view(P, 8)
+        dMp = dsum[:, :8]                                                    # strided views: no copies
+        dbp = ops.colsum(dsum[:, 8])
+        dq_loc = dsum[:, 9]
+        dM, gout, dmom = ops.locbn_bwd(M, mom, b_lt, g_lt, rmean_lt, saved, dMp, dbp, training, cnt)
+        dM2 = dM.view(B * 8, -1)
+        dX = ops.gemm_nn(dM2, wp)                                            # (B*8, Ppad)
+        dwp = ops.gemm_tn(dM2, X)                                            # (512, Ppad)
+        dw_lt = ops.pad_rows(dwp, P)
+        dobj, dE_b = ops.head_fold(dX, e8, obj_map)
+        dlogits, dsim = ops.head_dlogits(logits, sims, loc, only, d_out, d_only, obj_map, objn, dobj)
+        g88 = ops.locemb_bwd(coord, w_le, g_le, be_le, xh, stat, dE_a, dE_b, dmom, training)
+        shp = [t.shape for t in logits]
+        dsim = [d.view(s_[0], s_[1], s_[2]) for d, s_ in zip(dsim, shp)]
+        return (*dlogits, *dsim, dq_loc, None, g88[:64].view(8, 8), g88[64:72], g88[72:80], g88[80:88],
+                dw_lt.view(ctx.wshape), gout[2], gout[0], gout[1], None, None, None)
+
+
+class InterframeSample(torch.autograd.Function):
+    """K9 (model/DCNet_model.py:381-430): top-30 matches of each frame pair's affinity + gathers, on the scale-0 map.
+    fv (N,H,W,E), raw_neg (N/2,top_k,neg_n) host-drawn list positions.  Returns (frame (b,K,E), corr (b,K,E),
+    negf (b,K,neg_n,E), index (b,K), neg_idx (b,K,neg_n))."""
+
+    @staticmethod
+    def forward(ctx, fv, raw_neg, top_k: int):
+        n, h, w, e = fv.shape
+        f = fv.contiguous().view(n, h * w, e)
+        index, neg_idx, frame, corr, negf = ops.k9_fwd(f, raw_neg, top_k)
+        ctx.save_for_backward(index, neg_idx)
+        ctx.shape = (n, h, w, e)
+        ctx.mark_non_differentiable(index, neg_idx)
+        return frame, corr, negf, index, neg_idx
+
+    @staticmethod
+    def backward(ctx, d_frame, d_corr, d_neg, _a, _b):
+        index, neg_idx = ctx.saved_tensors
+        n, h, w, e = ctx.shape
+        z = lambda g, like: torch.zeros(like, dtype=torch.float32, device=index.device) if g is None else g.contiguous()
+        b, k, m = neg_idx.shape
+        dfv = ops.k9_bwd(index, neg_idx, z(d_frame, (b, k, e)), z(d_corr, (b, k, e)), z(d_neg, (b, k, m, e)), h * w)
+        return dfv.view(n, h, w, e), None, None
+
+
+class CrossModalSample(torch.autograd.Function):
+    """K14 (model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112).  fv (N,H,W,E), context (N,L,2E),
+    conv_w (L,L,3), conv_b (L), neg (N,HW,neg_n) positions in image N-1, csr_off/csr_src their inverse.
+    Returns (vit (N,HW,E), lag_pos (N,HW,1,E), neg_cross (N,HW,neg_n,E), cols (N,HW))."""
+
+    @staticmethod
+    def forward(ctx, fv, context, conv_w, conv_b, neg, csr_off, csr_src):
+        n, h, w, e = fv.shape
+        v = fv.contiguous().view(n, h * w, e)
+        context = context.contiguous()
+        vit, cn = ops.colnorm_fwd(v)                                          # :629
+        lag, ln = ops.lagnorm_fwd(context)                                    # :631-632
+        cols, _ = ops.crossmap(lag, vit, conv_w.detach().contiguous(), conv_b.detach().contiguous())   # :634-635, :48
+        lag_pos, neg_cross = ops.k14_gather(lag, vit, cols, neg)
+        ctx.save_for_backward(vit, cn, lag, ln, cols, csr_off, csr_src)
+        ctx.shape = (n, h, w, e)
+        ctx.mark_non_differentiable(cols)
+        return vit, lag_pos, neg_cross, cols
+
+    @staticmethod
+    def backward(ctx, d_vit, d_lag_pos, d_neg, _c):
+        vit, cn, lag, ln, cols, csr_off, csr_src = ctx.saved_tensors
+        n, h, w, e = ctx.shape
+        hw = h * w
+        dq = torch.zeros_like(vit) if d_vit is None else d_vit.contiguous()
+        extra = ops.k14_negscatter(d_neg.contiguous(), csr_off, csr_src, hw) if d_neg is not None else None
+        dv = ops.colnorm_bwd(vit, cn, dq, extra, n - 1)
+        dctx = None
+        if d_lag_pos is not None and ctx.needs_input_grad[1]:
+            dctx = ops.k14_dlag(lag, ln, cols, d_lag_pos.contiguous())
+        return dv.view(n, h, w, e), dctx, None, None, None, None, None
+
+
+class Contrastive(torch.autograd.Function):
+    """mean over rows of CE([cos(q,k), cos(q,neg_1..m)] / T, 0): Interframe_contrastive_loss / Crossmodal_constrastive_loss
+    (train_DCNet.py:114-166) on stacked rows."""
+
+    @staticmethod
+    def forward(ctx, q, pos, neg, temperature: float):
+        q, pos, neg = q.contiguous(), pos.contiguous(), neg.contiguous()
+        ctx.save_for_backward(q, pos, neg)
+        ctx.t = temperature
+        return ops.contrastive_fwd(q, pos, neg, temperature)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, pos, neg = ctx.saved_tensors
+        dq, dpos, dneg = ops.contrastive_bwd(q, pos, neg, ctx.t, g.contiguous().view(1))
+        return dq, dpos, dneg, None
+
+
+class DenseLosses(torch.autograd.Function):
+    """(yolo_loss, rank_loss, loc_loss) of train_DCNet.py:45-72,173-220 from the NCHW outbox, the sim / neg_sim / loc maps
+    and the compact targets of ops.build_target."""
+
+    @staticmethod
+    def forward(ctx, ob0, ob1, ob2, s0, s1, s2, n0, n1, n2, l0, l1, l2, ti, tf, size: int):
+        c = lambda t: t.contiguous()
+        outbox = [c(ob0), c(ob1), c(ob2)]; sim = [c(s0), c(s1), c(s2)]; neg = [c(n0), c(n1), c(n2)]; loc = [c(l0), c(l1), c(l2)]
+        out, lse = ops.dense_loss_fwd(outbox, sim, neg, loc, ti, tf, size)
+        ctx.save_for_backward(*outbox, *sim, *neg, *loc, ti, tf, lse)
+        ctx.size = size
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, gy, gr, gl):
+        sv = ctx.saved_tensors
+        outbox, sim, neg, loc = list(sv[0:3]), list(sv[3:6]), list(sv[6:9]), list(sv[9:12])
+        ti, tf, lse = sv[12:]
+        z = torch.zeros((), dtype=torch.float32, device=ti.device)
+        gout = torch.stack([z if g is None else g.reshape(()) for g in (gy, gr, gl)])
+        d_ob, d_sim, d_ns, d_loc = ops.dense_loss_bwd(outbox, sim, neg, loc, ti, tf, lse, gout, ctx.size)
+        return (*d_ob, *d_sim, *d_ns, *d_loc, None, None, None)
 
 
 class FusionConvBNAct(torch.autograd.Function):

@@ -45,8 +45,43 @@ SIGNATURES = {
     "dcn_coattn_fwd": (I, [P, P, I, L, P, P, I, L, P, P, P, P, I, I, I, F, P]),
     "dcn_coattn_bwd_ws": (L, [I, I, I]),
     "dcn_coattn_bwd": (I, [P, P, I, L, P, P, I, L, P, P, I, L, P, P, P, P, P, I, L, I, P, I, I, I, F, P]),
-    "dcn_l2norm_score_fwd": (I, [P, I, P, I, P, P, P, L, I, I, P]),
-    "dcn_l2norm_score_bwd": (I, [P, I, P, P, I, P, P, P, I, P, L, I, I, P]),
+    "dcn_l2norm_score_fwd": (I, [P, I, P, I, P, P, P, P, L, I, I, F, I, P]),
+    "dcn_l2norm_score_bwd": (I, [P, I, P, P, I, P, P, P, P, I, P, L, I, I, P]),
+    "dcn_rowdot_fwd": (I, [P, I, P, I, P, L, I, I, P]),
+    "dcn_rowdot_bwd": (I, [P, I, P, I, P, P, I, P, L, I, I, P]),
+    "dcn_phrase_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dcn_phrase_attn_bwd_ws": (L, [I, I, I]),
+    "dcn_phrase_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dcn_colsum": (I, [P, I, I, I, P, P]),
+    "dcn_locemb_fwd": (I, [P, P, P, P, P, P, P, F, F, I, L, I, P, P, P, P, P]),
+    "dcn_locemb_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P]),
+    "dcn_head_obj": (I, [P, P, P, P, P, P, P, P, P, I, P]),
+    "dcn_pad_rows": (I, [P, I, P, I, I, I, I, P]),
+    "dcn_locbn_fwd": (I, [P, P, P, P, P, P, P, F, F, I, I, L, I, P, P, P, P]),
+    "dcn_locbn_bwd": (I, [P, P, P, P, P, P, P, L, P, I, I, L, I, P, P, P, P]),
+    "dcn_head_final_fwd": (I, [P, P, P, P, P, P, P, P, I, P]),
+    "dcn_head_dloc": (I, [P, P, P, P, P, P, P, P, P, I, P]),
+    "dcn_head_fold": (I, [P, P, P, I, I, I, P, P, P]),
+    "dcn_head_dlogits": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
+    "dcn_k9_fwd": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
+    "dcn_k9_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "dcn_colnorm_fwd": (I, [P, I, I, I, P, P, P]),
+    "dcn_colnorm_bwd": (I, [P, P, P, P, I, I, I, I, P, P]),
+    "dcn_lagnorm_fwd": (I, [P, I, I, I, P, P, P]),
+    "dcn_crossmap": (I, [P, P, P, P, I, I, I, I, P, P, P]),
+    "dcn_k14_gather": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "dcn_k14_negscatter": (I, [P, P, P, I, I, P, P]),
+    "dcn_k14_dlag": (I, [P, P, P, P, I, I, I, I, P, P]),
+    "dcn_build_target": (I, [P, P, I, I, P, P, P]),
+    "dcn_target_dense": (I, [P, P, I, I, P, P, P]),
+    "dcn_dense_loss_fwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P]),
+    "dcn_dense_loss_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P, P, P, P, P]),
+    "dcn_contrastive_fwd": (I, [P, P, P, L, I, I, F, P, P, P]),
+    "dcn_contrastive_bwd": (I, [P, P, P, L, I, I, F, P, P, P, P, P]),
+    "dcn_decode_boxes": (I, [P, P, I, I, P, P, P]),
+    "dcn_box_iou": (I, [P, P, I, P, P]),
+    "dcn_gemm_nt_batched": (I, [P, I, L, P, I, L, P, I, L, I, I, I, I, P]),
+    "dcn_mt_sample_crossmodal_csr": (I, [P, I, I, I, P, P]),
     "dcn_upsample2_nhwc": (I, [P, I, P, I, I, I, I, I, P]),
     "dcn_upsample2_nhwc_bwd": (I, [P, I, P, I, I, I, I, I, I, P]),
     "dcn_copy_slice": (I, [P, I, P, I, L, I, I, P]),

@@ -28,12 +28,24 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import losses as losses_mod
 from . import ops
 from .darknet import Darknet
-from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, FusionConvBNAct,
-                        L2Norm, LinearAct, LocModule, NormScore, ToNCHW)
+from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, CrossModalSample,
+                        FusionConvBNAct, HeadTail, InterframeSample, L2Norm, LinearAct, NormAccumulate, NormScore, PhraseAttn, RowDot)
 from .lib import lib
+
+
+class OutputList(list):
+    """A plain list (what the reference returns and its callers index / overwrite in place) that also carries what the
+    product's own loss heads can use to skip work: ``stacked`` — the one tensor the entries are unbind() views of;
+    ``stream`` — the CUDA stream the entries were produced on (the sampling heads run on their own stream);
+    ``neg_sim`` — on ``sim_score``: the similarity of every position with the batch-reversed language vector
+    (train_DCNet.py:623-627), produced in the same pass as ``sim_score``.  Callers that ignore the attributes lose nothing."""
+    __slots__ = ("stacked", "stream", "neg_sim")
+
+    def __init__(self, items, stacked=None, stream=None, neg_sim=None):
+        super().__init__(items)
+        self.stacked, self.stream, self.neg_sim = stacked, stream, neg_sim
 
 
 class ConvBatchNormReLU(nn.Sequential):
@@ -96,17 +108,16 @@ class RNNEncoder(nn.Module):
 
 
 class PhraseAttention(nn.Module):
-    """model/DCNet_model.py:190-219."""
+    """model/DCNet_model.py:190-219 (csrc/phrase.hip).  grounding_model.forward evaluates its two instances in one launch
+    together with the F.normalize that follows them; this standalone forward keeps the reference's module contract."""
 
     def __init__(self, input_dim):
         super().__init__()
         self.fc = nn.Linear(input_dim, 1)
 
     def forward(self, context, embedded, input_labels):
-        attn = F.softmax(self.fc(context).squeeze(2), dim=1)
-        attn = attn * (input_labels != 0).float()
-        attn = attn / attn.sum(1, keepdim=True)
-        return attn, torch.bmm(attn.unsqueeze(1), embedded).squeeze(1)
+        weighted, _, attn = PhraseAttn.apply(context, embedded, input_labels, self.fc.weight, self.fc.bias, None, None, False)
+        return attn[0], weighted
 
 
 def generate_coord_nhwc(height: int, width: int, device) -> torch.Tensor:
@@ -193,12 +204,11 @@ class grounding_model(nn.Module):
         self._pinned = {}
         self._pin_event = None
         self._streams = {}
-        # run the three per-scale head branches on separate streams: -1 % step time in an in-process A/B, but
-        # the HBM-bound scoring kernels then share the memory system with the other scales' GEMMs; off by default
-        self.scale_streams = False
         # the two sampling heads (K9, K14) on their own stream under the head convs of scales 1 and 2 (forward()), and
         # their contrastive losses on that stream too (losses.total_loss), so that their backward overlaps as well
         self.sampling_stream = True
+        # the language branch (embedding, MLP, BiLSTM, mapping_lang, phrase attention) on its own stream under the backbone
+        self.language_stream = True
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
@@ -229,7 +239,7 @@ class grounding_model(nn.Module):
         return word_id, flang, context, embedded
 
     def _fusion_head(self, s: int, corr, flang):
-        """fcn_emb[s] + fcn_out[s] on one scale: corr (B,H,W,E) -> outbox logits (B,H,W,15)  (:491-506)."""
+        """fcn_emb[s] + fcn_out[s] on one scale: corr (B,H,W,E) -> outbox logits (B,H,W,32 = 15 + padding)  (:491-506)."""
         h, w = corr.shape[1], corr.shape[2]
         blk0 = self.fcn_emb[s][0]                                                # [corr | tile(flang) | coord] -> 1x1
         z = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
@@ -238,15 +248,16 @@ class grounding_model(nn.Module):
         z = self.fcn_emb[s][2](z)
         z = self.fcn_out[s][0](z)
         last = self.fcn_out[s][1]
-        return ConvBias.apply(z, last.weight, last.bias)[..., :15]
+        return ConvBias.apply(z, last.weight, last.bias)          # (B,H,W,32): channels 15..31 are zero padding
 
     def _scale_pairs(self, s: int, raw_s, flang, flang_attn):
         """Everything of scale s that depends only on its backbone tap (pair semantics): mapping + norm
-        (:356-359), co-attention + corr_conv (:449-468), normalise + sim (:469,530-535), fusion head."""
+        (:356-359), co-attention + corr_conv (:449-468), normalise + sim (:469,530-535), fusion head.
+        Returns (fv, corr, sim, neg_sim|None, logits (B,H,W,32))."""
         fv = L2Norm.apply(self.mapping_visu[s](raw_s))
         corr_raw = self.corr_conv[s][0](CoAttentionPairs.apply(fv, self.temperature))
-        corr, sim = NormScore.apply(corr_raw, flang_attn)
-        return fv, corr, sim, self._fusion_head(s, corr, flang)
+        corr, sim, neg_sim = NormScore.apply(corr_raw, flang_attn, self.training)
+        return fv, corr, sim, neg_sim, self._fusion_head(s, corr, flang)
 
     def _scale_nframe(self, s: int, raw_s, flang, flang_attn, B: int, n_frame: int):
         """Scale s of the inference model: centre frame vs every other frame, mean of the normalised
@@ -259,104 +270,28 @@ class grounding_model(nn.Module):
             if idx == ctr:
                 continue
             cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
-            z = L2Norm.apply(self.corr_conv[s][0](cat))                          # :277-280
-            acc = z if acc is None else acc + z
-        corr = acc / (n_frame - 1)                                               # :324-332
-        sim = torch.sum(corr * flang_attn.view(B, 1, 1, -1), dim=3)
-        return fv, corr, sim, self._fusion_head(s, corr, flang)
+            acc = NormAccumulate.apply(self.corr_conv[s][0](cat), acc, 1.0 / (n_frame - 1))   # :277-280, mean :324-332
+        corr = acc
+        sim = RowDot.apply(corr, flang_attn, False)                              # :386-391
+        return fv, corr, sim, None, self._fusion_head(s, corr, flang)
 
-    def _run_scales(self, branch, raws, main):
-        """Run the three per-scale branches on their own streams (finest scale first): the 13x13 and 26x26
-        branches are chains of small grids that fit under the 52x52 branch's kernels.  Autograd replays
-        each branch's backward on the same stream."""
-        dev = raws[0].device
-        res = [None] * 3
-        if not self.scale_streams:
-            return [branch(s_, raws[s_]) for s_ in range(3)]
-        for s_ in (2, 1, 0):
-            st = self._side_stream(dev, f"scale{s_}")
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                res[s_] = branch(s_, raws[s_])
-            raws[s_].record_stream(st)
-        for s_ in range(3):
-            main.wait_stream(self._side_stream(dev, f"scale{s_}"))
-            for t_ in res[s_]:
-                t_.record_stream(main)
-        return res
+    def _coord_rows(self, grids, device):
+        """(P,8) coordinate rows of the three scales, coarsest first (model/DCNet_model.py:565-567); identical for every image."""
+        key = ("rows", tuple(grids), str(device))
+        if key not in self._coord_cache:
+            self._coord_cache[key] = torch.cat([self._coord(g[0], g[1], device).reshape(-1, 8) for g in grids], dim=0).contiguous()
+        return self._coord_cache[key]
 
-    def _head(self, corr_feat, sim_score, outbox, word_id, flang, context, embedded, flang_attn):
-        """The cross-scale tail: objectness x similarity, location module, confidence modulation
-        (:545-621).  Inputs are NHWC per-scale tensors."""
-        B = flang.shape[0]
-        dev = flang.device
-        conf = [ob.reshape(B, ob.shape[1], ob.shape[2], 3, 5)[..., 4] for ob in outbox]   # (B,H,W,3)
-        only_obj = [c.mean(dim=3) for c in conf]                                 # :551
-        obj_score = [o * s for o, s in zip(only_obj, sim_score)]                 # :550
-
-        _, flang_loc = self.loc_attn(context, embedded, word_id)                 # :556
-        flang_loc = F.normalize(flang_loc, p=2, dim=1)
-        # ---- location module, rank-8 form (SURVEY.md K13; reference :559-597 builds a PxP tensor) ----
-        coord_map = torch.cat([self._coord(c.shape[1], c.shape[2], dev).reshape(-1, 8) for c in corr_feat], dim=0)  # (P,8)
-        P = coord_map.shape[0]
-        obj_map = F.normalize(torch.cat([o.reshape(B, -1) for o in obj_score], dim=1), p=2, dim=1)       # :566-569
-        lin, bn = self.loc_embedding[0], self.loc_embedding[1]
-        ce = F.linear(coord_map, lin.weight, lin.bias)                           # identical rows for every image
-        if self.training:
-            # BN over the B*P rows == BN over the P distinct rows (each repeated B times); the
-            # unbiased running_var uses the true row count B*P
-            mean = ce.mean(0); var = ce.var(0, unbiased=False)
-            with torch.no_grad():
-                cnt = B * P
-                bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * mean)
-                bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * cnt / (cnt - 1))
-                bn.num_batches_tracked += 1
-            ce = (ce - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
-        else:
-            ce = F.batch_norm(ce, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
-        E8 = F.normalize(F.relu(ce), p=2, dim=1)                                 # (P,8)   :578
-        lt, bn2 = self.loc_text_embedding[0], self.loc_text_embedding[1]
-        # rel[n,i,:] = sum_j <E_i,E_j> obj[n,j] W[:,j] + b  =  E_i . (E^T diag(obj_n) W^T) + b = E_i . M_n + b
-        M = torch.matmul((E8.t().unsqueeze(0) * obj_map.unsqueeze(1)), lt.weight.t())     # (B,8,512)   :581-585
-        # BatchNorm1d over the B*P rows of rel, from the 8x8 moments of E (no (B,P,512) tensor): with
-        # s1 = sum_i E_i and S2 = sum_i E_i E_i^T,  sum(rel) = sum_n s1.M_n + BP b,
-        # sum(rel^2) = sum_n M_n^T S2 M_n + 2 b sum_n s1.M_n + BP b^2   (fp64 on these tiny tensors)
-        cnt = float(B * P)
-        if self.training:
-            Ed, Md, bd = E8.double(), M.double(), lt.bias.double()
-            # (broadcast products, not matmul/einsum: rocBLAS runs these 8-wide fp64 shapes on a 128x128 DGEMM
-            #  tile — one of them took 3.5 ms — while the tensors here are a few MB)
-            s1 = Ed.sum(0); S2 = (Ed.unsqueeze(2) * Ed.unsqueeze(1)).sum(0)                  # (8,), (8,8)
-            t1 = (s1.view(1, 8, 1) * Md).sum((0, 1))
-            mean = t1 / cnt + bd
-            S2M = (S2.view(1, 8, 8, 1) * Md.unsqueeze(1)).sum(2)                              # (B,8,512)
-            ex2 = ((Md * S2M).sum((0, 1)) + 2 * bd * t1) / cnt + bd * bd                      # M_n^T S2 M_n per channel
-            var = torch.clamp(ex2 - mean * mean, min=0)
-            with torch.no_grad():
-                bn2.running_mean.mul_(1 - bn2.momentum).add_(bn2.momentum * mean.float())
-                bn2.running_var.mul_(1 - bn2.momentum).add_(bn2.momentum * (var * cnt / (cnt - 1)).float())
-                bn2.num_batches_tracked += 1
-            scale = bn2.weight.double() * torch.rsqrt(var + bn2.eps)
-            shift = bn2.bias.double() - mean * scale
-            scale, shift = scale.float(), shift.float()
-        else:
-            scale = bn2.weight * torch.rsqrt(bn2.running_var + bn2.eps)
-            shift = bn2.bias - bn2.running_mean * scale
-        # relu(bn(rel)) -> normalize over channels -> <., flang_loc>, fused on the device   :585-594
-        loc_map = LocModule.apply(E8, M * scale, lt.bias * scale + shift, flang_loc)       # (B,P)
-        mn = loc_map.min(dim=1, keepdim=True)[0]; mx = loc_map.max(dim=1, keepdim=True)[0]
-        loc_map = (loc_map - mn) / (mx - mn + 1e-6)                              # :597
-        loc_score, st = [], 0
-        for c in corr_feat:
-            h, w = c.shape[1], c.shape[2]
-            loc_score.append(loc_map[:, st:st + h * w].reshape(B, h, w)); st += h * w
-        final = []
-        for s in range(3):                                                       # :612-621
-            ob = outbox[s].reshape(B, outbox[s].shape[1], outbox[s].shape[2], 3, 5)
-            c4 = ob[..., 4] * (sim_score[s] * loc_score[s]).unsqueeze(3)
-            ob = torch.cat([ob[..., :4], c4.unsqueeze(4)], dim=4).reshape(B, ob.shape[1], ob.shape[2], 15)
-            final.append(ToNCHW.apply(ob, 15))
-        return final, loc_score, only_obj
+    def _head(self, sim_score, logits, flang_loc):
+        """The cross-scale tail (:545-621) as one autograd node of HIP kernels (functions.HeadTail): objectness x similarity,
+        location module (rank-8 form), min-max, confidence modulation, NCHW outbox.
+        Returns (outbox[3] NCHW, loc_score[3], only_obj[3])."""
+        dev = flang_loc.device
+        coord = self._coord_rows([(l.shape[1], l.shape[2]) for l in logits], dev)
+        le, lt = self.loc_embedding, self.loc_text_embedding
+        res = HeadTail.apply(*logits, *sim_score, flang_loc, coord, le[0].weight, le[0].bias, le[1].weight, le[1].bias,
+                             lt[0].weight, lt[0].bias, lt[1].weight, lt[1].bias, le[1], lt[1], self.training)
+        return list(res[0:3]), list(res[3:6]), list(res[6:9])
 
     # ------------------------------------------------------------------------------------------
     def _presample_start(self, n, g0, top_k=30, neg_n=10, neg_c=5):
@@ -374,8 +309,10 @@ class grounding_model(nn.Module):
             # until the queued backbone kernels drain).  Reuse is safe: the language branch of the next
             # forward syncs the stream before these buffers are written again.
             self._pinned[key] = (torch.empty((n // 2, top_k, neg_n), dtype=torch.int64).pin_memory(),
-                                 torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory())
-        k9, k14 = self._pinned[key]
+                                 torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory(),
+                                 torch.empty(hw + 1, dtype=torch.int32).pin_memory(),
+                                 torch.empty(n * hw * neg_c, dtype=torch.int32).pin_memory())
+        k9, k14, csr_off, csr_src = self._pinned[key]
         if self._pin_event is not None:
             self._pin_event.synchronize()        # the previous forward's upload of these buffers has completed
         st, arr = _mt_state()
@@ -386,15 +323,18 @@ class grounding_model(nn.Module):
             try:
                 L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
                 L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+                # the inverse table of the K14 negatives (by position of the last image): the gather's backward is then a
+                # deterministic segmented sum on the device
+                L.mt_sample_crossmodal_csr(k14.data_ptr(), n, hw, neg_c, csr_off.data_ptr(), csr_src.data_ptr())
             except BaseException as e:       # re-raised on the caller's thread by _presample_join
                 box["err"] = e
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
-        return th, st, arr, k9, k14, box
+        return th, st, arr, (k9, k14, csr_off, csr_src), box
 
     def _presample_join(self, handle, device):
-        th, st, arr, k9, k14, box = handle
+        th, st, arr, (k9, k14, csr_off, csr_src), box = handle
         th.join()
         if box["err"] is not None:
             raise box["err"]
@@ -406,48 +346,37 @@ class grounding_model(nn.Module):
             L = lib()
             L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
             L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
+            L.mt_sample_crossmodal_csr(k14.data_ptr(), n, hw, neg_c, csr_off.data_ptr(), csr_src.data_ptr())
         _mt_restore(st, arr)
-        out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True)}
+        if device is None:                   # eval mode: the draws only advance the RNG stream, as in the reference
+            return None, None
+        out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True),
+               "csr_off": csr_off.to(device, non_blocking=True), "csr_src": csr_src.to(device, non_blocking=True)}
         ev = torch.cuda.Event(); ev.record()
         return out, ev
 
-    def _interframe_sampling(self, fv0, presampled, top_k=30, neg_n=10):
-        """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E)."""
-        n, g, _, e = fv0.shape
-        hw = g * g
-        f = fv0.reshape(n // 2, 2, hw, e)
-        p1, p2 = f[:, 0], f[:, 1]
-        cmap = torch.bmm(p1, p2.transpose(1, 2)).flatten(1)                      # :390  [i*hw + j]
-        _, index = cmap.topk(top_k, dim=1, largest=True, sorted=True)            # :395
-        qi, ki = index // hw, index % hw                                         # :407,409
-        raw = presampled["k9"]                                                   # list positions, drawn on the host
-        ni = raw + (raw >= ki.unsqueeze(2)).long()                               # skip the removed element (:411-413)
-        self.last_choices["k9_index"] = index.detach()
-        self.last_choices["k9_neg"] = ni
-        # one batched gather per output; the reference's lists are zero-copy unbinds of them
-        ar = torch.arange(n // 2, device=fv0.device)
-        frame = p1[ar.unsqueeze(1), qi]                                          # (b,top_k,E)
-        corr = p2[ar.unsqueeze(1), ki]
-        negf = p2[ar.view(-1, 1, 1), ni]                                         # (b,top_k,neg_n,E)
-        return list(frame.unbind(1)), list(corr.unbind(1)), list(negf.unbind(1))
+    def _interframe_sampling(self, fv0, presampled, top_k=30):
+        """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E): csrc/sample.hip."""
+        frame, corr, negf, index, neg_idx = InterframeSample.apply(fv0, presampled["k9"], top_k)
+        self.last_choices["k9_index"] = index
+        self.last_choices["k9_neg"] = neg_idx
+        # the reference's lists are zero-copy unbinds of the stacked tensors
+        return frame, corr, negf
 
-    def _crossmodal(self, fv0, context, presampled, neg_n=5):
-        """model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112."""
-        n, g, _, e = fv0.shape
-        hw = g * g
-        v = fv0.reshape(n, hw, e)
-        vit = F.normalize(v, dim=1)                                              # over positions (:629)
-        lag = F.normalize(context[:, :, 0::2], dim=1)                            # interpolate(0.5) + over L (:631-632)
-        lv = torch.bmm(lag, vit.transpose(1, 2))                                 # (N,L,HW0)  :634
-        lv = self.feature_map(lv)                                                # :635
-        cols = lv.argmax(dim=1)                                                  # top-1 word per position (:48)
-        ni = presampled["k14"]
-        self.last_choices["k14_cols"] = cols.detach()
-        self.last_choices["k14_neg"] = ni
-        ar = torch.arange(n, device=fv0.device)
-        lag_pos = lag[ar.unsqueeze(1), cols].unsqueeze(2)                        # (N,HW0,1,E)
-        neg_cross = vit[n - 1][ni]                                               # (N,HW0,neg_n,E)
-        return list(vit.unbind(1)), list(lag_pos.unbind(1)), list(neg_cross.unbind(1))
+    def _crossmodal(self, fv0, context, presampled):
+        """model/DCNet_model.py:625-637 + Crossmodal_corrspondence :41-112: csrc/sample.hip."""
+        fm = self.feature_map[0]
+        vit, lag_pos, neg_cross, cols = CrossModalSample.apply(fv0, context, fm.weight, fm.bias, presampled["k14"],
+                                                               presampled["csr_off"], presampled["csr_src"])
+        self.last_choices["k14_cols"] = cols
+        self.last_choices["k14_neg"] = presampled["k14"]
+        return vit, lag_pos, neg_cross
+
+    def _phrases(self, context, embedded, word_id):
+        """sub_attn and loc_attn (:525,:556) with their F.normalize (:526,:557) in one launch."""
+        sa, la = self.sub_attn.fc, self.loc_attn.fc
+        flang_attn, flang_loc, _ = PhraseAttn.apply(context, embedded, word_id, sa.weight, sa.bias, la.weight, la.bias, True)
+        return flang_attn, flang_loc
 
     # ------------------------------------------------------------------------------------------
     def forward(self, image, word_id, word_mask=None, n_frame: Optional[int] = None):
@@ -459,56 +388,52 @@ class grounding_model(nn.Module):
         if N % 2:
             raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")
         # The forward issues no host synchronisation at all (lengths are handled on the device), so the
-        # host can queue step k+1 while the GPU still runs step k.  The language branch (a chain of ~100
-        # latency-bound small kernels) goes on a side stream: it runs under the backbone, and autograd
-        # replays its backward on the same side stream under the backbone's backward.
+        # host can queue step k+1 while the GPU still runs step k.  The language branch (latency-bound small
+        # kernels) goes on a side stream: it runs under the backbone, and autograd replays its backward on the
+        # same side stream under the backbone's backward.
         main = torch.cuda.current_stream()
-        side = self._side_stream(image.device)
+        side = self._side_stream(image.device) if self.language_stream else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
+            flang_attn, flang_loc = self._phrases(context, embedded, word_id)    # :525-526, :556-557
         handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
         main.wait_stream(side)
-        for t_ in (flang, context, embedded):
+        for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)
-        _, flang_attn = self.sub_attn(context, embedded, word_id)                # :525
-        flang_attn = F.normalize(flang_attn, p=2, dim=1)                         # :526
-        if self.sampling_stream and not self.scale_streams:
-            # The two correspondence-sampling heads read only the scale-0 features: a few hundred tiny launches (top-k,
-            # gathers, normalisations) that otherwise sit between the last head conv and the first backward kernel with
-            # nothing to overlap.  They go on their own stream as soon as scale 0 is queued and run under the head convs
-            # of scales 1 and 2; autograd replays their backward on the same stream, beside the heads' backward.
-            r0 = self._scale_pairs(0, raw[0], flang, flang_attn)
+        sampling = self.training
+        samp = None
+        r0 = self._scale_pairs(0, raw[0], flang, flang_attn)
+        if sampling:
+            # The two correspondence-sampling heads (:381-430, :625-637) read only the scale-0 features.  They go on their own
+            # stream as soon as scale 0 is queued and run under the head convs of scales 1 and 2; autograd replays their
+            # backward on the same stream, beside the heads' backward.  In eval mode the reference computes and discards
+            # them: here only the RNG stream is advanced (the draws), the device work is skipped.
             presampled, self._pin_event = self._presample_join(handle, image.device)
-            samp = self._side_stream(image.device, "samp")
+            samp = self._side_stream(image.device, "samp") if self.sampling_stream else main
             samp.wait_stream(main)
             with torch.cuda.stream(samp):
-                frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(r0[0], presampled)   # :381-430
-                vit_posit, lag_posit, neg_cross = self._crossmodal(r0[0], context, presampled)                      # :625-637
-            for t_ in (r0[0], context, presampled["k9"], presampled["k14"]):
+                frame, corrf, negf = self._interframe_sampling(r0[0], presampled)
+                vit, lag_pos, neg_cross = self._crossmodal(r0[0], context, presampled)
+            for t_ in (r0[0], context, *presampled.values()):
                 t_.record_stream(samp)
-            res = [r0, self._scale_pairs(1, raw[1], flang, flang_attn), self._scale_pairs(2, raw[2], flang, flang_attn)]
-            fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
-            outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
-            flang_attn = flang_attn.view(N, -1, 1, 1)
-            main.wait_stream(samp)               # callers read the sampled lists on the current stream
-            for t_ in frame_feature + corrspendence_feature + neg_feature + vit_posit + lag_posit + neg_cross:
-                t_.record_stream(main)
-            losses_mod.CONTRASTIVE_STREAM = samp if (self.training and torch.is_grad_enabled()) else None
         else:
-            losses_mod.CONTRASTIVE_STREAM = None
-            res = self._run_scales(lambda s_, r_: self._scale_pairs(s_, r_, flang, flang_attn), raw, main)
-            fv = [r[0] for r in res]; corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
-            presampled, self._pin_event = self._presample_join(handle, image.device)
-            frame_feature, corrspendence_feature, neg_feature = self._interframe_sampling(fv[0], presampled)   # :381-430
-            outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
-            flang_attn = flang_attn.view(N, -1, 1, 1)
-            vit_posit, lag_posit, neg_cross = self._crossmodal(fv[0], context, presampled)   # :625-637 (runs in eval too)
-        if self.training:
-            return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn,
-                    frame_feature, corrspendence_feature, neg_feature, vit_posit, lag_posit, neg_cross)
-        return outbox, sim, loc, only_obj
+            self._presample_join(handle, None)
+        res = [r0, self._scale_pairs(1, raw[1], flang, flang_attn), self._scale_pairs(2, raw[2], flang, flang_attn)]
+        corr_feat = [r[1] for r in res]
+        sim = OutputList([r[2] for r in res], neg_sim=[r[3] for r in res] if sampling else None)
+        outbox, loc, only_obj = self._head(sim, [r[4] for r in res], flang_loc)
+        if not self.training:
+            return outbox, sim, loc, only_obj
+        if samp is not main:
+            main.wait_stream(samp)               # callers read the sampled lists on the current stream
+            for t_ in (frame, corrf, negf, vit, lag_pos, neg_cross):
+                t_.record_stream(main)
+        st = samp if samp is not main else None
+        mk = lambda t: OutputList(t.unbind(1), stacked=t, stream=st)
+        return (outbox, sim, loc, [c.permute(0, 3, 1, 2) for c in corr_feat], flang_attn.view(N, -1, 1, 1),
+                mk(frame), mk(corrf), mk(negf), mk(vit), mk(lag_pos), mk(neg_cross))
 
     def _forward_nframe(self, image, word_id, n_frame: int):
         """model/test_DCNet_model.py:284-483."""
@@ -516,21 +441,19 @@ class grounding_model(nn.Module):
             raise ValueError("batch must be a multiple of n_frame (model/test_DCNet_model.py:287)")
         B = image.size(0) // n_frame
         main = torch.cuda.current_stream()
-        side = self._side_stream(image.device)
+        side = self._side_stream(image.device) if self.language_stream else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
+            flang_attn, flang_loc = self._phrases(context, embedded, word_id)
         raw = self.visumodel.forward_nhwc(image)
         main.wait_stream(side)
-        for t_ in (flang, context, embedded):
+        for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)
-        _, flang_attn = self.sub_attn(context, embedded, word_id)
-        flang_attn = F.normalize(flang_attn, p=2, dim=1)
-        res = self._run_scales(lambda s_, r_: self._scale_nframe(s_, r_, flang, flang_attn, B, n_frame), raw, main)
+        res = [self._scale_nframe(s_, raw[s_], flang, flang_attn, B, n_frame) for s_ in range(3)]
         corr_feat = [r[1] for r in res]; sim = [r[2] for r in res]
-        outbox, loc, only_obj = self._head(corr_feat, sim, [r[3] for r in res], word_id, flang, context, embedded, flang_attn)
-        flang_attn = flang_attn.view(B, -1, 1, 1)
+        outbox, loc, only_obj = self._head(sim, [r[4] for r in res], flang_loc)
         corr_nchw = [c.permute(0, 3, 1, 2) for c in corr_feat]
         if self.training:
-            return outbox, sim, loc, corr_nchw, flang_attn
+            return outbox, sim, loc, corr_nchw, flang_attn.view(B, -1, 1, 1)
         return outbox, sim, loc, corr_nchw, only_obj

@@ -376,8 +376,9 @@ def coattn_bwd(f1, f2, d_out1, d_out2, out1, out2, E, rc, d_f1, d_f2, accumulate
 
 
 # ---- scoring ------------------------------------------------------------------------------------------
-def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None):
-    """x (...,c) rows (pixel stride = x.stride(-2)).  Returns (out, norm, score|None)."""
+def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None, want_flip=False, out_scale=1.0, accumulate=False):
+    """x (...,c) rows (pixel stride = x.stride(-2)).  Returns (out, norm, score|None, score_flip|None); score_flip scores
+    row r against q[N-1-img(r)] (the caller-side neg_sim_score, train_DCNet.py:623-627)."""
     c = x.shape[-1]
     rows = x.numel() // c
     if out is None:
@@ -385,12 +386,13 @@ def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None):
     _rows(x, "l2norm x"); _rows(out, "l2norm out")
     norm = torch.empty(rows, dtype=torch.float32, device=x.device)
     score = torch.empty(rows, dtype=torch.float32, device=x.device) if q is not None else None
-    lib().l2norm_score_fwd(x.data_ptr(), x.stride(-2), out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(q), _p(score),
-                           rows, rows_per_image, c, _s())
-    return out, norm, score
+    flip = torch.empty(rows, dtype=torch.float32, device=x.device) if (q is not None and want_flip) else None
+    lib().l2norm_score_fwd(x.data_ptr(), x.stride(-2), out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(q), _p(score), _p(flip),
+                           rows, rows_per_image, c, float(out_scale), int(accumulate), _s())
+    return out, norm, score, flip
 
 
-def l2norm_score_bwd(out, norm, dout, q, dscore, rows_per_image, want_dq=True):
+def l2norm_score_bwd(out, norm, dout, q, dscore, rows_per_image, want_dq=True, dscore_flip=None):
     c = out.shape[-1]
     rows = out.numel() // c
     _rows(out, "l2norm_bwd out")
@@ -398,11 +400,361 @@ def l2norm_score_bwd(out, norm, dout, q, dscore, rows_per_image, want_dq=True):
         _rows(dout, "l2norm_bwd dout")
     dx = torch.empty(out.shape, dtype=torch.float32, device=out.device)
     dq = None
-    if q is not None and dscore is not None and want_dq:
+    if q is not None and (dscore is not None or dscore_flip is not None) and want_dq:
         dq = torch.empty((rows // rows_per_image, c), dtype=torch.float32, device=out.device)
     lib().l2norm_score_bwd(out.data_ptr(), out.stride(-2), norm.data_ptr(), _p(dout), 0 if dout is None else dout.stride(-2),
-                           _p(q), _p(dscore), dx.data_ptr(), c, _p(dq), rows, rows_per_image, c, _s())
+                           _p(q), _p(dscore), _p(dscore_flip), dx.data_ptr(), c, _p(dq), rows, rows_per_image, c, _s())
     return dx, dq
+
+
+def rowdot_fwd(x, q, rows_per_image, flip=False):
+    """score[row] = <x[row], q[img(row)]> (flip: q[N-1-img]) on rows that are not normalised here."""
+    c = x.shape[-1]
+    rows = x.numel() // c
+    _rows(x, "rowdot x"); _chk(q, "rowdot q")
+    score = torch.empty(rows, dtype=torch.float32, device=x.device)
+    lib().rowdot_fwd(x.data_ptr(), x.stride(-2), q.data_ptr(), int(flip), score.data_ptr(), rows, rows_per_image, c, _s())
+    return score
+
+
+def rowdot_bwd(x, q, dscore, rows_per_image, flip=False, want_dx=True, want_dq=True):
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_dx else None
+    dq = torch.empty((rows // rows_per_image, c), dtype=torch.float32, device=x.device) if want_dq else None
+    lib().rowdot_bwd(x.data_ptr(), x.stride(-2), q.data_ptr(), int(flip), dscore.data_ptr(), _p(dx), c, _p(dq), rows, rows_per_image, c, _s())
+    return dx, dq
+
+
+# ---- phrase attention ----------------------------------------------------------------------------------
+def phrase_attn_fwd(context, embedded, ids, w0, b0, w1=None, b1=None, normalize=True):
+    """Returns (attn (H,N,L), out (H,N,E), vnorm (H,N)|None) for H = 1 or 2 heads."""
+    n, L, d = context.shape
+    e = embedded.shape[2]
+    _chk(context, "phrase context"); _chk(embedded, "phrase embedded")
+    if not (ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous()):
+        raise ValueError("phrase_attn: ids must be a contiguous int64 CUDA tensor")
+    heads = 1 if w1 is None else 2
+    attn = torch.empty((heads, n, L), dtype=torch.float32, device=context.device)
+    out = torch.empty((heads, n, e), dtype=torch.float32, device=context.device)
+    vnorm = torch.empty((heads, n), dtype=torch.float32, device=context.device) if normalize else None
+    lib().phrase_attn_fwd(context.data_ptr(), embedded.data_ptr(), ids.data_ptr(), w0.data_ptr(), b0.data_ptr(), _p(w1), _p(b1),
+                          attn.data_ptr(), out.data_ptr(), _p(vnorm), n, L, d, e, int(normalize), _s())
+    return attn, out, vnorm
+
+
+def phrase_attn_bwd(context, embedded, w0, w1, attn, out, vnorm, dout, normalize=True):
+    """Returns (dcontext, dembedded, dwb) with dwb = [dw_0 (d) | dw_1 (d) | db_0 | db_1] (one head: [dw_0 | db_0])."""
+    n, L, d = context.shape
+    e = embedded.shape[2]
+    heads = 1 if w1 is None else 2
+    dctx = torch.empty_like(context); demb = torch.empty_like(embedded)
+    dwb = torch.empty(heads * d + heads, dtype=torch.float32, device=context.device)
+    ws = scratch(lib().phrase_attn_bwd_ws(n, d, heads), context.device, slot=0)
+    _chk(dout, "phrase dout")
+    lib().phrase_attn_bwd(context.data_ptr(), embedded.data_ptr(), w0.data_ptr(), _p(w1), attn.data_ptr(), out.data_ptr(), _p(vnorm),
+                          dout.data_ptr(), dctx.data_ptr(), demb.data_ptr(), dwb.data_ptr(), ws.data_ptr(), n, L, d, e, int(normalize), _s())
+    return dctx, demb, dwb
+
+
+def colsum(x2d):
+    """out[c] = sum_r x2d[r, c] (deterministic, for small row counts); rows may be strided."""
+    if not (x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and x2d.stride(1) == 1):
+        raise ValueError("colsum: expected an fp32 CUDA [rows][cols] view with contiguous columns")
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2d.device)
+    lib().colsum(x2d.data_ptr(), x2d.stride(0), rows, cols, out.data_ptr(), _s())
+    return out
+
+
+# ---- cross-scale head tail -------------------------------------------------------------------------------
+import ctypes as _ct
+
+
+def _ptrs(ts):
+    """Host array of three device pointers (None -> NULL); keeps nothing alive: callers hold the tensors."""
+    return (_ct.c_void_p * 3)(*[(None if t is None else t.data_ptr()) for t in ts])
+
+
+def _ints(vs):
+    return (_ct.c_int * 3)(*[int(v) for v in vs])
+
+
+def locemb_fwd(coord, w, b, gamma, beta, bn, training, count):
+    P = coord.shape[0]
+    dev = coord.device
+    e8 = torch.empty((P, 8), dtype=torch.float32, device=dev); xh = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    stat = torch.empty(16, dtype=torch.float32, device=dev); mom = torch.empty(72, dtype=torch.float64, device=dev)
+    lib().locemb_fwd(coord.data_ptr(), w.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                     bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), int(training), int(count), P,
+                     e8.data_ptr(), xh.data_ptr(), stat.data_ptr(), mom.data_ptr(), _s())
+    return e8, xh, stat, mom
+
+
+def locemb_bwd(coord, w, gamma, beta, xh, stat, de_a, de_b, dmom, training):
+    grads = torch.empty(88, dtype=torch.float32, device=coord.device)
+    lib().locemb_bwd(coord.data_ptr(), w.data_ptr(), gamma.data_ptr(), beta.data_ptr(), xh.data_ptr(), stat.data_ptr(),
+                     _p(de_a), _p(de_b), _p(dmom), int(training), coord.shape[0], grads.data_ptr(), _s())
+    return grads
+
+
+def head_obj(logits, sims, e8):
+    """logits[s] (B,H,W,ld) NHWC, sims[s] (B,HW).  Returns (only_obj[3] (B,h,w), obj_map (B,P), objn (B), X (B*8,Ppad))."""
+    B = logits[0].shape[0]
+    dev = e8.device
+    hw = [t.shape[1] * t.shape[2] for t in logits]
+    P = sum(hw); Ppad = pad32(P)
+    only = [torch.empty((B, t.shape[1], t.shape[2]), dtype=torch.float32, device=dev) for t in logits]
+    obj_map = torch.empty((B, P), dtype=torch.float32, device=dev); objn = torch.empty(B, dtype=torch.float32, device=dev)
+    X = torch.empty((B * 8, Ppad), dtype=torch.float32, device=dev)
+    for t in logits:
+        _chk(t, "head_obj logits")
+    lib().head_obj(_ptrs(logits), _ints([t.shape[3] for t in logits]), _ptrs(sims), _ints(hw), e8.data_ptr(), _ptrs(only),
+                   obj_map.data_ptr(), objn.data_ptr(), X.data_ptr(), B, _s())
+    return only, obj_map, objn, X
+
+
+def pad_rows(src, cols_out):
+    """(rows, cols) contiguous -> (rows, cols_out) with zero-filled / dropped tail columns."""
+    rows, cols = src.shape
+    _chk(src, "pad_rows")
+    dst = torch.empty((rows, cols_out), dtype=torch.float32, device=src.device)
+    lib().pad_rows(src.data_ptr(), cols, dst.data_ptr(), cols_out, rows, min(cols, cols_out), cols_out, _s())
+    return dst
+
+
+def locbn_fwd(M, mom, bias, gamma, beta, bn, training, count):
+    B = M.shape[0]
+    Mp = torch.empty_like(M); bp = torch.empty(512, dtype=torch.float32, device=M.device)
+    saved = torch.empty((3, 512), dtype=torch.float32, device=M.device)
+    lib().locbn_fwd(M.data_ptr(), mom.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                    bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), int(training), B, int(count), M.shape[2],
+                    Mp.data_ptr(), bp.data_ptr(), saved.data_ptr(), _s())
+    return Mp, bp, saved
+
+
+def locbn_bwd(M, mom, bias, gamma, running_mean, saved, dMp, dbp, training, count):
+    """dMp (B,8,512): a view whose image stride may exceed 8*512 (rows 0-7 of dcn_locmod_bwd's dsum)."""
+    B = M.shape[0]
+    assert dMp.stride(2) == 1 and dMp.stride(1) == M.shape[2]
+    dM = torch.empty_like(M); out = torch.empty((3, 512), dtype=torch.float32, device=M.device)
+    dmom = torch.empty(72, dtype=torch.float64, device=M.device) if training else None
+    lib().locbn_bwd(M.data_ptr(), mom.data_ptr(), bias.data_ptr(), gamma.data_ptr(), running_mean.data_ptr(), saved.data_ptr(),
+                    dMp.data_ptr(), dMp.stride(0), dbp.data_ptr(), int(training), B, int(count), M.shape[2], dM.data_ptr(), out.data_ptr(),
+                    _p(dmom), _s())
+    return dM, out, dmom
+
+
+def head_final_fwd(logits, sims, loc_map):
+    B = logits[0].shape[0]
+    dev = loc_map.device
+    hw = [t.shape[1] * t.shape[2] for t in logits]
+    outbox = [torch.empty((B, 15, t.shape[1], t.shape[2]), dtype=torch.float32, device=dev) for t in logits]
+    loc = [torch.empty((B, t.shape[1], t.shape[2]), dtype=torch.float32, device=dev) for t in logits]
+    mm = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    lib().head_final_fwd(_ptrs(logits), _ints([t.shape[3] for t in logits]), _ptrs(sims), _ints(hw), loc_map.data_ptr(),
+                         _ptrs(outbox), _ptrs(loc), mm.data_ptr(), B, _s())
+    return outbox, loc, mm
+
+
+def head_dloc(logits, sims, loc, d_outbox, d_loc, mm):
+    B = logits[0].shape[0]
+    hw = [t.shape[1] * t.shape[2] for t in logits]
+    dloc_map = torch.empty((B, sum(hw)), dtype=torch.float32, device=mm.device)
+    lib().head_dloc(_ptrs(logits), _ints([t.shape[3] for t in logits]), _ptrs(sims), _ints(hw), _ptrs(loc), _ptrs(d_outbox),
+                    _ptrs(d_loc), mm.data_ptr(), dloc_map.data_ptr(), B, _s())
+    return dloc_map
+
+
+def head_fold(dX, e8, obj_map):
+    B, P = obj_map.shape
+    dobj = torch.empty_like(obj_map); de8 = torch.empty_like(e8)
+    lib().head_fold(dX.data_ptr(), e8.data_ptr(), obj_map.data_ptr(), B, P, dX.shape[1], dobj.data_ptr(), de8.data_ptr(), _s())
+    return dobj, de8
+
+
+def head_dlogits(logits, sims, loc, only, d_outbox, d_only, obj_map, objn, dobj_map):
+    B = logits[0].shape[0]
+    hw = [t.shape[1] * t.shape[2] for t in logits]
+    dlogits = [torch.empty_like(t) for t in logits]
+    dsim = [torch.empty_like(t) for t in sims]
+    lib().head_dlogits(_ptrs(logits), _ints([t.shape[3] for t in logits]), _ptrs(sims), _ints(hw), _ptrs(loc), _ptrs(only),
+                       _ptrs(d_outbox), _ptrs(d_only), obj_map.data_ptr(), objn.data_ptr(), _p(dobj_map), _ptrs(dlogits), _ptrs(dsim), B, _s())
+    return dlogits, dsim
+
+
+# ---- correspondence sampling ---------------------------------------------------------------------------------
+def gemm_nt_batched(a, b, out=None):
+    """a (B,M,K), b (B,N,K) (last dim contiguous, uniform strides) -> (B,M,N) = a . b^T per batch item."""
+    B, M, K = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+    lib().gemm_nt_batched(a.data_ptr(), a.stride(1), a.stride(0), b.data_ptr(), b.stride(1), b.stride(0), out.data_ptr(), out.stride(1),
+                          out.stride(0), M, N, K, B, _s())
+    return out
+
+
+def k9_fwd(fv, raw_neg, top_k):
+    """fv (N,HW,E) contiguous; raw_neg (N/2,top_k,neg_n) int64.  Returns (index, neg_idx, frame, corr, negf)."""
+    n, hw, e = fv.shape
+    b = n // 2
+    neg_n = raw_neg.shape[2]
+    dev = fv.device
+    pairs = fv.view(b, 2, hw, e)
+    cmap = gemm_nt_batched(pairs[:, 0], pairs[:, 1])                               # (b,hw,hw): [i*hw + j]   :390
+    index = torch.empty((b, top_k), dtype=torch.int64, device=dev); neg_idx = torch.empty((b, top_k, neg_n), dtype=torch.int64, device=dev)
+    frame = torch.empty((b, top_k, e), dtype=torch.float32, device=dev); corr = torch.empty_like(frame)
+    negf = torch.empty((b, top_k, neg_n, e), dtype=torch.float32, device=dev)
+    lib().k9_fwd(cmap.data_ptr(), fv.data_ptr(), raw_neg.data_ptr(), b, hw, e, top_k, neg_n, index.data_ptr(), neg_idx.data_ptr(),
+                 frame.data_ptr(), corr.data_ptr(), negf.data_ptr(), _s())
+    return index, neg_idx, frame, corr, negf
+
+
+def k9_bwd(index, neg_idx, d_frame, d_corr, d_neg, hw):
+    b, top_k, neg_n = neg_idx.shape
+    e = d_frame.shape[2]
+    dfv = torch.empty((2 * b, hw, e), dtype=torch.float32, device=d_frame.device)
+    lib().k9_bwd(index.data_ptr(), neg_idx.data_ptr(), d_frame.data_ptr(), d_corr.data_ptr(), d_neg.data_ptr(), b, hw, e, top_k, neg_n,
+                 dfv.data_ptr(), _s())
+    return dfv
+
+
+def colnorm_fwd(v):
+    n, hw, e = v.shape
+    vit = torch.empty_like(v); cn = torch.empty((n, e), dtype=torch.float32, device=v.device)
+    lib().colnorm_fwd(v.data_ptr(), n, hw, e, vit.data_ptr(), cn.data_ptr(), _s())
+    return vit, cn
+
+
+def colnorm_bwd(vit, cn, dq, extra, n_extra):
+    n, hw, e = vit.shape
+    dv = torch.empty_like(vit)
+    lib().colnorm_bwd(vit.data_ptr(), cn.data_ptr(), dq.data_ptr(), _p(extra), n_extra, n, hw, e, dv.data_ptr(), _s())
+    return dv
+
+
+def lagnorm_fwd(context):
+    n, L, d = context.shape
+    lag = torch.empty((n, L, d // 2), dtype=torch.float32, device=context.device)
+    ln = torch.empty((n, d // 2), dtype=torch.float32, device=context.device)
+    lib().lagnorm_fwd(context.data_ptr(), n, L, d, lag.data_ptr(), ln.data_ptr(), _s())
+    return lag, ln
+
+
+def crossmap(lag, vit, conv_w, conv_b, want_map=False):
+    n, L, e = lag.shape
+    hw = vit.shape[1]
+    cols = torch.empty((n, hw), dtype=torch.int64, device=lag.device)
+    lv = torch.empty((n, L, hw), dtype=torch.float32, device=lag.device) if want_map else None
+    lib().crossmap(lag.data_ptr(), vit.data_ptr(), conv_w.data_ptr(), conv_b.data_ptr(), n, L, hw, e, cols.data_ptr(), _p(lv), _s())
+    return cols, lv
+
+
+def k14_gather(lag, vit, cols, neg):
+    n, L, e = lag.shape
+    hw = vit.shape[1]
+    neg_n = neg.shape[2]
+    lag_pos = torch.empty((n, hw, 1, e), dtype=torch.float32, device=lag.device)
+    neg_cross = torch.empty((n, hw, neg_n, e), dtype=torch.float32, device=lag.device)
+    lib().k14_gather(lag.data_ptr(), vit.data_ptr(), cols.data_ptr(), neg.data_ptr(), n, L, hw, e, neg_n, lag_pos.data_ptr(),
+                     neg_cross.data_ptr(), _s())
+    return lag_pos, neg_cross
+
+
+def k14_negscatter(d_neg, csr_off, csr_src, hw):
+    e = d_neg.shape[-1]
+    extra = torch.empty((hw, e), dtype=torch.float32, device=d_neg.device)
+    lib().k14_negscatter(d_neg.data_ptr(), csr_off.data_ptr(), csr_src.data_ptr(), hw, e, extra.data_ptr(), _s())
+    return extra
+
+
+def k14_dlag(lag, ln, cols, d_k):
+    n, L, e = lag.shape
+    hw = cols.shape[1]
+    dctx = torch.empty((n, L, 2 * e), dtype=torch.float32, device=lag.device)
+    lib().k14_dlag(lag.data_ptr(), ln.data_ptr(), cols.data_ptr(), d_k.data_ptr(), n, L, hw, e, dctx.data_ptr(), _s())
+    return dctx
+
+
+# ---- losses, targets, decode --------------------------------------------------------------------------------------
+def build_target(bbox, anchors, size):
+    n = bbox.shape[0]
+    ti = torch.empty((n, 4), dtype=torch.int32, device=bbox.device); tf = torch.empty((n, 4), dtype=torch.float32, device=bbox.device)
+    _chk(bbox, "build_target bbox")
+    lib().build_target(bbox.data_ptr(), anchors.data_ptr(), size, n, ti.data_ptr(), tf.data_ptr(), _s())
+    return ti, tf
+
+
+def target_dense(ti, tf, size):
+    n = ti.shape[0]
+    grids = [size // 32, size // 16, size // 8]
+    box = [torch.zeros((n, 3, 5, g, g), dtype=torch.float32, device=ti.device) for g in grids]
+    ctr = [torch.zeros((n, 5, g, g), dtype=torch.float32, device=ti.device) for g in grids]
+    lib().target_dense(ti.data_ptr(), tf.data_ptr(), size, n, _ptrs(box), _ptrs(ctr), _s())
+    return box, ctr
+
+
+def dense_loss_fwd(outbox, sim, negsim, loc, ti, tf, size):
+    n = ti.shape[0]
+    dev = ti.device
+    vals = torch.empty((n, 8), dtype=torch.float32, device=dev); lse = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    out = torch.empty(3, dtype=torch.float32, device=dev)
+    for t in list(outbox) + list(sim) + list(negsim) + list(loc):
+        _chk(t, "dense_loss map")
+    lib().dense_loss_fwd(_ptrs(outbox), _ptrs(sim), _ptrs(negsim), _ptrs(loc), ti.data_ptr(), tf.data_ptr(), size, n, vals.data_ptr(),
+                         lse.data_ptr(), out.data_ptr(), _s())
+    return out, lse
+
+
+def dense_loss_bwd(outbox, sim, negsim, loc, ti, tf, lse, gout, size):
+    n = ti.shape[0]
+    d_ob = [torch.empty_like(t) for t in outbox]; d_sim = [torch.empty_like(t) for t in sim]
+    d_ns = [torch.empty_like(t) for t in negsim]; d_loc = [torch.empty_like(t) for t in loc]
+    _chk(gout, "dense_loss gout")
+    lib().dense_loss_bwd(_ptrs(outbox), _ptrs(sim), _ptrs(negsim), _ptrs(loc), ti.data_ptr(), tf.data_ptr(), lse.data_ptr(), gout.data_ptr(),
+                         size, n, _ptrs(d_ob), _ptrs(d_sim), _ptrs(d_ns), _ptrs(d_loc), _s())
+    return d_ob, d_sim, d_ns, d_loc
+
+
+def contrastive_fwd(q, pos, neg, temperature):
+    """q, pos [rows][e], neg [rows][m][e] contiguous.  Returns the mean InfoNCE loss (0-dim tensor)."""
+    e = q.shape[-1]
+    rows = q.numel() // e
+    m = neg.numel() // (rows * e)
+    for t in (q, pos, neg):
+        _chk(t, "contrastive")
+    rl = scratch(rows, q.device, slot=4)
+    loss = torch.empty((), dtype=torch.float32, device=q.device)
+    lib().contrastive_fwd(q.data_ptr(), pos.data_ptr(), neg.data_ptr(), rows, e, m, float(temperature), rl.data_ptr(), loss.data_ptr(), _s())
+    return loss
+
+
+def contrastive_bwd(q, pos, neg, temperature, gout):
+    e = q.shape[-1]
+    rows = q.numel() // e
+    m = neg.numel() // (rows * e)
+    dq = torch.empty_like(q); dpos = torch.empty_like(pos); dneg = torch.empty_like(neg)
+    lib().contrastive_bwd(q.data_ptr(), pos.data_ptr(), neg.data_ptr(), rows, e, m, float(temperature), gout.data_ptr(),
+                          dq.data_ptr(), dpos.data_ptr(), dneg.data_ptr(), _s())
+    return dq, dpos, dneg
+
+
+def decode_boxes(outbox, anchors, size, want_cells=False):
+    n = outbox[0].shape[0]
+    for t in outbox:
+        _chk(t, "decode outbox")
+    boxes = torch.empty((n, 4), dtype=torch.float32, device=outbox[0].device)
+    cells = torch.empty((n, 3), dtype=torch.int32, device=outbox[0].device) if want_cells else None
+    lib().decode_boxes(_ptrs(outbox), anchors.data_ptr(), size, n, boxes.data_ptr(), _p(cells), _s())
+    return (boxes, cells) if want_cells else boxes
+
+
+def box_iou(b1, b2):
+    _chk(b1, "box_iou"); _chk(b2, "box_iou")
+    iou = torch.empty(b1.shape[0], dtype=torch.float32, device=b1.device)
+    lib().box_iou(b1.data_ptr(), b2.data_ptr(), b1.shape[0], iou.data_ptr(), _s())
+    return iou
 
 
 # ---- data movers ---------------------------------------------------------------------------------------

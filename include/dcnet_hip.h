@@ -161,16 +161,164 @@ int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
                    int b, int hw, int c, float temperature, void* stream);
 
 /* ---- cross-modal scoring (HBM-bound) --------------------------------------------------- */
-/* One pass over x [rows][c] (pixel stride ldx): out = x / max(||x||_2, 1e-12) over c
- * (F.normalize(dim=1), model/DCNet_model.py:359,469) and, when q != NULL,
- * score[row] = <out[row,:], q[img(row),:]> with img(row) = row / rows_per_image
- * (sim_score, model/DCNet_model.py:530-535).  norm [rows] keeps ||x|| for the backward. */
+/* One pass over x [rows][c] (pixel stride ldx): xn = x / max(||x||_2, 1e-12) over c
+ * (F.normalize(dim=1), model/DCNet_model.py:359,469), out = (accumulate ? out : 0) + out_scale*xn, and, when q != NULL,
+ * score[row] = <xn[row,:], q[img(row),:]> with img(row) = row / rows_per_image
+ * (sim_score, model/DCNet_model.py:530-535).  score_flip (optional) = <xn[row,:], q[N-1-img(row),:]>: the caller-side
+ * neg_sim_score (train_DCNet.py:623-627: flang_attn reversed along the batch) from the same pass.
+ * norm [rows] keeps ||x|| for the backward.  out_scale / accumulate serve the n_frame model's mean over the T-1
+ * correspondence features (model/test_DCNet_model.py:324-332). */
 int dcn_l2norm_score_fwd(const float* x, int ldx, float* out, int ldo, float* norm,
-                         const float* q, float* score, int64_t rows, int rows_per_image, int c, void* stream);
-/* dx from (dout, dscore) (either may be NULL); dq [n_img][c] = sum_rows dscore*out (NULL to skip). */
+                         const float* q, float* score, float* score_flip, int64_t rows, int rows_per_image, int c,
+                         float out_scale, int accumulate, void* stream);
+/* dx from (dout, dscore, dscore_flip) (each may be NULL); dq [n_img][c] = sum_rows dscore*out
+ * + (rows of image N-1-img) dscore_flip*out (NULL to skip).  `out` is the UNSCALED normalised tensor. */
 int dcn_l2norm_score_bwd(const float* out, int ldo, const float* norm, const float* dout, int lddo,
-                         const float* q, const float* dscore, float* dx, int lddx, float* dq,
+                         const float* q, const float* dscore, const float* dscore_flip, float* dx, int lddx, float* dq,
                          int64_t rows, int rows_per_image, int c, void* stream);
+/* score[row] = <x[row,:], q[img(row),:]> without normalising x (flip != 0: q[N-1-img]): sim_score of the n_frame model on
+ * the averaged correspondence feature (model/test_DCNet_model.py:386-391) and neg_sim_score on plain tensors. */
+int dcn_rowdot_fwd(const float* x, int ldx, const float* q, int flip, float* score, int64_t rows, int rows_per_image, int c,
+                   void* stream);
+/* dx[row,:] = dscore[row]*q[img,:] (NULL to skip); dq[img,:] = sum over the rows scored against q[img] of dscore*x (NULL to skip). */
+int dcn_rowdot_bwd(const float* x, int ldx, const float* q, int flip, const float* dscore, float* dx, int lddx, float* dq,
+                   int64_t rows, int rows_per_image, int c, void* stream);
+
+/* ---- phrase attention (language side of the cross-modal scores) --------------------------------- */
+/* PhraseAttention (model/DCNet_model.py:190-219) for one or two heads sharing their inputs (sub_attn :525 and loc_attn
+ * :556), with the F.normalize(p=2, dim=1) that follows each (:526,:557) when normalize != 0:
+ *   attn[h][n][l] = softmax_l(<w_h, context[n,l,:]> + b_h) * (ids[n,l] != 0), renormalised;  out[h][n][:] = (normalised)
+ *   sum_l attn*embedded[n,l,:].  context [n][l][d], embedded [n][l][e], ids int64 [n][l]; w1/b1 NULL = one head.
+ * vnorm [heads][n] keeps ||sum|| for the backward. */
+int dcn_phrase_attn_fwd(const float* context, const float* embedded, const int64_t* ids,
+                        const float* w0, const float* b0, const float* w1, const float* b1,
+                        float* attn, float* out, float* vnorm, int n, int l, int d, int e, int normalize, void* stream);
+/* dout [heads][n][e] -> dcontext [n][l][d], dembedded [n][l][e] (sums over the heads), dw [heads*d + heads] = dw_h | db_h.
+ * ws: dcn_phrase_attn_bwd_ws floats. */
+int64_t dcn_phrase_attn_bwd_ws(int n, int d, int heads);
+int dcn_phrase_attn_bwd(const float* context, const float* embedded, const float* w0, const float* w1,
+                        const float* attn, const float* out, const float* vnorm, const float* dout,
+                        float* dcontext, float* dembedded, float* dw, float* ws,
+                        int n, int l, int d, int e, int normalize, void* stream);
+/* out[c] = sum_r in[r*ld + c] in index order (small row counts: per-image partial sums of parameter gradients). */
+int dcn_colsum(const float* in, int ld, int rows, int cols, float* out, void* stream);
+
+/* ---- cross-scale head tail (model/DCNet_model.py:545-621 == model/test_DCNet_model.py:413-477) -------------- */
+/* Arrays of three entries are per scale, coarsest first (the order of every list the reference returns); hw[s] = positions
+ * of scale s, P = sum hw, Ppad = P rounded up to 32.  logits[s] is the NHWC output of fcn_out[s] (pixel stride ld[s] >= 15,
+ * channels a*5+k), sim[s] [b][hw[s]] the similarity map.
+ *
+ * dcn_locemb_fwd: loc_embedding = Linear(8,8) + BatchNorm1d(8) + ReLU (:257-258,573) on the coordinate rows (identical
+ *   for every image: coord is [p][8]; `count` = b*p is the row count of the reference's BatchNorm, used for the unbiased
+ *   running variance), then F.normalize(dim=2) (:578) -> e8 [p][8].  xhat [p][8], stat [16] (mean | rstd) are kept for
+ *   the backward, mom [72] (fp64) = sum_p e8[p] | sum_p e8[p] e8[p]^T feeds dcn_locbn_fwd.
+ * dcn_locemb_bwd: grads [88] = dW (64) | db (8) | dgamma (8) | dbeta (8) from dE = de_a + de_b (+ the moment
+ *   gradients dmom [72] of dcn_locbn_bwd); any of the three may be NULL. */
+int dcn_locemb_fwd(const float* coord, const float* w, const float* b, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, int training, int64_t count,
+                   int p, float* e8, float* xhat, float* stat, double* mom, void* stream);
+int dcn_locemb_bwd(const float* coord, const float* w, const float* gamma, const float* beta, const float* xhat,
+                   const float* stat, const float* de_a, const float* de_b, const double* dmom, int training, int p,
+                   float* grads, void* stream);
+/* only_obj[s] = mean over the 3 anchors of the confidence logit (:551); obj = only_obj*sim (:550); obj_map [b][P] =
+ * F.normalize(obj, dim=1) (:569), objn [b] its norm; x [(b*8)][Ppad] = e8[p,k]*obj_map[n,p], zero in the pad columns:
+ * the left operand of  M[(n,k)][c] = sum_p x*W[c][p]  (dcn_gemm_nt against the Ppad-padded loc_text_embedding weight),
+ * the rank-8 form of bmm(P x P) + Linear(P,512) (:581-585). */
+int dcn_head_obj(const float* const* logits, const int* ld, const float* const* sim, const int* hw, const float* e8,
+                 float* const* only_obj, float* obj_map, float* objn, float* x, int b, void* stream);
+/* dst[r][0:cols) = src[r][0:cols), dst[r][cols:cols_out) = 0 for rows of any alignment (row strides lds / ldd): the
+ * (512, P) <-> (512, Ppad) copies of the loc_text_embedding weight and its gradient. */
+int dcn_pad_rows(const float* src, int lds, float* dst, int ldd, int rows, int cols, int cols_out, void* stream);
+/* BatchNorm1d(512) of loc_text_embedding (:259,585) over the b*P rows  rel = e8_i . M[n] + bias  from the moments of e8
+ * (fp64; no (b,P,512) tensor): mp = M*scale, bp = bias*scale + shift; train mode updates the running statistics
+ * (count = b*P).  saved [3][512] (rstd | mean-without-bias | scale) for the backward. */
+int dcn_locbn_fwd(const float* m, const double* mom, const float* bias, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float momentum, float eps, int training, int batch,
+                  int64_t count, int c, float* mp, float* bp, float* saved, void* stream);
+/* dmp [b][8][512] (image stride dmp_bs floats; <= 0: dense), dbp [512] -> dm, out [3][512] = dgamma | dbeta | dbias, dmom [72] (train mode; feed to dcn_locemb_bwd). */
+int dcn_locbn_bwd(const float* m, const double* mom, const float* bias, const float* gamma, const float* running_mean,
+                  const float* saved, const float* dmp, int64_t dmp_bs, const float* dbp, int training, int batch,
+                  int64_t count, int c, float* dm, float* out, double* dmom, void* stream);
+/* loc_score = (x - min)/(max - min + 1e-6) per image over the P positions of loc_map [b][P] (:597), split per scale
+ * (:604-610); outbox[s] (NCHW [b][15][hw]) = logits with every confidence channel multiplied by sim*loc (:612-621).
+ * minmax [b][4] keeps min, max and their positions (as int bits) for the backward. */
+int dcn_head_final_fwd(const float* const* logits, const int* ld, const float* const* sim, const int* hw,
+                       const float* loc_map, float* const* outbox, float* const* loc_score, float* minmax, int b, void* stream);
+/* d(loc_map) [b][P] from d(outbox) / d(loc_score) (entries may be NULL). */
+int dcn_head_dloc(const float* const* logits, const int* ld, const float* const* sim, const int* hw,
+                  const float* const* loc_score, const float* const* d_outbox, const float* const* d_loc,
+                  const float* minmax, float* dloc_map, int b, void* stream);
+/* dx [(b*8)][ppad] (gradient of dcn_head_obj's x) -> dobj_map [b][p] and the e8 gradient de8 [p][8]. */
+int dcn_head_fold(const float* dx, const float* e8, const float* obj_map, int b, int p, int ppad, float* dobj_map,
+                  float* de8, void* stream);
+/* d(logits) (NHWC, pad channels zeroed) and d(sim) from d(outbox), d(only_obj) (entries may be NULL) and dobj_map (may be NULL). */
+int dcn_head_dlogits(const float* const* logits, const int* ld, const float* const* sim, const int* hw,
+                     const float* const* loc_score, const float* const* only_obj, const float* const* d_outbox,
+                     const float* const* d_only, const float* obj_map, const float* objn, const float* dobj_map,
+                     float* const* dlogits, float* const* dsim, int b, void* stream);
+
+/* ---- correspondence sampling heads (scale 0) ------------------------------------------------------------- */
+/* K9, inter-frame (model/DCNet_model.py:381-430).  cmap [pairs][hw*hw] = <frame-1 position i, frame-2 position j> at
+ * [i*hw + j] (:390, a batched dcn_gemm_nt), fv [2*pairs][hw][e] the normalised scale-0 features (frames of a pair adjacent),
+ * raw_neg [pairs][top_k][neg_n] the list positions drawn by dcn_mt_sample_interframe(kpos = NULL).
+ * index [pairs][top_k]: torch.topk(largest, sorted) of the row, ties by lowest flat index (:395); frame / corr
+ * [pairs][top_k][e] = fv rows at index / hw (:407) and index % hw (:409); neg_idx, negf [pairs][top_k][neg_n]([e]) the
+ * negatives after skipping the matched position (:411-418). */
+int dcn_k9_fwd(const float* cmap, const float* fv, const int64_t* raw_neg, int pairs, int hw, int e, int top_k, int neg_n,
+               int64_t* index, int64_t* neg_idx, float* frame, float* corr, float* negf, void* stream);
+/* dfv [2*pairs][hw][e] = scatter of the three gradients (every row written; deterministic, no atomics). */
+int dcn_k9_bwd(const int64_t* index, const int64_t* neg_idx, const float* d_frame, const float* d_corr, const float* d_neg,
+               int pairs, int hw, int e, int top_k, int neg_n, float* dfv, void* stream);
+/* K14, cross-modal (model/DCNet_model.py:625-637, Crossmodal_corrspondence :41-112):
+ *   colnorm  vit = F.normalize(fvisu[0].flatten(-2), dim=2): over the POSITIONS of each channel (:629); v, vit [n][hw][e]
+ *   lagnorm  lag = F.normalize(F.interpolate(context, 0.5), dim=1): even channels, over the WORDS (:631-632); lag [n][l][d/2]
+ *   crossmap cols [n][hw] = arg-max over words of Conv1d(l,l,3,pad 1)(lag . vit^T) (:634-635,:48; the Softmax is monotone);
+ *            lvmap [n][l][hw] (optional) receives the conv output
+ *   gather   lag_pos [n][hw][e] = lag[n][cols] (:66-70), neg_cross [n][hw][neg_n][e] = vit[n-1 (LAST image)][neg] (:75-96)
+ *   backward negscatter: extra [hw][e] = sum of d(neg_cross) rows per position of the last image (CSR from
+ *            dcn_mt_sample_crossmodal_csr); colnorm_bwd: dv from dq (+ extra on image n_extra); dlag: d(context). */
+int dcn_colnorm_fwd(const float* v, int n, int hw, int e, float* vit, float* cnorm, void* stream);
+int dcn_colnorm_bwd(const float* vit, const float* cnorm, const float* dq, const float* extra, int n_extra,
+                    int n, int hw, int e, float* dv, void* stream);
+int dcn_lagnorm_fwd(const float* context, int n, int l, int d, float* lag, float* lnorm, void* stream);
+int dcn_crossmap(const float* lag, const float* vit, const float* conv_w, const float* conv_b, int n, int l, int hw, int e,
+                 int64_t* cols, float* lvmap, void* stream);
+int dcn_k14_gather(const float* lag, const float* vit, const int64_t* cols, const int64_t* neg, int n, int l, int hw, int e,
+                   int neg_n, float* lag_pos, float* neg_cross, void* stream);
+int dcn_k14_negscatter(const float* d_neg, const int* csr_off, const int* csr_src, int hw, int e, float* extra, void* stream);
+int dcn_k14_dlag(const float* lag, const float* lnorm, const int64_t* cols, const float* d_k, int n, int l, int hw, int e,
+                 float* dcontext, void* stream);
+
+/* ---- caller-side losses, targets and decode (train_DCNet.py) -------------------------------------------------- */
+/* anchors [3][3][2]: the reference's reversed anchor table (train_DCNet.py:404-406) divided by (anchor_imsize / grid)
+ * per scale, computed in double and rounded to float on the host (as the reference's Python does, :293-296,789-793).
+ * build_target (:265-332), compact: target_i [n][4] = best anchor (0..8), gi, gj, cell index in the concatenated [P] axis;
+ * target_f [n][4] = tx, ty, tw, th.  bbox [n][4] xyxy pixels (clamped to [0, size-1] here, :605). */
+int dcn_build_target(const float* bbox, const float* anchors, int size, int n, int* target_i, float* target_f, void* stream);
+/* the reference's dense tensors (pre-zeroed by the caller): bbox_list[s] [n][3][5][g][g], center_list[s] [n][5][g][g] (:322-323) */
+int dcn_target_dense(const int* target_i, const float* target_f, int size, int n, float* const* bbox_list,
+                     float* const* center_list, void* stream);
+/* out [3] = yolo_loss (:45-72), rank_loss (:173-203, margin 0.1), loc_loss (:205-220) on outbox[s] [n][15][g][g] (NCHW),
+ * sim[s] / negsim[s] / loc[s] [n][g][g].  vals [n][8], lse [n][2]: per-sample terms / log-sum-exps kept for the backward. */
+int dcn_dense_loss_fwd(const float* const* outbox, const float* const* sim, const float* const* negsim, const float* const* loc,
+                       const int* target_i, const float* target_f, int size, int n, float* vals, float* lse, float* out,
+                       void* stream);
+/* grad_out [3] = upstream gradients of the three losses (device); every element of the twelve outputs is written. */
+int dcn_dense_loss_bwd(const float* const* outbox, const float* const* sim, const float* const* negsim, const float* const* loc,
+                       const int* target_i, const float* target_f, const float* lse, const float* grad_out, int size, int n,
+                       float* const* d_outbox, float* const* d_sim, float* const* d_negsim, float* const* d_loc, void* stream);
+/* InfoNCE over `rows` rows of (q [e], pos [e], neg [m][e]): mean over rows of CE([cos(q,pos), cos(q,neg_*)]/T, 0) —
+ * Interframe_contrastive_loss (:114-136) and Crossmodal_constrastive_loss with one positive per row (:140-166).
+ * loss_rows [rows] scratch, loss [1]. */
+int dcn_contrastive_fwd(const float* q, const float* pos, const float* neg, int64_t rows, int e, int m, float temperature,
+                        float* loss_rows, float* loss, void* stream);
+int dcn_contrastive_bwd(const float* q, const float* pos, const float* neg, int64_t rows, int e, int m, float temperature,
+                        const float* grad_out, float* dq, float* dpos, float* dneg, void* stream);
+/* evaluation decode (:764-810): per image the global arg-max of the 3 x 3 x g x g confidences (first maximum), box =
+ * (sigmoid(tx)+gi, sigmoid(ty)+gj, exp(tw)*aw, exp(th)*ah)*stride as xyxy.  cellinfo [n][3] (optional) = anchor, gi, gj. */
+int dcn_decode_boxes(const float* const* outbox, const float* anchors, int size, int n, float* boxes, int* cellinfo, void* stream);
+/* utils/utils.py:76-104 (x1y1x2y2) row by row. */
+int dcn_box_iou(const float* box1, const float* box2, int n, float* iou, void* stream);
 
 /* ---- location module core (rank-8 form of model/DCNet_model.py:581-594) ------------------------- */
 /* loc[n,i] = < normalize_c( relu( E[i,:8] . Mp[n,:8,:c] + bp[:c] ) ), q[n,:c] >   for i < p, c == 512.
@@ -258,6 +406,13 @@ int dcn_prof_collect(int64_t* counts, double* ms, double* work);
  *   the index == N-1 draw of every (ii, jj); out [n][rows][neg_n] int64 (positions in image N-1). */
 int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, int pairs, int top_k, int hw, int neg_n, int64_t* out);
 int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int neg_n, int64_t* out);
+/* The inverse of `out` for the backward of the gather: csr_off [rows+1], csr_src [n*rows*neg_n] = flat source indices
+ * ((ii*rows + jj)*neg_n + m, ascending) of the negatives that point at each position of the last image. */
+int dcn_mt_sample_crossmodal_csr(const int64_t* out, int n, int rows, int neg_n, int32_t* csr_off, int32_t* csr_src);
+/* C[b][M][N] = A[b][M][K] . B[b][N][K]^T for `batch` problems (strides in floats between problems; ldc may be any
+ * value >= N): the HW0 x HW0 inter-frame affinity of K9 (model/DCNet_model.py:390). */
+int dcn_gemm_nt_batched(const float* A, int lda, int64_t a_bs, const float* B, int ldb, int64_t b_bs, float* C, int ldc, int64_t c_bs,
+                        int M, int N, int K, int batch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,9 +5,21 @@ of the total loss with respect to every model output."""
 import pytest
 import torch
 
-from test_losses_cpu import _fake_outputs
-
 pytestmark = pytest.mark.gpu
+
+
+def _fake_outputs(n, size, seed):
+    g = torch.Generator().manual_seed(seed)
+    grids = [size // 32, size // 16, size // 8]
+    r = lambda *s: torch.randn(*s, generator=g)
+    out = dict(outbox=[r(n, 15, x, x) for x in grids], sim_score=[r(n, x, x) for x in grids],
+               loc_score=[torch.rand(n, x, x, generator=g) for x in grids], corr_feat=[r(n, 512, x, x) for x in grids],
+               flang_attn=r(n, 512, 1, 1),
+               frame_feature=[r(n // 2, 512) for _ in range(30)], corrspendence_feature=[r(n // 2, 512) for _ in range(30)],
+               neg_feature=[r(n // 2, 10, 512) for _ in range(30)],
+               vit_posit=[r(n, 512) for _ in range(grids[0] ** 2)], lag_posit=[r(n, 1, 512) for _ in range(grids[0] ** 2)],
+               neg_cross=[r(n, 5, 512) for _ in range(grids[0] ** 2)])
+    return out
 
 NAMES = ["outbox", "sim_score", "loc_score", "corr_feat", "flang_attn", "frame_feature", "corrspendence_feature",
          "neg_feature", "vit_posit", "lag_posit", "neg_cross"]
@@ -56,8 +68,9 @@ def test_build_target_matches_oracle_on_device(dev):
         b1, gi1, gj1, n1, c1 = losses.build_target(bbox.to(dev), size)
         b2, gi2, gj2, n2, c2 = TO.build_target(bbox, size)
         assert n1.tolist() == n2 and gi1.tolist() == [int(x) for x in gi2] and gj1.tolist() == [int(x) for x in gj2]
-        for a, b in zip(b1 + c1, b2 + c2):
-            assert torch.allclose(a.cpu(), b, atol=1e-6)
+        for k, (a, b) in enumerate(zip(b1 + c1, b2 + c2)):
+            d = float((a.cpu() - b).abs().max())
+            assert d < 2e-5, (size, k, d)            # device logf vs host logf: a few ulp of values up to ~4
 
 
 def test_decode_and_iou_match_oracle_and_reference_fixture_on_device(dev, golden_dir):
