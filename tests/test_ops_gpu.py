@@ -193,12 +193,12 @@ def test_l2norm_score_fwd_bwd(dev):
     o = F.normalize(xd, dim=2); sc = (o * qd.unsqueeze(1)).sum(2)
     do = _rand(n, hw, c, seed=42); ds = _rand(n, hw, seed=43)
     ((o * do.double()).sum() + (sc * ds.double()).sum()).backward()
-    out, norm, score = ops.l2norm_score_fwd(x.to(dev), q.to(dev), hw)
+    out, norm, score, _ = ops.l2norm_score_fwd(x.to(dev), q.to(dev), hw)
     _close(out, o.float(), 1e-6, "normalize"); _close(score.view(n, hw), sc.float(), 1e-5, "score")
     dx, dq = ops.l2norm_score_bwd(out, norm, do.to(dev), q.to(dev), ds.to(dev).view(-1), hw)
     _close(dx, xd.grad.float(), 2e-5, "dx"); _close(dq, qd.grad.float(), 2e-5, "dq")
-    out2, norm2, none = ops.l2norm_score_fwd(x.to(dev))
-    assert none is None
+    out2, norm2, none, none2 = ops.l2norm_score_fwd(x.to(dev))
+    assert none is None and none2 is None
     _close(out2, o.float(), 1e-6)
     dx2, _ = ops.l2norm_score_bwd(out2, norm2, do.to(dev), None, None, 0)
     xd2 = x.double().requires_grad_(True)
