@@ -22,7 +22,7 @@ namespace {
 
 constexpr int LS_H = 512;         // hidden size the kernels are built for
 constexpr int LS_UNITS = 8;       // hidden units per workgroup
-constexpr int LS_MAXC = 4;        // row chunks of 64: batch rows <= 256
+constexpr int LS_MAXC = 8;        // row chunks of 64: batch rows <= 512
 constexpr unsigned LS_SPIN_LIMIT = 1u << 24;
 
 typedef __attribute__((address_space(1))) unsigned gu32;

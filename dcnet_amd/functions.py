@@ -545,63 +545,40 @@ class BatchNormRowsAct(torch.autograd.Function):
 
 class BiLSTM(torch.autograd.Function):
     """One-layer bidirectional LSTM over (N,L,I) with per-row lengths (packed-sequence semantics:
-    model/DCNet_model.py:172-183): input projections of all steps as one GEMM per direction, then per
-    step a recurrent GEMM (M = N rows) with the projected input added in the epilogue, and the gate
-    kernel.  Returns (N,L,2H).  Parameter order: w_ih, w_hh, b_ih, b_hh for the forward direction, then
-    the reverse direction."""
+    model/DCNet_model.py:172-183): the input projections of all steps as one GEMM per direction, then the whole
+    recurrence — 2 x L dependent steps — as ONE persistent launch (csrc/lstm.hip); the backward mirrors it and
+    finishes with the weight / input gradients as GEMMs over all (row, time) pairs.  Returns (N,L,2H).
+    Parameter order: w_ih, w_hh, b_ih, b_hh for the forward direction, then the reverse direction."""
 
     @staticmethod
     def forward(ctx, x, lengths, *params):
         n, L, I = x.shape
         H = params[1].shape[1]
-        dev = x.device
         x2d = x.contiguous().view(n * L, I)
-        out = torch.empty((n, L, 2 * H), dtype=torch.float32, device=dev)
-        acts = torch.empty((2, L, n, 5 * H), dtype=torch.float32, device=dev)
-        hs = torch.zeros((2, L + 1, n, H), dtype=torch.float32, device=dev)
-        cs = torch.zeros((2, L + 1, n, H), dtype=torch.float32, device=dev)
-        gates = torch.empty((n, 4 * H), dtype=torch.float32, device=dev)
-        lens = lengths.contiguous()
+        det = [p.detach().contiguous() for p in params]
+        xg = torch.empty((2, n, L, 4 * H), dtype=torch.float32, device=x.device)
         for d in range(2):
-            w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * d:4 * d + 4])
-            xg = ops.gemm_nt(x2d, w_ih, (b_ih + b_hh)).view(n, L, 4 * H)
-            order = range(L) if d == 0 else range(L - 1, -1, -1)
-            for s, t in enumerate(order):
-                ops.gemm_nt(hs[d, s], w_hh, residual=xg[:, t], out=gates)
-                ops.lstm_cell_fwd(gates, cs[d, s], hs[d, s], lens, t, acts[d, s], cs[d, s + 1], hs[d, s + 1],
-                                  out[:, t, d * H:(d + 1) * H])
-        ctx.save_for_backward(x2d, lens, acts, hs, cs, *params)
+            ops.gemm_nt(x2d, det[4 * d], det[4 * d + 2], out=xg[d].view(n * L, 4 * H))
+        lens = lengths.contiguous()
+        out, hprev, cprev, acts = ops.bilstm_fwd(xg, det[1], det[5], det[3], det[7], lens)
+        ctx.save_for_backward(x2d, lens, acts, hprev, cprev, *params)
         ctx.dims = (n, L, I, H)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2d, lens, acts, hs, cs, *params = ctx.saved_tensors
+        x2d, lens, acts, hprev, cprev, *params = ctx.saved_tensors
         n, L, I, H = ctx.dims
-        dev = x2d.device
-        dout = dout.contiguous()
-        dx = torch.empty((n * L, I), dtype=torch.float32, device=dev)
+        det = [p.detach().contiguous() for p in params]
+        dxg = ops.bilstm_bwd(dout.contiguous(), det[1], det[5], acts, cprev, lens)
+        dx = torch.empty((n * L, I), dtype=torch.float32, device=x2d.device)
         grads = []
         for d in range(2):
-            w_ih, w_hh = params[4 * d].detach(), params[4 * d + 1].detach()
-            dxg = torch.empty((n, L, 4 * H), dtype=torch.float32, device=dev)
-            dw_hh = torch.zeros_like(w_hh)
-            dh = torch.zeros((n, H), dtype=torch.float32, device=dev)
-            dc = torch.zeros((n, H), dtype=torch.float32, device=dev)
-            dc2 = torch.empty_like(dc); dh2 = torch.empty_like(dh)
-            order = list(range(L)) if d == 0 else list(range(L - 1, -1, -1))
-            for s in range(L - 1, -1, -1):
-                t = order[s]
-                g = dxg[:, t]                                   # (n,4H) view, row stride L*4H
-                ops.lstm_cell_bwd(dout[:, t, d * H:(d + 1) * H], dh, dc, acts[d, s], cs[d, s], lens, t, g, dc2, dh2)
-                ops.gemm_nn(g, w_hh, out=dh2, accumulate=True)                  # dh_{s-1} = dgates . W_hh + pass-through
-                ops.gemm_tn(g, hs[d, s], out=dw_hh, accumulate=True)            # dW_hh += dgates^T . h_{s-1}
-                dh, dh2 = dh2, dh
-                dc, dc2 = dc2, dc
-            dxg2 = dxg.view(n * L, 4 * H)
-            dw_ih = ops.gemm_tn(dxg2, x2d)
-            ops.gemm_nn(dxg2, w_ih, out=dx, accumulate=(d == 1))
-            db = dxg2.sum(0)
+            g2 = dxg[d].view(n * L, 4 * H)
+            dw_ih = ops.gemm_tn(g2, x2d)
+            dw_hh = ops.gemm_tn(g2, hprev[d].view(n * L, H))                # sum over (row, time) of dgates^T . h_before
+            ops.gemm_nn(g2, det[4 * d], out=dx, accumulate=(d == 1))
+            db = ops.rows_sum(g2)
             grads += [dw_ih, dw_hh, db, db]
         return (dx.view(n, L, I), None) + tuple(grads)
 

@@ -93,6 +93,9 @@ SIGNATURES = {
     "dcn_gemm_tn": (I, [P, I, P, I, P, I, I, I, I, I, P]),
     "dcn_lstm_cell_fwd": (I, [P, P, P, P, I, P, P, P, P, I, I, I, P]),
     "dcn_lstm_cell_bwd": (I, [P, I, P, P, P, P, P, I, P, I, P, P, I, I, P]),
+    "dcn_bilstm_sync_bytes": (L, []),
+    "dcn_bilstm_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "dcn_bilstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "dcn_rmsprop_step": (I, [P, P, P, P, I, F, F, F, F, P]),
     "dcn_set_tuning": (I, [c_char_p, I]),
     "dcn_stream_create": (P, [I]),

@@ -824,6 +824,59 @@ def lstm_cell_bwd(dy, dh_rec, dc_next, act, c_prev, lens, t, dgates, dc_prev, dh
                         dgates.data_ptr(), dgates.stride(0), dc_prev.data_ptr(), dh_pass.data_ptr(), n, h, _s())
 
 
+_lstm_sync = {}
+
+
+def _bilstm_sync(device):
+    key = (torch.device(device).index, torch.cuda.current_stream().cuda_stream)
+    t = _lstm_sync.get(key)
+    if t is None:
+        t = torch.zeros(int(lib().bilstm_sync_bytes()) // 4, dtype=torch.int32, device=device)
+        _lstm_sync[key] = t
+    return t
+
+
+def bilstm_fwd(xg, whh_f, whh_r, bhh_f, bhh_r, lens):
+    """xg (2,N,L,4H).  Returns (out (N,L,2H), hprev, cprev (2,N,L,H), acts (2,N,L,5H))."""
+    _, n, L, h4 = xg.shape
+    H = h4 // 4
+    dev = xg.device
+    out = torch.empty((n, L, 2 * H), dtype=torch.float32, device=dev)
+    hprev = torch.zeros((2, n, L, H), dtype=torch.float32, device=dev)
+    cprev = torch.empty((2, n, L, H), dtype=torch.float32, device=dev)
+    acts = torch.empty((2, n, L, 5 * H), dtype=torch.float32, device=dev)
+    for t in (xg, whh_f, whh_r, bhh_f, bhh_r):
+        _chk(t, "bilstm_fwd")
+    lib().bilstm_fwd(xg.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), bhh_f.data_ptr(), bhh_r.data_ptr(), _p(lens), out.data_ptr(),
+                     hprev.data_ptr(), cprev.data_ptr(), acts.data_ptr(), _bilstm_sync(dev).data_ptr(), n, L, H, _s())
+    return out, hprev, cprev, acts
+
+
+def bilstm_bwd(dout, whh_f, whh_r, acts, cprev, lens):
+    _, n, L, H = cprev.shape
+    dxg = torch.empty((2, n, L, 4 * H), dtype=torch.float32, device=dout.device)
+    _chk(dout, "bilstm_bwd dout")
+    lib().bilstm_bwd(dout.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), acts.data_ptr(), cprev.data_ptr(), _p(lens), dxg.data_ptr(),
+                     _bilstm_sync(dout.device).data_ptr(), n, L, H, _s())
+    return dxg
+
+
+def bilstm_sync_error(device) -> bool:
+    """True if a bounded spin of the last persistent launch on this stream gave up (host-synchronising: debugging only)."""
+    return bool(_bilstm_sync(device)[8].item())
+
+
+def rows_sum(x2d):
+    """out[c] = sum over MANY rows of x2d[r, c] (two deterministic passes: per-block partials, then their sum)."""
+    rows, c = x2d.shape
+    _chk(x2d, "rows_sum")
+    part = channel_stats(x2d)
+    sums = torch.empty((2, c), dtype=torch.float32, device=x2d.device)
+    ws = scratch(lib().bn_ws(c), x2d.device, slot=2)
+    lib().bn_bwd_sums(part.data_ptr(), part.shape[0], c, sums.data_ptr(), ws.data_ptr(), _s())
+    return sums[0]
+
+
 # ---- location module core ------------------------------------------------------------------------------------
 def locmod_fwd(E, Mp, bp, q):
     n, _, c = Mp.shape

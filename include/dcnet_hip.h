@@ -352,6 +352,22 @@ int dcn_lstm_cell_bwd(const float* dy, int lddy, const float* dh_rec, const floa
                       const float* c_prev, const int64_t* lens, int t, float* dgates, int ldg, float* dc_prev,
                       float* dh_pass, int n, int hidden, void* stream);
 
+/* The whole recurrence of nn.LSTM(512, 512, 1, batch_first=True, bidirectional=True) over a packed batch
+ * (model/DCNet_model.py:134-137,172-183) as ONE persistent launch per pass (csrc/lstm.hip): 64 workgroups per direction
+ * keep their slice of W_hh in LDS and hand h_t to each other through global memory with agent-scope release/acquire.
+ * xg [2][n][l][4H] = x.W_ih^T + b_ih per direction (dcn_gemm_nt); whh_* [4H][H], bhh_* [4H]; lens [n] int64 or NULL.
+ * out [n][l][2H] (zeros where t >= len); hprev / cprev [2][n][l][H] = state BEFORE time t (hprev must arrive zeroed),
+ * acts [2][n][l][5H] = i,f,g,o,tanh(c): kept for the backward.  sync: dcn_bilstm_sync_bytes() bytes of device memory,
+ * zeroed on the stream by the call itself; word 8 is set if a bounded spin gave up.  hidden must be 512, n <= 512. */
+int64_t dcn_bilstm_sync_bytes(void);
+int dcn_bilstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd, const float* bhh_rev,
+                   const int64_t* lens, float* out, float* hprev, float* cprev, float* acts, void* sync,
+                   int n, int l, int hidden, void* stream);
+/* dout [n][l][2H] -> dxg [2][n][l][4H], the gradient of the gate pre-activations of every (row, time): the weight, input
+ * and bias gradients are dcn_gemm_tn / dcn_gemm_nn / column sums over its n*l rows. */
+int dcn_bilstm_bwd(const float* dout, const float* whh_fwd, const float* whh_rev, const float* acts, const float* cprev,
+                   const int64_t* lens, float* dxg, void* sync, int n, int l, int hidden, void* stream);
+
 /* ---- small data movers ------------------------------------------------------------------ */
 /* nearest x2 upsample of NHWC src (n,h,w,c) into dst (n,2h,2w,·) pixel stride ldd
  * (MyUpsample2, model/darknet.py:158-160; fused with the route concat :400-402). */

@@ -261,14 +261,17 @@ def test_linear_bn1d_functions(dev):
     _close(o2, r2.float(), 2e-5); _close(x2d.grad, x2r.grad.float(), 5e-5); _close(l2.weight.grad, l2r.weight.grad.float(), 5e-5)
 
 
-@pytest.mark.parametrize("ragged", [False, True])
-def test_bilstm_matches_torch_packed_lstm(dev, ragged):
+@pytest.mark.parametrize("ragged,n", [(False, 6), (True, 6), (True, 64), (True, 130)])
+def test_bilstm_matches_torch_packed_lstm(dev, ragged, n):
+    """The persistent BiLSTM (csrc/lstm.hip: one launch per pass, 128 co-resident workgroups exchanging h_t through
+    global memory) against nn.LSTM on a packed batch in fp64; n = 64 fills every lane, n = 130 needs three row chunks."""
+    from dcnet_amd import ops
     from dcnet_amd.functions import BiLSTM
     torch.manual_seed(1)
-    n, L, I, H = 6, 20, 512, 512
+    L, I, H = 20, 512, 512
     ref = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True).double()
     x = _rand(n, L, I, seed=70)
-    lengths = torch.tensor([20, 7, 20, 13, 1, 20]) if ragged else torch.full((n,), L)
+    lengths = (torch.tensor([20, 7, 20, 13, 1, 20] * 22)[:n] if ragged else torch.full((n,), L))
     xr = x.double().requires_grad_(True)
     packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lengths, batch_first=True, enforce_sorted=False)
     yr, _ = ref(packed)
@@ -281,6 +284,7 @@ def test_bilstm_matches_torch_packed_lstm(dev, ragged):
     xd = x.to(dev).requires_grad_(True)
     y = BiLSTM.apply(xd, lengths.to(dev), *params)
     (y * g.to(dev)).sum().backward()
+    assert not ops.bilstm_sync_error(dev), "a bounded spin of the persistent kernel gave up"
     _close(y, yr.float(), 2e-5, "lstm out")
     _close(xd.grad, xr.grad.float(), 1e-4, "lstm dx")
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
