@@ -32,7 +32,8 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, == fp32 vector rate
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # 256 CU x 4 SIMD x 1024 FLOP/clk (v_mfma_f32_32x32x16_bf16, 32 cycles) x 2.4 GHz
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6      # split pipe: six bf16 MFMAs per fp32 product term
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6      # bf16 three-piece split: six bf16 MFMAs per fp32 product term
+PEAK_H2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3         # f16 two-piece split (the default): three f16 MFMAs (same rate) per product
 PEAK_HBM_GBS = 8000.0
 
 
@@ -179,7 +180,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    NT = 24
+    NT = 32
 
     def collect():
         c = (ctypes.c_int64 * NT)(); m = (ctypes.c_double * NT)(); w = (ctypes.c_double * NT)()
@@ -208,12 +209,13 @@ def main():
         el = time.perf_counter() - t1
         L.prof_enable(0)
         _ops.WGRAD_SIDE, model.language_stream, model.sampling_stream = was
-        L.set_tuning(b"precision", 1)
+        L.set_tuning(b"precision", 4)
         return collect() + (el / args.exclusive_steps * 1e3,)
 
-    excl = native = bf16 = fp8 = None
+    excl = native = bf16 = fp8 = bf16x3 = None
     if args.exclusive_steps > 0:
-        excl = extra_pass(1)
+        excl = extra_pass(4)
+        bf16x3 = extra_pass(1)
         native = extra_pass(0)
         bf16 = extra_pass(2)
         _ops._precision = "fp8"            # conv wrappers compute the operand scales in this mode
@@ -237,10 +239,14 @@ def main():
                  20: "wgrad_kernel<128,128,16,true,0,1> (bf16 operands)",
                  21: "igemm_kernel<128,128,2,2,1,false,16,true> (NN)",
                  22: "channel_partials_kernel<1>",
-                 23: "igemm_kernel<*,*,*,*,0,false,32,true,0,1,1,true> (fp8 operands)"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23)
-                       else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
+                 23: "igemm_kernel<*,*,*,*,0,false,32,true,0,1,1,true> (fp8 operands)",
+                 24: "igemm_kernel<128,128,2,2,0,false,16,true,0,2> (f16 two-piece split)",
+                 25: "wgrad_kernel<128,128,16,true,0,2> (f16 two-piece split)",
+                 26: "igemm_kernel<256,64,4,1,0,false,16,true,0,2> (f16 two-piece split)",
+                 27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2> (NN, f16 two-piece split)"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27)
+                       else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
             out = {}
@@ -268,9 +274,13 @@ def main():
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": ach, "peak": peak_of[dom], "unit": "TFLOP/s",
                     "frac": ach / peak_of[dom], "traffic": traffic,
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
-                    "peak_note": ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
+                    "peak_note": ("fp32 operands as 2 f16 pieces (per-tensor power-of-two scale), 3 cross terms on "
+                                  "v_mfma_f32_32x32x16_f16: peak = 2516.6 TFLOP/s dense f16 / 3 = 838.9 algorithmic fp32 TFLOP/s")
+                                 if dom in (24, 25, 26, 27) else
+                                 ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
                                   "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
                                  if dom in (16, 17, 18, 21) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",
+                    "frac_of_bf16x3_ceiling": ach / PEAK_SPLIT_TFLOPS, "frac_of_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                     "overlap": "the timed region runs the weight-gradient GEMMs on a second stream beside the data-gradient "
                                "chain; per-launch durations here include the time a launch shared the CUs",
                     # every FLOP the MFMA kernels were asked for in a step over the whole step's wall time
@@ -288,6 +298,15 @@ def main():
                                          "avg_launch_ms": m2[dom] / c2[dom], "steps": args.exclusive_steps, "ms_per_step": ms_step,
                                          "note": "same launches with the weight-gradient stream switched off (untimed pass)",
                                          "kernels": table(c2, m2, w2, args.exclusive_steps)}
+            cb, mb, wb, ms_stepb = bf16x3
+            db = max(mm_tags, key=lambda t: wb[t])
+            ab = wb[db] / (mb[db] * 1e-3) / 1e12
+            roofline["fp32_bf16x3"] = {"kernel": names[db], "achieved": ab, "peak": PEAK_SPLIT_TFLOPS, "frac": ab / PEAK_SPLIT_TFLOPS,
+                                       "avg_launch_ms": mb[db] / cb[db], "ms_per_step": ms_stepb,
+                                       "clips_per_s": args.clips * world / (ms_stepb * 1e-3),
+                                       "note": "dcn_set_tuning('precision', 1): the round-1 arithmetic (three bf16 pieces, six MFMAs per "
+                                               "product), side streams off (untimed pass)",
+                                       "kernels": table(cb, mb, wb, args.exclusive_steps)}
             c3, m3, w3, ms_step3 = native
             d3 = max(mm_tags, key=lambda t: w3[t])
             a3 = w3[d3] / (m3[d3] * 1e-3) / 1e12
@@ -322,9 +341,9 @@ def main():
         res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt, "unit": "clips/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "precision": "fp32 tensors and fp32 accumulation everywhere; the 128x128 GEMM tiles multiply on the bf16 matrix "
-                            "pipe with each operand cut into 3 exact bf16 pieces (6 cross terms >= 2^-16 kept): error vs fp64 "
-                            "<= that of the fp32 MFMA instruction (tests/test_ops_gpu.py::test_split_pipe_is_fp32_accurate)",
+               "precision": "fp32 tensors and fp32 accumulation everywhere; the wide GEMM tiles multiply on the f16 matrix pipe with "
+                            "each operand scaled by a per-tensor power of two and cut into 2 f16 pieces (11 + 11 bits; l*h + h*l + h*h): "
+                            "error vs fp64 <= that of the fp32 MFMA instruction (tests/test_ops_gpu.py::test_split_pipe_is_fp32_accurate)",
                "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips} clips/GPU, 20-token query, fp32, "
                                       f"pair semantics ({n_img} images/GPU/step), fwd + 5 losses + bwd + RMSprop",
                           "images_per_gpu": n_img, "parallelism": f"dp{world}"},

@@ -174,9 +174,10 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
 __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int act, float slope,
                                                         const float* __restrict__ residual, float* __restrict__ out,
-                                                        int64_t rows, int c, int ldo) {
+                                                        int64_t rows, int c, int ldo, unsigned* __restrict__ amax) {
   const int c4 = c >> 2;
   const int64_t total = rows * c4;
+  float vmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
@@ -190,6 +191,11 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
     }
     if (residual) v += *reinterpret_cast<const f32x4*>(residual + r * c + ch);
     *reinterpret_cast<f32x4*>(out + r * ldo + ch) = v;
+    vmax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), vmax);
+  }
+  if (amax) {                             // abs-max of the tensor just written (order-independent: reproducible)
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(amax, __float_as_uint(vmax));
   }
 }
 
@@ -197,9 +203,11 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout, int lddo,
                                                                const float* mean, const float* invstd, const float* gamma,
                                                                const float* beta, int act, float slope, const float* sums,
-                                                               float inv_count, int64_t rows, int c, float* __restrict__ dy) {
+                                                               float inv_count, int64_t rows, int c, float* __restrict__ dy,
+                                                               unsigned* __restrict__ amax) {
   const int c4 = c >> 2;
   const int64_t total = rows * c4;
+  float vmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
@@ -218,6 +226,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
       o[k] = g[k] * is[k] * (dd - sg[k] * inv_count - xh * sgx[k] * inv_count);
     }
     *reinterpret_cast<f32x4*>(dy + r * c + ch) = o;
+    vmax = fmaxf(fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))), vmax);
+  }
+  if (amax) {
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(amax, __float_as_uint(vmax));
   }
 }
 
@@ -292,13 +305,13 @@ extern "C" int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, fl
 }
 
 extern "C" int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
-                             const float* residual, float* out, int64_t rows, int c, int ldo, void* stream) {
+                             const float* residual, float* out, int64_t rows, int c, int ldo, uint32_t* amax, void* stream) {
   DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 4 == 0, "scale_act: bad argument (c=%d must be a multiple of 4)", c);
   if (ldo <= 0) ldo = c;
   DCN_CHECK_ARG(ldo % 4 == 0, "scale_act: ldo=%d must be a multiple of 4", ldo);
   const int pid = prof_begin(10, (double)rows * c * 4.0 * (residual ? 3 : 2), (hipStream_t)stream);
   hipLaunchKernelGGL(scale_act_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, scale, shift, act, slope, residual, out, rows, c, ldo);
+                     y, scale, shift, act, slope, residual, out, rows, c, ldo, amax);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("scale_act");
   return DCN_OK;
@@ -338,12 +351,12 @@ extern "C" int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums,
 
 extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, int act, float slope,
-                                    const float* sums, int64_t count, int64_t rows, int c, float* dy, void* stream) {
+                                    const float* sums, int64_t count, int64_t rows, int c, float* dy, uint32_t* amax, void* stream) {
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 4 == 0, "bn_act_bwd_apply: bad argument");
   if (lddo <= 0) lddo = c;
   const int pid = prof_begin(11, (double)rows * c * 4.0 * 3, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy);
+                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply");
   return DCN_OK;

@@ -42,7 +42,8 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride,
                               const float* scale, const float* shift, int act, float slope,
                               const float* residual, int ldr, int ldy,
-                              float* stats, int accumulate, const float* f8_scales, void* stream) {
+                              float* stats, int accumulate, const float* f8_scales,
+                              const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, void* stream) {
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize=%d (1 or 3)", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride=%d (1 or 2)", stride);
   DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0, "conv2d_fwd: bad shape");
@@ -50,6 +51,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   DCN_CHECK_ARG(cin != 4 || (ksize == 3 && stride == 1), "conv2d_fwd: cin=4 path is the 3x3 stride-1 stem only");
   const int pad = (ksize - 1) / 2;
   IgemmParams p; base_params(p);
+  p.amax_a = cin == 4 ? nullptr : amax_x; p.amax_b = cin == 4 ? nullptr : amax_w; p.amax_out = amax_y;
   p.in = x; p.wt = w; p.f8 = cin == 4 ? nullptr : f8_scales; p.out = y; p.scale = scale; p.shift = shift; p.residual = residual; p.stats = stats;
   p.N = n; p.Hi = h; p.Wi = wd; p.Ci = cin; p.ldi = cin;
   p.Ho = (h + 2 * pad - ksize) / stride + 1; p.Wo = (wd + 2 * pad - ksize) / stride + 1;
@@ -75,7 +77,8 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
 
 extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                                   int accumulate, const float* f8_scales, void* stream_) {
+                                   int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_data: ksize=%d", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_data: stride=%d", stride);
@@ -88,7 +91,7 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
                      w, wt, cout, T, cin);
   DCN_CHECK_LAUNCH("transpose_filter");
   IgemmParams p; base_params(p);
-  p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx;
+  p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx; p.amax_a = amax_dy; p.amax_b = amax_w;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
   p.accumulate = accumulate;

@@ -16,6 +16,9 @@ struct IgemmParams {
   const float* in;        // gathered tensor, NHWC, pixel stride ldi
   const float* wt;        // [Co][ldw] K-contiguous rows
   const float* f8;        // optional device {sA, sB}: power-of-two operand scales of the fp8 path (dcn_f8_scale); null = off
+  const unsigned* amax_a; // optional device word: float bits of max|in| (f16 two-piece split: the kernel derives its power-of-two
+  const unsigned* amax_b; //   scales from these); both needed, else the launch stays on the bf16 three-piece split
+  unsigned* amax_out;     // optional device word: atomicMax of |stored values| (the abs-max of the tensor this launch produces)
   float* out;             // NHWC, pixel stride ldo
   const float* scale;     // per-Co, may be null
   const float* shift;     // per-Co, may be null

@@ -56,6 +56,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 // XOR-swizzled) and the k-contiguous MFMA fragments come from the hardware transpose read (as in wgrad.hip).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+// amax bits -> the power of two that maps amax into [2^13, 2^14): amax = f * 2^e with f in [0.5, 1), s = 2^(14 - e).
+// Zero / non-finite maxima give 1 (nothing to scale, or Inf/NaN data that stays Inf/NaN).
+__device__ __forceinline__ float pow2_scale(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xFF);            // biased exponent: amax in [2^(be-127), 2^(be-126))
+  if (be == 0 || be == 255) return 1.f;
+  int e = 14 - (be - 126);                                    // s = 2^e
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
 __device__ __forceinline__ int nn_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 __device__ __forceinline__ int nn_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ nn_swz(row)) + 8 * ((c >> 2) & 1); }
 __device__ __forceinline__ bf16x8 nn_frag(const unsigned char* base, int byte0, int byte1) {
@@ -65,6 +74,13 @@ __device__ __forceinline__ bf16x8 nn_frag(const unsigned char* base, int byte0, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// NP = 2: the fp32-accurate split on the FP16 pipe.  Each operand tensor carries its abs-max (IgemmParams::amax_a/b, kept
+// up to date by the kernels that produce the tensor); the tile loader scales by the power of two that maps the maximum
+// below 2^14, cuts x = h + l with two round-to-nearest f16 conversions (11 + 11 significant bits; elements far below the
+// maximum lose bits only in ABSOLUTE terms, 2^-39 of the maximum) and accumulates l*h, h*l, h*h with
+// v_mfma_f32_32x32x16_f16: three MFMAs per product instead of six, 3 vector-ALU operations per element instead of 5.5
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, v_cvt_f32_f16 x2, v_pk_add_f32, v_cvt_pk_f16_f32 per element pair).  The accumulator
+// is rescaled by the exact 1/(sA*sB) before the epilogue.  Measured error against fp64: that of an fp32 GEMM.
 // NP = number of bf16 pieces per operand: 3 = fp32-accurate split (six cross terms); 1 = plain bf16 operands
 // (round-to-nearest-even, one MFMA per product, fp32 accumulate): the builder-defined bf16 mode of
 // BASELINE.json configs[2] (dcn_set_tuning("precision", 2)); tensors in HBM stay fp32.
@@ -81,7 +97,8 @@ template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = 
 __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   static_assert(!F8 || (SP && NP == 1 && BK == 32 && BMODE == 0), "fp8 operands: NT tiles, 32-deep K-step");
   static_assert(!SP || !C4, "split mode: no stem path");
-  static_assert(!SP || BMODE == 0 || (BN == 128 && BK == 16 && NP == 3), "split NN mode: 128-wide tile, 16-deep K-step");
+  static_assert(!SP || BMODE == 0 || (BN == 128 && BK == 16 && (NP == 3 || NP == 2)), "split NN mode: 128-wide tile, 16-deep K-step");
+  constexpr bool H2 = SP && NP == 2;       // f16 two-piece split with per-tensor power-of-two scales
   constexpr int LDS_LD = BK + 4;           // padded LDS row: conflict-free ds_read_b128 fragments
   // SP: bf16 plane row in ushorts.  BK = 16: unpadded 32-B rows whose two 16-B halves swap places in rows
   // 8-15 (mod 16) — conflict-free for the ds_read_b128 fragments (16-lane groups see 16 distinct 16-B slots)
@@ -95,7 +112,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   auto sp_r = [](int row, int half) {       // ushort offset of the 16-B half `half` (K-step slice 0) of `row`
     return (BK == 16 || F8) ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
   };
-  const float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
+  float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
+  if constexpr (H2) { f8_sa = pow2_scale(p.amax_a[0]); f8_sb = pow2_scale(p.amax_b[0]); }
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -229,6 +247,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       *reinterpret_cast<int*>(plane0 + off) = w;
       return;
     }
+    if constexpr (NP == 2) {             // x*s = h + l, both f16 (round to nearest): v_pk_mul, v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_add
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      const f32x4 t = v * sc;
+      const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+      const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                         (_Float16)(t[3] - (float)h[3])};
+      *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, h);
+      *reinterpret_cast<uint2*>(plane0 + plane_stride + off) = __builtin_bit_cast(uint2, l);
+      return;
+    }
     if constexpr (NP == 1) {             // plain bf16 operands: v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
       typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
       const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -263,7 +291,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < B_LD; ++j) {
         if constexpr (BMODE == 0) { if (!B_PART || row0 < BN) split_store(b16, B_PLANE, sp_w(row0 + RPP * j, chunk), b_reg[j], f8_sb); }
-        else split_store(b16, B_PLANE, nn_off((tid + 256 * j) >> 5, ((tid + 256 * j) & 31) * 4) >> 1, b_reg[j]);
+        else split_store(b16, B_PLANE, nn_off((tid + 256 * j) >> 5, ((tid + 256 * j) & 31) * 4) >> 1, b_reg[j], f8_sb);
       }
       return;
     }
@@ -314,7 +342,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       unsigned short* na = As16 + (cur ^ 1) * NP * BM * LD16;
       unsigned short* nb = Bs16 + (cur ^ 1) * NP * B_PLANE;
       constexpr int PIECES = A_LD + B_LD;
-      constexpr int TERMS = NP == 3 ? 6 : 1;
+      constexpr int TERMS = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
       constexpr int KK = F8 ? 1 : BK / 16;          // fragment reads per K-step (fp8: one 16-B read covers 16 k)
       constexpr int GROUPS = TERMS * KK;
 #pragma unroll
@@ -333,7 +361,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
             else bf[ni][q] = nn_frag(reinterpret_cast<const unsigned char*>(b16 + q * B_PLANE), nn_tr[ni][0], nn_tr[ni][1]);
           }
         // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-        constexpr int QA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+        // (f16 split: (l,h) (h,l) (h,h))
+        constexpr int QA[6] = {NP == 3 ? 2 : (NP == 2 ? 1 : 0), 0, NP == 2 ? 0 : 1, 1, 0, 0}, QB[6] = {0, NP == 2 ? 1 : 2, NP == 2 ? 0 : 1, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < (ABL == 2 ? 1 : TERMS); ++t) {
 #pragma unroll
@@ -345,6 +374,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
                 const l64x2 a2 = __builtin_bit_cast(l64x2, af[mi][0]), b2 = __builtin_bit_cast(l64x2, bf[ni][0]);
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[0], b2[0], acc[mi][ni], 0, 0, 0);
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a2[1], b2[1], acc[mi][ni], 0, 0, 0);
+              } else if constexpr (NP == 2) {
+                typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[mi][QA[t]]),
+                                                                     __builtin_bit_cast(f16x8_t, bf[ni][QB[t]]), acc[mi][ni], 0, 0, 0);
               } else
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t]], bf[ni][QB[t]], acc[mi][ni], 0, 0, 0);
             }
@@ -354,16 +387,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
             for (int pc = kk * TERMS + t; pc < PIECES; pc += GROUPS) {
               if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc], f8_sa);
               else if constexpr (BMODE == 1)
-                split_store(nb, B_PLANE, nn_off((tid + 256 * (pc - A_LD)) >> 5, ((tid + 256 * (pc - A_LD)) & 31) * 4) >> 1, br[pc - A_LD]);
+                split_store(nb, B_PLANE, nn_off((tid + 256 * (pc - A_LD)) >> 5, ((tid + 256 * (pc - A_LD)) & 31) * 4) >> 1, br[pc - A_LD], f8_sb);
               else if (!B_PART || row0 < BN) split_store(nb, B_PLANE, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD], f8_sb);
             }
           }
         }
       }
-      if constexpr (decltype(do_store)::value && NP == 3) {
-        // ask the scheduler for: 1 MFMA, then up to 5 VALU and an LDS write in its 32-cycle shadow, x24
+      if constexpr (decltype(do_store)::value && (NP == 3 || NP == 2)) {
+        // ask the scheduler for: 1 MFMA, then up to 5 VALU and an LDS write in its 32-cycle shadow, x24 (x12: f16 split)
 #pragma unroll
-        for (int g = 0; g < MI * NI * 6 * (BK / 16); ++g) {
+        for (int g = 0; g < MI * NI * TERMS * (BK / 16); ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
           if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -428,7 +461,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   }
   }
 
-  if constexpr (F8) {
+  if constexpr (F8 || H2) {
     const float dq = 1.f / (f8_sa * f8_sb);          // powers of two: exact
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -500,6 +533,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     sc[ni] = (p.scale && co < p.Co) ? p.scale[co] : 1.f;
     sh[ni] = (p.shift && co < p.Co) ? p.shift[co] : 0.f;
   }
+  float vmax = 0.f;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -523,8 +557,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
         if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
         if (p.residual) v += p.residual[pix * p.ldr + co_[ni]];
         gout[pix * p.ldo + co_[ni]] = v;
+        vmax = fmaxf(vmax, fabsf(v));
       }
     }
+  }
+  if (p.amax_out) {                       // abs-max of what was stored: the scale of the tensor's next consumer (order-independent)
+    vmax = wave_max(vmax);
+    if (lane == 0 && vmax > 0.f) atomicMax(p.amax_out, __float_as_uint(vmax));
   }
 }
 
@@ -546,7 +585,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
-  const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+  const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : NP == 2 ? (BMODE == 1 ? 27 : BN == 64 ? 26 : 24) : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
@@ -563,8 +602,11 @@ int g_split = 0;          // dcn_set_tuning("split", 16|32): force every NT tile
 int g_nn_split = 1;       // dcn_set_tuning("nnsplit", 0): NN products back on the fp32 MFMA
 int g_occ3 = 1 << 30;     // dcn_set_tuning("occ3", n): split launches of <= n K-steps use the 3-waves/SIMD build (A/B: 0 = never)
 int g_abl = 0;            // dcn_set_tuning("abl", 1|2): timing-only ablations of the split kernel (results are wrong)
-int g_precision = 1;      // dcn_set_tuning("precision", 0|1|2): 0 = fp32 MFMA everywhere; 1 = wide NT tiles of >= 1024 rows on the
-                          // split-bf16 pipe (fp32 accuracy); 2 = those tiles with plain bf16 operands (configs[2], reduced precision)
+int g_precision = 4;      // dcn_set_tuning("precision", 0..4): 0 = fp32 MFMA everywhere; 1 = wide NT tiles of >= 1024 rows on the
+                          // split-bf16 pipe (fp32 accuracy, six MFMAs per product); 2 = those tiles with plain bf16 operands
+                          // (configs[2], reduced precision); 3 = fp8 operands (configs[4]); 4 (default) = the f16 two-piece split
+                          // (fp32 accuracy, three MFMAs per product) wherever the operands carry their abs-max, else as 1
+int g_h2_occ3 = 1;        // dcn_set_tuning("h2occ", 0): f16-split 128x128 tile built for 2 instead of 3 waves/SIMD
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
@@ -576,9 +618,14 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
     if (p.f8 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
-    if (g_precision >= 2 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
+    if (g_precision == 4 && p.amax_a && p.amax_b && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024) {
+      // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
+      if (BM == 128 && BN == 128 && g_h2_occ3) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 3>(p, stream);
+      return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2>(p, stream);
+    }
+    if (g_precision >= 2 && g_precision <= 3 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1>(p, stream);     // bf16 operands: 8 MFMAs per 32-wide K-step
-    if (g_split || (g_precision == 1 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)) {
+    if (g_split || ((g_precision == 1 || g_precision == 4) && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)) {
       if (g_split == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true>(p, stream);
       if (g_abl == 1) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 1>(p, stream);   // ablation: no split arithmetic (wrong results)
       if (g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2>(p, stream);   // ablation: 1 of 6 MFMA groups (wrong results)
@@ -589,7 +636,8 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
   }
   if constexpr (BMODE == 1 && BM == 128 && BN == 128) {
     // NN products of the co-attention (E.f2, dA.f2): the same split body with transposed B fragments
-    if (g_precision == 1 && g_nn_split && rows >= 1024) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 3, 3>(p, stream);
+    if (g_precision == 4 && p.amax_a && p.amax_b && g_nn_split && rows >= 1024) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 3>(p, stream);
+    if ((g_precision == 1 || g_precision == 4) && g_nn_split && rows >= 1024) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 3, 3>(p, stream);
   }
   if (bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32>(p, stream);
   return launch_bk<BM, BN, WM, WN, BMODE, C4, 16>(p, stream);
@@ -626,11 +674,12 @@ void wgrad_set_abl(int v);
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
-  if (k == 'p') { g_precision = value; wgrad_set_split(value > 2 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
+  if (k == 'p') { g_precision = value; wgrad_set_split(value == 3 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
   else if (k == 'k') g_force_bk = value;     // "k": force the K-step (16 or 32, 0 = automatic)
   else if (k == 'n') g_nn_split = value;     // "nnsplit"
   else if (k == 'o') g_occ3 = value;         // "occ3"
+  else if (k == 'h') g_h2_occ3 = value;      // "h2occ"
   else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step

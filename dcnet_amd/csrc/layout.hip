@@ -136,6 +136,20 @@ extern "C" int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* 
   return DCN_OK;
 }
 
+// amax (float bits of a non-negative maximum) = max(amax, max|x|): the word the f16 two-piece split of the GEMM engines
+// derives its power-of-two operand scale from.  Accumulating: call on every tensor that makes up one operand.
+extern "C" int dcn_absmax(const float* x, int64_t rows, int c, int ld, uint32_t* amax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ld <= 0) ld = c;
+  DCN_CHECK_ARG(x && amax && rows > 0 && c > 0 && c % 4 == 0 && ld % 4 == 0 && ld >= c, "absmax: bad argument (c=%d ld=%d)", c, ld);
+  DCN_CHECK_ARG(((uintptr_t)x & 15) == 0, "absmax: x must be 16-byte aligned");
+  const int64_t items = rows * (c / 4);
+  const int blocks = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)amax);
+  DCN_CHECK_LAUNCH("absmax");
+  return DCN_OK;
+}
+
 extern "C" int dcn_oihw_to_ohwi(const float* src, float* dst, int co, int ci, int kh, int kw, int ci_pad, void* stream) {
   DCN_CHECK_ARG(src && dst && co > 0 && ci > 0 && kh > 0 && kw > 0 && ci_pad >= ci, "oihw_to_ohwi: bad argument");
   // per output channel: [Ci][T] -> [T][ci_pad]

@@ -38,7 +38,18 @@ struct WgradParams {
   int Co_ld;                     // dy columns that may be LOADED (>= Co, zero padded by the producer)
   int accumulate;
   const unsigned* geom;          // per output pixel: (centre input pixel << 5) | edge flags; null = identity (plain GEMM)
+  const unsigned* amax_dy;       // abs-max words (float bits) of dy / x: the f16 two-piece split derives its scales from them
+  const unsigned* amax_x;
 };
+
+// amax bits -> the power of two that maps amax into [2^13, 2^14) (igemm.hip); zero / non-finite maxima give 1
+__device__ __forceinline__ float pow2_scale(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xFF);
+  if (be == 0 || be == 255) return 1.f;
+  int e = 14 - (be - 126);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
 
 // geometry table entry flags (dcn_conv2d_geom)
 constexpr unsigned GEOM_TOP = 1, GEOM_BOTTOM = 2, GEOM_LEFT = 4, GEOM_RIGHT = 8, GEOM_INVALID = 16;
@@ -85,7 +96,8 @@ __device__ __forceinline__ int sp_swz(int row) { return ((row & 3) << 2) | ((row
 // byte offset of channels c..c+3 (c % 4 == 0) of pixel row `row` inside one [16][128] bf16 plane
 __device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ sp_swz(row)) + 8 * ((c >> 2) & 1); }
 
-// NP: bf16 pieces per operand (3 = fp32-accurate split, 1 = plain bf16 operands; igemm.hip)
+// NP: 16-bit pieces per operand (3 = fp32-accurate bf16 split, 1 = plain bf16 operands, 2 = fp32-accurate f16 split with
+// per-tensor power-of-two scales and three MFMAs per product; igemm.hip)
 template <int TM, int TN, int KP, bool SP = false, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kernel(const WgradParams p) {
   static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
@@ -180,7 +192,19 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
   auto load_tiles = [&]() { load_tiles_into(a_reg, b_reg); };
   unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][NP planes][16][256 B]
   constexpr int SP_OPND = NP * 4096, SP_BUF = 2 * SP_OPND;
-  auto split_store = [&](unsigned char* plane0, int off, const f32x4 v) {
+  float s_a = 1.f, s_b = 1.f;
+  if constexpr (SP && NP == 2) { s_a = pow2_scale(p.amax_dy[0]); s_b = pow2_scale(p.amax_x[0]); }
+  auto split_store = [&](unsigned char* plane0, int off, const f32x4 v, const float sc) {
+    if constexpr (NP == 2) {
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      const f32x4 t = v * sc;
+      const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+      const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                         (_Float16)(t[3] - (float)h[3])};
+      *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, h);
+      *reinterpret_cast<uint2*>(plane0 + 4096 + off) = __builtin_bit_cast(uint2, l);
+      return;
+    }
     if constexpr (NP == 1) {
       typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
       const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
     const int j = isb ? pc - A_LD : pc;
     const int idx = tid + 256 * j;
     const int pix = idx / 32, c = (idx - pix * 32) * 4;
-    split_store(sp_base + buf * SP_BUF + (isb ? SP_OPND : 0), sp_off(pix, c), isb ? br[j] : ar[j]);
+    split_store(sp_base + buf * SP_BUF + (isb ? SP_OPND : 0), sp_off(pix, c), isb ? br[j] : ar[j], isb ? s_b : s_a);
   };
   auto store_tiles = [&](int buf) {
     if constexpr (SP) {
@@ -275,27 +299,37 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
           bf[ni][pl] = frag(cur * SP_BUF + pl * 4096 + b_tr[ni][0], cur * SP_BUF + pl * 4096 + b_tr[ni][1]);
-      constexpr int TERMS = NP == 3 ? 6 : 1;
-      constexpr int QA[6] = {NP == 3 ? 2 : 0, 0, 1, 1, 0, 0}, QB[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int TERMS = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+      constexpr int QA[6] = {NP == 3 ? 2 : (NP == 2 ? 1 : 0), 0, NP == 2 ? 0 : 1, 1, 0, 0}, QB[6] = {0, NP == 2 ? 1 : 2, NP == 2 ? 0 : 1, 0, 1, 0};
 #pragma unroll
       for (int t6 = 0; t6 < TERMS; ++t6) {
         if (ABL != 2 || t6 == 5)        // timing ablation 2: one of the six MFMA groups
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (NP == 2) {
+              typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[mi][QA[t6]]),
+                                                                   __builtin_bit_cast(f16x8_t, bf[ni][QB[t6]]), acc[mi][ni], 0, 0, 0);
+            } else
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][QA[t6]], bf[ni][QB[t6]], acc[mi][ni], 0, 0, 0);
+          }
         if constexpr (decltype(do_store)::value) {
           if constexpr (NP == 3) { if (t6 < A_LD + B_LD) sp_store_piece(cur ^ 1, t6, ar, br); }
+          else if constexpr (NP == 2) {          // four pieces over three MFMA groups
+#pragma unroll
+            for (int pc = t6; pc < A_LD + B_LD; pc += 3) sp_store_piece(cur ^ 1, pc, ar, br);
+          }
           else {
 #pragma unroll
             for (int pc = 0; pc < A_LD + B_LD; ++pc) sp_store_piece(cur ^ 1, pc, ar, br);
           }
         }
       }
-      if constexpr (decltype(do_store)::value && NP == 3) {
+      if constexpr (decltype(do_store)::value && (NP == 3 || NP == 2)) {
 #pragma unroll
-        for (int g = 0; g < MI * NI * 6; ++g) {
+        for (int g = 0; g < MI * NI * TERMS; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
           if (g & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -372,6 +406,13 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
     }
   }
   if (wk != 0) return;
+  if constexpr (SP && NP == 2) {
+    const float dq = 1.f / (s_a * s_b);              // powers of two: exact
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= dq;
+  }
   float* out = p.out + (size_t)split * p.Co * p.ld_out + (long long)blockIdx.y * p.out_bs;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -447,7 +488,8 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
 }
 
 int g_wabl = 0;            // timing-only ablations of the split kernel (wrong results): dcn_set_tuning("abl", v)
-int g_wsplit = 1;          // 128x128 weight-gradient / TN tiles on the split-bf16 pipe (dcn_set_tuning("precision"|"wsplit", 0) = native)
+int g_wsplit = 4;          // 128x128 weight-gradient / TN tiles: 0 native fp32 MFMA, 1 bf16 three-piece split, 2 bf16 operands,
+                           // 4 f16 two-piece split where the operands carry their abs-max (else as 1)   (dcn_set_tuning("precision"|"wsplit"))
 
 template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
@@ -463,7 +505,7 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
     attr_done = true;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
-  const int pid = prof_begin(SP ? (NP == 1 ? 20 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
+  const int pid = prof_begin(SP ? (NP == 1 ? 20 : NP == 2 ? 25 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
   hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL, NP>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
@@ -475,6 +517,8 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
     return g_wabl == 1 ? launch_wgrad<128, 128, true, 1>(p, grid, batch, stream)
          : launch_wgrad<128, 128, true, 2>(p, grid, batch, stream);
   if (tm == 128 && tn == 128 && g_wsplit == 2 && !p.c4 && p.M >= 1024) return launch_wgrad<128, 128, true, 0, 1>(p, grid, batch, stream);
+  if (tm == 128 && tn == 128 && g_wsplit == 4 && p.amax_dy && p.amax_x && !p.c4 && p.M >= 1024)
+    return launch_wgrad<128, 128, true, 0, 2>(p, grid, batch, stream);                  // f16 two-piece split
   if (tm == 128 && tn == 128) return (g_wsplit && !p.c4 && p.M >= 1024) ? launch_wgrad<128, 128, true>(p, grid, batch, stream)
                                                          : launch_wgrad<128, 128>(p, grid, batch, stream);
   if (tm == 128 && tn == 64) return launch_wgrad<128, 64>(p, grid, batch, stream);
@@ -537,7 +581,8 @@ extern "C" int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize,
 
 extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                                      const uint32_t* geom,
-                                     int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream_) {
+                                     int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                                     const uint32_t* amax_x, const uint32_t* amax_dy, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_weight: ksize=%d", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_weight: stride=%d", stride);
@@ -555,7 +600,7 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   p.Co = cout; p.lddy = lddy > 0 ? lddy : cout;
   p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = cin == 4; p.ld_out = pl.ld_out;
-  p.Co_ld = cout; p.geom = geom;
+  p.Co_ld = cout; p.geom = geom; p.amax_x = amax_x; p.amax_dy = amax_dy;
   const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
   int rc = dispatch_wgrad(p, pl.tm, pl.tn, grid, 1, stream);
   if (rc != DCN_OK) return rc;

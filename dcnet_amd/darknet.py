@@ -275,20 +275,26 @@ def _cpad(c: int) -> int:
 def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
     """P[slot] = dict(w=OIHW weight, b=conv bias|None, gamma, beta, rm, rv).  Returns tap tensors."""
     out: Dict[int, torch.Tensor] = {-1: x_nhwc}
+    # abs-max word of every activation (ops.amax_*): written by the kernel that produces the tensor, read by the GEMMs
+    # that consume it (forward here, weight gradient in the backward) to pick their power-of-two operand scales
+    am = ops.use_amax()
+    amx: Dict[int, Optional[torch.Tensor]] = {-1: None}
     for op in plan:
         if isinstance(op, _ConvOp):
             p = P[op.slot]
-            x = out[op.src]
+            x = out[op.src]; ax = amx.get(op.src)
             w = ops.weight_to_ohwi(p["w"])
+            aw = ops.absmax(p["w"]) if (am and op.cin > 4 and op.cout > 32) else None
+            ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
             if op.bn and training:
-                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True)
+                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw)
                 cnt = y.numel() // op.cout
                 mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
-                o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res)
+                o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
                 if save is not None:
-                    save[op.slot] = (x, y, mi, w)
+                    save[op.slot] = (x, y, mi, w, ax, aw)
             else:
                 if op.bn:
                     ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5)
@@ -296,12 +302,16 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
                 else:
                     scale, shift = None, p["b"]
                 if save is None:      # inference: one kernel per layer, shortcut fused in the epilogue
-                    o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res)
+                    o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res, amax_x=ax, amax_w=aw, amax_out=ao)
                 else:                 # frozen-BN fine-tuning: keep the pre-shortcut activation for act'
-                    a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1)
-                    o = a if res is None else ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res)
-                    save[op.slot] = (x, a, scale, w)
-            out[op.dst] = o
+                    if res is None:
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, amax_out=ao)
+                        o = a
+                    else:
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw)
+                        o = ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res, amax_out=ao)
+                    save[op.slot] = (x, a, scale, w, ax, aw)
+            out[op.dst] = o; amx[op.dst] = ao
         elif isinstance(op, _UpCatOp):
             up, lat = out[op.up_src], out[op.lat_src]
             n, h, w_, _ = lat.shape
@@ -309,9 +319,11 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
             ops.upsample2_into(up, buf[..., :op.c_up])
             ops.copy_slice(lat, buf[..., op.c_up:])
             out[op.dst] = buf
+            # the concat holds exactly the values of its two sources: its abs-max is the larger of theirs
+            amx[op.dst] = ops.absmax(lat, ops.absmax(up)) if am else None
         else:
-            out[op.dst] = out[op.src]
-    return [out[t] for t in taps]
+            out[op.dst] = out[op.src]; amx[op.dst] = amx.get(op.src)
+    return [out[t] for t in taps], [amx.get(t) for t in taps]
 
 
 def _run_backward(plan, taps, grads_taps, P, save, training: bool):
@@ -351,13 +363,14 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
             add(op.lat_src, dout[..., op.c_up:])
         else:
             p = P[op.slot]
-            x, y, aux, w = save.pop(op.slot)
+            x, y, aux, w, ax, aw = save.pop(op.slot)
             shape = tuple(p["w"].shape)
             d = {}
+            ady = ops.amax_slot(dout.device) if ops.use_amax() else None
             if op.bn and training:
                 mi = aux
                 dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], p["gamma"], p["beta"],
-                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1)
+                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1, amax_out=ady)
                 d["gamma"], d["beta"] = dgamma, dbeta
             else:
                 # frozen statistics: y holds act(scale*conv+shift) before the shortcut add
@@ -375,16 +388,17 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
                     dy = dz
                     if p["b"] is not None:
                         d["b"] = dz.reshape(-1, op.cout).sum(0)
+                ady = None            # (frozen-BN path: the GEMMs below compute the abs-max of dy themselves)
             if op.res is not None:
                 add(op.res, dout)
-            d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape)     # overlaps with the data gradient below
+            d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)     # overlaps with the data gradient below
             if op.need_dx:
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
                 if cur is None:
-                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride)
+                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw)
                 else:
-                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True)
+                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw)
             pg[op.slot] = d
     if pg:
         ops.join_side(next(iter(P.values()))["w"].device)
@@ -402,7 +416,8 @@ class _DarknetFn(torch.autograd.Function):
         x = ops.nchw_to_nhwc(image.contiguous(), 4)
         need_grad = any(ctx.needs_input_grad[3:])
         save = {} if need_grad else None
-        outs = _run_forward(plan, taps, x, P, training, save)
+        outs, tap_amax = _run_forward(plan, taps, x, P, training, save)
+        net._tap_amax = tap_amax              # abs-max words of the three taps (read by the head's first convolutions)
         if save is not None:
             # outputs must go through save_for_backward (an attribute reference would make a
             # ctx <-> output cycle and pin the whole activation set until the GC runs)

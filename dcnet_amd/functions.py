@@ -15,31 +15,42 @@ class ConvBNAct(torch.autograd.Function):
     + ReLU.  x may carry zero-padded channels beyond the weight's Cin (K-padding to 32)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float):
+    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float, amax_x=None):
+        """Returns (out, amax_out): amax_* are the abs-max words of ops.amax_* (None outside the f16-split precision)."""
         w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3])
         cout = weight.shape[0]
+        am = ops.use_amax()
+        ax = (amax_x if amax_x is not None else ops.absmax(x)) if am else None
+        aw = ops.absmax(weight.detach()) if am else None
+        ao = ops.amax_slot(x.device) if am else None
         if training:
-            y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True)
+            y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True, amax_x=ax, amax_w=aw)
             mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                  bn.running_mean, bn.running_var)
             bn.num_batches_tracked += 1
-            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope)
+            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope, amax_out=ao)
             ctx.save_for_backward(x, y, mi, w, gamma, beta)
         else:
             ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
-            out, _ = ops.conv2d_fwd(x, w, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope)
+            out, _ = ops.conv2d_fwd(x, w, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, amax_x=ax, amax_w=aw, amax_out=ao)
             ctx.save_for_backward(x, out, ss, w, gamma, beta)
         ctx.meta = (ksize, training, slope, tuple(weight.shape))
-        return out
+        ctx.amax = (ax, aw)
+        if ao is not None:
+            ctx.mark_non_differentiable(ao)
+        return out, ao
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _ga=None):
         x, y, aux, w, gamma, beta = ctx.saved_tensors
         gamma, beta = gamma.detach(), beta.detach()
         ksize, training, slope, wshape = ctx.meta
+        ax, aw = ctx.amax
         dout = dout.contiguous()
+        ady = None
         if training:
-            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, slope)
+            ady = ops.amax_slot(dout.device) if ops.use_amax() else None
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, slope, amax_out=ady)
         else:
             dz = ops.act_bwd(y, dout, slope)
             dy = dz * aux[0]
@@ -47,10 +58,10 @@ class ConvBNAct(torch.autograd.Function):
             z = y if slope == 0 else torch.where(y > 0, y, y / slope)
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
-        dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape)
-        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1) if ctx.needs_input_grad[0] else None
+        dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
+        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
         ops.join_side(x.device)
-        return dx, dwt, dgamma, dbeta, None, None, None, None
+        return dx, dwt, dgamma, dbeta, None, None, None, None, None
 
 
 class ConvBias(torch.autograd.Function):
@@ -59,27 +70,30 @@ class ConvBias(torch.autograd.Function):
     caller slices [..., :cout]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, amax_x=None):
         cout = weight.shape[0]
         cop = ops.pad32(cout)
         w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3], co_pad=cop)
         b = torch.zeros(cop, dtype=torch.float32, device=x.device)
         b[:cout] = bias.detach()
-        y, _ = ops.conv2d_fwd(x, w, weight.shape[2], 1, None, b)
+        y, _ = ops.conv2d_fwd(x, w, weight.shape[2], 1, None, b)          # (32 filters: the fp32-pipe tile, no scales)
         ctx.save_for_backward(x, w)
         ctx.wshape = tuple(weight.shape)
+        ctx.amax = (amax_x, ops.absmax(weight.detach()) if ops.use_amax() else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         co, ci, k, _ = ctx.wshape
+        ax, aw = ctx.amax
         dy = dy.contiguous()
-        dwt = ops.wgrad_on_side(x, dy, k, 1, ctx.wshape)
-        db = dy.reshape(-1, dy.shape[-1]).sum(0)[:co]
-        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1) if ctx.needs_input_grad[0] else None
+        ady = ops.absmax(dy) if ops.use_amax() else None
+        dwt = ops.wgrad_on_side(x, dy, k, 1, ctx.wshape, amax_x=ax, amax_dy=ady)
+        db = ops.colsum_rows(dy.view(-1, dy.shape[-1]))[:co]
+        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
         ops.join_side(x.device)
-        return dx, dwt, db
+        return dx, dwt, db, None
 
 
 class L2Norm(torch.autograd.Function):
@@ -366,8 +380,11 @@ class FusionConvBNAct(torch.autograd.Function):
     of the 1032-channel form, and no (N,H,W,1032) tensor.  Then BatchNorm2d (momentum 0.999) + ReLU."""
 
     @staticmethod
-    def forward(ctx, corr, flang, coord, weight, gamma, beta, bn, training: bool):
+    def forward(ctx, corr, flang, coord, weight, gamma, beta, bn, training: bool, amax_x=None):
         n, h, w, e = corr.shape
+        am = ops.use_amax()
+        ax = (amax_x if amax_x is not None else ops.absmax(corr)) if am else None
+        ao = ops.amax_slot(corr.device) if am else None
         co = weight.shape[0]
         wd = weight.detach().view(co, -1)
         w1 = wd[:, :e].contiguous().view(co, e, 1, 1)
@@ -375,29 +392,36 @@ class FusionConvBNAct(torch.autograd.Function):
         coord2d = coord.reshape(h * w, -1)
         y = (torch.matmul(flang.detach(), w2.t()).view(n, 1, co) + torch.matmul(coord2d, w3.t()).view(1, h * w, co)).view(n, h, w, co)
         wk = ops.weight_to_ohwi(w1)
+        aw = ops.absmax(wk) if am else None
         if training:
-            y, stats = ops.conv2d_fwd(corr, wk, 1, 1, out=y, want_stats=True, accumulate=True)
+            y, stats = ops.conv2d_fwd(corr, wk, 1, 1, out=y, want_stats=True, accumulate=True, amax_x=ax, amax_w=aw)
             mi = ops.bn_finalize(stats, n * h * w, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
             bn.num_batches_tracked += 1
-            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0)
+            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0, amax_out=ao)
             ctx.save_for_backward(corr, y, mi, wk, gamma, beta, flang, weight)
         else:
             ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
-            out, _ = ops.conv2d_fwd(corr, wk, 1, 1, ss[0], ss[1], ops.ACT_LEAKY, 0.0, out=y, accumulate=True)
+            out, _ = ops.conv2d_fwd(corr, wk, 1, 1, ss[0], ss[1], ops.ACT_LEAKY, 0.0, out=y, accumulate=True, amax_x=ax, amax_w=aw, amax_out=ao)
             ctx.save_for_backward(corr, out, ss, wk, gamma, beta, flang, weight)
         ctx.training = training
         ctx.coord2d = coord2d
-        return out
+        ctx.amax = (ax, aw)
+        if ao is not None:
+            ctx.mark_non_differentiable(ao)
+        return out, ao
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _ga=None):
         corr, y, aux, wk, gamma, beta, flang, weight = ctx.saved_tensors
         gamma, beta = gamma.detach(), beta.detach()
         n, h, w, e = corr.shape
         co = weight.shape[0]
+        ax, aw = ctx.amax
         dout = dout.contiguous()
+        ady = None
         if ctx.training:
-            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, 0.0)
+            ady = ops.amax_slot(dout.device) if ops.use_amax() else None
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, 0.0, amax_out=ady)
         else:
             dz = ops.act_bwd(y, dout, 0.0)
             dy = dz * aux[0]
@@ -405,8 +429,8 @@ class FusionConvBNAct(torch.autograd.Function):
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (y - beta) / gs).reshape(-1, co).sum(0)
         wd = weight.detach().view(co, -1)
-        dw1 = ops.wgrad_on_side(corr, dy, 1, 1, (co, e, 1, 1)).view(co, e)      # overlaps with the data gradient
-        dcorr = ops.conv2d_bwd_data(dy, wk, (h, w), 1, 1) if ctx.needs_input_grad[0] else None
+        dw1 = ops.wgrad_on_side(corr, dy, 1, 1, (co, e, 1, 1), amax_x=ax, amax_dy=ady).view(co, e)      # overlaps with the data gradient
+        dcorr = ops.conv2d_bwd_data(dy, wk, (h, w), 1, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
         ops.join_side(corr.device)
         d_img = dy.sum((1, 2))                                  # (N,co): gradient of the per-image term
         d_pos = dy.sum(0).view(h * w, co)                       # (HW,co): gradient of the per-position term
@@ -414,7 +438,7 @@ class FusionConvBNAct(torch.autograd.Function):
         dw2 = torch.matmul(d_img.t(), flang.detach())
         dw3 = torch.matmul(d_pos.t(), ctx.coord2d)
         dweight = torch.cat([dw1, dw2, dw3], dim=1).view_as(weight)
-        return dcorr, dflang, None, dweight, dgamma, dbeta, None, None
+        return dcorr, dflang, None, dweight, dgamma, dbeta, None, None, None
 
 
 class CoAttentionPairs(torch.autograd.Function):

@@ -22,23 +22,24 @@ SIGNATURES = {
     "dcn_nhwc_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "dcn_oihw_to_ohwi": (I, [P, P, I, I, I, I, I, P]),
     "dcn_ohwi_to_oihw": (I, [P, P, I, I, I, I, I, P]),
-    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P]),
+    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P, P, P, P]),
+    "dcn_absmax": (I, [P, L, I, I, P, P]),
     "dcn_f8_scale": (I, [P, L, I, I, P, P, P]),
     "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),
-    "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, P, P]),
     "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
     "dcn_conv2d_geom": (I, [P, I, I, I, I, I, P]),
-    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
     "dcn_bn_ws": (L, [I]),
     "dcn_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
     "dcn_bn_fold": (I, [P, P, P, P, F, I, P, P, P]),
     "dcn_channel_stats": (I, [P, L, I, I, P, P]),
     "dcn_channel_stats_rows": (I, [L]),
-    "dcn_scale_act": (I, [P, P, P, I, F, P, P, L, I, I, P]),
+    "dcn_scale_act": (I, [P, P, P, I, F, P, P, L, I, I, P, P]),
     "dcn_bn_act_bwd_reduce": (I, [P, P, I, P, P, P, P, I, F, L, I, P, P]),
     "dcn_bn_bwd_sums": (I, [P, I, I, P, P, P]),
-    "dcn_bn_act_bwd_apply": (I, [P, P, I, P, P, P, P, I, F, P, L, L, I, P, P]),
+    "dcn_bn_act_bwd_apply": (I, [P, P, I, P, P, P, P, I, F, P, L, L, I, P, P, P]),
     "dcn_act_bwd": (I, [P, P, I, F, L, I, P, P]),
     "dcn_coattn_e_size": (L, [I, I]),
     "dcn_coattn_fwd_ws": (L, [I, I, I]),

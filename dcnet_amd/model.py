@@ -66,9 +66,13 @@ class ConvBatchNormReLU(nn.Sequential):
         else:
             raise NotImplementedError("relu=False is not used by DCNet")
 
-    def forward(self, x_nhwc):
-        return ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
-                               self.conv.kernel_size[0], self.training, self.slope)
+    def forward(self, x_nhwc, amax=None):
+        """``amax`` / the ``_dcn_amax`` attribute of the input: abs-max word of x (ops.amax_*); the output carries its own."""
+        amax = amax if amax is not None else getattr(x_nhwc, "_dcn_amax", None)
+        out, a = ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
+                                 self.conv.kernel_size[0], self.training, self.slope, amax)
+        out._dcn_amax = a
+        return out
 
 
 class RNNEncoder(nn.Module):
@@ -242,27 +246,31 @@ class grounding_model(nn.Module):
         """fcn_emb[s] + fcn_out[s] on one scale: corr (B,H,W,E) -> outbox logits (B,H,W,32 = 15 + padding)  (:491-506)."""
         h, w = corr.shape[1], corr.shape[2]
         blk0 = self.fcn_emb[s][0]                                                # [corr | tile(flang) | coord] -> 1x1
-        z = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
-                                  blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training)
+        one = ops.amax_const(corr.device, 1.0) if ops.use_amax() else None        # corr is L2-normalised: |x| <= 1
+        z, za = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
+                                      blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training, one)
+        z._dcn_amax = za
         z = self.fcn_emb[s][1](z)
         z = self.fcn_emb[s][2](z)
         z = self.fcn_out[s][0](z)
         last = self.fcn_out[s][1]
-        return ConvBias.apply(z, last.weight, last.bias)          # (B,H,W,32): channels 15..31 are zero padding
+        return ConvBias.apply(z, last.weight, last.bias, getattr(z, "_dcn_amax", None))    # (B,H,W,32): channels 15..31 are zero padding
 
     def _scale_pairs(self, s: int, raw_s, flang, flang_attn):
         """Everything of scale s that depends only on its backbone tap (pair semantics): mapping + norm
         (:356-359), co-attention + corr_conv (:449-468), normalise + sim (:469,530-535), fusion head.
         Returns (fv, corr, sim, neg_sim|None, logits (B,H,W,32))."""
-        fv = L2Norm.apply(self.mapping_visu[s](raw_s))
-        corr_raw = self.corr_conv[s][0](CoAttentionPairs.apply(fv, self.temperature))
+        one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None       # unit-norm features and their convex combinations
+        fv = L2Norm.apply(self.mapping_visu[s](raw_s, self.visumodel._tap_amax[s]))
+        corr_raw = self.corr_conv[s][0](CoAttentionPairs.apply(fv, self.temperature), one)
         corr, sim, neg_sim = NormScore.apply(corr_raw, flang_attn, self.training)
         return fv, corr, sim, neg_sim, self._fusion_head(s, corr, flang)
 
     def _scale_nframe(self, s: int, raw_s, flang, flang_attn, B: int, n_frame: int):
         """Scale s of the inference model: centre frame vs every other frame, mean of the normalised
         correspondence features (model/test_DCNet_model.py:299-332), then the shared head."""
-        fv = L2Norm.apply(self.mapping_visu[s](raw_s))
+        one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None
+        fv = L2Norm.apply(self.mapping_visu[s](raw_s, self.visumodel._tap_amax[s]))
         _, h, w, e = fv.shape
         clips = fv.view(B, n_frame, h * w, e)
         ctr, acc = n_frame // 2, None                                            # :303
@@ -270,7 +278,7 @@ class grounding_model(nn.Module):
             if idx == ctr:
                 continue
             cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
-            acc = NormAccumulate.apply(self.corr_conv[s][0](cat), acc, 1.0 / (n_frame - 1))   # :277-280, mean :324-332
+            acc = NormAccumulate.apply(self.corr_conv[s][0](cat, one), acc, 1.0 / (n_frame - 1))   # :277-280, mean :324-332
         corr = acc
         sim = RowDot.apply(corr, flang_attn, False)                              # :386-391
         return fv, corr, sim, None, self._fusion_head(s, corr, flang)

@@ -15,13 +15,16 @@ from .lib import DcnError, lib
 ACT_NONE, ACT_LEAKY = 0, 1
 
 # Matrix-pipe precision of the wide GEMM tiles (conv forward / data gradient / weight gradient, co-attention GEMMs):
-#   "fp32"      fp32 accuracy on the bf16 matrix pipe (3 exact bf16 pieces per operand, 6 cross terms) — the default
+#   "fp32"      fp32 accuracy on the f16 matrix pipe — the default: operands scaled by a per-tensor power of two (from the
+#               tensor's tracked abs-max), cut into two f16 pieces (11 + 11 bits), three MFMAs per product; launches whose
+#               operands carry no abs-max run as "fp32_bf16x3"
+#   "fp32_bf16x3" fp32 accuracy on the bf16 matrix pipe (3 exact bf16 pieces per operand, 6 cross terms)
 #   "fp32_mfma" the native fp32 MFMA instruction on every tile
 #   "bf16"      bf16 operands (round to nearest even), fp32 accumulate: BASELINE.json configs[2]; reduced precision,
 #               builder-defined (the reference has no bf16 semantics); tensors in HBM stay fp32
 #   "fp8"       forward and data-gradient tiles with OCP fp8 e4m3 operands (per-tensor power-of-two scales from an abs-max
 #               pass, fp32 accumulate), weight gradient with bf16 operands: BASELINE.json configs[4]; reduced precision
-PRECISIONS = {"fp32_mfma": 0, "fp32": 1, "bf16": 2, "fp8": 3}
+PRECISIONS = {"fp32_mfma": 0, "fp32_bf16x3": 1, "bf16": 2, "fp8": 3, "fp32": 4}
 _precision = "fp32"
 
 
@@ -35,6 +38,60 @@ def set_precision(mode: str) -> None:
 
 def get_precision() -> str:
     return _precision
+
+
+# ---- abs-max words of GEMM operands (the f16 two-piece split derives its power-of-two scales from them) --------------
+# A word holds the float bits of max|tensor| and is written with order-independent atomic maxima by the kernels that
+# produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool and are
+# used once, so a saved activation keeps its word for the backward whatever runs in between.
+_amax_pools = {}
+_amax_consts = {}
+
+
+def use_amax() -> bool:
+    return _precision == "fp32"
+
+
+def amax_slot(device) -> torch.Tensor:
+    key = torch.device(device).index
+    pool = _amax_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+        _amax_pools[key] = pool
+    t = pool[0][pool[1]:pool[1] + 1]
+    pool[1] += 1
+    return t
+
+
+def amax_const(device, value: float) -> torch.Tensor:
+    """A word holding a KNOWN bound (e.g. 1.0 for L2-normalised features): no pass over the data."""
+    key = (torch.device(device).index, float(value))
+    t = _amax_consts.get(key)
+    if t is None:
+        t = torch.tensor([value], dtype=torch.float32).view(torch.int32).to(device)
+        _amax_consts[key] = t
+    return t
+
+
+def absmax(x: torch.Tensor, slot: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """slot = max(slot, max|x|) for an fp32 [rows][c] view (or any contiguous tensor); returns the slot."""
+    if slot is None:
+        slot = amax_slot(x.device)
+    if x.is_contiguous() and x.numel() % 4 == 0:
+        rows, c, ld = 1, x.numel(), x.numel()
+        if c > (1 << 30):
+            c = x.shape[-1]; rows = x.numel() // c; ld = c
+    else:
+        _rows(x, "absmax")
+        c = x.shape[-1]; rows = x.numel() // c; ld = x.stride(-2)
+    lib().absmax(x.data_ptr(), rows, c, ld, slot.data_ptr(), _s())
+    return slot
+
+
+def _amax_or_pass(t: torch.Tensor, given: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if not use_amax():
+        return None
+    return given if given is not None else absmax(t)
 
 
 def _s() -> int:
@@ -162,9 +219,11 @@ def f8_scales(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
-               residual=None, out=None, want_stats=False, accumulate=False):
+               residual=None, out=None, want_stats=False, accumulate=False, amax_x=None, amax_w=None, amax_out=None):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
-    where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats)."""
+    where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats).
+    amax_x / amax_w: abs-max words of the operands (computed here by a pass over the data when missing and the
+    precision mode needs them); amax_out: word that receives the abs-max of what is stored."""
     _chk(x, "conv2d_fwd x")
     n, h, wd, cin = x.shape
     cout = w_ohwi.shape[0]
@@ -177,13 +236,16 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
         rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     f8 = f8_scales(x, w_ohwi) if (_precision == "fp8" and cin != 4) else None
+    if cin != 4 and cout > 32:              # (the 32-filter tiles stay on the fp32 pipe: no scales needed)
+        amax_x = _amax_or_pass(x, amax_x); amax_w = _amax_or_pass(w_ohwi, amax_w)
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
-                     0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8), _s())
+                     0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8),
+                     _p(amax_x), _p(amax_w), _p(amax_out), _s())
     return out, stats
 
 
-def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False):
+def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None):
     """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin)."""
     n, ho, wo, cout = dy.shape
     cin = w_ohwi.shape[3]
@@ -192,8 +254,10 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     wt = scratch(w_ohwi.numel(), dy.device, slot=1)
     f8 = f8_scales(dy, w_ohwi) if _precision == "fp8" else None
+    if cin > 32:
+        amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
-                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _s())
+                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w), _s())
     return out
 
 
@@ -212,7 +276,7 @@ def conv_geom(device, n: int, h: int, wd: int, ksize: int, stride: int) -> torch
     return t
 
 
-def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0):
+def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=None, amax_dy=None):
     """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
     ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0)."""
     n, h, wd, cin = x.shape
@@ -221,8 +285,10 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0):
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     geom = conv_geom(x.device, n, h, wd, ksize, stride)
+    if cin >= 128 and cout >= 128:          # the 128x128 weight-gradient tile is the one with a split mode
+        amax_x = _amax_or_pass(x, amax_x); amax_dy = _amax_or_pass(dy, amax_dy)
     lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
-                            n, h, wd, cin, cout, ksize, stride, _s())
+                            n, h, wd, cin, cout, ksize, stride, _p(amax_x), _p(amax_dy), _s())
     return dw
 
 
@@ -252,11 +318,11 @@ SIDE_PRIORITY = 0      # 0: a normal torch stream; +1 (lowest dispatch priority,
 WGRAD_SIDE = True      # A/B switch: False runs the weight gradient on the caller's stream
 
 
-def wgrad_on_side(x, dy, ksize, stride, wshape):
+def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
     """Launch the weight gradient (+ its OHWI->OIHW conversion) on the side stream.  Returns the OIHW
     gradient; the caller must make the main stream wait for side_stream() before the result is consumed."""
     if not WGRAD_SIDE:
-        dw = conv2d_bwd_weight(x, dy, ksize, stride)
+        dw = conv2d_bwd_weight(x, dy, ksize, stride, amax_x=amax_x, amax_dy=amax_dy)
         if wshape[0] != dw.shape[0]:
             dw = dw[:wshape[0]].contiguous()
         return weight_grad_to_oihw(dw, wshape)
@@ -264,7 +330,7 @@ def wgrad_on_side(x, dy, ksize, stride, wshape):
     side = side_stream(x.device)
     side.wait_stream(main)                       # dy (and x) are produced on the main stream
     with torch.cuda.stream(side):
-        dw = conv2d_bwd_weight(x, dy, ksize, stride, slot=3)
+        dw = conv2d_bwd_weight(x, dy, ksize, stride, slot=3, amax_x=amax_x, amax_dy=amax_dy)
         if wshape[0] != dw.shape[0]:
             dw = dw[:wshape[0]].contiguous()
         out = weight_grad_to_oihw(dw, wshape)
@@ -308,19 +374,20 @@ def channel_stats(x2d):
     return stats
 
 
-def scale_act(y, scale, shift, act, slope, residual=None, out=None):
+def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None):
     c = y.shape[-1]
     rows = y.numel() // c
     if out is None:
         out = torch.empty_like(y)
     _chk(y, "scale_act y"); _rows(out, "scale_act out")
     lib().scale_act(y.data_ptr(), _p(scale), _p(shift), act, float(slope), _p(residual), out.data_ptr(), rows, c,
-                    out.stride(-2), _s())
+                    out.stride(-2), _p(amax_out), _s())
     return out
 
 
-def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope):
-    """Returns (dy, dgamma, dbeta) for out = act(gamma*(y-mean)*invstd+beta) with batch statistics."""
+def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None):
+    """Returns (dy, dgamma, dbeta) for out = act(gamma*(y-mean)*invstd+beta) with batch statistics; amax_out: word that
+    receives the abs-max of dy (the A operand of the data / weight gradient GEMMs that follow)."""
     c = y.shape[-1]
     rows = y.numel() // c
     dev = y.device
@@ -334,7 +401,7 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope):
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
     dy = torch.empty_like(y)
     lib().bn_act_bwd_apply(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
-                           act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _s())
+                           act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _p(amax_out), _s())
     return dy, sums[1], sums[0]
 
 
@@ -864,6 +931,11 @@ def bilstm_bwd(dout, whh_f, whh_r, acts, cprev, lens):
 def bilstm_sync_error(device) -> bool:
     """True if a bounded spin of the last persistent launch on this stream gave up (host-synchronising: debugging only)."""
     return bool(_bilstm_sync(device)[8].item())
+
+
+def colsum_rows(x2d):
+    """Column sums over MANY rows (alias of rows_sum for [rows][c] views with c % 4 == 0)."""
+    return rows_sum(x2d.contiguous())
 
 
 def rows_sum(x2d):

@@ -64,7 +64,16 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
                    const float* scale, const float* shift, int act, float slope,
                    const float* residual, int ldr, int ldy,
-                   float* stats, int accumulate, const float* f8_scales, void* stream);
+                   float* stats, int accumulate, const float* f8_scales,
+                   const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, void* stream);
+/* amax_* (dcn_conv2d_fwd / bwd_data / bwd_weight; NULL = off): device words holding the float bits of max|tensor|.  With both
+ * operand maxima given, the wide tiles run the fp32-accurate f16 two-piece split (the default "fp32" precision of this
+ * library, dcn_set_tuning("precision", 4)): operands scaled by the power of two that brings the maximum below 2^14, cut
+ * x = h + l into two f16 (11 + 11 significant bits), l*h + h*l + h*h on v_mfma_f32_32x32x16_f16 — three MFMAs per product
+ * instead of six on the bf16 three-piece split they fall back to without maxima.  The words are maintained by the producing
+ * kernels (amax_y here, dcn_scale_act, dcn_bn_act_bwd_apply) or by dcn_absmax, all with an order-independent atomic max on
+ * a word the caller zeroed once. */
+int dcn_absmax(const float* x, int64_t rows, int c, int ld, uint32_t* amax, void* stream);
 int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride);
 /* f8_scales (dcn_conv2d_fwd / dcn_conv2d_bwd_data; NULL = off): device pointer to {s_activation, s_weight}, the
  * power-of-two operand scales of the builder-defined fp8 e4m3 conv path (BASELINE.json configs[4]): the wide tiles
@@ -79,7 +88,7 @@ int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* scale, void
  * accumulate != 0: dx += result (used where a tensor feeds two consumers). */
 int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                        int accumulate, const float* f8_scales, void* stream);
+                        int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w, void* stream);
 
 /* Geometry table of a convolution (depends on n, h, wd, ksize, stride only; build once, reuse every step):
  * dcn_conv2d_geom_size entries of uint32, entry m = (index of the input pixel under the centre tap of
@@ -93,7 +102,8 @@ int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize, int stride
  * (split-K partial slabs, reduced deterministically).  geom = dcn_conv2d_geom table of this geometry. */
 int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                           const uint32_t* geom,
-                          int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
+                          int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                          const uint32_t* amax_x, const uint32_t* amax_dy, void* stream);
 int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 
 /* ---- BatchNorm (train mode) + activation + shortcut ---------------------------------- */
@@ -116,10 +126,11 @@ int dcn_bn_fold(const float* gamma, const float* beta, const float* running_mean
  * BatchNorm inputs not produced by dcn_conv2d_fwd.  stats: [dcn_channel_stats_rows(rows)][2][c]. */
 int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, float* stats, void* stream);
 int dcn_channel_stats_rows(int64_t rows);
-/* out = act(scale[c]*y + shift[c]) + residual  over [rows][c] (y, residual pixel stride c; out ldo).
+/* out = act(scale[c]*y + shift[c]) + residual  over [rows][c] (y, residual pixel stride c; out ldo); amax (optional):
+ * running abs-max word of `out` (see dcn_absmax).
  * The normalise+LeakyReLU/ReLU(+shortcut) half of a train-mode block: model/darknet.py:189-191,403-405. */
 int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
-                  const float* residual, float* out, int64_t rows, int c, int ldo, void* stream);
+                  const float* residual, float* out, int64_t rows, int c, int ldo, uint32_t* amax, void* stream);
 /* Backward of out = act(bn(y)) (a residual's gradient is the identity and handled by the caller):
  *   reduce: partials of g = dout*act'(.) and g*xhat per channel -> stats [dcn_channel_stats_rows(rows)][2][c]
  *   sums:   totals [2][c]  (sums[0] = dbeta, sums[1] = dgamma)
@@ -130,7 +141,7 @@ int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo, const flo
 int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums, float* ws, void* stream);
 int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int act, float slope,
-                         const float* sums, int64_t count, int64_t rows, int c, float* dy, void* stream);
+                         const float* sums, int64_t count, int64_t rows, int c, float* dy, uint32_t* amax, void* stream);
 /* Backward of out = act(z) alone: dy = dout * (out > 0 ? 1 : slope). */
 int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int64_t rows, int c, float* dy, void* stream);
 
@@ -388,10 +399,11 @@ int dcn_set_tuning(const char* key, int value);
  * momentum = 0, centered = False (train_DCNet.py:528-534), which the reference steps at train_DCNet.py:646. */
 int dcn_rmsprop_step(float* const* params, const float* const* grads, float* const* square_avgs, const int64_t* numel,
                      int count, float lr, float alpha, float eps, float weight_decay, void* stream);
-/* Keys: "precision" 1 (default): the 128x128 tiles of the conv engine and of the weight-gradient / TN GEMM run on
- *         the bf16 matrix pipe with every fp32 operand cut into three bf16 pieces (exact) and the six cross terms
+/* Keys: "precision" 4 (default): the wide tiles of the conv engine and of the weight-gradient GEMM run the f16 two-piece
+ *         split (see dcn_absmax) wherever both operands carry their abs-max word, and as 1 otherwise;
+ *         1: the bf16 matrix pipe with every fp32 operand cut into three bf16 pieces (exact) and the six cross terms
  *         >= 2^-16 accumulated in fp32 — measured error against fp64 is at or below that of v_mfma_f32_32x32x2_f32;
- *         0: v_mfma_f32_32x32x2_f32 everywhere.
+ *         0: v_mfma_f32_32x32x2_f32 everywhere; 2: bf16 operands; 3: fp8 operands (dcn_f8_scale).
  *       "bm", "k": tile / K-step overrides; "split" 16|32, "wsplit" 1: force the split pipe on every NT / TN tile. */
 
 /* ---- streams with a dispatch priority ------------------------------------------------------- */
@@ -405,7 +417,7 @@ int dcn_stream_priority_range(int* least, int* greatest);
 
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
- * returns, per kernel tag (24 slots; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
+ * returns, per kernel tag (32 slots; 24-27 = f16 two-piece split tiles: igemm 128x128 / wgrad / igemm 256x64 / NN; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
  * tile, 17 = split-bf16 128x128 weight-gradient / TN tile; 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
  * 5 weight-gradient/TN GEMM, 6-7 64x128 tiles, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward,
  * 12 exp+sums, 13/14 small latency-bound GEMMs of the LSTM steps),

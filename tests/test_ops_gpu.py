@@ -330,7 +330,7 @@ def test_fusion_conv_fold_matches_concat_form(dev):
     ref.backward(gup.double())
     conv, bn = conv.to(dev), bn.to(dev)
     cd = corr.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True); fd = flang.to(dev).requires_grad_(True)
-    out = FusionConvBNAct.apply(cd, fd, coord.to(dev), conv.weight, bn.weight, bn.bias, bn, True)
+    out, _ = FusionConvBNAct.apply(cd, fd, coord.to(dev), conv.weight, bn.weight, bn.bias, bn, True)
     out.backward(gup.permute(0, 2, 3, 1).contiguous().to(dev))
     _close(out.permute(0, 3, 1, 2), ref.float(), 3e-5, "fusion fwd")
     _close(cd.grad.permute(0, 3, 1, 2), cr.grad.float(), 5e-5, "dcorr"); _close(fd.grad, fr.grad.float(), 5e-5, "dflang")
@@ -350,18 +350,22 @@ SPLIT_CASES = [
 
 @pytest.mark.parametrize("case", SPLIT_CASES)
 def test_split_pipe_is_fp32_accurate(dev, case):
-    """Forward, data gradient and weight gradient on the bf16 pipe with 3-way split operands against an fp64
-    reference, next to the native fp32 MFMA kernels on the same inputs: the split path must be at least as
-    close (factor 2 slack + 1e-6) — it is a different instruction sequence, not a different precision."""
+    """Forward, data gradient and weight gradient on the split matrix pipes — mode 4 (the default): two f16 pieces per
+    operand with per-tensor power-of-two scales, three MFMAs per product; mode 1: three bf16 pieces, six MFMAs — against
+    an fp64 reference, next to the native fp32 MFMA kernels (mode 0) on the same inputs: a split path must be at least as
+    close (factor 2 slack + 1e-6) — it is a different instruction sequence, not a different precision.  The inputs carry
+    a wide dynamic range (a few elements 1e4 x larger, many 1e-4 x smaller) so that the scaling is exercised."""
     from dcnet_amd import ops
     from dcnet_amd.lib import lib
     n, h, w, cin, cout, k, st = case
-    x = _rand(n, h, w, cin, seed=1).to(dev)
+    x = _rand(n, h, w, cin, seed=1)
+    spread = torch.exp(2.5 * _rand(n, h, w, cin, seed=7))          # log-normal magnitudes: ~1e-4 .. 1e4
+    x = (x * spread).to(dev)
     wt = (_rand(cout, k, k, cin, seed=2) / (cin * k * k) ** 0.5).to(dev)
     xd = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     wd = wt.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     yd = F.conv2d(xd, wd, stride=st, padding=(k - 1) // 2)
-    dy = (_rand(*yd.shape, seed=3) / 8).permute(0, 2, 3, 1).contiguous().to(dev)
+    dy = (_rand(*yd.shape, seed=3) * 1e-6 * torch.exp(2.0 * _rand(*yd.shape, seed=8))).permute(0, 2, 3, 1).contiguous().to(dev)   # tiny gradients
     yd.backward(dy.permute(0, 3, 1, 2).double().cpu())
     ref = {"fwd": yd.detach().permute(0, 2, 3, 1), "dgrad": xd.grad.permute(0, 2, 3, 1), "wgrad": wd.grad.permute(0, 2, 3, 1)}
     cout_p = (cout + 31) // 32 * 32                     # dgrad contracts over Cout: padded filter bank / dy
@@ -369,7 +373,7 @@ def test_split_pipe_is_fp32_accurate(dev, case):
     dy_p = torch.zeros(*dy.shape[:3], cout_p, device=dev); dy_p[..., :cout] = dy
     err = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 4):
             lib().set_tuning(b"precision", mode)
             got = {"fwd": ops.conv2d_fwd(x, wt, k, st)[0],
                    "dgrad": ops.conv2d_bwd_data(dy_p, wt_p, (h, w), k, st),
@@ -377,11 +381,39 @@ def test_split_pipe_is_fp32_accurate(dev, case):
             for name, t in got.items():
                 err[(name, mode)] = float((t.double().cpu().reshape(ref[name].shape) - ref[name]).abs().max())
     finally:
-        lib().set_tuning(b"precision", 1)
+        lib().set_tuning(b"precision", 4)
     for name in ref:
-        scale = max(1.0, float(ref[name].abs().max()))
-        assert err[(name, 1)] <= 2 * err[(name, 0)] + 1e-6 * scale, (name, err)
-        assert err[(name, 1)] <= 3e-5 * scale, (name, err)
+        scale = float(ref[name].abs().max())
+        for mode in (1, 4):
+            assert err[(name, mode)] <= 2 * err[(name, 0)] + 1e-6 * scale, (name, mode, err)
+            assert err[(name, mode)] <= 3e-5 * scale, (name, mode, err)
+
+
+def test_f16_split_is_live_and_survives_extreme_operands(dev):
+    """Mode 4 really runs the f16 kernels (its result differs in the last bits from the bf16 three-piece split), and the
+    abs-max scaling keeps huge (1e30), tiny (1e-30) and all-zero operands finite and accurate."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout = 2, 32, 32, 128, 128
+    base = _rand(n, h, w, cin, seed=11)
+    wt = (_rand(cout, 3, 3, cin, seed=12) / 34).to(dev)
+    try:
+        for mag in (1.0, 1e30, 1e-30):
+            x = (base * mag).to(dev)
+            ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1)
+            lib().set_tuning(b"precision", 4)
+            y4 = ops.conv2d_fwd(x, wt, 3, 1)[0]
+            lib().set_tuning(b"precision", 1)
+            y1 = ops.conv2d_fwd(x, wt, 3, 1)[0]
+            assert torch.isfinite(y4).all()
+            _close(y4 / mag, ref / mag, 3e-6, f"f16 split at magnitude {mag}")
+            if mag == 1.0:
+                assert not torch.equal(y4, y1), "precision 4 did not select the f16-split kernel"
+        lib().set_tuning(b"precision", 4)
+        z = ops.conv2d_fwd(torch.zeros_like(base).to(dev), wt, 3, 1)[0]
+        assert float(z.abs().max()) == 0.0
+    finally:
+        lib().set_tuning(b"precision", 4)
 
 
 def test_split_pipe_forced_on_every_nt_tile(dev):
@@ -395,11 +427,13 @@ def test_split_pipe_forced_on_every_nt_tile(dev):
             wt = (_rand(cout, 3, 3, 64, seed=5) / 24).to(dev)
             ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.permute(0, 3, 1, 2).double().cpu(), padding=1).permute(0, 2, 3, 1)
             for mode in (16, 32):
+                lib().set_tuning(b"precision", 1)          # the forced split is the bf16 three-piece one
                 lib().set_tuning(b"split", mode)
                 y = ops.conv2d_fwd(x, wt, 3, 1)[0]
                 _close(y, ref, 1e-5, f"cout {cout} split {mode}")
     finally:
         lib().set_tuning(b"split", 0)
+        lib().set_tuning(b"precision", 4)
 
 
 @pytest.mark.parametrize("case", SPLIT_CASES)
