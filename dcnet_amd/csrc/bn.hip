@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
   }
   if (amax) {                             // abs-max of the tensor just written (order-independent: reproducible)
     vmax = wave_max(vmax);
-    if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(amax, __float_as_uint(vmax));
+    if ((threadIdx.x & 63) == 0) amax_update(amax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
   }
 }
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
   }
   if (amax) {
     vmax = wave_max(vmax);
-    if ((threadIdx.x & 63) == 0 && vmax > 0.f) atomicMax(amax, __float_as_uint(vmax));
+    if ((threadIdx.x & 63) == 0) amax_update(amax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
   }
 }
 

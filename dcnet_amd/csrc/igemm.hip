@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     return (BK == 16 || F8) ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
   };
   float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
-  if constexpr (H2) { f8_sa = pow2_scale(p.amax_a[0]); f8_sb = pow2_scale(p.amax_b[0]); }
+  if constexpr (H2) { f8_sa = pow2_scale(amax_read(p.amax_a)); f8_sb = pow2_scale(amax_read(p.amax_b)); }
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   }
   if (p.amax_out) {                       // abs-max of what was stored: the scale of the tensor's next consumer (order-independent)
     vmax = wave_max(vmax);
-    if (lane == 0 && vmax > 0.f) atomicMax(p.amax_out, __float_as_uint(vmax));
+    if (lane == 0) amax_update(p.amax_out, vmax, blockIdx.x * 4 + wave);
   }
 }
 
@@ -607,6 +607,8 @@ int g_precision = 4;      // dcn_set_tuning("precision", 0..4): 0 = fp32 MFMA ev
                           // (configs[2], reduced precision); 3 = fp8 operands (configs[4]); 4 (default) = the f16 two-piece split
                           // (fp32 accuracy, three MFMAs per product) wherever the operands carry their abs-max, else as 1
 int g_h2_occ3 = 1;        // dcn_set_tuning("h2occ", 0): f16-split 128x128 tile built for 2 instead of 3 waves/SIMD
+int g_h2_narrow = 0;      // dcn_set_tuning("rnarrow", 1): the narrow NT tiles (128x64, 256x32, 64x128) on the f16 split as well
+int g_h2_bk = 16;         // dcn_set_tuning("qbk", 32): K-step of the f16-split tiles
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
@@ -618,8 +620,10 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
     if (p.f8 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
-    if (g_precision == 4 && p.amax_a && p.amax_b && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024) {
+    if (g_precision == 4 && p.amax_a && p.amax_b && rows >= 1024 &&
+        ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || g_h2_narrow)) {
       // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
+      if (g_h2_bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 2>(p, stream);
       if (BM == 128 && BN == 128 && g_h2_occ3) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 3>(p, stream);
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2>(p, stream);
     }
@@ -680,6 +684,8 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   else if (k == 'n') g_nn_split = value;     // "nnsplit"
   else if (k == 'o') g_occ3 = value;         // "occ3"
   else if (k == 'h') g_h2_occ3 = value;      // "h2occ"
+  else if (k == 'r') g_h2_narrow = value;    // "rnarrow"
+  else if (k == 'q') g_h2_bk = value;        // "qbk"
   else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step

@@ -101,7 +101,9 @@ extern "C" int dcn_nhwc_to_nchw(const float* src, float* dst, int n, int c, int 
 // ---- fp8 path: per-tensor power-of-two scale ------------------------------------------------------------------
 // scale = 2^floor(log2(448 / max|x|)) (1 for an all-zero tensor): x*scale fits the finite e4m3 range and the scaling is
 // exact.  max is order-independent, so the atomic (on the bits of a non-negative float) keeps results reproducible.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int c4, int ld, unsigned* __restrict__ out) {
+// spread != 0: `out` is a DCN_AMAX_WORDS-word abs-max vector (common.h); 0: a single word (the fp8 path's scratch)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int c4, int ld, unsigned* __restrict__ out,
+                                                     int spread) {
   const int64_t total = rows * c4;
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) amax_update(out, m, spread ? blockIdx.x * 4 + (threadIdx.x >> 6) : 0u);
 }
 __global__ void f8_scale_finish_kernel(unsigned* bits, float* scale) {
   const float amax = __uint_as_float(*bits);
@@ -130,7 +132,7 @@ extern "C" int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* 
   if (hipMemsetAsync(ws, 0, 4, stream) != hipSuccess) { dcn_set_error("f8_scale: memset failed"); return DCN_ERR_LAUNCH; }
   const int64_t total = rows * (c / 4);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)ws);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)ws, 0);
   hipLaunchKernelGGL(f8_scale_finish_kernel, dim3(1), dim3(1), 0, stream, (unsigned*)ws, scale);
   DCN_CHECK_LAUNCH("f8_scale");
   return DCN_OK;
@@ -145,7 +147,7 @@ extern "C" int dcn_absmax(const float* x, int64_t rows, int c, int ld, uint32_t*
   DCN_CHECK_ARG(((uintptr_t)x & 15) == 0, "absmax: x must be 16-byte aligned");
   const int64_t items = rows * (c / 4);
   const int blocks = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)amax);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)amax, 1);
   DCN_CHECK_LAUNCH("absmax");
   return DCN_OK;
 }

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
   unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][NP planes][16][256 B]
   constexpr int SP_OPND = NP * 4096, SP_BUF = 2 * SP_OPND;
   float s_a = 1.f, s_b = 1.f;
-  if constexpr (SP && NP == 2) { s_a = pow2_scale(p.amax_dy[0]); s_b = pow2_scale(p.amax_x[0]); }
+  if constexpr (SP && NP == 2) { s_a = pow2_scale(amax_read(p.amax_dy)); s_b = pow2_scale(amax_read(p.amax_x)); }
   auto split_store = [&](unsigned char* plane0, int off, const f32x4 v, const float sc) {
     if constexpr (NP == 2) {
       typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));

@@ -284,7 +284,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
             p = P[op.slot]
             x = out[op.src]; ax = amx.get(op.src)
             w = ops.weight_to_ohwi(p["w"])
-            aw = ops.absmax(p["w"]) if (am and op.cin > 4 and op.cout > 32) else None
+            aw = ops.absmax(p["w"]) if (am and op.cin > 4) else None
             ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE

@@ -44,6 +44,7 @@ def get_precision() -> str:
 # A word holds the float bits of max|tensor| and is written with order-independent atomic maxima by the kernels that
 # produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool and are
 # used once, so a saved activation keeps its word for the backward whatever runs in between.
+AMAX_WORDS = 64          # DCN_AMAX_WORDS: the waves of a producer spread their atomic maxima over this many words
 _amax_pools = {}
 _amax_consts = {}
 
@@ -55,11 +56,11 @@ def use_amax() -> bool:
 def amax_slot(device) -> torch.Tensor:
     key = torch.device(device).index
     pool = _amax_pools.get(key)
-    if pool is None or pool[1] >= pool[0].numel():
-        pool = [torch.zeros(4096, dtype=torch.int32, device=device), 0]
+    if pool is None or pool[1] + AMAX_WORDS > pool[0].numel():
+        pool = [torch.zeros(1024 * AMAX_WORDS, dtype=torch.int32, device=device), 0]
         _amax_pools[key] = pool
-    t = pool[0][pool[1]:pool[1] + 1]
-    pool[1] += 1
+    t = pool[0][pool[1]:pool[1] + AMAX_WORDS]
+    pool[1] += AMAX_WORDS
     return t
 
 
@@ -68,7 +69,7 @@ def amax_const(device, value: float) -> torch.Tensor:
     key = (torch.device(device).index, float(value))
     t = _amax_consts.get(key)
     if t is None:
-        t = torch.tensor([value], dtype=torch.float32).view(torch.int32).to(device)
+        t = torch.full((AMAX_WORDS,), value, dtype=torch.float32).view(torch.int32).to(device)
         _amax_consts[key] = t
     return t
 
@@ -236,7 +237,7 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
         rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     f8 = f8_scales(x, w_ohwi) if (_precision == "fp8" and cin != 4) else None
-    if cin != 4 and cout > 32:              # (the 32-filter tiles stay on the fp32 pipe: no scales needed)
+    if cin != 4:
         amax_x = _amax_or_pass(x, amax_x); amax_w = _amax_or_pass(w_ohwi, amax_w)
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
@@ -254,7 +255,7 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     wt = scratch(w_ohwi.numel(), dy.device, slot=1)
     f8 = f8_scales(dy, w_ohwi) if _precision == "fp8" else None
-    if cin > 32:
+    if True:
         amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
                           n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w), _s())

@@ -30,6 +30,8 @@ extern "C" {
 #define DCN_ERR_ARG (-1)      /* bad shape / null pointer / unsupported size */
 #define DCN_ERR_LAUNCH (-2)   /* hipLaunch failed */
 
+#define DCN_AMAX_WORDS 64      /* words per abs-max vector (see dcn_absmax) */
+
 #define DCN_ACT_NONE 0
 #define DCN_ACT_LEAKY 1       /* y = x > 0 ? x : slope*x   (slope 0 == ReLU) */
 
@@ -66,7 +68,9 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    const float* residual, int ldr, int ldy,
                    float* stats, int accumulate, const float* f8_scales,
                    const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, void* stream);
-/* amax_* (dcn_conv2d_fwd / bwd_data / bwd_weight; NULL = off): device words holding the float bits of max|tensor|.  With both
+/* amax_* (dcn_conv2d_fwd / bwd_data / bwd_weight; NULL = off): abs-max "words" of the tensors — each is a vector of
+ * DCN_AMAX_WORDS (64) device words holding float bits of non-negative values whose maximum is max|tensor| (the waves of a
+ * producing kernel spread their atomic maxima over the 64 words; readers take the maximum; a known bound is 64 copies).  With both
  * operand maxima given, the wide tiles run the fp32-accurate f16 two-piece split (the default "fp32" precision of this
  * library, dcn_set_tuning("precision", 4)): operands scaled by the power of two that brings the maximum below 2^14, cut
  * x = h + l into two f16 (11 + 11 significant bits), l*h + h*l + h*h on v_mfma_f32_32x32x16_f16 — three MFMAs per product

@@ -22,6 +22,98 @@ class _Tiny(torch.nn.Module):
         return self.b(torch.relu(self.a(x)))
 
 
+class _ManyGrads(torch.autograd.Function):
+    """The shape of the real backbone (dcnet_amd.darknet._DarknetFn): ONE autograd node that takes every parameter of a
+    deep stack and hands back all their gradients at once when its backward returns."""
+
+    @staticmethod
+    def forward(ctx, x, *ws):
+        acts = [x]
+        for w in ws:
+            acts.append(torch.tanh(acts[-1] @ w))
+        ctx.save_for_backward(*acts, *ws)
+        ctx.n = len(ws)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        sv = ctx.saved_tensors
+        acts, ws = sv[:ctx.n + 1], sv[ctx.n + 1:]
+        grads = [None] * ctx.n
+        for i in range(ctx.n - 1, -1, -1):
+            g = g * (1 - acts[i + 1] ** 2)
+            grads[i] = acts[i].t() @ g if ctx.needs_input_grad[1 + i] else None
+            g = g @ ws[i].t()
+        return (g,) + tuple(grads)
+
+
+class _Backbone(torch.nn.Module):
+    """40 layers behind one autograd node, 6 of them frozen (the dead YOLO heads of the real model), plus a head that
+    autograd differentiates the ordinary way."""
+
+    def __init__(self, depth=40, width=12):
+        super().__init__()
+        self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(width, width) * 0.3) for _ in range(depth)])
+        self.dead = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(5)) for _ in range(6)])
+        self.head = torch.nn.Linear(width, 3)
+
+    def forward(self, x):
+        return self.head(_ManyGrads.apply(x, *self.ws))
+
+
+def _worker_backbone(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dcnet_amd.parallel import FlatGradAllReduce, broadcast_parameters, shard_indices, wrap_ddp
+    torch.manual_seed(5 + rank)
+    m = _Backbone()
+    for i in (3, 17):                                # frozen layers INSIDE the single node as well
+        m.ws[i].requires_grad_(False)
+    for p in m.dead:
+        p.requires_grad_(False)
+    broadcast_parameters(m, src=0)
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(16, 12, generator=g); tgt = torch.randn(16, 3, generator=g)
+    idx = shard_indices(16, rank, world)
+    res = {}
+    for it in range(2):                              # two steps: DDP rebuilds its buckets after the first
+        m.zero_grad(set_to_none=True)
+        ((m(data[idx]) - tgt[idx]) ** 2).mean().backward()
+        res[f"local{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        FlatGradAllReduce(m.parameters())()
+        res[f"flat{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m2 = _Backbone(); m2.load_state_dict(m.state_dict())
+    for i in (3, 17):
+        m2.ws[i].requires_grad_(False)
+    for p in m2.dead:
+        p.requires_grad_(False)
+    d = wrap_ddp(m2, 0)                              # static graph: no find_unused_parameters
+    for it in range(2):
+        d.zero_grad(set_to_none=True)
+        ((d(data[idx]) - tgt[idx]) ** 2).mean().backward()
+        res[f"ddp{it}"] = {k: p.grad.clone() for k, p in m2.named_parameters() if p.grad is not None}
+    res["frozen_grads"] = [m.ws[3].grad, m.dead[0].grad, m2.ws[17].grad]
+    torch.save(res, os.path.join(out, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_with_a_single_node_backbone(tmp_path):
+    """The real model hands 200 gradients to the reducer from ONE autograd node and keeps 20 parameters frozen: both the
+    flat all-reduce and the DDP wrapper must give the mean of the rank gradients on that shape, two steps in a row."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_backbone, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"b{i}.pt")) for i in range(world)]
+    for it in range(2):
+        keys = list(r[0][f"local{it}"].keys())
+        assert len(keys) == 38 + 2 and not any(".3" == k[-2:] and k.startswith("ws") for k in keys)
+        for k in keys:
+            mean = (r[0][f"local{it}"][k] + r[1][f"local{it}"][k]) / 2
+            for i in range(world):
+                assert torch.allclose(r[i][f"flat{it}"][k], mean, atol=1e-6), (it, k)
+                assert torch.allclose(r[i][f"ddp{it}"][k], mean, atol=1e-6), (it, k)
+    assert all(gr is None for gr in r[0]["frozen_grads"])
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

