@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--exclusive-steps", type=int, default=2,
                     help="untimed steps after the timed region with all side streams off, for the per-kernel "
                          "exclusive duration (0 = skip, e.g. under rocprofv3 so its averages match the timed region)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
     return ap.parse_args()
 
@@ -77,7 +77,9 @@ def parity_check(size: int = 256, n: int = 4):
 
 
 def cpu_baseline(size: int, frames: int, steps: int):
-    """Oracle forward+backward on the host cores, 1 clip (bs 8 would need ~80 GB of host RAM)."""
+    """Oracle forward+backward on the host cores, 1 clip (bs 8 would need ~80 GB of host RAM).  The thread count is
+    chosen by a short sweep (an eval forward of one frame pair at each of 8/16/32/64 threads): more threads than that only
+    slow torch's CPU kernels down on this workload (128 threads measured half the 8-thread rate in round 1)."""
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs, synth_state_dict
     from oracle import dcnet_oracle as O
     from oracle import train_oracle as TO
@@ -89,6 +91,21 @@ def cpu_baseline(size: int, frames: int, steps: int):
     sd0 = synth_state_dict(shapes, seed=0)
     image, word_id, _ = synth_inputs(frames, size, seed=1)
     bbox = synth_boxes(frames, size, seed=1)
+    had = torch.get_num_threads()
+    sweep = {}
+    for nt in (8, 16, 32, 64):
+        if nt > (os.cpu_count() or 8):
+            continue
+        torch.set_num_threads(nt)
+        ts = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.grounding_forward_pairs({k: v.clone() for k, v in sd0.items()}, image[:2], word_id[:2], training=False, sample=False)
+            ts.append(time.perf_counter() - t0)
+        sweep[nt] = min(ts[1:])
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     times = []
     for it in range(steps + 1):
         sd = {k: v.clone() for k, v in sd0.items()}
@@ -101,11 +118,14 @@ def cpu_baseline(size: int, frames: int, steps: int):
         loss, _ = TO.total_loss(o, bbox, size)
         loss.backward()
         times.append(time.perf_counter() - t0)
+    torch.set_num_threads(had)
     t = float(np.median(times[1:]))
-    return {"value": 1.0 / t, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": 1.0 / t, "unit": "clips/s", "cores": best, "kind": "port",
+            "thread_sweep_eval_pair_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "parity": parity_check(),
             "sample": f"oracle/ (CPU restatement pinned to the reference) fwd+5 losses+bwd on 1 clip T={frames} "
-                      f"{size}x{size}, {steps} timed steps after 1 warm-up, median; host has {os.cpu_count()} cpus"}
+                      f"{size}x{size}, {steps} timed steps after 1 warm-up, median, at the best of 8/16/32/64 threads "
+                      f"(picked on an eval forward of one frame pair); host has {os.cpu_count()} cpus"}
 
 
 def main():

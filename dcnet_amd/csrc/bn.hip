@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
     vmax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), vmax);
   }
   if (amax) {                             // abs-max of the tensor just written (order-independent: reproducible)
-    vmax = wave_max(vmax);
-    if ((threadIdx.x & 63) == 0) amax_update(amax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    amax_update_block(amax, vmax, red);
   }
 }
 
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
     vmax = fmaxf(fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))), vmax);
   }
   if (amax) {
-    vmax = wave_max(vmax);
-    if ((threadIdx.x & 63) == 0) amax_update(amax, vmax, blockIdx.x * 4 + (threadIdx.x >> 6));
+    __shared__ float red[4];
+    amax_update_block(amax, vmax, red);
   }
 }
 
@@ -310,7 +310,8 @@ extern "C" int dcn_scale_act(const float* y, const float* scale, const float* sh
   if (ldo <= 0) ldo = c;
   DCN_CHECK_ARG(ldo % 4 == 0, "scale_act: ldo=%d must be a multiple of 4", ldo);
   const int pid = prof_begin(10, (double)rows * c * 4.0 * (residual ? 3 : 2), (hipStream_t)stream);
-  hipLaunchKernelGGL(scale_act_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
+  // (with an abs-max word: at most 1024 workgroups, i.e. 1024 atomics over 64 words; they all finish together)
+  hipLaunchKernelGGL(scale_act_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
                      y, scale, shift, act, slope, residual, out, rows, c, ldo, amax);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("scale_act");
@@ -355,7 +356,7 @@ extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo,
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 4 == 0, "bn_act_bwd_apply: bad argument");
   if (lddo <= 0) lddo = c;
   const int pid = prof_begin(11, (double)rows * c * 4.0 * 3, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
                      y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply");

@@ -58,6 +58,13 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+// One atomic per WORKGROUP (256 threads): the waves' maxima meet in LDS first.  `red` = 4 floats of shared memory.
+__device__ __forceinline__ void amax_update_block(unsigned* amax, float vmax, float* red) {
+  vmax = wave_max(vmax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) amax_update(amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), blockIdx.x);
+}
 // the abs-max held by a DCN_AMAX_WORDS-word vector, as float bits (wave-uniform; every lane of the wave must call)
 __device__ __forceinline__ unsigned amax_read(const unsigned* amax) {
   return __float_as_uint(wave_max(__uint_as_float(amax[threadIdx.x & (DCN_AMAX_WORDS - 1)])));

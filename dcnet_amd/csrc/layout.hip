@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), m);
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) amax_update(out, m, spread ? blockIdx.x * 4 + (threadIdx.x >> 6) : 0u);
+  __shared__ float red[4];
+  m = wave_max(m);            // (already a wave maximum: cheap)
+  if (spread) amax_update_block(out, m, red);
+  else if ((threadIdx.x & 63) == 0) amax_update(out, m, 0u);
 }
 __global__ void f8_scale_finish_kernel(unsigned* bits, float* scale) {
   const float amax = __uint_as_float(*bits);
@@ -146,7 +149,7 @@ extern "C" int dcn_absmax(const float* x, int64_t rows, int c, int ld, uint32_t*
   DCN_CHECK_ARG(x && amax && rows > 0 && c > 0 && c % 4 == 0 && ld % 4 == 0 && ld >= c, "absmax: bad argument (c=%d ld=%d)", c, ld);
   DCN_CHECK_ARG(((uintptr_t)x & 15) == 0, "absmax: x must be 16-byte aligned");
   const int64_t items = rows * (c / 4);
-  const int blocks = (int)((items + 255) / 256 < 2048 ? (items + 255) / 256 : 2048);
+  const int blocks = (int)((items + 255) / 256 < 1024 ? (items + 255) / 256 : 1024);
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c / 4, ld, (unsigned*)amax, 1);
   DCN_CHECK_LAUNCH("absmax");
   return DCN_OK;

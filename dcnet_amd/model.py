@@ -162,8 +162,6 @@ class grounding_model(nn.Module):
         if corpus is None:
             raise NotImplementedError("corpus=None selects the BERT text encoder, which is outside the LSTM hot path "
                                       "(train_DCNet.py is run with --lstm); pass the dataset corpus")
-        if light:
-            raise NotImplementedError("light=True (1-layer fcn_emb) is not used by the released scripts")
         if not coordmap:
             raise NotImplementedError("coordmap=False is not used by the released scripts")
         self.coordmap, self.light, self.lstm, self.emb_size = coordmap, light, True, emb_size
@@ -197,13 +195,19 @@ class grounding_model(nn.Module):
             nn.Conv1d(in_channels=query_len, out_channels=query_len, stride=1, kernel_size=3, padding=1, bias=True),
             nn.Softmax(dim=1))
         embin_size = emb_size * 2 + 8
-        self.fcn_emb = nn.Sequential(OrderedDict([
-            (str(i), nn.Sequential(ConvBatchNormReLU(embin_size, emb_size, 1, 1, 0, 1, leaky=leaky),
-                                   ConvBatchNormReLU(emb_size, emb_size, 3, 1, 1, 1, leaky=leaky),
-                                   ConvBatchNormReLU(emb_size, emb_size, 1, 1, 0, 1, leaky=leaky))) for i in range(3)]))
-        self.fcn_out = nn.Sequential(OrderedDict([
-            (str(i), nn.Sequential(ConvBatchNormReLU(emb_size, emb_size // 2, 1, 1, 0, 1, leaky=leaky),
-                                   nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
+        if light:                                                # model/DCNet_model.py:296-312
+            self.fcn_emb = nn.Sequential(OrderedDict([
+                (str(i), nn.Sequential(ConvBatchNormReLU(embin_size, emb_size, 1, 1, 0, 1, leaky=leaky))) for i in range(3)]))
+            self.fcn_out = nn.Sequential(OrderedDict([
+                (str(i), nn.Sequential(nn.Conv2d(emb_size, 3 * 5, kernel_size=1))) for i in range(3)]))
+        else:                                                    # :313-338
+            self.fcn_emb = nn.Sequential(OrderedDict([
+                (str(i), nn.Sequential(ConvBatchNormReLU(embin_size, emb_size, 1, 1, 0, 1, leaky=leaky),
+                                       ConvBatchNormReLU(emb_size, emb_size, 3, 1, 1, 1, leaky=leaky),
+                                       ConvBatchNormReLU(emb_size, emb_size, 1, 1, 0, 1, leaky=leaky))) for i in range(3)]))
+            self.fcn_out = nn.Sequential(OrderedDict([
+                (str(i), nn.Sequential(ConvBatchNormReLU(emb_size, emb_size // 2, 1, 1, 0, 1, leaky=leaky),
+                                       nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
         self._pinned = {}
         self._pin_event = None
@@ -250,10 +254,9 @@ class grounding_model(nn.Module):
         z, za = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
                                       blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training, one)
         z._dcn_amax = za
-        z = self.fcn_emb[s][1](z)
-        z = self.fcn_emb[s][2](z)
-        z = self.fcn_out[s][0](z)
-        last = self.fcn_out[s][1]
+        for blk in list(self.fcn_emb[s])[1:] + list(self.fcn_out[s])[:-1]:       # (none of them with light=True)
+            z = blk(z)
+        last = self.fcn_out[s][-1]
         return ConvBias.apply(z, last.weight, last.bias, getattr(z, "_dcn_amax", None))    # (B,H,W,32): channels 15..31 are zero padding
 
     def _scale_pairs(self, s: int, raw_s, flang, flang_attn):

@@ -335,10 +335,15 @@ def _head(sd: SD, corr_feat: List[Tensor], word_id: Tensor, training: bool,
         tile = flang.view(B, -1, 1, 1).repeat(1, 1, h, w)            # :492-493
         coord = generate_coord(B, h, w); coord_list.append(coord)    # :495-496
         z = torch.cat([corr_feat[ii], tile, coord], dim=1)           # :497
-        for j, k in enumerate((1, 3, 1)):                            # fcn_emb :314-327
-            z = conv_bn_relu(sd, f"fcn_emb.{ii}.{j}", z, k, training)
-        z = conv_bn_relu(sd, f"fcn_out.{ii}.0", z, 1, training)      # :328-338
-        z = F.conv2d(z, sd[f"fcn_out.{ii}.1.weight"], sd[f"fcn_out.{ii}.1.bias"])
+        j = 0
+        while f"fcn_emb.{ii}.{j}.conv.weight" in sd:                 # fcn_emb :314-327 (three blocks; light=True: one, :296-303)
+            z = conv_bn_relu(sd, f"fcn_emb.{ii}.{j}", z, sd[f"fcn_emb.{ii}.{j}.conv.weight"].shape[-1], training)
+            j += 1
+        if f"fcn_out.{ii}.0.conv.weight" in sd:                      # :328-338
+            z = conv_bn_relu(sd, f"fcn_out.{ii}.0", z, 1, training)
+            z = F.conv2d(z, sd[f"fcn_out.{ii}.1.weight"], sd[f"fcn_out.{ii}.1.bias"])
+        else:                                                        # light=True: a bare Conv2d (:304-312)
+            z = F.conv2d(z, sd[f"fcn_out.{ii}.0.weight"], sd[f"fcn_out.{ii}.0.bias"])
         outbox.append(z)
 
     _, flang_attn = phrase_attention(sd, "sub_attn", context, embedded, word_id)   # :525

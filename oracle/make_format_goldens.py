@@ -196,6 +196,28 @@ def main():
             "square_avg_crc32": {str(i): _crc(ref_state[i]["square_avg"]) for i in (0, 92, 93, 314) if i in ref_state}}
         print("checkpoint: reference save_checkpoint -> product load_checkpoint ok;", rep["checkpoint_reference_writer"]["optimizer_group_sizes"],
               "groups,", len(ref_state), "state entries")
+    # ---- 4. light=True head (model/DCNet_model.py:296-312) -------------------------------------------------
+    from dcnet_amd.utils.synth import apply_bn_calibration, synth_inputs
+    lm = _ref_model_module("DCNet_model", _P(256)).grounding_model(
+        corpus=list(range(1000)), light=True, emb_size=512, coordmap=True, bert_model="bert-base-uncased", dataset="vid")
+    lshapes = {k: tuple(v.shape) for k, v in lm.state_dict().items()}
+    lsd = apply_bn_calibration(synth_state_dict(lshapes, seed=0), os.path.join(GOLD, "bn_calib.npz"))
+    lm.load_state_dict(lsd, strict=True)
+    lm.eval()
+    image, word_id, word_mask = synth_inputs(2, 256, seed=77)
+    random.seed(13)
+    with torch.no_grad():
+        outbox, sim, loc, only_obj = lm(image, word_id, word_mask)
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in lsd.items()}, image, word_id, training=False, sample=False)
+    d = max(max(float((a - b).abs().max()) for a, b in zip(outbox, o["outbox"])), max(float((a - b).abs().max()) for a, b in zip(sim, o["sim_score"])))
+    dl = max(float((a - b).abs().max()) for a, b in zip(loc, o["loc_score"]))
+    print(f"light=True eval 256 N=2: max|ref-oracle| = {d:.2e} (loc {dl:.2e}); {len(lshapes)} state_dict keys")
+    assert d < 1e-5 and dl < 2e-4
+    lg = dict(size=256, n=2, seed_inputs=77, keys=np.array(list(lshapes.keys())))
+    for s_ in range(3):
+        lg[f"outbox{s_}"] = outbox[s_].numpy(); lg[f"sim{s_}"] = sim[s_].numpy(); lg[f"loc{s_}"] = loc[s_].numpy()
+    np.savez_compressed(os.path.join(GOLD, "eval_light_S256_N2.npz"), **lg)
+    rep["light_model"] = {"n_keys": len(lshapes), "n_params": int(sum(p.numel() for p in lm.parameters()))}
     with open(os.path.join(GOLD, "formats_ref.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print("format fixtures written to", GOLD)
