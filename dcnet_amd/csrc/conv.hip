@@ -25,6 +25,40 @@ __global__ __launch_bounds__(256) void transpose_filter_kernel(const float* __re
   }
 }
 
+// x*s = h + l (two f16, round to nearest) for every element; 8 consecutive k of a row become [8 x h | 8 x l] in the same
+// 32 bytes, so the pre-split bank has the size, row stride and tap offsets of the fp32 one.  s (the power of two that maps
+// the bank's abs-max below 2^14) goes to scale_out[0].  In place (src == dst) is fine: a thread rewrites its own 32 bytes.
+__global__ __launch_bounds__(256) void presplit_kernel(const float* src, float* dst, int64_t groups,
+                                                       const unsigned* __restrict__ amax, float* __restrict__ scale_out) {
+  const unsigned bits = amax_read(amax);
+  const int be = (int)((bits >> 23) & 0xFF);
+  int e = (be == 0 || be == 255) ? 0 : 14 - (be - 126);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  const float s = __uint_as_float((unsigned)(e + 127) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+  typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + g * 8), b = *reinterpret_cast<const f32x4*>(src + g * 8 + 4);
+    f16x8_t h, l;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ta = a[k] * s, tb = b[k] * s;
+      h[k] = (_Float16)ta; h[4 + k] = (_Float16)tb;
+      l[k] = (_Float16)(ta - (float)h[k]); l[4 + k] = (_Float16)(tb - (float)h[4 + k]);
+    }
+    *reinterpret_cast<f16x8_t*>(dst + g * 8) = h;
+    *reinterpret_cast<f16x8_t*>(dst + g * 8 + 4) = l;
+  }
+}
+
+int launch_presplit(const float* src, float* dst, int64_t numel, const uint32_t* amax, float* scale_out, hipStream_t stream) {
+  const int64_t groups = numel / 8;
+  const int blocks = (int)((groups + 255) / 256 < 2048 ? (groups + 255) / 256 : 2048);
+  hipLaunchKernelGGL(presplit_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, groups, (const unsigned*)amax, scale_out);
+  DCN_CHECK_LAUNCH("presplit_f16");
+  return DCN_OK;
+}
+
 void base_params(IgemmParams& p) {
   p = IgemmParams{};
   p.osy = p.osx = 1; p.isy = p.isx = 1; p.dense_out = 1;
@@ -43,7 +77,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                               const float* scale, const float* shift, int act, float slope,
                               const float* residual, int ldr, int ldy,
                               float* stats, int accumulate, const float* f8_scales,
-                              const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, void* stream) {
+                              const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, void* stream) {
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize=%d (1 or 3)", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride=%d (1 or 2)", stride);
   DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0, "conv2d_fwd: bad shape");
@@ -72,6 +106,13 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
         p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
       }
   }
+  if (w_split && amax_x && amax_w && !p.c4 && igemm_will_presplit(p.M, cout, p.ntaps, cin)) {
+    // split the filter bank once (into the caller's scratch: cout*k*k*cin + 16 floats), not once per M-tile
+    const int64_t numel = (int64_t)cout * p.ntaps * cin;
+    int rc = launch_presplit(w, w_split, numel, amax_w, w_split + numel, (hipStream_t)stream);
+    if (rc != DCN_OK) return rc;
+    p.wt = w_split; p.b_scale = w_split + numel;
+  }
   return igemm_launch(p, (hipStream_t)stream);
 }
 
@@ -95,6 +136,13 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
   p.accumulate = accumulate;
+  if (amax_dy && amax_w && igemm_will_presplit((long long)n * (stride == 1 ? h * wd : (h / 2) * (wd / 2)), cin, stride == 1 ? T : 1, cout)) {
+    // (stride 2: the four parity classes share one bank; the smallest class, with 1 tap, decides for all of them)
+    const int64_t numel = (int64_t)cin * T * cout;
+    int rc = launch_presplit(wt, wt, numel, amax_w, wt + numel, stream);     // in place; the scale lands behind the bank
+    if (rc != DCN_OK) return rc;
+    p.b_scale = wt + numel;
+  }
   if (stride == 1) {
     // dx[hi,wi] = sum_{r,s} dy[hi+pad-r, wi+pad-s] . w[:,r,s,:]
     p.Hs = h; p.Ws = wd; p.M = n * h * wd; p.ntaps = T;

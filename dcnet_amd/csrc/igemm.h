@@ -18,6 +18,7 @@ struct IgemmParams {
   const float* f8;        // optional device {sA, sB}: power-of-two operand scales of the fp8 path (dcn_f8_scale); null = off
   const unsigned* amax_a; // optional device word: float bits of max|in| (f16 two-piece split: the kernel derives its power-of-two
   const unsigned* amax_b; //   scales from these); both needed, else the launch stays on the bf16 three-piece split
+  const float* b_scale;   // non-null: wt is pre-split (dcn_presplit_f16) with this power-of-two scale; igemm_will_presplit() says when
   unsigned* amax_out;     // optional device word: atomicMax of |stored values| (the abs-max of the tensor this launch produces)
   float* out;             // NHWC, pixel stride ldo
   const float* scale;     // per-Co, may be null
@@ -46,3 +47,6 @@ struct IgemmParams {
 // rows of the stats partial buffer (= number of M-blocks) the launch will use
 int igemm_grid_m(int M, int Co, int ntaps);
 int igemm_launch(const IgemmParams& p, hipStream_t stream);
+// true if a launch with these dimensions (rows = M x batch, filters Co, taps, channels Ci) would take a tile that reads a
+// pre-split filter bank in the current precision mode: the caller then pre-splits (dcn_presplit_f16) and sets b_scale
+bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci);

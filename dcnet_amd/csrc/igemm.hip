@@ -92,9 +92,13 @@ __device__ __forceinline__ bf16x8 nn_frag(const unsigned char* base, int byte0, 
 // rounded to OCP fp8 e4m3 (v_cvt_pk_fp8_f32) when the tile is staged, multiplied by v_mfma_f32_32x32x16_fp8_fp8 (one
 // 16-B LDS fragment = 16 fp8 feeds two MFMAs), accumulated in fp32 and rescaled by 1/(sA*sB) before the epilogue:
 // the builder-defined fp8 conv path of BASELINE.json configs[4] (ops.set_precision("fp8")).
+// BPRE (with NP = 2): the B operand (filter bank) arrives ALREADY split — dcn_presplit_f16 rewrote every 8 consecutive k of
+// a row as [8 x f16 high | 8 x f16 low] (same 32 bytes), scaled by *b_scale — so its tile is a plain 16-B copy into the two
+// LDS planes: the split of the weights happens once per layer and step instead of once per M-tile (338 times on a 26x26 map).
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1,
-          bool F8 = false>
+          bool F8 = false, bool BPRE = false>
 __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
+  static_assert(!BPRE || (SP && NP == 2 && BMODE == 0 && BK == 16), "pre-split B: f16 split, NT tiles, 16-deep K-step");
   static_assert(!F8 || (SP && NP == 1 && BK == 32 && BMODE == 0), "fp8 operands: NT tiles, 32-deep K-step");
   static_assert(!SP || !C4, "split mode: no stem path");
   static_assert(!SP || BMODE == 0 || (BN == 128 && BK == 16 && (NP == 3 || NP == 2)), "split NN mode: 128-wide tile, 16-deep K-step");
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     return (BK == 16 || F8) ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
   };
   float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
-  if constexpr (H2) { f8_sa = pow2_scale(amax_read(p.amax_a)); f8_sb = pow2_scale(amax_read(p.amax_b)); }
+  if constexpr (H2) { f8_sa = pow2_scale(amax_read(p.amax_a)); f8_sb = BPRE ? p.b_scale[0] : pow2_scale(amax_read(p.amax_b)); }
+  // pre-split B: chunk c of a K-step row holds plane c & 1, k-half c >> 1 (ushort offset of the 16-B piece inside the plane)
+  auto bpre_w = [](int row, int chunk) { return row * 16 + ((((chunk >> 1) ^ (row >> 3)) & 1) << 3); };
   constexpr int CPR = BK / 4;              // 16-B chunks per K-step row
   constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
   constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -290,6 +296,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       for (int j = 0; j < A_LD; ++j) split_store(a16, BM * LD16, sp_w(row0 + RPP * j, chunk), a_reg[j], f8_sa);
 #pragma unroll
       for (int j = 0; j < B_LD; ++j) {
+        if constexpr (BPRE) {
+          if (!B_PART || row0 < BN) *reinterpret_cast<f32x4*>(b16 + (chunk & 1) * B_PLANE + bpre_w(row0 + RPP * j, chunk)) = b_reg[j];
+        } else
         if constexpr (BMODE == 0) { if (!B_PART || row0 < BN) split_store(b16, B_PLANE, sp_w(row0 + RPP * j, chunk), b_reg[j], f8_sb); }
         else split_store(b16, B_PLANE, nn_off((tid + 256 * j) >> 5, ((tid + 256 * j) & 31) * 4) >> 1, b_reg[j], f8_sb);
       }
@@ -388,6 +397,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
               if (pc < A_LD) split_store(na, BM * LD16, sp_w(row0 + RPP * pc, chunk), ar[pc], f8_sa);
               else if constexpr (BMODE == 1)
                 split_store(nb, B_PLANE, nn_off((tid + 256 * (pc - A_LD)) >> 5, ((tid + 256 * (pc - A_LD)) & 31) * 4) >> 1, br[pc - A_LD], f8_sb);
+              else if constexpr (BPRE) {
+                if (!B_PART || row0 < BN) *reinterpret_cast<f32x4*>(nb + (chunk & 1) * B_PLANE + bpre_w(row0 + RPP * (pc - A_LD), chunk)) = br[pc - A_LD];
+              }
               else if (!B_PART || row0 < BN) split_store(nb, B_PLANE, sp_w(row0 + RPP * (pc - A_LD), chunk), br[pc - A_LD], f8_sb);
             }
           }
@@ -567,7 +579,8 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1, bool F8 = false>
+template <int BM, int BN, int WM, int WN, int BMODE, bool C4, int BK, bool SP = false, int ABL = 0, int NP = 3, int OCC = 1, bool F8 = false,
+          bool BPRE = false>
 int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   IgemmParams p = p0;
   p.cpt = p.c4 ? 1 : p.Ci / BK;
@@ -579,7 +592,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
@@ -588,7 +601,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : NP == 2 ? (BMODE == 1 ? 27 : BN == 64 ? 26 : 24) : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
   const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
-  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
   return DCN_OK;
@@ -609,6 +622,7 @@ int g_precision = 4;      // dcn_set_tuning("precision", 0..4): 0 = fp32 MFMA ev
 int g_h2_occ3 = 0;        // dcn_set_tuning("h2occ", 0): f16-split 128x128 tile built for 2 instead of 3 waves/SIMD
 int g_h2_narrow = 0;      // dcn_set_tuning("rnarrow", 1): the narrow NT tiles (128x64, 256x32, 64x128) on the f16 split as well
 int g_h2_bk = 16;         // dcn_set_tuning("qbk", 32): K-step of the f16-split tiles
+int g_h2_presplit = 1;    // dcn_set_tuning("ypresplit", 0): filter banks split inside every workgroup again
 
 template <int BM, int BN, int WM, int WN, int BMODE, bool C4 = false>
 int launch_variant(const IgemmParams& p, hipStream_t stream) {
@@ -620,9 +634,10 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
     if (p.f8 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
-    if (g_precision == 4 && p.amax_a && p.amax_b && rows >= 1024 &&
+    if (g_precision == 4 && p.amax_a && (p.amax_b || p.b_scale) && rows >= 1024 &&
         ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || g_h2_narrow)) {
       // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
+      if (p.b_scale) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 1, false, true>(p, stream);    // pre-split filter bank
       if (g_h2_bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 2>(p, stream);
       if (BM == 128 && BN == 128 && g_h2_occ3) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 3>(p, stream);
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2>(p, stream);
@@ -686,11 +701,18 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   else if (k == 'h') g_h2_occ3 = value;      // "h2occ"
   else if (k == 'r') g_h2_narrow = value;    // "rnarrow"
   else if (k == 'q') g_h2_bk = value;        // "qbk"
+  else if (k == 'y') g_h2_presplit = value;  // "ypresplit"
   else if (k == 't') g_tile64 = value;       // "tile64"
   else if (k == 'a') { g_abl = value; wgrad_set_abl(value); }         // "abl"
   else if (k == 's') g_split = value;        // "split": 0 = fp32 MFMA, 16 / 32 = split-bf16 MFMA with that K-step
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
   return DCN_OK;
+}
+
+bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci) {
+  if (g_precision != 4 || !g_h2_presplit || g_split || rows < 1024 || Co <= 32) return false;
+  if (Co <= 64) return tile_bm((int)rows, Co, ntaps, Ci) == 256;       // the 256x64 split tile
+  return tile_bm((int)rows, Co, ntaps, Ci) == 128;                     // the 128x128 tile
 }
 
 int igemm_launch(const IgemmParams& p, hipStream_t stream) {
@@ -701,6 +723,9 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.ldi % 4 == 0 && p.ldw % 4 == 0, "igemm: ldi=%d ldw=%d must be multiples of 4 floats", p.ldi, p.ldw);
   DCN_CHECK_ARG(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wt & 15) == 0, "igemm: in/wt must be 16-byte aligned");
   DCN_CHECK_ARG(p.stats == nullptr || p.batch <= 1, "igemm: stats are not supported on batched launches");
+  DCN_CHECK_ARG(p.b_scale == nullptr || (p.amax_a && p.bmode == 0 && !p.c4 &&
+                                         igemm_will_presplit((long long)p.M * (p.batch > 0 ? p.batch : 1), p.Co, p.ntaps, p.Ci)),
+                "igemm: a pre-split filter bank on a launch whose tile cannot read it (M=%d Co=%d taps=%d)", p.M, p.Co, p.ntaps);
   // 32-bit offset windows: one M-tile spans at most ceil(BM/(Hs*Ws))+1 images of the gathered tensor
   {
     const long long img_bytes = (long long)p.Hi * p.Wi * p.ldi * 4;

@@ -22,7 +22,7 @@ SIGNATURES = {
     "dcn_nhwc_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "dcn_oihw_to_ohwi": (I, [P, P, I, I, I, I, I, P]),
     "dcn_ohwi_to_oihw": (I, [P, P, I, I, I, I, I, P]),
-    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P, P, P, P]),
+    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P, P, P, P, P]),
     "dcn_absmax": (I, [P, L, I, I, P, P]),
     "dcn_f8_scale": (I, [P, L, I, I, P, P, P]),
     "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),

@@ -237,12 +237,15 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
         rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
     f8 = f8_scales(x, w_ohwi) if (_precision == "fp8" and cin != 4) else None
+    wsplit = None
     if cin != 4:
         amax_x = _amax_or_pass(x, amax_x); amax_w = _amax_or_pass(w_ohwi, amax_w)
+        if amax_w is not None:
+            wsplit = scratch(w_ohwi.numel() + 16, x.device, slot=5)       # the filter bank, split once per launch
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
                      0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8),
-                     _p(amax_x), _p(amax_w), _p(amax_out), _s())
+                     _p(amax_x), _p(amax_w), _p(amax_out), _p(wsplit), _s())
     return out, stats
 
 
@@ -253,7 +256,7 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     h, wd = in_hw
     if out is None:
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
-    wt = scratch(w_ohwi.numel(), dy.device, slot=1)
+    wt = scratch(w_ohwi.numel() + 16, dy.device, slot=1)
     f8 = f8_scales(dy, w_ohwi) if _precision == "fp8" else None
     if True:
         amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)

@@ -67,7 +67,11 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    const float* scale, const float* shift, int act, float slope,
                    const float* residual, int ldr, int ldy,
                    float* stats, int accumulate, const float* f8_scales,
-                   const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, void* stream);
+                   const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, void* stream);
+/* w_split (optional scratch, cout*k*k*cin + 16 floats): with the f16 split, the filter bank is cut into its two f16 pieces
+ * ONCE into this buffer (8 consecutive k -> [8 high | 8 low], same bytes) and the tiles copy it, instead of every M-tile
+ * splitting the same weights again.  dcn_conv2d_bwd_data does the same in place on its `wt` scratch, which therefore
+ * must hold 16 floats more than the bank when amax_w is given. */
 /* amax_* (dcn_conv2d_fwd / bwd_data / bwd_weight; NULL = off): abs-max "words" of the tensors — each is a vector of
  * DCN_AMAX_WORDS (64) device words holding float bits of non-negative values whose maximum is max|tensor| (the waves of a
  * producing kernel spread their atomic maxima over the 64 words; readers take the maximum; a known bound is 64 copies).  With both

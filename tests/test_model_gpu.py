@@ -418,3 +418,36 @@ def test_eval_forward_at_an_unlisted_size(dev):
         o = O.grounding_forward_nframe({k: v.clone() for k, v in sd.items()}, image, word_id, 3)
     for s in range(3):
         assert maxdiff(ob[s], o["outbox"][s]) < TOL and maxdiff(lc[s], o["loc_score"][s]) < TOL and maxdiff(cf[s], o["corr_feat"][s]) < TOL
+
+
+def test_light_head_matches_oracle_and_reference_fixture(dev):
+    """light=True (train_DCNet.py:479 passes args.light; model/DCNet_model.py:296-312): eval outputs against the oracle and
+    the reference's stored outputs, a training step runs, and the state_dict has the reference's 543 keys."""
+    from dcnet_amd import losses
+    from dcnet_amd.utils.synth import apply_bn_calibration, synth_boxes, synth_inputs, synth_state_dict
+    from model.DCNet_model import grounding_model
+    from oracle import dcnet_oracle as O
+    from util import ROOT
+    gold = np.load(os.path.join(GOLD, "eval_light_S256_N2.npz"), allow_pickle=True)
+    m = grounding_model(corpus=list(range(1000)), light=True, emb_size=512, coordmap=True, img_size=256,
+                        config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None)
+    assert list(m.state_dict().keys()) == [str(k) for k in gold["keys"]]
+    sd = apply_bn_calibration(synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=0), os.path.join(GOLD, "bn_calib.npz"))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    image, word_id, word_mask = synth_inputs(2, 256, seed=77)
+    with torch.no_grad():
+        outbox, sim, loc, only_obj = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image, word_id, training=False, sample=False)
+    for s in range(3):
+        assert maxdiff(outbox[s], o["outbox"][s]) < TOL and maxdiff(loc[s], o["loc_score"][s]) < TOL
+        assert maxdiff(outbox[s], torch.from_numpy(gold[f"outbox{s}"])) < TOL and maxdiff(sim[s], torch.from_numpy(gold[f"sim{s}"])) < TOL
+        assert maxdiff(loc[s], torch.from_numpy(gold[f"loc{s}"])) < TOL
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    random.seed(13)
+    loss, _ = losses.total_loss(m(image.to(dev), word_id.to(dev), word_mask.to(dev)), synth_boxes(2, 256, seed=77).to(dev), 256)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(m.fcn_out[0][0].weight.grad).all() and float(m.fcn_emb[2][0].conv.weight.grad.abs().max()) > 0

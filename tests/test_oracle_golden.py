@@ -89,3 +89,30 @@ def test_pin_report_is_within_bounds():
     for k, v in rep.items():
         if k.endswith("_eval") or k.endswith("_nframe") or k.endswith("_train_out"):
             assert v < 1e-4, (k, v)
+
+
+def test_oracle_light_head_matches_reference_fixture():
+    """light=True (model/DCNet_model.py:296-312): one-block fcn_emb, bare Conv2d fcn_out; fixture written by
+    oracle/make_format_goldens.py from the real reference."""
+    import numpy as np
+    import os
+    from dcnet_amd.utils.synth import apply_bn_calibration, synth_inputs, synth_state_dict
+    from oracle import dcnet_oracle as O
+    from util import GOLD, ref_shapes
+    g = np.load(os.path.join(GOLD, "eval_light_S256_N2.npz"), allow_pickle=True)
+    full = ref_shapes(256)
+    shapes = {}
+    for k in (str(x) for x in g["keys"]):
+        if k in full:
+            shapes[k] = full[k]
+        elif k.startswith("fcn_out."):                       # fcn_out.{s}.0.{weight,bias}: Conv2d(512, 15, 1)
+            shapes[k] = (15, 512, 1, 1) if k.endswith("weight") else (15,)
+    assert len(shapes) == len(g["keys"]) == 543
+    sd = apply_bn_calibration(synth_state_dict(shapes, seed=0), os.path.join(GOLD, "bn_calib.npz"))
+    image, word_id, _ = synth_inputs(2, 256, seed=77)
+    with torch.no_grad():
+        o = O.grounding_forward_pairs(sd, image, word_id, training=False, sample=False)
+    for s in range(3):
+        assert float((o["outbox"][s] - torch.from_numpy(g[f"outbox{s}"])).abs().max()) < 2e-5
+        assert float((o["sim_score"][s] - torch.from_numpy(g[f"sim{s}"])).abs().max()) < 2e-5
+        assert float((o["loc_score"][s] - torch.from_numpy(g[f"loc{s}"])).abs().max()) < 5e-4
