@@ -201,13 +201,16 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     NT = 32
+    alg_bytes = []
 
     def collect():
-        c = (ctypes.c_int64 * NT)(); m = (ctypes.c_double * NT)(); w = (ctypes.c_double * NT)()
-        L.prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(w))
+        c = (ctypes.c_int64 * NT)(); m = (ctypes.c_double * NT)(); w = (ctypes.c_double * NT)(); by = (ctypes.c_double * NT)()
+        L.prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(w), ctypes.addressof(by))
+        alg_bytes.clear(); alg_bytes.extend(list(by))
         return list(c), list(m), list(w)
 
     counts, ms, work = collect()
+    timed_bytes = list(alg_bytes)
 
     # Untimed passes after the timed region (every rank runs them, so DDP stays in step):
     #  * "exclusive": the product configuration with the weight-gradient stream switched off.  The timed region
@@ -260,10 +263,11 @@ def main():
                  21: "igemm_kernel<128,128,2,2,1,false,16,true> (NN)",
                  22: "channel_partials_kernel<1>",
                  23: "igemm_kernel<*,*,*,*,0,false,32,true,0,1,1,true> (fp8 operands)",
-                 24: "igemm_kernel<128,128,2,2,0,false,16,true,0,2> (f16 two-piece split)",
-                 25: "wgrad_kernel<128,128,16,true,0,2> (f16 two-piece split)",
-                 26: "igemm_kernel<256,64,4,1,0,false,16,true,0,2> (f16 two-piece split)",
-                 27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2> (NN, f16 two-piece split)"}
+                 # 24-27: the f16 two-piece split (fp32 accuracy, three MFMAs per product): the default arithmetic
+                 24: "igemm_kernel<128,128,2,2,0,false,16,true,0,2>",
+                 25: "wgrad_kernel<128,128,16,true,0,2>",
+                 26: "igemm_kernel<256,64,4,1,0,false,16,true,0,2>",
+                 27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2>"}
         flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27}
         peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27)
                        else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
@@ -282,17 +286,20 @@ def main():
         kern = table(counts, ms, work, args.steps)
         mm_tags = sorted(flop_tags - {13, 14})
         dom = max(mm_tags, key=lambda t: work[t])       # the kernel that carries most of the step's FLOPs
-        traffic = None
+        traffic = None; traffic_src = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
             with open(pmc_file) as f:
                 pmc = json.load(f)
             if pmc.get("kernel") == names[dom]:
                 traffic = pmc.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/pmc_latest.json (rocprofv3 --pmc passes of an earlier run of this command, not this run)"
+        alg_b = timed_bytes[dom] / counts[dom] if counts[dom] else None
         mfma_ms = sum(ms[t] for t in mm_tags); mfma_work = sum(work[t] for t in mm_tags)
         ach = work[dom] / (ms[dom] * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": ach, "peak": peak_of[dom], "unit": "TFLOP/s",
-                    "frac": ach / peak_of[dom], "traffic": traffic,
+                    "frac": ach / peak_of[dom], "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": alg_b, "traffic_ratio": (traffic / alg_b) if (traffic and alg_b) else None,
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
                     "peak_note": ("fp32 operands as 2 f16 pieces (per-tensor power-of-two scale), 3 cross terms on "
                                   "v_mfma_f32_32x32x16_f16: peak = 2516.6 TFLOP/s dense f16 / 3 = 838.9 algorithmic fp32 TFLOP/s")

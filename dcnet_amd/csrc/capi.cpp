@@ -41,14 +41,14 @@ extern "C" int dcn_stream_priority_range(int* least, int* greatest) {
 
 // ---- profiler ---------------------------------------------------------------------------------
 namespace {
-struct Rec { hipEvent_t a, b; int tag; double work; };
+struct Rec { hipEvent_t a, b; int tag; double work, bytes; };
 std::vector<Rec> g_recs;
 size_t g_used = 0;
 bool g_on = false;
 constexpr size_t kMaxRecs = 1 << 16;
 }  // namespace
 
-int prof_begin(int tag, double work, hipStream_t s) {
+int prof_begin(int tag, double work, hipStream_t s, double bytes) {
   if (!g_on || g_used >= kMaxRecs) return -1;
   if (g_used == g_recs.size()) {
     Rec r{};
@@ -56,7 +56,7 @@ int prof_begin(int tag, double work, hipStream_t s) {
     g_recs.push_back(r);
   }
   Rec& r = g_recs[g_used];
-  r.tag = tag; r.work = work;
+  r.tag = tag; r.work = work; r.bytes = bytes;
   (void)hipEventRecord(r.a, s);
   return (int)g_used++;
 }
@@ -73,15 +73,15 @@ extern "C" int dcn_prof_enable(int on) {
 }
 
 // Host-synchronising: waits for every recorded event, then sums per tag.  counts/ms/work: [DCN_PROF_TAGS].
-extern "C" int dcn_prof_collect(int64_t* counts, double* ms, double* work) {
+extern "C" int dcn_prof_collect(int64_t* counts, double* ms, double* work, double* bytes) {
   DCN_CHECK_ARG(counts && ms && work, "prof_collect: null pointer");
-  for (int t = 0; t < DCN_PROF_TAGS; ++t) { counts[t] = 0; ms[t] = 0.0; work[t] = 0.0; }
+  for (int t = 0; t < DCN_PROF_TAGS; ++t) { counts[t] = 0; ms[t] = 0.0; work[t] = 0.0; if (bytes) bytes[t] = 0.0; }
   for (size_t i = 0; i < g_used; ++i) {
     Rec& r = g_recs[i];
     if (hipEventSynchronize(r.b) != hipSuccess) continue;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
-    if (r.tag >= 0 && r.tag < DCN_PROF_TAGS) { counts[r.tag]++; ms[r.tag] += t; work[r.tag] += r.work; }
+    if (r.tag >= 0 && r.tag < DCN_PROF_TAGS) { counts[r.tag]++; ms[r.tag] += t; work[r.tag] += r.work; if (bytes) bytes[r.tag] += r.bytes; }
   }
   return DCN_OK;
 }

@@ -116,7 +116,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   auto sp_r = [](int row, int half) {       // ushort offset of the 16-B half `half` (K-step slice 0) of `row`
     return (BK == 16 || F8) ? row * 16 + (((half ^ (row >> 3)) & 1) << 3) : row * LD16 + half * 8;
   };
-  float f8_sa = F8 ? p.f8[0] : 1.f, f8_sb = F8 ? p.f8[1] : 1.f;
+  // fp8: the scales either come ready (p.f8, from dcn_f8_scale's abs-max pass) or are derived here from the operands' tracked
+  // abs-max words: the power of two that maps the maximum into [2^7, 2^8) — inside e4m3's finite range (448), no extra pass
+  float f8_sa = 1.f, f8_sb = 1.f;
+  if constexpr (F8) {
+    if (p.f8) { f8_sa = p.f8[0]; f8_sb = p.f8[1]; }
+    else { f8_sa = pow2_scale(amax_read(p.amax_a)) * (1.f / 64.f); f8_sb = pow2_scale(amax_read(p.amax_b)) * (1.f / 64.f); }
+  }
   if constexpr (H2) { f8_sa = pow2_scale(amax_read(p.amax_a)); f8_sb = BPRE ? p.b_scale[0] : pow2_scale(amax_read(p.amax_b)); }
   // pre-split B: chunk c of a K-step row holds plane c & 1, k-half c >> 1 (ushort offset of the 16-B piece inside the plane)
   auto bpre_w = [](int row, int chunk) { return row * 16 + ((((chunk >> 1) ^ (row >> 3)) & 1) << 3); };
@@ -600,7 +606,9 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
   const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : NP == 2 ? (BMODE == 1 ? 27 : BN == 64 ? 26 : 24) : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
   const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
-  const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream);
+  // algorithmic bytes: the gathered tensor once (rows actually addressed: N*Hi*Wi pixels of Ci), the filter bank, the output
+  const double alg_bytes = 4.0 * nb * ((double)p.N * p.Hi * p.Wi * (p.c4 ? 4 : p.Ci) + (double)p.Co * k_alg + (double)p.M * p.Co);
+  const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
@@ -632,7 +640,7 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // narrow tiles gain nothing from the split (its vector-ALU cost per MFMA grows as the tile shrinks:
     // measured 0.6-1.0x on the 128x64 / 256x32 tiles, 1.4-1.8x on 128x128)
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
-    if (p.f8 && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
+    if ((p.f8 || (g_precision == 3 && p.amax_a && p.amax_b)) && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
     if (g_precision == 4 && p.amax_a && (p.amax_b || p.b_scale) && rows >= 1024 &&
         ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || g_h2_narrow)) {

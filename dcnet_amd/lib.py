@@ -103,7 +103,7 @@ SIGNATURES = {
     "dcn_stream_destroy": (I, [P]),
     "dcn_stream_priority_range": (I, [P, P]),
     "dcn_prof_enable": (I, [I]),
-    "dcn_prof_collect": (I, [P, P, P]),
+    "dcn_prof_collect": (I, [P, P, P, P]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }

@@ -50,7 +50,9 @@ _amax_consts = {}
 
 
 def use_amax() -> bool:
-    return _precision == "fp32"
+    """The precision modes whose GEMM tiles scale their operands by a power of two derived from the tensors' abs-max words:
+    the f16 two-piece split ("fp32") and the fp8 path (whose separate abs-max passes, dcn_f8_scale, they replace)."""
+    return _precision in ("fp32", "fp8")
 
 
 def amax_slot(device) -> torch.Tensor:
@@ -236,11 +238,11 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
     if want_stats:
         rows = lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride)
         stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=x.device)
-    f8 = f8_scales(x, w_ohwi) if (_precision == "fp8" and cin != 4) else None
+    f8 = None                        # (fp8 mode: the tiles derive their scales from the abs-max words below)
     wsplit = None
     if cin != 4:
         amax_x = _amax_or_pass(x, amax_x); amax_w = _amax_or_pass(w_ohwi, amax_w)
-        if amax_w is not None:
+        if amax_w is not None and _precision == "fp32":
             wsplit = scratch(w_ohwi.numel() + 16, x.device, slot=5)       # the filter bank, split once per launch
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
@@ -257,7 +259,7 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     if out is None:
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
     wt = scratch(w_ohwi.numel() + 16, dy.device, slot=1)
-    f8 = f8_scales(dy, w_ohwi) if _precision == "fp8" else None
+    f8 = None
     if True:
         amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),

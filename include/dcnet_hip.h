@@ -431,7 +431,7 @@ int dcn_stream_priority_range(int* least, int* greatest);
  * 12 exp+sums, 13/14 small latency-bound GEMMs of the LSTM steps),
  * the launch count, the summed kernel milliseconds and the summed algorithmic work (FLOP or bytes). */
 int dcn_prof_enable(int on);
-int dcn_prof_collect(int64_t* counts, double* ms, double* work);
+int dcn_prof_collect(int64_t* counts, double* ms, double* work, double* bytes /* algorithmic HBM bytes of the FLOP-priced tags; may be NULL */);
 
 /* ---- host-side negative sampling (CPU; bit-exact with Python's random.sample) -------------- */
 /* state = the 625 uint32 of random.getstate()[1], advanced in place.
