@@ -193,6 +193,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    host_dt = time.perf_counter() - t0          # the host has queued every step (no synchronisation inside a step)
     barrier()
     dt = time.perf_counter() - t0
     L.prof_enable(0)
@@ -374,6 +375,7 @@ def main():
                "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips} clips/GPU, 20-token query, fp32, "
                                       f"pair semantics ({n_img} images/GPU/step), fwd + 5 losses + bwd + RMSprop",
                           "images_per_gpu": n_img, "parallelism": f"dp{world}"},
+               "host_queue_ms_per_step": host_dt / args.steps * 1e3,
                "loss": float(last.detach()), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.size, args.frames, args.cpu_steps)

@@ -38,8 +38,9 @@ def _train_step(m, sd, image, word_id, word_mask, bbox, size):
 def _round_operand(t, mode):
     if mode == "bf16":
         return t.bfloat16().float(), 1.0
-    amax = float(t.abs().max())
-    s = 2.0 ** torch.floor(torch.log2(torch.tensor(448.0 / amax))).item()
+    import math
+    _, e = math.frexp(float(t.abs().max()))                     # the fp8 tiles map the tensor's maximum into [128, 256)
+    s = 2.0 ** (8 - e)
     return (t * s).clamp(-448, 448).to(torch.float8_e4m3fn).float(), s
 
 
