@@ -50,3 +50,8 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream);
 // true if a launch with these dimensions (rows = M x batch, filters Co, taps, channels Ci) would take a tile that reads a
 // pre-split filter bank in the current precision mode: the caller then pre-splits (dcn_presplit_f16) and sets b_scale
 bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci);
+
+// conv3.hip: the 3x3 stride-1 strip kernel (f16 split, pre-split filter bank).  gran = output rows per statistics partial.
+bool conv3_applicable(const IgemmParams& p, int precision, int gran);
+int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream);
+void conv3_set_tuning(int key, int value);

@@ -215,7 +215,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
   f32x4 a_reg2[SP ? A_LD : 1], b_reg2[SP ? B_LD : 1];   // SP: second register stage (loads run two K-steps ahead)
-  auto load_tiles_into = [&](f32x4* a_reg, f32x4* b_reg, int it) {
+  // live = false: the same instructions with every offset out of range (zeros, no memory traffic).  A load inside a
+  // wave-uniform branch makes the s_waitcnt in front of the OLDER stage's LDS stores conservative — it then also waits for the
+  // loads just issued, i.e. exposes a full L2/HBM latency per pair of K-steps — so the K loop never branches around a load.
+  auto load_tiles_into = [&](f32x4* a_reg, f32x4* b_reg, int it, bool live = true) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       unsigned v;
@@ -226,13 +229,13 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
         v = (a_msk[j] & bit) ? a_off[j] + (unsigned)dlt : OOB;
       }
       else v = (a_msk[j] & tap_bit) ? a_off[j] + (unsigned)a_delta : OOB;
-      a_reg[j] = buf_load16(a_rs, v, a_soff);
+      a_reg[j] = buf_load16(a_rs, live ? v : OOB, live ? a_soff : 0u);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       unsigned v = b_off[j];
       if (BMODE == 1) { const int k = (tid + 256 * j) / (BN / 4); v = (kbase + k < p.kvalid) ? v : OOB; }
-      b_reg[j] = buf_load16(b_rs, v, b_soff);
+      b_reg[j] = buf_load16(b_rs, live ? v : OOB, live ? b_soff : 0u);
     }
     // advance to the next K-step (scalar unit)
     if (C4) { b_soff += BK * 4; }
@@ -427,13 +430,14 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     store_tiles_from(a_reg, b_reg, 0);
     __syncthreads();
     int it = 0;
+    using ST = std::conditional_t<ABL == 4, F, T>;      // (timing ablations: 3 = no global loads in the loop, 4 = no split / LDS stores)
     for (; it + 2 < p.kiters; it += 2) {
       // even step: LDS buffer 0 is current, stage 2 holds step it+1, stage 1 is free for step it+2
-      load_tiles_into(a_reg, b_reg, it + 2);
-      step(0, a_reg2, b_reg2, T{});
+      if (ABL != 3) load_tiles_into(a_reg, b_reg, it + 2);
+      step(0, a_reg2, b_reg2, ST{});
       __syncthreads();
-      if (it + 3 < p.kiters) load_tiles_into(a_reg2, b_reg2, it + 3);
-      step(1, a_reg, b_reg, T{});
+      if (ABL != 3) load_tiles_into(a_reg2, b_reg2, it + 3, it + 3 < p.kiters);
+      step(1, a_reg, b_reg, ST{});
       __syncthreads();
     }
     if (it + 1 < p.kiters) {      // two steps left: buffer 0 current, stage 2 holds the last step
@@ -645,6 +649,11 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     if (g_precision == 4 && p.amax_a && (p.amax_b || p.b_scale) && rows >= 1024 &&
         ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || g_h2_narrow)) {
       // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
+      if constexpr (BM == 128 && BN == 128) {
+        if (p.b_scale && g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2, 2, 1, false, true>(p, stream);
+        if (p.b_scale && g_abl == 3) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 3, 2, 1, false, true>(p, stream);
+        if (p.b_scale && g_abl == 4) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 4, 2, 1, false, true>(p, stream);
+      }
       if (p.b_scale) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 1, false, true>(p, stream);    // pre-split filter bank
       if (g_h2_bk == 32) return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 2>(p, stream);
       if (BM == 128 && BN == 128 && g_h2_occ3) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 0, 2, 3>(p, stream);
@@ -700,6 +709,7 @@ void wgrad_set_abl(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
   if (k == 'p') { g_precision = value; wgrad_set_split(value == 3 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)
@@ -740,6 +750,11 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
     const long long span = (256 / (p.Hs * p.Ws) + 2) * img_bytes;
     DCN_CHECK_ARG(span < 0x7FFFFFF0LL, "igemm: image too large for 32-bit buffer offsets (%lld bytes per M-tile window)", span);
     DCN_CHECK_ARG((long long)(p.bmode == 1 ? p.kvalid : p.Co) * p.ldw * 4 < 0x7FFFFFF0LL, "igemm: filter bank exceeds 2 GB");
+  }
+  {
+    // 3x3 stride-1 launches with a pre-split filter bank: the strip kernel of conv3.hip (activations staged once per 16 channels)
+    const int gran = tile_bm(p.M, p.Co, p.ntaps, 32);
+    if (conv3_applicable(p, g_precision, gran)) return conv3_launch(p, gran, stream);
   }
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);

@@ -174,18 +174,27 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
   f32x4 a_reg[A_LD], b_reg[B_LD];
   f32x4 a_reg2[SP ? A_LD : 1], b_reg2[SP ? B_LD : 1];    // SP: second register stage (two K-steps of loads in flight)
   unsigned a_soff = 0; int rows_left = m_end - m_begin;
+  // Past the end of the split (rows_left <= 0) every offset is out of range: the K loop calls this unconditionally (a load
+  // inside a wave-uniform branch makes the s_waitcnt in front of the older stage's LDS stores wait for the loads just
+  // issued as well, igemm.hip).  The geometry entries of the NEXT step are requested before this step's tiles: vmcnt
+  // retires in order, so waiting for an entry that was issued behind the tiles meant waiting for the tiles.
   auto load_tiles_into = [&](f32x4* a_reg, f32x4* b_reg) {
+    m_cur += KP;
+    unsigned e_cur[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      e_cur[j] = b_ent[j];
+      b_ent[j] = entry(m_cur + b_pix[j]);          // next K-step's pixel (the table is padded past M by GEOM_SLACK)
+    }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j)
       a_reg[j] = buf_load16(a_rs, a_pix[j] < rows_left ? a_voff[j] : OOB, a_soff);
-    m_cur += KP;
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const unsigned e = b_ent[j];
+      const unsigned e = e_cur[j];
       const bool ok = b_ok[j] && b_pix[j] < rows_left && !(e & b_tmask[j]);
       const unsigned voff = (unsigned)(((int)(e >> 5) + b_tdelta[j]) * ldx4) + b_coff[j];
       b_reg[j] = buf_load16(b_rs, ok ? voff : OOB, 0);
-      b_ent[j] = entry(m_cur + b_pix[j]);          // next K-step's pixel (the table is padded past M)
     }
     a_soff += (unsigned)(KP * p.lddy * 4); rows_left -= KP;
   };
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
       load_tiles_into(a_reg, b_reg);                       // step it+2
       step(0, a_reg2, b_reg2, T{});
       __syncthreads();
-      if (it + 3 < iters) load_tiles_into(a_reg2, b_reg2); // step it+3
+      load_tiles_into(a_reg2, b_reg2);                     // step it+3 (all zeros past the end)
       step(1, a_reg, b_reg, T{});
       __syncthreads();
     }

@@ -605,3 +605,84 @@ def test_conv_engines_random_shapes(dev, seed):
     _close(ops.conv2d_bwd_data(dy_p, wt_p, (h, w), k, st), xd.grad.permute(0, 2, 3, 1), 3e-5, "dgrad")
     dw = ops.conv2d_bwd_weight(x, dy_p[..., :cout_p], k, st)[:cout] if cout % 4 else ops.conv2d_bwd_weight(x, dy, k, st)
     _close(dw, wd.grad.permute(0, 2, 3, 1), 3e-5, "wgrad")
+
+
+STRIP_CASES = [
+    # n, h, w, cin, cout     (3x3 stride 1; >= 1024 output rows so that the filter bank is pre-split)
+    (8, 13, 13, 64, 128),      # 13x13 map, 128x128-or-256x128 tile, M tail
+    (7, 13, 13, 32, 1024),     # many N tiles
+    (3, 26, 26, 32, 64),       # 64 filters: stays on the implicit-GEMM tile (statistics partial per 256 rows)
+    (2, 52, 52, 32, 128),
+    (2, 40, 24, 96, 160),      # non-square map, ragged Cout
+    (5, 17, 31, 64, 136),
+    (1, 104, 104, 32, 128),    # wide map: strip of 466 pixels for 256 outputs
+    (1, 208, 208, 32, 128),    # too wide for the strip (674 pixels): falls back
+    (1, 33, 35, 32, 128),      # one image, odd sizes
+]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_conv3_strip_kernel(dev, case):
+    """The 3x3 stride-1 strip kernel (csrc/conv3.hip: activations staged once per 16 channels for all nine taps) against
+    fp64, and against the implicit-GEMM tile it replaces on the same inputs: forward with the fused epilogue, BatchNorm
+    partial sums, shortcut add, a concat-slice destination, accumulate; data gradient plain and accumulating.  Both M tile
+    sizes are forced.  Image borders, the wrap of the strip into neighbouring rows / images and the M / Cout tails all matter
+    here."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout = case
+    x = _rand(n, h, w, cin, seed=21).to(dev)
+    wt = (_rand(cout, 3, 3, cin, seed=22) / (cin * 9) ** 0.5).to(dev)
+    scale = (_rand(cout, seed=23).abs() + 0.5).to(dev); shift = _rand(cout, seed=24).to(dev)
+    res = _rand(n, h, w, cout, seed=25).to(dev)
+    xd = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wd = wt.permute(0, 3, 1, 2).double().cpu()
+    raw = F.conv2d(xd, wd, padding=1)
+    dy = (_rand(n, h, w, cout, seed=26) / 8)
+    raw.backward(dy.permute(0, 3, 1, 2).double())
+    rawl = raw.detach().permute(0, 2, 3, 1)
+    ref = F.leaky_relu(rawl * scale.double().cpu() + shift.double().cpu(), 0.1) + res.double().cpu()
+    cout_p = (cout + 31) // 32 * 32
+    wt_p = torch.zeros(cout_p, 3, 3, cin, device=dev); wt_p[:cout] = wt
+    dy_p = torch.zeros(n, h, w, cout_p, device=dev); dy_p[..., :cout] = dy.to(dev)
+    base = _rand(n, h, w, cin, seed=27).to(dev)
+
+    def run():
+        out = {}
+        out["y"], out["stats"] = ops.conv2d_fwd(x, wt, 3, 1, scale, shift, ops.ACT_LEAKY, 0.1, residual=res, want_stats=True)
+        buf = torch.zeros(n, h, w, cout + 64, device=dev)
+        am = ops.amax_slot(dev)
+        ops.conv2d_fwd(x, wt, 3, 1, out=buf[..., 32:32 + cout], amax_out=am)
+        out["slice"] = buf; out["amax"] = am.clone()
+        acc = rawl.float().to(dev).clone()
+        ops.conv2d_fwd(x, wt, 3, 1, out=acc, accumulate=True)
+        out["acc"] = acc
+        out["dx"] = ops.conv2d_bwd_data(dy_p, wt_p, (h, w), 3, 1)
+        dx2 = base.clone()
+        ops.conv2d_bwd_data(dy_p, wt_p, (h, w), 3, 1, out=dx2, accumulate=True)
+        out["dx_acc"] = dx2
+        return out
+
+    try:
+        lib().set_tuning(b"3x3strip", 0)
+        old = run()
+        for bm in (0, 128, 256):
+            lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", bm)
+            new = run()
+            _close(new["y"], ref, 2e-5, f"strip fwd epilogue bm={bm}")
+            _close(new["stats"][:, 0].double().sum(0), rawl.reshape(-1, cout).sum(0), 1e-4, "strip stats sum")
+            _close(new["stats"][:, 1].double().sum(0), (rawl * rawl).reshape(-1, cout).sum(0), 1e-4, "strip stats sumsq")
+            assert new["stats"].shape == old["stats"].shape
+            _close(new["slice"][..., 32:32 + cout], rawl, 2e-5, "strip slice")
+            assert float(new["slice"][..., :32].abs().max()) == 0 and float(new["slice"][..., 32 + cout:].abs().max()) == 0
+            assert float(new["amax"].view(torch.float32).max()) == float(new["slice"].abs().max())
+            _close(new["acc"], 2 * rawl, 2e-5, "strip accumulate")
+            _close(new["dx"], xd.grad.permute(0, 2, 3, 1), 2e-5, "strip dgrad")
+            _close(new["dx_acc"], xd.grad.permute(0, 2, 3, 1) + base.double().cpu(), 2e-5, "strip dgrad accumulate")
+            # same split arithmetic, different summation order over the taps only: agreement far inside the fp64 tolerance
+            for k in ("y", "dx"):
+                _close(new[k], old[k], 2e-6, f"strip vs tile {k}")
+        if cout >= 128 and w <= 64:         # (64-filter layers and maps wider than ~120 pixels stay on the implicit-GEMM tile)
+            assert not torch.equal(new["y"], old["y"]) or not torch.equal(new["dx"], old["dx"]), "the strip kernel did not run"
+    finally:
+        lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
