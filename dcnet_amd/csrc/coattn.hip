@@ -17,7 +17,8 @@
 
 int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
                     float* C, int ldc, long long c_bs, const float* row_scale,
-                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream);
+                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream,
+                    const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr);
 
 namespace {
 
@@ -75,32 +76,52 @@ __global__ __launch_bounds__(256) void colsum_inv_kernel(const float* __restrict
   cinv[(size_t)bb * hw + j] = 1.f / s;
 }
 
-// one wave per row: delta[row] = <d[row], o[row]>, ds[row] = d[row] * inv[row]
+// Abs-max words of the co-attention GEMM operands (DCN_AMAX_WORDS each, in the caller's workspace): slot 0 holds the
+// constant 1 — unit-norm features, E = exp(t*A - t) <= 1 — the others start at 0 and are raised by the kernels that write
+// or read the gradient operands.  With both words present a GEMM runs on the f16 two-piece split (igemm.hip).
+enum { AM_ONE = 0, AM_DO1, AM_DO2, AM_DO1S, AM_DO2S, AM_DA, AM_SLOTS };
+__global__ __launch_bounds__(256) void amax_init_kernel(unsigned* __restrict__ w) {
+  for (int i = threadIdx.x; i < AM_SLOTS * DCN_AMAX_WORDS; i += 256) w[i] = i < DCN_AMAX_WORDS ? 0x3F800000u : 0u;
+}
+
+// one wave per row: delta[row] = <d[row], o[row]>, ds[row] = d[row] * inv[row]; abs-max of d and ds
 __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restrict__ d, int ldd, int64_t bsd,
                                                            const float* __restrict__ o, int ldo, int64_t bso, int hw,
                                                            const float* __restrict__ inv, int64_t rows, int c,
-                                                           float* __restrict__ delta, float* __restrict__ ds) {
+                                                           float* __restrict__ delta, float* __restrict__ ds,
+                                                           unsigned* __restrict__ amax_d, unsigned* __restrict__ amax_ds) {
+  __shared__ float red[4];
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int64_t bb = row / hw, i = row - bb * hw;
-  const float s = inv[row];
-  float acc = 0.f;
-  for (int k = lane * 4; k < c; k += 256) {
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + bb * bsd + i * ldd + k);
-    const f32x4 ov = *reinterpret_cast<const f32x4*>(o + bb * bso + i * ldo + k);
-    acc += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
-    *reinterpret_cast<f32x4*>(ds + row * c + k) = dv * s;
+  float vmax = 0.f, s = 0.f;
+  if (row < rows) {
+    const int64_t bb = row / hw, i = row - bb * hw;
+    s = inv[row];
+    float acc = 0.f;
+    for (int k = lane * 4; k < c; k += 256) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(d + bb * bsd + i * ldd + k);
+      const f32x4 ov = *reinterpret_cast<const f32x4*>(o + bb * bso + i * ldo + k);
+      acc += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
+      *reinterpret_cast<f32x4*>(ds + row * c + k) = dv * s;
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(dv[0]), fabsf(dv[1]))), fmaxf(fabsf(dv[2]), fabsf(dv[3])));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) delta[row] = acc;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) delta[row] = acc;
+  // (s > 0: one max serves both words; the scaled tensor's maximum is bounded by max|d| * max s of the block's rows)
+  const float vs = wave_max(vmax * s);
+  amax_update_block(amax_d, vmax, red);
+  __syncthreads();
+  amax_update_block(amax_ds, vs, red);
 }
 
 // dA = t * E * ((dP1 - d1[i]) * rinv[i] + (dP2 - d2[j]) * cinv[j]), written over dP1; pad columns -> 0
 __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, float* __restrict__ dP1, const float* __restrict__ dP2,
                                                  const float* __restrict__ rinv, const float* __restrict__ cinv,
                                                  const float* __restrict__ d1, const float* __restrict__ d2,
-                                                 int hw, int ldE, float t, int64_t total4) {
+                                                 int hw, int ldE, float t, int64_t total4, unsigned* __restrict__ amax_da) {
+  __shared__ float red[4];
+  float vmax = 0.f;
   const int l4 = ldE >> 2;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / l4;                 // = b*hw + i
@@ -118,7 +139,9 @@ __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, fl
       o[k] = v;
     }
     *reinterpret_cast<f32x4*>(dP1 + row * ldE + j) = o;
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
+  amax_update_block(amax_da, vmax, red);
 }
 
 inline int ld_pad(int hw) { return (hw + 31) / 32 * 32; }
@@ -137,7 +160,7 @@ void gemm_params(IgemmParams& p, const float* A, int lda, long long a_bs, const 
 
 extern "C" int64_t dcn_coattn_fwd_ws(int b, int hw, int c) {
   (void)c;
-  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw);
+  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw) + AM_SLOTS * DCN_AMAX_WORDS;
 }
 extern "C" int64_t dcn_coattn_e_size(int b, int hw) { return (int64_t)b * hw * ld_pad(hw); }
 
@@ -154,9 +177,14 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   if (bso <= 0) bso = (int64_t)hw * ldo;
   DCN_CHECK_ARG(bsf % 4 == 0 && bso % 4 == 0, "coattn_fwd: batch strides must be multiples of 4");
   const int ldE = ld_pad(hw);
+  unsigned* am = reinterpret_cast<unsigned*>(ws + (int64_t)cdiv(hw, EXP_ROWS) * b * ldE);
+  hipLaunchKernelGGL(amax_init_kernel, dim3(1), dim3(256), 0, stream, am);
+  DCN_CHECK_LAUNCH("coattn amax_init");
+  const unsigned* one = am + AM_ONE * DCN_AMAX_WORDS;
   IgemmParams p;
   // 1. A = f1 . f2^T  -> E                                             (NT)
   gemm_params(p, f1, ldf, bsf, f2, ldf, bsf, E, ldE, (long long)hw * ldE, hw, hw, c, b);
+  p.amax_a = one; p.amax_b = one;
   int rc = igemm_launch(p, stream);
   if (rc) return rc;
   // 2. E = exp(t*A - t), rinv = 1/rowsum, cinv = 1/colsum
@@ -169,18 +197,18 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   DCN_CHECK_LAUNCH("colsum_inv");
   // 3. f1_attn = diag(rinv) E f2                                       (NN, K = keys j)
   gemm_params(p, E, ldE, (long long)hw * ldE, f2, ldf, bsf, f1_attn, ldo, bso, hw, c, ldE, b);
-  p.bmode = 1; p.kvalid = hw; p.row_scale = rinv;
+  p.bmode = 1; p.kvalid = hw; p.row_scale = rinv; p.amax_a = one; p.amax_b = one;
   rc = igemm_launch(p, stream);
   if (rc) return rc;
   // 4. f2_attn = diag(cinv) E^T f1                                     (TN, K = queries i)
   if (f2_attn)
     rc = tn_gemm_batched(E, ldE, (long long)hw * ldE, f1, ldf, bsf, f2_attn, ldo, bso,
-                         cinv, hw, ldE, c, hw, b, 0, stream);
+                         cinv, hw, ldE, c, hw, b, 0, stream, one, one);
   return rc;
 }
 
 extern "C" int64_t dcn_coattn_bwd_ws(int b, int hw, int c) {
-  return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw;
+  return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw + AM_SLOTS * DCN_AMAX_WORDS;
 }
 
 extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
@@ -209,34 +237,43 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
   float* dO2s = dO1s + rows * c;
   float* del1 = dO2s + rows * c;
   float* del2 = del1 + rows;
+  unsigned* am = reinterpret_cast<unsigned*>(del2 + rows);
+  hipLaunchKernelGGL(amax_init_kernel, dim3(1), dim3(256), 0, stream, am);
+  DCN_CHECK_LAUNCH("coattn amax_init");
+  auto slot = [&](int i) { return am + i * DCN_AMAX_WORDS; };
   // 1. delta and pre-scaled upstream gradients
-  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f1_attn, lddo, bsdo, f1_attn, ldo, bso, hw, rinv, rows, c, del1, dO1s);
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f1_attn, lddo, bsdo, f1_attn, ldo, bso, hw, rinv, rows, c, del1, dO1s,
+                     slot(AM_DO1), slot(AM_DO1S));
   DCN_CHECK_LAUNCH("rowdot_scale");
-  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, bsdo, f2_attn, ldo, bso, hw, cinv, rows, c, del2, dO2s);
+  hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, bsdo, f2_attn, ldo, bso, hw, cinv, rows, c, del2, dO2s,
+                     slot(AM_DO2), slot(AM_DO2S));
   DCN_CHECK_LAUNCH("rowdot_scale");
   IgemmParams p;
   int rc;
   // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                  (NT x2)
   gemm_params(p, d_f1_attn, lddo, bsdo, f2, ldf, bsf, dP1, ldE, (long long)hw * ldE, hw, hw, c, b);
+  p.amax_a = slot(AM_DO1); p.amax_b = slot(AM_ONE);
   if ((rc = igemm_launch(p, stream))) return rc;
   gemm_params(p, f1, ldf, bsf, d_f2_attn, lddo, bsdo, dP2, ldE, (long long)hw * ldE, hw, hw, c, b);
+  p.amax_a = slot(AM_ONE); p.amax_b = slot(AM_DO2);
   if ((rc = igemm_launch(p, stream))) return rc;
   // 3. dA (over dP1)
   const int64_t total4 = rows * (ldE / 4);
   int64_t g = (total4 + 255) / 256; if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4);
+  if (g > 1024) g = 1024;      // (one abs-max atomic per workgroup)
+  hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
   DCN_CHECK_LAUNCH("dA");
   // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                   (NN x2)
   gemm_params(p, dP1, ldE, (long long)hw * ldE, f2, ldf, bsf, d_f1, lddf, bsdf, hw, c, ldE, b);
-  p.bmode = 1; p.kvalid = hw; p.accumulate = accumulate;
+  p.bmode = 1; p.kvalid = hw; p.accumulate = accumulate; p.amax_a = slot(AM_DA); p.amax_b = slot(AM_ONE);
   if ((rc = igemm_launch(p, stream))) return rc;
   gemm_params(p, E, ldE, (long long)hw * ldE, dO2s, c, (long long)hw * c, d_f1, lddf, bsdf, hw, c, ldE, b);
-  p.bmode = 1; p.kvalid = hw; p.accumulate = 1;
+  p.bmode = 1; p.kvalid = hw; p.accumulate = 1; p.amax_a = slot(AM_ONE); p.amax_b = slot(AM_DO2S);
   if ((rc = igemm_launch(p, stream))) return rc;
   // 5. d_f2 (+)= dA^T f1 + E^T (dO1 / rowsum)                               (TN x2)
   rc = tn_gemm_batched(dP1, ldE, (long long)hw * ldE, f1, ldf, bsf, d_f2, lddf, bsdf,
-                       nullptr, hw, ldE, c, hw, b, accumulate, stream);
+                       nullptr, hw, ldE, c, hw, b, accumulate, stream, slot(AM_DA), slot(AM_ONE));
   if (rc) return rc;
   return tn_gemm_batched(E, ldE, (long long)hw * ldE, dO1s, c, (long long)hw * c, d_f2, lddf, bsdf,
-                         nullptr, hw, ldE, c, hw, b, 1, stream);
+                         nullptr, hw, ldE, c, hw, b, 1, stream, slot(AM_ONE), slot(AM_DO1S));
 }

@@ -6,7 +6,8 @@
 
 int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
                     float* C, int ldc, long long c_bs, const float* row_scale,
-                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream);
+                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream,
+                    const unsigned* amax_a = nullptr, const unsigned* amax_b = nullptr);
 
 namespace {
 

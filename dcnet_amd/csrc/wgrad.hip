@@ -549,7 +549,8 @@ void wgrad_set_abl(int v) { g_wabl = v; }
 // both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.
 int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int ldb, long long b_bs,
                     float* C, int ldc, long long c_bs, const float* row_scale,
-                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream) {
+                    int M, int m_ld, int N, int K, int batch, int accumulate, hipStream_t stream,
+                    const unsigned* amax_a, const unsigned* amax_b) {
   DCN_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0, "tn_gemm: bad argument");
   DCN_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && N % 4 == 0 && m_ld % 4 == 0 && m_ld >= M && m_ld <= lda,
                 "tn_gemm: alignment (lda=%d ldb=%d N=%d m_ld=%d)", lda, ldb, N, m_ld);
@@ -557,6 +558,7 @@ int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int
   p.dy = A; p.lddy = lda; p.dy_bs = a_bs; p.Co = M; p.Co_ld = m_ld;
   p.x = B; p.ldx = ldb; p.x_bs = b_bs; p.Ci = N;
   p.out = C; p.ld_out = ldc; p.out_bs = c_bs; p.row_scale = row_scale; p.accumulate = accumulate;
+  p.amax_dy = amax_a; p.amax_x = amax_b;      // both present: the 128x128 tile takes the f16 two-piece split
   p.N = 1; p.H = 1; p.W = K; p.Ho = 1; p.Wo = K; p.ksize = 1; p.stride = 1; p.pad = 0; p.T = 1;
   p.M = K; p.kchunk = cdiv(K, 32) * 32; p.splits = 1;
   const int tm = M >= 128 ? 128 : (M >= 64 ? 64 : 32), tn = N >= 128 ? 128 : (N >= 64 ? 64 : 32);

@@ -158,7 +158,7 @@ def test_bn_fold_and_act_bwd(dev):
     _close(got, torch.where(o > 0, d, d * 0.1), 1e-6)
 
 
-@pytest.mark.parametrize("b,g,c", [(2, 8, 64), (1, 13, 512), (3, 5, 96)])
+@pytest.mark.parametrize("b,g,c", [(2, 8, 64), (1, 13, 512), (3, 5, 96), (8, 13, 128), (2, 26, 128), (1, 52, 128)])   # (the last three: >= 1024 rows, the f16-split GEMMs; 52x52: the TN tile too)
 def test_coattn_fwd_bwd(dev, b, g, c):
     from dcnet_amd import ops
     hw = g * g
