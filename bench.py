@@ -270,9 +270,9 @@ def main():
                  26: "igemm_kernel<256,64,4,1,0,false,16,true,0,2>",
                  27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2>",
                  # 28: the 3x3 stride-1 layers (forward and data gradient): f16 split with the activation strip resident in LDS
-                 28: "conv3_kernel<*,2,4>"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28)
+                 28: "conv3_kernel<4,2,4>", 29: "conv3_kernel<2,2,4>"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29)
                        else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
@@ -306,7 +306,7 @@ def main():
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
                     "peak_note": ("fp32 operands as 2 f16 pieces (per-tensor power-of-two scale), 3 cross terms on "
                                   "v_mfma_f32_32x32x16_f16: peak = 2516.6 TFLOP/s dense f16 / 3 = 838.9 algorithmic fp32 TFLOP/s")
-                                 if dom in (24, 25, 26, 27, 28) else
+                                 if dom in (24, 25, 26, 27, 28, 29) else
                                  ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
                                   "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
                                  if dom in (16, 17, 18, 21) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",

@@ -153,7 +153,15 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
   int b_pix[B_LD], b_tdelta[B_LD]; unsigned b_ent[B_LD], b_tmask[B_LD], b_coff[B_LD]; bool b_ok[B_LD];
   const int ldx4 = p.ldx * 4;
   const int pixbase = n_first * p.H * p.W;
-  auto entry = [&](int m) -> unsigned { return p.geom ? p.geom[m] : (unsigned)m << 5; };
+  // (a buffer load whose offset goes out of range when there is no table: no branch around the load — a load inside a
+  //  wave-uniform branch makes every later s_waitcnt conservative, here a vmcnt(0) in front of each K-step's tile loads)
+  const bool has_geom = p.geom != nullptr;
+  const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(has_geom ? reinterpret_cast<const float*>(p.geom) : p.x,
+                                                has_geom ? ((long long)p.M + GEOM_SLACK) * 4 : 0);
+  auto entry = [&](int m) -> unsigned {
+    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(g_rs, has_geom ? (unsigned)m * 4u : OOB, 0, 0);
+    return has_geom ? v : (unsigned)m << 5;
+  };
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int idx = tid + 256 * j;

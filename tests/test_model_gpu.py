@@ -332,7 +332,9 @@ def test_full_size_c2_batch_invariance_and_determinism(dev):
     (~80 GB of host memory).  Size-independent properties instead:
       * eval mode is per-pair independent (frozen BatchNorm): pairs taken out of the 64-image batch and run alone —
         at a size the oracle DOES check in test_eval_forward_matches_oracle_and_golden — must give the same outputs
-        (different tile/grid shapes, so equal to accumulation-order accuracy, 1e-4);
+        (different tile/grid shapes and, with the f16 two-piece split, per-tensor scales derived from a different batch's
+        abs-max, so equal to accumulation-order accuracy: 2e-4 absolute on outputs of magnitude ~10, five times inside the
+        1e-3 criterion; measured 1.1e-4);
       * the oracle itself, on one of those pairs, agrees with the slice of the full-size run to 1e-3;
       * a training step (forward, five losses, backward) is bitwise reproducible: split-K slabs and BatchNorm partials
         are reduced in a fixed order, there are no float atomics, side streams join before results are read."""
@@ -349,7 +351,7 @@ def test_full_size_c2_batch_invariance_and_determinism(dev):
             part = m(image[lo:lo + 2].to(dev), word_id[lo:lo + 2].to(dev), word_mask[lo:lo + 2].to(dev))
             for k in range(3):                                   # outbox, sim_score, loc_score
                 for s in range(3):
-                    assert maxdiff(full[k][s][lo:lo + 2], part[k][s]) < 1e-4, (lo, k, s)
+                    assert maxdiff(full[k][s][lo:lo + 2], part[k][s]) < 2e-4, (lo, k, s)
         o = O.grounding_forward_pairs({k: v.clone() for k, v in sd.items()}, image[30:32], word_id[30:32], training=False, sample=False)
     for s in range(3):
         assert maxdiff(full[0][s][30:32], o["outbox"][s]) < TOL and maxdiff(full[1][s][30:32], o["sim_score"][s]) < TOL
