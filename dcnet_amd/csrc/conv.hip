@@ -77,7 +77,8 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                               const float* scale, const float* shift, int act, float slope,
                               const float* residual, int ldr, int ldy,
                               float* stats, int accumulate, const float* f8_scales,
-                              const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, void* stream) {
+                              const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, int w_split_ready,
+                              void* stream) {
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_fwd: ksize=%d (1 or 3)", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_fwd: stride=%d (1 or 2)", stride);
   DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cout > 0, "conv2d_fwd: bad shape");
@@ -109,8 +110,10 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   if (w_split && amax_x && amax_w && !p.c4 && igemm_will_presplit(p.M, cout, p.ntaps, cin)) {
     // split the filter bank once (into the caller's scratch: cout*k*k*cin + 16 floats), not once per M-tile
     const int64_t numel = (int64_t)cout * p.ntaps * cin;
-    int rc = launch_presplit(w, w_split, numel, amax_w, w_split + numel, (hipStream_t)stream);
-    if (rc != DCN_OK) return rc;
+    if (!w_split_ready) {         // (ready: dcn_prepare_filters already wrote the split bank and its scale there)
+      int rc = launch_presplit(w, w_split, numel, amax_w, w_split + numel, (hipStream_t)stream);
+      if (rc != DCN_OK) return rc;
+    }
     p.wt = w_split; p.b_scale = w_split + numel;
   }
   return igemm_launch(p, (hipStream_t)stream);
@@ -119,7 +122,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
 extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
                                    int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
-                                   void* stream_) {
+                                   int wt_ready, const float* wt_split, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_data: ksize=%d", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_data: stride=%d", stride);
@@ -128,9 +131,14 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   const int pad = (ksize - 1) / 2, T = ksize * ksize;
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
   if (lddy <= 0) lddy = cout;
-  hipLaunchKernelGGL(transpose_filter_kernel, dim3(cdiv(cin, 32), cdiv(cout, 32), T), dim3(256), 0, stream,
-                     w, wt, cout, T, cin);
-  DCN_CHECK_LAUNCH("transpose_filter");
+  // wt_ready: wt already holds the transposed bank (dcn_prepare_filters) and, when given, wt_split its split form with the
+  // scale behind it; nothing is written to either here
+  DCN_CHECK_ARG(wt_ready || !wt_split, "conv2d_bwd_data: wt_split needs wt_ready");
+  if (!wt_ready) {
+    hipLaunchKernelGGL(transpose_filter_kernel, dim3(cdiv(cin, 32), cdiv(cout, 32), T), dim3(256), 0, stream,
+                       w, wt, cout, T, cin);
+    DCN_CHECK_LAUNCH("transpose_filter");
+  }
   IgemmParams p; base_params(p);
   p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx; p.amax_a = amax_dy; p.amax_b = amax_w;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
@@ -139,9 +147,13 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   if (amax_dy && amax_w && igemm_will_presplit((long long)n * (stride == 1 ? h * wd : (h / 2) * (wd / 2)), cin, stride == 1 ? T : 1, cout)) {
     // (stride 2: the four parity classes share one bank; the smallest class, with 1 tap, decides for all of them)
     const int64_t numel = (int64_t)cin * T * cout;
-    int rc = launch_presplit(wt, wt, numel, amax_w, wt + numel, stream);     // in place; the scale lands behind the bank
-    if (rc != DCN_OK) return rc;
-    p.b_scale = wt + numel;
+    if (wt_ready) {
+      if (wt_split) { p.wt = wt_split; p.b_scale = wt_split + numel; }       // else: the tiles split the fp32 bank themselves
+    } else {
+      int rc = launch_presplit(wt, wt, numel, amax_w, wt + numel, stream);   // in place; the scale lands behind the bank
+      if (rc != DCN_OK) return rc;
+      p.b_scale = wt + numel;
+    }
   }
   if (stride == 1) {
     // dx[hi,wi] = sum_{r,s} dy[hi+pad-r, wi+pad-s] . w[:,r,s,:]

@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   for (int j = 0; j < A_LD; ++j) {
     const int m = bm * BM + row0 + RPP * j;
     a_off[j] = 0; a_msk[j] = 0;
+    if (p.ntaps == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && !C4 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 && p.Ws == p.Wi && p.Hs == p.Hi) {
+      // plain GEMM rows (1x1 convolutions, their data gradients, the co-attention products): row m IS pixel m — no divisions
+      if (m < p.M) { a_off[j] = (unsigned)((m - n0 * hsws) * p.ldi * 4 + chunk * 16); a_msk[j] = 1u; }
+    } else
     if (m < p.M) {
       const int n = m / hsws, rem = m - n * hsws;
       const int i = rem / p.Ws, jx = rem - i * p.Ws;

@@ -272,8 +272,9 @@ def _cpad(c: int) -> int:
     return 4 if c <= 4 else ops.pad32(c)
 
 
-def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
-    """P[slot] = dict(w=OIHW weight, b=conv bias|None, gamma, beta, rm, rv).  Returns tap tensors."""
+def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], banks=None):
+    """P[slot] = dict(w=OIHW weight, b=conv bias|None, gamma, beta, rm, rv).  Returns tap tensors.
+    banks (ops.FilterBanks, refreshed by the caller): the filter banks of all slots in their GEMM forms."""
     out: Dict[int, torch.Tensor] = {-1: x_nhwc}
     # abs-max word of every activation (ops.amax_*): written by the kernel that produces the tensor, read by the GEMMs
     # that consume it (forward here, weight gradient in the backward) to pick their power-of-two operand scales
@@ -283,13 +284,18 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
         if isinstance(op, _ConvOp):
             p = P[op.slot]
             x = out[op.src]; ax = amx.get(op.src)
-            w = ops.weight_to_ohwi(p["w"])
-            aw = ops.absmax(p["w"]) if (am and op.cin > 4) else None
+            bank = banks.get(op.slot, p["w"]) if banks is not None else None
+            if bank is not None:       # prepared for the whole network in one go (no per-layer transpose / abs-max / pre-split)
+                w, aw, wsp = bank["ohwi"], (bank["amax"] if am else None), bank["split"]
+                w._dcn_wt = (bank["t"], bank["tsplit"])
+            else:
+                w = ops.weight_to_ohwi(p["w"]); wsp = None
+                aw = ops.absmax(p["w"]) if (am and op.cin > 4) else None
             ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
             if op.bn and training:
-                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw)
+                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp)
                 cnt = y.numel() // op.cout
                 mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
                 o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
@@ -302,13 +308,14 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict]):
                 else:
                     scale, shift = None, p["b"]
                 if save is None:      # inference: one kernel per layer, shortcut fused in the epilogue
-                    o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res, amax_x=ax, amax_w=aw, amax_out=ao)
+                    o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res, amax_x=ax, amax_w=aw, amax_out=ao,
+                                          w_split_ready=wsp)
                 else:                 # frozen-BN fine-tuning: keep the pre-shortcut activation for act'
                     if res is None:
-                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, amax_out=ao)
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, amax_out=ao, w_split_ready=wsp)
                         o = a
                     else:
-                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw)
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, w_split_ready=wsp)
                         o = ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res, amax_out=ao)
                     save[op.slot] = (x, a, scale, w, ax, aw)
             out[op.dst] = o; amx[op.dst] = ao
@@ -395,10 +402,11 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
             if op.need_dx:
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
+                wtr = getattr(w, "_dcn_wt", None)      # the transposed banks of this step (ops.FilterBanks)
                 if cur is None:
-                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw)
+                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw, wt_ready=wtr)
                 else:
-                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw)
+                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr)
             pg[op.slot] = d
     if pg:
         ops.join_side(next(iter(P.values()))["w"].device)
@@ -416,7 +424,7 @@ class _DarknetFn(torch.autograd.Function):
         x = ops.nchw_to_nhwc(image.contiguous(), 4)
         need_grad = any(ctx.needs_input_grad[3:])
         save = {} if need_grad else None
-        outs, tap_amax = _run_forward(plan, taps, x, P, training, save)
+        outs, tap_amax = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P))
         net._tap_amax = tap_amax              # abs-max words of the three taps (read by the head's first convolutions)
         if save is not None:
             # outputs must go through save_for_backward (an attribute reference would make a
@@ -497,6 +505,20 @@ class Darknet(nn.Module):
                 d["b"] = next(it).detach()
             P[op.slot] = d
         return P
+
+    def _filter_banks(self, P):
+        """All filter banks of the backbone in their GEMM forms, refreshed once per forward (ops.FilterBanks: three launches
+        instead of ~5 small kernels per layer; the banks of a step serve its backward too).  The job table holds raw parameter
+        addresses, so it is rebuilt when a parameter moved."""
+        if not ops.FILTER_BANKS:
+            return None
+        ws = {slot: d["w"] for slot, d in P.items()}
+        fb = self.__dict__.get("_fbanks")
+        if fb is None or not fb.valid_for(ws):
+            fb = ops.FilterBanks(ws, next(iter(ws.values())).device)
+            self.__dict__["_fbanks"] = fb
+        fb.refresh()
+        return fb
 
     def forward_nhwc(self, x: torch.Tensor) -> List[torch.Tensor]:
         if not x.is_cuda:

@@ -22,11 +22,13 @@ SIGNATURES = {
     "dcn_nhwc_to_nchw": (I, [P, P, I, I, I, I, I, P]),
     "dcn_oihw_to_ohwi": (I, [P, P, I, I, I, I, I, P]),
     "dcn_ohwi_to_oihw": (I, [P, P, I, I, I, I, I, P]),
-    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P, P, P, P, P]),
+    "dcn_conv2d_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P, P, P, P, P, I, P]),
     "dcn_absmax": (I, [P, L, I, I, P, P]),
     "dcn_f8_scale": (I, [P, L, I, I, P, P, P]),
     "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),
-    "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, P, P]),
+    "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P, P]),
+    "dcn_filter_job_bytes": (I, []),
+    "dcn_prepare_filters": (I, [P, I, I, I, P, L, P]),
     "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
     "dcn_conv2d_geom": (I, [P, I, I, I, I, I, P]),
     "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P, P, P]),
@@ -107,7 +109,7 @@ SIGNATURES = {
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
-_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows"}      # int-returning value functions
+_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes"}      # int-returning value functions
 
 
 class DcnError(RuntimeError):

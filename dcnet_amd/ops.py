@@ -222,7 +222,8 @@ def f8_scales(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
-               residual=None, out=None, want_stats=False, accumulate=False, amax_x=None, amax_w=None, amax_out=None):
+               residual=None, out=None, want_stats=False, accumulate=False, amax_x=None, amax_w=None, amax_out=None,
+               w_split_ready=None):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
     where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats).
     amax_x / amax_w: abs-max words of the operands (computed here by a pass over the data when missing and the
@@ -242,29 +243,97 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
     wsplit = None
     if cin != 4:
         amax_x = _amax_or_pass(x, amax_x); amax_w = _amax_or_pass(w_ohwi, amax_w)
-        if amax_w is not None and _precision == "fp32":
+        if w_split_ready is not None and amax_w is not None and _precision == "fp32":
+            wsplit = w_split_ready                                        # prepared for the whole network (FilterBanks)
+        elif amax_w is not None and _precision == "fp32":
             wsplit = scratch(w_ohwi.numel() + 16, x.device, slot=5)       # the filter bank, split once per launch
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
                      0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8),
-                     _p(amax_x), _p(amax_w), _p(amax_out), _p(wsplit), _s())
+                     _p(amax_x), _p(amax_w), _p(amax_out), _p(wsplit), int(wsplit is not None and wsplit is w_split_ready), _s())
     return out, stats
 
 
-def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None):
-    """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin)."""
+def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None, wt_ready=None):
+    """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin).
+    wt_ready = (transposed fp32 bank, its split form | None) prepared by FilterBanks: nothing is converted here."""
     n, ho, wo, cout = dy.shape
     cin = w_ohwi.shape[3]
     h, wd = in_hw
     if out is None:
         out = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
-    wt = scratch(w_ohwi.numel() + 16, dy.device, slot=1)
     f8 = None
-    if True:
-        amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)
+    amax_dy = _amax_or_pass(dy, amax_dy); amax_w = _amax_or_pass(w_ohwi, amax_w)
+    if wt_ready is not None:
+        wt, wts = wt_ready
+        if _precision != "fp32":
+            wts = None
+    else:
+        wt, wts = scratch(w_ohwi.numel() + 16, dy.device, slot=1), None
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
-                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w), _s())
+                          n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w),
+                          int(wt_ready is not None), _p(wts), _s())
     return out
+
+
+FILTER_BANKS = True      # A/B switch: False = per-layer transposes / abs-max / pre-split again
+
+
+class FilterBanks:
+    """The filter banks of a list of convolutions in every form a step needs, refreshed by ONE dcn_prepare_filters call
+    (three launches) instead of four small kernels per layer and direction: OHWI fp32, OHWI split into f16 pieces, the
+    channel-transposed bank of the data gradient (fp32 and split) and the bank's abs-max word.
+    ``weights``: OIHW parameters with Cin and Cout multiples of 32 (others keep the per-layer path: ``get`` returns None)."""
+
+    def __init__(self, weights, device):
+        import struct
+        self.device = torch.device(device)
+        self.items = {}
+        pairs = weights.items() if isinstance(weights, dict) else enumerate(weights)
+        ok = [(i, w) for i, w in pairs if w is not None and w.dim() == 4 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0
+              and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
+        self.amax = torch.zeros(max(1, len(ok)) * AMAX_WORDS, dtype=torch.int32, device=self.device)
+        rec = lib().filter_job_bytes()
+        assert rec == 6 * 8 + 6 * 4, rec
+        blob = bytearray()
+        blk = ablk = 0
+        self._ptrs = []
+        for j, (i, w) in enumerate(ok):
+            co, ci, kh, kw = w.shape
+            T = kh * kw
+            numel = w.numel()
+            ohwi = torch.empty((co, kh, kw, ci), dtype=torch.float32, device=self.device) if T > 1 else None
+            split = torch.empty(numel + 16, dtype=torch.float32, device=self.device)
+            t = torch.empty(numel + 16, dtype=torch.float32, device=self.device)
+            tsplit = torch.empty(numel + 16, dtype=torch.float32, device=self.device)
+            am = self.amax[j * AMAX_WORDS:(j + 1) * AMAX_WORDS]
+            self.items[i] = dict(ohwi=ohwi, split=split, t=t, tsplit=tsplit, amax=am, shape=(co, ci, kh, kw))
+            blob += struct.pack("<6Q6i", w.data_ptr(), 0 if ohwi is None else ohwi.data_ptr(), split.data_ptr(), t.data_ptr(),
+                                tsplit.data_ptr(), am.data_ptr(), co, ci, T, blk, ablk, 0)
+            self._ptrs.append((i, w.data_ptr()))
+            blk += T * (co // 32) * (ci // 32); ablk += (numel + 4095) // 4096
+        self.njobs, self.blocks, self.ablocks = len(ok), blk, ablk
+        self.jobs = torch.frombuffer(blob, dtype=torch.uint8).clone().to(self.device) if ok else None
+
+    def valid_for(self, weights) -> bool:
+        """The job table holds raw parameter addresses: it is stale once a parameter moved (``.to()``, a new tensor)."""
+        return all(weights.get(i) is not None and weights[i].data_ptr() == ptr for i, ptr in self._ptrs) if isinstance(weights, dict) \
+            else all(weights[i] is not None and weights[i].data_ptr() == ptr for i, ptr in self._ptrs)
+
+    def refresh(self):
+        if self.njobs:
+            lib().prepare_filters(self.jobs.data_ptr(), self.njobs, self.blocks, self.ablocks, self.amax.data_ptr(),
+                                  self.amax.numel(), _s())
+
+    def get(self, i, w):
+        """dict(ohwi (Cout,k,k,Cin), split, t, tsplit, amax) of weight ``i``, or None when it is not in the table."""
+        it = self.items.get(i)
+        if it is None:
+            return None
+        if it["ohwi"] is None:
+            co, ci, kh, kw = it["shape"]
+            it = dict(it); it["ohwi"] = w.detach().view(co, 1, 1, ci)       # a 1x1 bank is the same bytes in OIHW and OHWI
+        return it
 
 
 _geom = {}

@@ -67,7 +67,8 @@ int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                    const float* scale, const float* shift, int act, float slope,
                    const float* residual, int ldr, int ldy,
                    float* stats, int accumulate, const float* f8_scales,
-                   const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, void* stream);
+                   const uint32_t* amax_x, const uint32_t* amax_w, uint32_t* amax_y, float* w_split, int w_split_ready,
+                   void* stream);
 /* w_split (optional scratch, cout*k*k*cin + 16 floats): with the f16 split, the filter bank is cut into its two f16 pieces
  * ONCE into this buffer (8 consecutive k -> [8 high | 8 low], same bytes) and the tiles copy it, instead of every M-tile
  * splitting the same weights again.  dcn_conv2d_bwd_data does the same in place on its `wt` scratch, which therefore
@@ -96,7 +97,22 @@ int dcn_f8_scale(const float* x, int64_t rows, int c, int ld, float* scale, void
  * accumulate != 0: dx += result (used where a tensor feeds two consumers). */
 int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
-                        int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w, void* stream);
+                        int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                        int wt_ready, const float* wt_split, void* stream);
+/* w_split_ready / wt_ready / wt_split: the banks were prepared for the whole network by dcn_prepare_filters (below) — w_split
+ * holds the split OHWI bank, wt the transposed fp32 bank and wt_split its split form; nothing is converted per call.
+ *
+ * dcn_prepare_filters: every filter bank of a network in three launches (abs-max of each bank, then one LDS-tile pass that
+ * writes, per job, any of: the OHWI bank, its f16-split form, the channel-transposed [Ci][T][Co] bank of the data gradient and
+ * its split form; split banks carry their power-of-two scale in the float behind the bank, so they are numel + 16 floats).
+ * jobs: device array of records {const float* src (OIHW); float* ohwi, *ohwi_split, *t, *t_split (NULL = not wanted);
+ * uint32_t* amax; int co, ci, T, blk0, ablk0, pad} of dcn_filter_job_bytes() bytes each; co and ci multiples of 32; blk0 /
+ * ablk0 = ascending prefix sums of T*(co/32)*(ci/32) and ceil(co*ci*T/4096); amax_all/amax_words: the region that holds all
+ * the jobs' abs-max words (zeroed here).  Replaces, per layer and step: the OIHW->OHWI transpose, dcn_absmax of the bank,
+ * the pre-split and the data gradient's filter transpose (model/darknet.py:179-191 holds the parameters as OIHW). */
+int dcn_filter_job_bytes(void);
+int dcn_prepare_filters(const void* jobs, int njobs, int total_blocks, int total_amax_blocks,
+                        uint32_t* amax_all, int64_t amax_words, void* stream);
 
 /* Geometry table of a convolution (depends on n, h, wd, ksize, stride only; build once, reuse every step):
  * dcn_conv2d_geom_size entries of uint32, entry m = (index of the input pixel under the centre tap of

@@ -39,10 +39,10 @@ def test_bad_arguments_are_rejected_with_a_message():
     from dcnet_amd.lib import DcnError, lib
     L = lib()
     with pytest.raises(DcnError) as e:
-        L.conv2d_fwd(0, 0, 0, 1, 8, 8, 33, 16, 3, 1, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)     # cin not a multiple of 32
+        L.conv2d_fwd(0, 0, 0, 1, 8, 8, 33, 16, 3, 1, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)     # cin not a multiple of 32
     assert "cin" in str(e.value)
     with pytest.raises(DcnError):
-        L.conv2d_fwd(0, 0, 0, 1, 8, 8, 32, 16, 5, 1, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)     # ksize 5
+        L.conv2d_fwd(0, 0, 0, 1, 8, 8, 32, 16, 5, 1, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)     # ksize 5
 
 
 def test_product_has_no_cpu_path():

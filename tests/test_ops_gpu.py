@@ -686,3 +686,41 @@ def test_conv3_strip_kernel(dev, case):
             assert not torch.equal(new["y"], old["y"]) or not torch.equal(new["dx"], old["dx"]), "the strip kernel did not run"
     finally:
         lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
+
+
+def test_filter_banks_match_the_per_layer_preparation(dev):
+    """ops.FilterBanks (dcn_prepare_filters: every filter bank of a network in three launches) writes the same OHWI bank,
+    transposed bank, abs-max and f16-split banks as the per-layer kernels it replaces, and convolutions fed from it give
+    bitwise the results of the per-layer path (forward and data gradient, 3x3 and 1x1, strides 1 and 2)."""
+    from dcnet_amd import ops
+    shapes = [(128, 64, 3, 3), (64, 128, 1, 1), (256, 96, 3, 3), (96, 32, 1, 1), (33, 64, 3, 3), (64, 3, 3, 3)]
+    ws = {i: (_rand(*sh, seed=70 + i) * (10.0 ** (i - 2))).to(dev) for i, sh in enumerate(shapes)}
+    fb = ops.FilterBanks(ws, dev)
+    assert fb.valid_for(ws) and fb.get(4, ws[4]) is None and fb.get(5, ws[5]) is None      # 33 filters / 3 channels: per-layer path
+    fb.refresh()
+    for i in range(4):
+        w = ws[i]; co, ci, kh, kw = w.shape
+        b = fb.get(i, w)
+        assert torch.equal(b["ohwi"], w.permute(0, 2, 3, 1).contiguous())
+        assert torch.equal(b["t"][:w.numel()].view(ci, kh, kw, co), w.permute(1, 2, 3, 0).contiguous())
+        assert float(b["amax"].view(torch.float32).max()) == float(w.abs().max())
+        for name, ref in (("split", w.permute(0, 2, 3, 1)), ("tsplit", w.permute(1, 2, 3, 0))):
+            s = float(b[name][w.numel()])
+            hl = b[name][:w.numel()].view(-1, 8).view(torch.float16).view(-1, 2, 8).double()
+            back = (hl[:, 0] + hl[:, 1]).reshape(-1) / s
+            amax = float(w.abs().max())
+            assert 2.0 ** 13 <= amax * s < 2.0 ** 14
+            assert float((back - ref.reshape(-1).double()).abs().max()) <= amax * 2.0 ** -21
+    x = _rand(4, 20, 20, 64, seed=80).to(dev)
+    for i, k, st in ((0, 3, 1), (0, 3, 2)):
+        b = fb.get(i, ws[i])
+        y0, _ = ops.conv2d_fwd(x, b["ohwi"], k, st)
+        y1, _ = ops.conv2d_fwd(x, b["ohwi"], k, st, amax_w=b["amax"], w_split_ready=b["split"])
+        assert torch.equal(y0, y1)
+        dy = _rand(*y0.shape, seed=81).to(dev)
+        d0 = ops.conv2d_bwd_data(dy, b["ohwi"], (20, 20), k, st)
+        d1 = ops.conv2d_bwd_data(dy, b["ohwi"], (20, 20), k, st, amax_w=b["amax"], wt_ready=(b["t"], b["tsplit"]))
+        assert torch.equal(d0, d1)
+    x1 = _rand(4, 20, 20, 128, seed=82).to(dev)
+    b = fb.get(1, ws[1])
+    assert torch.equal(ops.conv2d_fwd(x1, b["ohwi"], 1, 1)[0], ops.conv2d_fwd(x1, b["ohwi"], 1, 1, amax_w=b["amax"], w_split_ready=b["split"])[0])
