@@ -51,6 +51,9 @@ def parse():
                          "exclusive duration (0 = skip, e.g. under rocprofv3 so its averages match the timed region)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
+    ap.add_argument("--reducer", choices=["overlap", "ddp"], default="overlap",
+                    help="multi-GPU gradient averaging: 'overlap' = dcnet_amd.parallel.OverlappedGradReducer (buckets all-reduced on a "
+                         "communication stream while the backbone's backward is still running), 'ddp' = torch DDP wrapper")
     return ap.parse_args()
 
 
@@ -161,7 +164,13 @@ def main():
     # freezing them gives DDP a static graph instead of find_unused_parameters=True (train_DCNet.py:483)
     from dcnet_amd.parallel import freeze_gradless, wrap_ddp
     freeze_gradless(model)
-    net = wrap_ddp(model, local_rank) if use_ddp else model
+    red = None
+    if use_ddp and args.reducer == "overlap":
+        from dcnet_amd.parallel import attach_overlapped_reducer
+        red = attach_overlapped_reducer(model)
+        net = model
+    else:
+        net = wrap_ddp(model, local_rank) if use_ddp else model
     from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
     opt = make_optimizer(model, 1e-4)
 
@@ -176,7 +185,11 @@ def main():
         out = net(image, word_id, word_mask)
         loss, _ = losses.total_loss(out, bbox, args.size)
         opt.zero_grad(set_to_none=True)
+        if red is not None:
+            red.begin_step()
         loss.backward()
+        if red is not None:
+            red.finish()             # heads / language gradients in one flat bucket; joins the communication stream
         opt.step()
         return loss
 
@@ -270,7 +283,8 @@ def main():
                  26: "igemm_kernel<256,64,4,1,0,false,16,true,0,2>",
                  27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2>",
                  # 28: the 3x3 stride-1 layers (forward and data gradient): f16 split with the activation strip resident in LDS
-                 28: "conv3_kernel<4,2,4>", 29: "conv3_kernel<2,2,4>"}
+                 28: "conv3_kernel<4,2,4>", 29: "conv3_kernel<2,2,4>",
+                 30: "reduce_slabs_kernel", 31: "dA_kernel"}
         flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29}
         peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29)
                        else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}

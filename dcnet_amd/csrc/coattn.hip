@@ -261,7 +261,9 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
   const int64_t total4 = rows * (ldE / 4);
   int64_t g = (total4 + 255) / 256; if (g > 8192) g = 8192;
   if (g > 1024) g = 1024;      // (one abs-max atomic per workgroup)
+  const int pid_da = prof_begin(31, (double)total4 * 16.0 * 4.0, stream);             // HBM-priced: E, dP1, dP2 read, dA written
   hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
+  prof_end(pid_da, stream);
   DCN_CHECK_LAUNCH("dA");
   // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                   (NN x2)
   gemm_params(p, dP1, ldE, (long long)hw * ldE, f2, ldf, bsf, d_f1, lddf, bsdf, hw, c, ldE, b);

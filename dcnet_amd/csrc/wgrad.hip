@@ -626,7 +626,9 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   if (pl.splits > 1) {
     const int64_t n4 = (int64_t)cout * pl.ld_out / 4;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    const int pid = prof_begin(30, (double)(pl.splits + 1) * n4 * 16.0, stream);     // HBM-priced: slabs read + dw written
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, pl.splits);
+    prof_end(pid, stream);
     DCN_CHECK_LAUNCH("reduce_slabs");
   }
   return DCN_OK;

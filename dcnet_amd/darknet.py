@@ -333,8 +333,12 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
     return [out[t] for t in taps], [amx.get(t) for t in taps]
 
 
-def _run_backward(plan, taps, grads_taps, P, save, training: bool):
-    """Hand-scheduled reverse sweep.  Returns {slot: dict(w=, b=, gamma=, beta=)} parameter grads."""
+def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bucket_bytes: int = 0):
+    """Hand-scheduled reverse sweep.  Returns {slot: dict(w=, b=, gamma=, beta=)} parameter grads.
+    sink (optional): called with [(slot, key, tensor), ...] every time ``bucket_bytes`` of parameter gradients are final —
+    the data-parallel reducer starts their all-reduce while the sweep continues (parallel.OverlappedGradReducer)."""
+    pending: list = []
+    pending_bytes = 0
     g: Dict[int, Optional[torch.Tensor]] = {}
 
     def add(slot, t):
@@ -408,6 +412,14 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool):
                 else:
                     ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr)
             pg[op.slot] = d
+            if sink is not None:
+                for k_, t_ in d.items():
+                    if t_ is not None:
+                        pending.append((op.slot, k_, t_)); pending_bytes += t_.numel() * 4
+                if pending_bytes >= bucket_bytes:
+                    sink(pending); pending = []; pending_bytes = 0
+    if sink is not None and pending:
+        sink(pending)
     if pg:
         ops.join_side(next(iter(P.values()))["w"].device)
     return pg
@@ -444,7 +456,14 @@ class _DarknetFn(torch.autograd.Function):
         outs = ctx.saved_tensors
         save = {slot: ((outs[t[0][1]],) + t[1:] if isinstance(t[0], tuple) else t) for slot, t in ctx.save.items()}
         ctx.save = None
-        pg = _run_backward(net._plan, net._taps, grads, ctx.P, save, ctx.training)
+        red = net.__dict__.get("_grad_reducer")       # parallel.OverlappedGradReducer (data-parallel runs), else None
+        sink = None
+        if red is not None:
+            pmap = net._slot_params()
+            sink = lambda items: red.push([(pmap[(slot, key)], t) for slot, key, t in items if (slot, key) in pmap])
+        pg = _run_backward(net._plan, net._taps, grads, ctx.P, save, ctx.training, sink, red.bucket_bytes if red is not None else 0)
+        if red is not None:
+            red.join_backward()                        # the averaged gradients are complete before autograd sees them
         flat_grads: List[Optional[torch.Tensor]] = []
         for op in net._conv_ops:
             d = pg.get(op.slot, {})
@@ -505,6 +524,18 @@ class Darknet(nn.Module):
                 d["b"] = next(it).detach()
             P[op.slot] = d
         return P
+
+    def _slot_params(self):
+        """{(slot, "w" | "gamma" | "beta" | "b"): parameter} of the live convolutions."""
+        out = {}
+        for op in self._conv_ops:
+            seq = self.module_list[op.slot]
+            out[(op.slot, "w")] = seq[0].weight
+            if op.bn:
+                out[(op.slot, "gamma")] = seq[1].weight; out[(op.slot, "beta")] = seq[1].bias
+            elif seq[0].bias is not None:
+                out[(op.slot, "b")] = seq[0].bias
+        return out
 
     def _filter_banks(self, P):
         """All filter banks of the backbone in their GEMM forms, refreshed once per forward (ops.FilterBanks: three launches

@@ -87,6 +87,139 @@ class FlatGradAllReduce:
                 p.grad.copy_(v)
 
 
+class OverlappedGradReducer:
+    """Gradient all-reduce that runs UNDER the backward pass (what the reference gets from DDP's bucket hooks,
+    train_DCNet.py:483), for a model whose backbone is one autograd node.
+
+    DDP's hooks fire when autograd hands a gradient to its parameter; our backbone (darknet._DarknetFn) hands over all its
+    ~220 gradients at once when its hand-scheduled backward returns, i.e. after the LAST kernel of the step — the all-reduce
+    of 160 MB of backbone gradients would start when nothing is left to hide it behind.  Instead the backbone's reverse
+    sweep calls ``push`` every time ``bucket_bytes`` of parameter gradients are final (deepest layers first: the 1024-channel
+    banks, most of the bytes, are ready while the long early-layer backward is still ahead): the bucket is averaged over the
+    ranks on a communication stream, in place, while the data-gradient chain continues.  ``finish`` reduces what autograd
+    produced outside the backbone (heads, language branch: one flat bucket) and joins the streams.
+
+    Semantics: every reduced gradient ends up as the mean over ranks, exactly as with DDP / FlatGradAllReduce.  The pushing
+    node joins the communication stream before it returns its gradients to autograd, so whatever autograd does with them
+    next (adopt, copy) sees averaged values; start each step from ``zero_grad(set_to_none=True)`` — a pushed gradient ADDED
+    into an existing ``.grad`` would be averaged while the old content is not (DDP has the same contract under no_sync).
+    On CPU tensors (gloo, tests) the same calls run synchronously."""
+
+    def __init__(self, model_or_params, bucket_bytes: int = 48 << 20, group=None):
+        params = model_or_params.parameters() if hasattr(model_or_params, "parameters") else model_or_params
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket_bytes = int(bucket_bytes)
+        self.group = group
+        self._comm = None
+        self._pushed = set()         # id(param) of the parameters whose gradient was reduced during the backward
+        self._bufs = {}
+        self.buckets_last_step = 0
+
+    # -- plumbing --------------------------------------------------------------------------------------
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _stream(self, device):
+        if device.type != "cuda":
+            return None
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=device)
+        return self._comm
+
+    def _buffer(self, key, n, like):
+        b = self._bufs.get(key)
+        if b is None or b.numel() < n or b.device != like.device:
+            b = torch.empty(n, dtype=like.dtype, device=like.device)
+            self._bufs[key] = b
+        return b[:n]
+
+    def _reduce(self, tensors: Sequence[torch.Tensor], key) -> None:
+        """Average ``tensors`` over the ranks in place: pack, one all-reduce, unpack.  On a GPU everything is queued on the
+        communication stream, which first waits for the streams that produced the gradients."""
+        if not tensors:
+            return
+        dev = tensors[0].device
+        comm = self._stream(dev)
+        world = self._world()
+        n = sum(t.numel() for t in tensors)
+        if comm is not None:
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            for s in self._producer_streams(dev):
+                comm.wait_stream(s)
+        ctx = torch.cuda.stream(comm) if comm is not None else _null()
+        with ctx:
+            flat = self._buffer(key, n, tensors[0])
+            views = []
+            off = 0
+            for t in tensors:
+                views.append(flat[off:off + t.numel()].view(t.shape)); off += t.numel()
+            torch._foreach_copy_(views, list(tensors))
+            if world > 1:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # (on a GPU: ordered on `comm` by ProcessGroupNCCL)
+                flat.div_(world)
+            torch._foreach_copy_(list(tensors), views)
+            if comm is not None:
+                for t in tensors:
+                    t.record_stream(comm)
+        self.buckets_last_step += 1
+
+    def _producer_streams(self, device):
+        from . import ops
+        try:
+            return [ops.side_stream(device)] if ops.WGRAD_SIDE else []
+        except Exception:
+            return []
+
+    # -- the three calls of a step ------------------------------------------------------------------------
+    def begin_step(self) -> None:
+        self._pushed.clear()
+        self.buckets_last_step = 0
+
+    def push(self, pairs: Sequence) -> None:
+        """pairs = [(parameter, its final gradient tensor), ...]: called from inside a backward pass as gradients complete."""
+        pairs = [(p, g) for p, g in pairs if g is not None and p.requires_grad]
+        if not pairs:
+            return
+        for p, _ in pairs:
+            self._pushed.add(id(p))
+        self._reduce([g for _, g in pairs], "bucket")
+
+    def join_backward(self, device=None) -> None:
+        """The current stream waits for every bucket pushed so far (call before the pushed gradients are read or handed to
+        autograd's accumulation)."""
+        if self._comm is not None:
+            torch.cuda.current_stream(self._comm.device).wait_stream(self._comm)
+
+    def finish(self) -> None:
+        """After backward(): reduce the gradients that were not pushed (one flat bucket) and join the streams."""
+        rest = [p.grad for p in self.params if id(p) not in self._pushed and p.grad is not None]
+        self._reduce(rest, "rest")
+        self.join_backward()
+
+    def sync_buffers(self, model, src: int = 0) -> None:
+        """BatchNorm running statistics of rank ``src`` to every rank — what DDP(broadcast_buffers=True) leaves behind (rank 0's
+        buffers overwrite the others' every forward; train-mode forwards never read them, so once before eval/save is the same)."""
+        if self._world() > 1:
+            for b in model.buffers():
+                dist.broadcast(b.data, src=src, group=self.group)
+
+
+def attach_overlapped_reducer(model, bucket_bytes: int = 48 << 20, group=None) -> OverlappedGradReducer:
+    """Data-parallel setup without the DDP wrapper: parameters of rank 0 to every rank, a reducer over all trainable
+    parameters, and the backbone told to push its gradients into it during its backward.  Per step:
+    ``red.begin_step(); loss.backward(); red.finish(); optimizer.step()``."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        broadcast_parameters(model, 0, group)
+    red = OverlappedGradReducer(model, bucket_bytes, group)
+    model.visumodel.__dict__["_grad_reducer"] = red
+    return red
+
+
+class _null:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 def broadcast_parameters(model, src: int = 0, group=None) -> None:
     """Initial parameter/buffer broadcast (what DDP does at wrap time, C3 in SURVEY.md)."""
     for t in list(model.parameters()) + list(model.buffers()):

@@ -114,6 +114,90 @@ def test_two_rank_allreduce_with_a_single_node_backbone(tmp_path):
     assert all(gr is None for gr in r[0]["frozen_grads"])
 
 
+class _PushingGrads(torch.autograd.Function):
+    """_ManyGrads whose backward hands finished gradients to a reducer in groups while it is still running — the shape of
+    darknet._DarknetFn with parallel.OverlappedGradReducer attached (sink called per bucket, join before returning)."""
+
+    @staticmethod
+    def forward(ctx, red, params, x, *ws):
+        acts = [x]
+        for w in ws:
+            acts.append(torch.tanh(acts[-1] @ w))
+        ctx.save_for_backward(*acts, *ws)
+        ctx.n, ctx.red, ctx.params = len(ws), red, params
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        sv = ctx.saved_tensors
+        acts, ws = sv[:ctx.n + 1], sv[ctx.n + 1:]
+        grads = [None] * ctx.n
+        pending = []
+        for i in range(ctx.n - 1, -1, -1):
+            g = g * (1 - acts[i + 1] ** 2)
+            if ctx.needs_input_grad[3 + i]:
+                grads[i] = acts[i].t() @ g
+                pending.append((ctx.params[i], grads[i]))
+            if len(pending) >= 7:                      # a bucket is full: its all-reduce starts now
+                ctx.red.push(pending); pending = []
+            g = g @ ws[i].t()
+        ctx.red.push(pending)
+        ctx.red.join_backward()
+        return (None, None, g) + tuple(grads)
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dcnet_amd.parallel import OverlappedGradReducer, broadcast_parameters, shard_indices
+    torch.manual_seed(21 + rank)
+    m = _Backbone()
+    for i in (3, 17):
+        m.ws[i].requires_grad_(False)
+    for p in m.dead:
+        p.requires_grad_(False)
+    broadcast_parameters(m, src=0)
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(16, 12, generator=g); tgt = torch.randn(16, 3, generator=g)
+    idx = shard_indices(16, rank, world)
+    red = OverlappedGradReducer(m)
+    res = {}
+    for it in range(2):
+        # reference: plain local gradients
+        m.zero_grad(set_to_none=True)
+        ((m(data[idx]) - tgt[idx]) ** 2).mean().backward()
+        res[f"local{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        # the same step with buckets pushed from inside the backbone's backward and the head reduced by finish()
+        m.zero_grad(set_to_none=True)
+        red.begin_step()
+        y = m.head(_PushingGrads.apply(red, list(m.ws), data[idx], *m.ws))
+        ((y - tgt[idx]) ** 2).mean().backward()
+        res[f"pushed_before_finish{it}"] = len(red._pushed)
+        red.finish()
+        res[f"red{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        res[f"buckets{it}"] = red.buckets_last_step
+    torch.save(res, os.path.join(out, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_reducer_pushes_buckets_from_inside_the_backbone_backward(tmp_path):
+    """parallel.OverlappedGradReducer: the backbone node pushes buckets of finished gradients while its backward runs, the
+    head's gradients go in one bucket at finish(); every gradient ends up as the mean over the two ranks, frozen parameters
+    stay out, two steps in a row."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_overlap, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"o{i}.pt")) for i in range(world)]
+    for it in range(2):
+        keys = list(r[0][f"local{it}"].keys())
+        assert len(keys) == 38 + 2
+        assert r[0][f"pushed_before_finish{it}"] == 38            # all live backbone layers were reduced during the backward
+        assert r[0][f"buckets{it}"] == 38 // 7 + 1 + 1            # 5 full buckets + the remainder, + the head's flat bucket
+        for k in keys:
+            mean = (r[0][f"local{it}"][k] + r[1][f"local{it}"][k]) / 2
+            for i in range(world):
+                assert torch.allclose(r[i][f"red{it}"][k], mean, atol=1e-6), (it, k)
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
