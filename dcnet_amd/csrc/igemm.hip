@@ -710,10 +710,14 @@ int igemm_grid_m(int M, int Co, int ntaps) { return cdiv(M, tile_bm(M, Co, ntaps
 
 void wgrad_set_split(int v);
 void wgrad_set_abl(int v);
+void wgrad_set_target(int v);
+void wgrad_set_target_small(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'z') { wgrad_set_target_small(value); return DCN_OK; }   // "zwgsmall"
+  if (k == 'x') { wgrad_set_target(value); return DCN_OK; }   // "xwgtarget"
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
   if (k == 'p') { g_precision = value; wgrad_set_split(value == 3 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles
   if (k == 'b') g_force_bm = value;          // "bm": force the M tile (0 = automatic)

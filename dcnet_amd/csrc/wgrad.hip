@@ -473,6 +473,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 struct Plan { int tm, tn, tiles_co, tiles_ci, T, splits, kchunk, M, ld_out; };
+int g_wg_target = 1024;    // dcn_set_tuning("xwgtarget", n): workgroups a 3x3 stride-1 weight-gradient launch aims for (split-K sizing)
+int g_wg_target_small = 512;   // dcn_set_tuning("zwgsmall", n): the same for 1x1 and stride-2 layers
 int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream);
 
 Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
@@ -492,13 +494,18 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   // workgroups (two full rounds) and never for "a round plus a few" — 1026 workgroups cost a third round
   // for 2 of them (measured: -20 % on the 3x3 layers with the naive ceil(1024/base) choice).
   const int max_splits = pl.M / 256 > 0 ? pl.M / 256 : 1;   // at least 8 K-steps per split
-  int splits = 1024 / base;
+  // 1x1 and stride-2 layers on the 128x128 tile (2 workgroups per CU = 512 slots) have few tiles, so the slab traffic of many
+  // splits (splits x |W| written and read again) outweighs the finer balance: one full round of 512 workgroups beats 1024 by
+  // 5-20 % there (256->128 @52: 0.105 -> 0.088 ms, 1024->512 @13: 0.079 -> 0.064), 256 loses again; the 3x3 stride-1 layers
+  // lose 15-90 % at 512, and the narrow tiles of the 32/64-channel layers (more workgroups per CU, 11 M pixels) want all 1024.
+  const int target = ((ksize == 1 || stride == 2) && pl.tm == 128 && pl.tn == 128) ? g_wg_target_small : g_wg_target;
+  int splits = target / base;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   for (;;) {
     pl.kchunk = cdiv(cdiv(pl.M, splits), 32) * 32;
     pl.splits = cdiv(pl.M, pl.kchunk);
-    if (base * pl.splits <= 1024 || splits == 1 || base > 1024) break;
+    if (base * pl.splits <= target || splits == 1 || base > target) break;
     --splits;
   }
   return pl;
@@ -552,6 +559,8 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
 
 void wgrad_set_split(int v) { g_wsplit = v; }
 void wgrad_set_abl(int v) { g_wabl = v; }
+void wgrad_set_target(int v) { g_wg_target = v > 0 ? v : 1024; }
+void wgrad_set_target_small(int v) { g_wg_target_small = v > 0 ? v : 512; }
 
 // C[b][m][n] (+)= row_scale[b][m] * sum_k A[b][k][m] * B[b][k][n]   ("TN" GEMM: K is the strided dim of
 // both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.
