@@ -56,10 +56,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   static_assert((4 * BN) % NT == 0 && B_LD >= 1, "filter tile: whole loads per thread");
   static_assert(A_LD % 2 == 0, "strip pieces are split in two halves (taps 0 and 1)");
   constexpr int PB = BN * 32;                 // bytes per filter plane of one tap
+  // plane 1 sits 64 B past a multiple of 128: a ds_write_b128 wave-instruction stores the (plane 0, plane 1) chunks of the same
+  // row side by side in lane order, and with planes a multiple of 128 B apart they fell on the same banks (PMC:
+  // SQ_LDS_BANK_CONFLICT 23 % of SQ_LDS_IDX_ACTIVE)
+  constexpr int PB1 = PB + 64, SLOT = 2 * PB + 128;      // offset of plane 1 inside a tap slot / bytes per tap slot
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int PA = (S + 2) * 32;                // bytes per strip plane (+ the zero row at position S, + a dump row for predicated-off stores)
   unsigned char* const Abase = smem3;                     // [2 buffers][2 planes][PA]
-  unsigned char* const Bbase = smem3 + 4 * PA;            // [2 buffers][3 taps][2 planes][PB]
+  unsigned char* const Bbase = smem3 + 4 * PA;            // [2 buffers][3 taps][SLOT]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, half = lane >> 5;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     const int idx = tid + l * NT, row = idx >> 2, chunk = idx & 3;
     const int co = bn * BN + row;
     b_off[l] = co < p.Co ? (unsigned)(co * p.ldw * 4 + chunk * 16) : OOB3;
-    b_st[l] = (chunk & 1) * PB + row32(row, chunk >> 1);           // chunk: plane = chunk & 1, k-half = chunk >> 1
+    b_st[l] = (chunk & 1) * PB1 + row32(row, chunk >> 1);           // chunk: plane = chunk & 1, k-half = chunk >> 1
   }
   // rows of this lane (one per 32x32 block along M): in-image tap masks
   unsigned msk[2];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   };
   auto store_b_tap = [&](unsigned char* bbuf, const f32x4* br, int j) {
 #pragma unroll
-    for (int l = 0; l < B_LD; ++l) *reinterpret_cast<f32x4*>(bbuf + j * 2 * PB + b_st[l]) = br[j * B_LD + l];
+    for (int l = 0; l < B_LD; ++l) *reinterpret_cast<f32x4*>(bbuf + j * SLOT + b_st[l]) = br[j * B_LD + l];
   };
 
   f32x16 acc[2][2];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   // fragments of tap J of the iteration with constants (G, CP, IP) into stage ST
   auto read_frags = [&](const int G, const int CP, const int IP, const int J, const int ST) {
     const unsigned char* ab = Abase + CP * 2 * PA;
-    const unsigned char* bb = Bbase + IP * 6 * PB;
+    const unsigned char* bb = Bbase + IP * 3 * SLOT;
     const int t = 3 * G + J;
     const int sh = (p.tap_dy[t] + 1) * W + p.tap_dx[t] + 1;
 #pragma unroll
@@ -187,8 +191,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      bf[ST][ni][0] = *reinterpret_cast<const f16x8_t*>(bb + J * 2 * PB + b_fr[ni]);
-      bf[ST][ni][1] = *reinterpret_cast<const f16x8_t*>(bb + J * 2 * PB + PB + b_fr[ni]);
+      bf[ST][ni][0] = *reinterpret_cast<const f16x8_t*>(bb + J * SLOT + b_fr[ni]);
+      bf[ST][ni][1] = *reinterpret_cast<const f16x8_t*>(bb + J * SLOT + PB1 + b_fr[ni]);
     }
   };
   // one of the three cross terms, smallest first: (l,h) (h,l) (h,h)
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, in_a ? a_off[j] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
     }
     unsigned char* an = Abase + (CP ^ 1) * 2 * PA;
-    unsigned char* bnx = Bbase + (IP ^ 1) * 6 * PB;
+    unsigned char* bnx = Bbase + (IP ^ 1) * 3 * SLOT;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int st = (IP + j) & 1;
@@ -353,7 +357,7 @@ template <int WM, int WN, int A_LD>
 int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   const int S = BM + 2 * p.Wi + 2;
-  const size_t lds = (size_t)4 * (S + 2) * 32 + (size_t)2 * 3 * 2 * BN * 32;
+  const size_t lds = (size_t)4 * (S + 2) * 32 + (size_t)2 * 3 * (2 * BN * 32 + 128);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -408,7 +412,7 @@ bool conv3_applicable(const IgemmParams& p, int precision, int gran) {
   int a_need; const int wmm = conv3_tile(p, gran, &a_need);
   if (a_need > A_LD_MAX) return false;
   const int S = 64 * wmm + 2 * p.Wi + 2, bn = 128;
-  if ((size_t)4 * (S + 2) * 32 + (size_t)12 * bn * 32 > 160 * 1024) return false;
+  if ((size_t)4 * (S + 2) * 32 + (size_t)6 * (2 * bn * 32 + 128) > 160 * 1024) return false;
   // 32-bit strip offsets: S pixels of ldi floats
   if ((long long)S * p.ldi * 4 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 4 >= 0x7FFFFFF0LL) return false;
   return true;

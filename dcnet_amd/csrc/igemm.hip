@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   constexpr int B_TILE = BMODE == 0 ? BN * LDS_LD : BK * BN;
   unsigned short* As16 = reinterpret_cast<unsigned short*>(smem);      // SP: [2][NP][BM][LD16]
   unsigned short* Bs16 = As16 + 2 * NP * BM * LD16;                    // SP: [2][NP][BN][LD16]   (NN: [2][NP][16][128])
-  constexpr int B_PLANE = BMODE == 0 ? BN * LD16 : 2048;               // ushorts per B plane
+  // (pre-split B: +64 B between the planes — a ds_write_b128 stores the high and the low chunk of a row from neighbouring
+  //  lanes, and with planes 4096 B apart both fell on the same banks: two-way conflict on every filter store)
+  constexpr int B_PLANE = (BMODE == 0 ? BN * LD16 : 2048) + (BPRE ? 32 : 0);   // ushorts per B plane
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -602,7 +604,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   constexpr int LDS_LD = BK + 4;
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   constexpr int LD16 = (BK == 16 || F8) ? 16 : BK + 8;
-  const size_t lds = SP ? (size_t)2 * NP * (BM * LD16 + (BMODE == 0 ? BN * LD16 : 2048)) * sizeof(unsigned short)
+  const size_t lds = SP ? (size_t)2 * NP * (BM * LD16 + (BMODE == 0 ? BN * LD16 : 2048) + (BPRE ? 32 : 0)) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
