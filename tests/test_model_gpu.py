@@ -453,3 +453,58 @@ def test_light_head_matches_oracle_and_reference_fixture(dev):
     loss, _ = losses.total_loss(m(image.to(dev), word_id.to(dev), word_mask.to(dev)), synth_boxes(2, 256, seed=77).to(dev), 256)
     loss.backward()
     assert torch.isfinite(loss) and torch.isfinite(m.fcn_out[0][0].weight.grad).all() and float(m.fcn_emb[2][0].conv.weight.grad.abs().max()) > 0
+
+
+def test_overlapped_reducer_on_the_real_backbone_world_size_1(dev):
+    """parallel.OverlappedGradReducer wired into darknet._DarknetFn (the path bench.py takes for N > 1), on a one-rank RCCL group:
+    the backbone pushes its gradients in buckets from inside its backward (weight gradients come from the side stream, gamma /
+    beta from the main stream), the heads' gradients go in finish().  With one rank the average is the identity, so every
+    gradient must equal, bit for bit, the one of the same step without a reducer — which checks the stream plumbing (no bucket
+    packed before its gradients were complete, none read back late) — and every trainable parameter must have been visited."""
+    import torch.distributed as dist
+    from dcnet_amd import losses
+    from dcnet_amd.parallel import attach_overlapped_reducer, freeze_gradless
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n = 256, 4
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(n, size, seed=91)
+    bbox = synth_boxes(n, size, seed=91).to(dev)
+    m = build_product(size, sd, dev).train()
+    freeze_gradless(m)
+
+    def step(red):
+        m.load_state_dict(sd, strict=True)
+        m.zero_grad(set_to_none=True)
+        random.seed(13)
+        out = m(image.to(dev), word_id.to(dev), word_mask.to(dev))
+        loss, _ = losses.total_loss(out, bbox, size)
+        if red is not None:
+            red.begin_step()
+        loss.backward()
+        if red is not None:
+            red.finish()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    base = step(None)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        red = attach_overlapped_reducer(m, bucket_bytes=8 << 20)
+        got = step(red)
+        assert red.buckets_last_step >= 4, red.buckets_last_step               # several buckets during the backward + the flat rest
+        n_backbone = sum(1 for k, p in m.visumodel.named_parameters() if p.requires_grad)
+        assert len(red._pushed) == n_backbone, (len(red._pushed), n_backbone)   # every live backbone parameter went through push()
+        assert got.keys() == base.keys()
+        for k in base:
+            assert torch.equal(got[k], base[k]), k
+        got2 = step(red)                                                        # a second step reuses the bucket buffers
+        for k in base:
+            assert torch.equal(got2[k], base[k]), k
+    finally:
+        m.visumodel.__dict__.pop("_grad_reducer", None)
+        if created:
+            dist.destroy_process_group()
