@@ -383,8 +383,12 @@ int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
   int wmm = 4;
   const int wn = 2;
   if (wn == 2 && gran == 128) {
-    const long long wgs256 = (long long)cdiv(p.M, 256) * cdiv(p.Co, 128);
-    if (g_conv3_bm == 128 || (g_conv3_bm == 0 && wgs256 < 256)) wmm = 2;
+    const int gn = cdiv(p.Co, 128);
+    const long long wgs256 = (long long)cdiv(p.M, 256) * gn;
+    // Measured per layer at N = 64 (tools/bench_convs.py --ab 3bm=128): the 128-row tile (two workgroups per CU, epilogues
+    // overlap the other's K loop) wins 4-9 % with 2 or >= 8 filter tiles, the 256-row tile (half the filter traffic, shorter
+    // strip per output) wins 7-11 % with 1 or 4; both fill the same number of rounds.
+    if (g_conv3_bm == 128 || (g_conv3_bm == 0 && (wgs256 < 256 || gn == 2 || gn >= 8))) wmm = 2;
   }
   const int S = 64 * wmm + 2 * p.Wi + 2;
   *a_need = cdiv(4 * S, 64 * wmm * wn);
