@@ -214,7 +214,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    NT = 32
+    NT = 40            # DCN_PROF_TAGS
     alg_bytes = []
 
     def collect():
@@ -284,9 +284,11 @@ def main():
                  27: "igemm_kernel<128,128,2,2,1,false,16,true,0,2>",
                  # 28: the 3x3 stride-1 layers (forward and data gradient): f16 split with the activation strip resident in LDS
                  28: "conv3_kernel<4,2,4>", 29: "conv3_kernel<2,2,4>",
-                 30: "reduce_slabs_kernel", 31: "dA_kernel"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29}
-        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29)
+                 30: "reduce_slabs_kernel", 31: "dA_kernel",
+                 # 32: weight gradient of the 3x3 stride-1 layers, one filter row per workgroup (f16 split)
+                 32: "wgrad3_kernel"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32}
+        peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32)
                        else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
@@ -302,7 +304,9 @@ def main():
 
         kern = table(counts, ms, work, args.steps)
         mm_tags = sorted(flop_tags - {13, 14})
-        dom = max(mm_tags, key=lambda t: work[t])       # the kernel that carries most of the step's FLOPs
+        # the kernel that carries most of the step's FLOPs; the two tile builds of the strip kernel count as one family
+        fam = lambda t: work[28] + work[29] if t in (28, 29) else work[t]
+        dom = max(mm_tags, key=lambda t: (fam(t), work[t]))
         traffic = None; traffic_src = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
@@ -320,7 +324,7 @@ def main():
                     "avg_launch_ms": ms[dom] / counts[dom], "flop_per_launch": work[dom] / counts[dom],
                     "peak_note": ("fp32 operands as 2 f16 pieces (per-tensor power-of-two scale), 3 cross terms on "
                                   "v_mfma_f32_32x32x16_f16: peak = 2516.6 TFLOP/s dense f16 / 3 = 838.9 algorithmic fp32 TFLOP/s")
-                                 if dom in (24, 25, 26, 27, 28, 29) else
+                                 if dom in (24, 25, 26, 27, 28, 29, 32) else
                                  ("fp32 operands as 3 exact bf16 pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16: peak = "
                                   "2516.6 TFLOP/s dense bf16 / 6 = 419.4 algorithmic fp32 TFLOP/s (fp32 pipe: 157.3)")
                                  if dom in (16, 17, 18, 21) else "v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s",

@@ -714,10 +714,13 @@ void wgrad_set_split(int v);
 void wgrad_set_abl(int v);
 void wgrad_set_target(int v);
 void wgrad_set_target_small(int v);
+void wgrad3_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
+  if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"
   if (k == 'z') { wgrad_set_target_small(value); return DCN_OK; }   // "zwgsmall"
   if (k == 'x') { wgrad_set_target(value); return DCN_OK; }   // "xwgtarget"
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe

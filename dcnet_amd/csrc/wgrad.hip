@@ -557,6 +557,16 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
 
 }  // namespace
 
+int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream) {
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  const int pid = prof_begin(30, (double)(splits + 1) * n4 * 16.0, stream);     // HBM-priced: slabs read + dw written
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, splits);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("reduce_slabs");
+  return DCN_OK;
+}
+int wgrad_split_mode() { return g_wsplit; }
+
 void wgrad_set_split(int v) { g_wsplit = v; }
 void wgrad_set_abl(int v) { g_wabl = v; }
 void wgrad_set_target(int v) { g_wg_target = v > 0 ? v : 1024; }
@@ -583,9 +593,20 @@ int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int
   return dispatch_wgrad(p, tm, tn, p.tiles_co * p.tiles_ci, batch, stream);
 }
 
+// wgrad3.hip: 3x3 stride-1 layers, one filter row per workgroup (f16 split)
+bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout);
+int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream);
+
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
-  return pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  if (wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride)) {       // (which kernel runs depends on the abs-max words: size for both)
+    const int64_t w3 = wgrad3_ws(n, h, wd, cin, cout);
+    if (w3 > ws) ws = w3;
+  }
+  return ws;
 }
 
 extern "C" int64_t dcn_conv2d_geom_size(int n, int h, int wd, int ksize, int stride) {
@@ -618,6 +639,13 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   DCN_CHECK_ARG(cin != 4 || (ksize == 3 && stride == 1), "conv2d_bwd_weight: cin=4 path is the 3x3 stride-1 stem only");
   DCN_CHECK_ARG(cout % 4 == 0, "conv2d_bwd_weight: cout=%d must be a multiple of 4", cout);
   DCN_CHECK_ARG(x && dy && dw && geom, "conv2d_bwd_weight: null pointer (geom = table of dcn_conv2d_geom for this geometry)");
+  {
+    const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
+    const long long npix = (long long)n * h * wd;
+    if (g_wsplit == 4 && !g_wabl && amax_x && amax_dy && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
+        npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
+      return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, stream);
+  }
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
   WgradParams p{};
@@ -633,12 +661,7 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   int rc = dispatch_wgrad(p, pl.tm, pl.tn, grid, 1, stream);
   if (rc != DCN_OK) return rc;
   if (pl.splits > 1) {
-    const int64_t n4 = (int64_t)cout * pl.ld_out / 4;
-    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    const int pid = prof_begin(30, (double)(pl.splits + 1) * n4 * 16.0, stream);     // HBM-priced: slabs read + dw written
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, pl.splits);
-    prof_end(pid, stream);
-    DCN_CHECK_LAUNCH("reduce_slabs");
+    return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   }
   return DCN_OK;
 }

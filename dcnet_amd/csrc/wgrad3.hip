@@ -1,0 +1,283 @@
+// Weight gradient of the 3x3 stride-1 layers, one filter ROW (three taps) per workgroup, f16 two-piece split.
+//
+//   dW[co][r][s][ci] = sum_px dY[px][co] * X[px + (r-1)*W + (s-1)][ci]        (terms whose tap leaves the image are absent)
+//
+// wgrad.hip gives every tap its own workgroups: the dY tile is loaded, split into f16 pieces and written to LDS nine times per
+// (co, ci) tile, the X tile once per tap — 4 global loads and ~40 split operations per thread for 12 MFMAs per wave.  The three
+// taps of a filter row read X at pixel shifts -1, 0, +1, so one strip of 16 + 2 pixels serves all three, and the dY tile is
+// staged once for them: 3 loads per thread for 18 MFMAs per wave.  What stood in the way is the masking — the term (px, s) is
+// absent when px sits in column 0 (s = 0) or W-1 (s = 2), a different set per tap, which a SHARED strip cannot express at load
+// time.  It disappears in PADDED pixel coordinates: K runs over positions p of rows of W + 1 entries whose last entry is a
+// pad (dY = 0, X = 0 there).  Then X_pad[p - 1] of a column-0 pixel and X_pad[p + 1] of a column-(W-1) pixel are pads, i.e.
+// zero, for every row — no mask, no branch; the vertical taps (r = 0 on image row 0, r = 2 on row H-1) are the same for the
+// three taps of the workgroup's filter row and are applied to dY when it is loaded.  Cost: (W+1)/W more K (2-8 %).
+// The padded position is kept per load slot as (row index, column) and advanced by 16 per K-step: no division in the loop,
+// no geometry table.  LDS planes keep the HBM orientation [position][128 channels] (256-B rows, XOR-swizzled 16-B chunks) and
+// the MFMA operands come from ds_read_b64_tr_b16, as in wgrad.hip; the B fragment of tap s is the same read one row lower.
+// 8 waves: wave (wm, wn) owns 64 filters x 32 channels x 3 taps (96 accumulator registers).  Split-K over padded positions
+// into slabs summed in a fixed order (wgrad.hip reduce_slabs_kernel): bitwise reproducible.  Roofline: MFMA, 838.9 TFLOP/s.
+#include "common.h"
+#include "prof.h"
+#include <type_traits>
+
+int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream);
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOBW = 0x80000000u;
+
+struct W3Params {
+  const float* x; const float* dy; float* out;
+  int N, H, W, Ci, ldx, Co, lddy;
+  int Mp, kchunk, splits;          // padded positions N*H*(W+1); per split (multiple of 16)
+  int tiles_co, tiles_ci, ld_out;
+  const unsigned* amax_dy; const unsigned* amax_x;
+};
+
+__device__ __forceinline__ f32x4 ldw16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrcw(const float* base, long long bytes) {
+  const unsigned n = bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0u : (unsigned)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, n, 0x00020000);
+}
+__device__ __forceinline__ float pow2w(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xFF);
+  if (be == 0 || be == 255) return 1.f;
+  int e = 14 - (be - 126);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+// byte offset of channels c..c+3 (c % 4 == 0) of row `row` inside one [rows][128] f16 plane
+__device__ __forceinline__ int poff(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ swz(row)) + 8 * ((c >> 2) & 1); }
+
+constexpr int A_PLANE = 16 * 256, B_PLANE = 18 * 256;
+constexpr int B_BASE = 2 * A_PLANE, BUF = 2 * A_PLANE + 2 * B_PLANE;
+
+__global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];       // [2 buffers][A: 2 planes x 16 rows | B: 2 planes x 18 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;            // 64 filters x 32 channels per wave
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = p.tiles_ci * p.tiles_co * 3;
+  const int split = b / per_split; b -= split * per_split;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int r = b;                                    // filter row of this workgroup
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int Wp = p.W + 1;
+  const int p_begin = split * p.kchunk;
+  const int p_end = min(p.Mp, p_begin + p.kchunk);
+  const int iters = (p_end - p_begin + 15) / 16;
+  const float s_a = pow2w(amax_read(p.amax_dy)), s_b = pow2w(amax_read(p.amax_x));
+
+  const long long npix = (long long)p.N * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t a_rs = rsrcw(p.dy, ((npix - 1) * p.lddy + p.Co) * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrcw(p.x, ((npix - 1) * p.ldx + p.Ci) * 4);
+  const int nrows = p.N * p.H;                        // image rows in the tensor
+
+  // ---- load slots: A = dY row (position p_begin + ra), B0 / B1 = strip rows s (position p_begin - 1 + s, filter row r-1 down) --
+  const int ra = tid >> 5, cch = (tid & 31) * 4;      // row within the K-step, first of 4 channels
+  const bool a_chan = co0 + cch < p.Co, b_chan = ci0 + cch < p.Ci;
+  // state (row index = n*H + y, column in [0, Wp)); A also keeps y for the vertical tap test
+  int a_row, a_col, a_y;
+  { const int q = p_begin + ra; a_row = q / Wp; a_col = q - a_row * Wp; a_y = a_row % p.H; }
+  int b_row[2], b_col[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = p_begin - 1 + ra + 16 * j;          // >= -1
+    if (q < 0) { b_row[j] = -1; b_col[j] = Wp + q; }
+    else { b_row[j] = q / Wp; b_col[j] = q - b_row[j] * Wp; }
+    b_row[j] += r - 1;
+  }
+  const bool b1_on = tid < 64;                        // strip rows 16, 17
+  int pos_a = p_begin + ra;                           // padded position of the A row (end-of-split test)
+
+  auto advance = [&](int& row, int& col) {
+    col += 16;
+    while (col >= Wp) { col -= Wp; ++row; }
+  };
+  auto load_into = [&](f32x4& ar, f32x4* br) {
+    {
+      const bool vert = (r == 0 && a_y == 0) || (r == 2 && a_y == p.H - 1);
+      const bool ok = a_chan && pos_a < p_end && a_col < p.W && !vert;
+      const unsigned off = (unsigned)(((a_row * p.W + a_col) * p.lddy + co0 + cch) * 4);
+      ar = ldw16(a_rs, ok ? off : OOBW);
+      // advance (column, row, y)
+      a_col += 16;
+      while (a_col >= Wp) { a_col -= Wp; ++a_row; a_y = a_y + 1 == p.H ? 0 : a_y + 1; }
+      pos_a += 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = b_chan && (j == 0 || b1_on) && b_col[j] < p.W && (unsigned)b_row[j] < (unsigned)nrows;
+      const unsigned off = (unsigned)(((b_row[j] * p.W + b_col[j]) * p.ldx + ci0 + cch) * 4);
+      br[j] = ldw16(b_rs, ok ? off : OOBW);
+      advance(b_row[j], b_col[j]);
+    }
+  };
+  auto split_store = [&](unsigned char* plane0, int plane_stride, int off, const f32x4 v, const float sc) {
+    const f32x4 t = v * sc;
+    const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+    const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                       (_Float16)(t[3] - (float)h[3])};
+    *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(plane0 + plane_stride + off) = __builtin_bit_cast(uint2, l);
+  };
+  const int a_st = poff(ra, cch), b_st0 = poff(ra, cch), b_st1 = poff(16 + (ra & 1), cch);   // (b1: rows 16, 17 <- tid < 64: ra in {0, 1})
+  auto store_a = [&](int buf, const f32x4& ar) { split_store(sm3 + buf * BUF, A_PLANE, a_st, ar, s_a); };
+  auto store_b = [&](int buf, const f32x4* br) {
+    split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st0, br[0], s_b);
+    if (b1_on) split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st1, br[1], s_b);
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mi][d][q] = 0.f;
+
+  // transposed-read addresses: 16-lane group (hh, gg): k rows 8hh + 4r2 + q, channels blk*32 + 16gg + 4pp
+  const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+  int a_tr[2][2], b_tr[3][2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int row = 8 * hh + 4 * r2 + qq;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a_tr[mi][r2] = poff(row, wm * 64 + mi * 32 + 16 * gg + 4 * pp);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b_tr[d][r2] = B_BASE + poff(row + d, wn * 32 + 16 * gg + 4 * pp);
+  }
+  auto tr_read = [&](int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm3 + byte_off));
+  };
+  auto frag = [&](int byte0, int byte1) {
+    const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+
+  // one K-step: fragments of buffer `cur`, tap by tap (the B fragment of a tap is read right before its six MFMAs: 8 live
+  // registers instead of 24 — the kernel sits at the 256-register limit of two waves per SIMD); the split + LDS store of the
+  // NEXT step (registers ar/br) rides behind the first and second tap.  Every load of the loop is unconditional (igemm.hip).
+  auto step = [&](int cur, const f32x4& ar, const f32x4* br) {
+    f16x8_t af[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[mi][pl] = frag(cur * BUF + pl * A_PLANE + a_tr[mi][0], cur * BUF + pl * A_PLANE + a_tr[mi][1]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      f16x8_t bf[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bf[pl] = frag(cur * BUF + pl * B_PLANE + b_tr[d][0], cur * BUF + pl * B_PLANE + b_tr[d][1]);
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {             // smallest terms first: (l,h) (h,l) (h,h)
+        const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][qa], bf[qb], acc[mi][d], 0, 0, 0);
+      }
+      if (d == 0) store_a(cur ^ 1, ar);
+      if (d == 1) store_b(cur ^ 1, br);
+    }
+  };
+
+  // loads run one K-step ahead in registers, one more in the other LDS buffer
+  f32x4 ar, br[2];
+  if (iters > 0) {
+    load_into(ar, br);
+    store_a(0, ar); store_b(0, br);
+    load_into(ar, br);
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int cur = it & 1;
+    f32x4 an, bn[2];
+    load_into(an, bn);                                  // step it+2 (zeros past the end of the split)
+    step(cur, ar, br);                                  // multiplies step it, stores step it+1
+    ar = an; br[0] = bn[0]; br[1] = bn[1];
+    __syncthreads();
+  }
+
+  const float dq = 1.f / (s_a * s_b);                   // powers of two: exact
+  float* out = p.out + (size_t)split * p.Co * p.ld_out;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + wm * 64 + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (co >= p.Co) continue;
+      const int ci = ci0 + wn * 32 + (lane & 31);
+      if (ci >= p.Ci) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) out[(size_t)co * p.ld_out + (3 * r + d) * p.Ci + ci] = acc[mi][d][q] * dq;
+    }
+}
+
+int g_w3 = 1;             // dcn_set_tuning("u3row", 0): 3x3 stride-1 weight gradients back on the per-tap kernel
+int g_w3_target = 512;    // dcn_set_tuning("v3target", n): workgroups a launch aims for (split-K sizing; 512 threads, 1-2 per CU)
+
+struct Plan3 { int tiles_co, tiles_ci, splits, kchunk, Mp; };
+Plan3 plan3(int n, int h, int wd, int cin, int cout) {
+  Plan3 pl;
+  pl.tiles_co = cdiv(cout, 128); pl.tiles_ci = cdiv(cin, 128);
+  pl.Mp = n * h * (wd + 1);
+  const int base = pl.tiles_co * pl.tiles_ci * 3;
+  const int max_splits = pl.Mp / 256 > 0 ? pl.Mp / 256 : 1;
+  int splits = g_w3_target / base;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  pl.kchunk = cdiv(cdiv(pl.Mp, splits), 16) * 16;
+  pl.splits = cdiv(pl.Mp, pl.kchunk);
+  return pl;
+}
+
+}  // namespace
+
+void wgrad3_set_tuning(int key, int value) { if (key == 0) g_w3 = value; else g_w3_target = value > 0 ? value : 512; }
+
+// shape test only (the workspace is sized without knowing whether the abs-max words will be there)
+bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  if (!g_w3 || ksize != 3 || stride != 1 || cin < 128 || cout < 128 || cin % 4 || cout % 4 || wd < 2) return false;
+  const long long npix = (long long)n * h * wd;
+  if (npix * (cin > cout ? cin : cout) * 4 >= 0x7FFFFFF0LL) return false;        // 32-bit byte offsets from the tensor base
+  if ((long long)n * h * (wd + 1) >= 0x7FFFFFF0LL || npix < 1024) return false;
+  return true;
+}
+int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout) {
+  const Plan3 pl = plan3(n, h, wd, cin, cout);
+  return pl.splits > 1 ? (int64_t)pl.splits * cout * 9 * cin : 0;
+}
+
+int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
+  const Plan3 pl = plan3(n, h, wd, cin, cout);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
+  W3Params p{};
+  p.x = x; p.dy = dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy;
+  p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
+  p.amax_dy = amax_dy; p.amax_x = amax_x;
+  const size_t lds = 2 * BUF;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
+  const int pid = prof_begin(32, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);
+  hipLaunchKernelGGL(wgrad3_kernel, dim3(grid), dim3(512), lds, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("wgrad3");
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
+  return DCN_OK;
+}

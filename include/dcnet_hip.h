@@ -441,7 +441,8 @@ int dcn_stream_priority_range(int* least, int* greatest);
 
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
- * returns, per kernel tag (32 slots; 24-27 = f16 two-piece split tiles: igemm 128x128 / wgrad / igemm 256x64 / NN; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
+ * returns, per kernel tag (40 slots; 24-27 = f16 two-piece split tiles: igemm 128x128 / wgrad / igemm 256x64 / NN; 28/29 = conv3 strip
+ * kernel 256x128 / 128x128, 30 = reduce_slabs, 31 = dA, 32 = wgrad3; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
  * tile, 17 = split-bf16 128x128 weight-gradient / TN tile; 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
  * 5 weight-gradient/TN GEMM, 6-7 64x128 tiles, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward,
  * 12 exp+sums, 13/14 small latency-bound GEMMs of the LSTM steps),

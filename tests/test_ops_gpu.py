@@ -724,3 +724,49 @@ def test_filter_banks_match_the_per_layer_preparation(dev):
     x1 = _rand(4, 20, 20, 128, seed=82).to(dev)
     b = fb.get(1, ws[1])
     assert torch.equal(ops.conv2d_fwd(x1, b["ohwi"], 1, 1)[0], ops.conv2d_fwd(x1, b["ohwi"], 1, 1, amax_w=b["amax"], w_split_ready=b["split"])[0])
+
+
+W3_CASES = [
+    # n, h, w, cin, cout   (3x3 stride 1, >= 128 channels both sides, >= 1024 pixels)
+    (8, 13, 13, 128, 256),
+    (4, 26, 26, 256, 128),
+    (2, 33, 31, 136, 160),     # ragged channel tiles, odd map
+    (3, 20, 45, 128, 128),     # wide rows
+    (2, 52, 52, 128, 128),
+    (9, 11, 12, 192, 320),     # short rows: two padded rows per 16-position K-step
+]
+
+
+@pytest.mark.parametrize("case", W3_CASES)
+def test_wgrad3_filter_row_kernel(dev, case):
+    """csrc/wgrad3.hip (weight gradient of the 3x3 stride-1 layers, one filter row per workgroup, K over padded pixel
+    coordinates) against fp64 and against the per-tap kernel it replaces, including a dY that is a slice of a wider tensor.
+    Image borders (no masks: the pads must read as zero), image-to-image wrap of the strip, split-K slabs and ragged channel
+    tiles all matter here."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout = case
+    x = _rand(n, h, w, cin, seed=41).to(dev)
+    wide = (_rand(n, h, w, cout + 32, seed=42) / 8).to(dev)
+    dy = wide[..., 16:16 + cout]                                   # pixel stride cout + 32
+    xd = x.permute(0, 3, 1, 2).double().cpu()
+    wgt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, wgt, padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = wgt.grad.permute(0, 2, 3, 1)                             # OHWI
+    try:
+        lib().set_tuning(b"u3row", 0)
+        old = ops.conv2d_bwd_weight(x, dy, 3, 1)
+        lib().set_tuning(b"u3row", 1)
+        new = ops.conv2d_bwd_weight(x, dy, 3, 1)
+        new_c = ops.conv2d_bwd_weight(x, dy.contiguous(), 3, 1)
+        for target in (96, 2048):                                  # one split ... many splits
+            lib().set_tuning(b"v3target", target)
+            alt = ops.conv2d_bwd_weight(x, dy, 3, 1)
+            _close(alt, ref, 3e-5, f"wgrad3 target {target}")
+    finally:
+        lib().set_tuning(b"u3row", 1); lib().set_tuning(b"v3target", 512)
+    _close(new, ref, 3e-5, "wgrad3")
+    _close(old, ref, 3e-5, "per-tap wgrad")
+    _close(new, old, 3e-6, "wgrad3 vs per-tap")
+    assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
+    assert not torch.equal(new, old), "the filter-row kernel did not run"
