@@ -98,9 +98,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   const bool b1_on = tid < 64;                        // strip rows 16, 17
   int pos_a = p_begin + ra;                           // padded position of the A row (end-of-split test)
 
-  auto advance = [&](int& row, int& col) {
+  // 16 positions further: at most two row wraps (W >= 8), as selects — a loop here puts branches into the K loop
+  auto advance = [&](int& row, int& col) -> int {
     col += 16;
-    while (col >= Wp) { col -= Wp; ++row; }
+    const int w1 = col >= Wp ? 1 : 0; col -= w1 ? Wp : 0;
+    const int w2 = col >= Wp ? 1 : 0; col -= w2 ? Wp : 0;
+    row += w1 + w2;
+    return w1 + w2;
   };
   auto load_into = [&](f32x4& ar, f32x4* br) {
     {
@@ -108,9 +112,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
       const bool ok = a_chan && pos_a < p_end && a_col < p.W && !vert;
       const unsigned off = (unsigned)(((a_row * p.W + a_col) * p.lddy + co0 + cch) * 4);
       ar = ldw16(a_rs, ok ? off : OOBW);
-      // advance (column, row, y)
-      a_col += 16;
-      while (a_col >= Wp) { a_col -= Wp; ++a_row; a_y = a_y + 1 == p.H ? 0 : a_y + 1; }
+      a_y += advance(a_row, a_col);
+      a_y -= a_y >= p.H ? p.H : 0; a_y -= a_y >= p.H ? p.H : 0;
       pos_a += 16;
     }
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   auto store_a = [&](int buf, const f32x4& ar) { split_store(sm3 + buf * BUF, A_PLANE, a_st, ar, s_a); };
   auto store_b = [&](int buf, const f32x4* br) {
     split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st0, br[0], s_b);
-    if (b1_on) split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st1, br[1], s_b);
+    if (b1_on) split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st1, br[1], s_b);      // (one wave of the eight: wave-uniform)
   };
 
   f32x16 acc[2][3];
@@ -164,48 +167,64 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     return __builtin_bit_cast(f16x8_t, v);
   };
 
-  // one K-step: fragments of buffer `cur`, tap by tap (the B fragment of a tap is read right before its six MFMAs: 8 live
-  // registers instead of 24 — the kernel sits at the 256-register limit of two waves per SIMD); the split + LDS store of the
-  // NEXT step (registers ar/br) rides behind the first and second tap.  Every load of the loop is unconditional (igemm.hip).
-  auto step = [&](int cur, const f32x4& ar, const f32x4* br) {
-    f16x8_t af[2][2];
+  auto read_a = [&](int buf, f16x8_t (*af)[2]) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) af[mi][pl] = frag(cur * BUF + pl * A_PLANE + a_tr[mi][0], cur * BUF + pl * A_PLANE + a_tr[mi][1]);
+      for (int pl = 0; pl < 2; ++pl) af[mi][pl] = frag(buf * BUF + pl * A_PLANE + a_tr[mi][0], buf * BUF + pl * A_PLANE + a_tr[mi][1]);
+  };
+  auto read_b = [&](int buf, int d, f16x8_t* bf) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      f16x8_t bf[2];
+    for (int pl = 0; pl < 2; ++pl) bf[pl] = frag(buf * BUF + pl * B_PLANE + b_tr[d][0], buf * BUF + pl * B_PLANE + b_tr[d][1]);
+  };
+  auto mfma_tap = [&](int d, f16x8_t (*af)[2], const f16x8_t* bf) {      // smallest terms first: (l,h) (h,l) (h,h)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bf[pl] = frag(cur * BUF + pl * B_PLANE + b_tr[d][0], cur * BUF + pl * B_PLANE + b_tr[d][1]);
+    for (int term = 0; term < 3; ++term) {
+      const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
 #pragma unroll
-      for (int term = 0; term < 3; ++term) {             // smallest terms first: (l,h) (h,l) (h,h)
-        const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-          acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][qa], bf[qb], acc[mi][d], 0, 0, 0);
-      }
-      if (d == 0) store_a(cur ^ 1, ar);
-      if (d == 1) store_b(cur ^ 1, br);
+      for (int mi = 0; mi < 2; ++mi) acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][qa], bf[qb], acc[mi][d], 0, 0, 0);
     }
   };
 
-  // loads run one K-step ahead in registers, one more in the other LDS buffer
+  // Issue order of one K-step, fixed with scheduling barriers (the compiler's own order issued the global loads at the END of
+  // the step and read every fragment right in front of its MFMAs): global loads of step it+2 first | fragment of tap 1 |
+  // 6 MFMAs of tap 0, split + store of dY(it+1) | fragment of tap 2 | 6 MFMAs of tap 1, split + store of X(it+1) | barrier |
+  // fragments of step it+1 (dY and tap 0) | 6 MFMAs of tap 2.  Every LDS read is issued >= 6 MFMAs before its use; every
+  // load of the loop is unconditional (past the end of the split: zeros, igemm.hip).
   f32x4 ar, br[2];
+  f16x8_t af[2][2], bf0[2];
   if (iters > 0) {
     load_into(ar, br);
     store_a(0, ar); store_b(0, br);
     load_into(ar, br);
   }
   __syncthreads();
+  read_a(0, af); read_b(0, 0, bf0);
   for (int it = 0; it < iters; ++it) {
     const int cur = it & 1;
     f32x4 an, bn[2];
-    load_into(an, bn);                                  // step it+2 (zeros past the end of the split)
-    step(cur, ar, br);                                  // multiplies step it, stores step it+1
-    ar = an; br[0] = bn[0]; br[1] = bn[1];
+    f16x8_t bf1[2], bf2[2], afn[2][2], bf0n[2];
+    load_into(an, bn);                                  // step it+2
+    read_b(cur, 1, bf1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(0, af, bf0);
+    store_a(cur ^ 1, ar);
+    __builtin_amdgcn_sched_barrier(0);
+    read_b(cur, 2, bf2);
+    mfma_tap(1, af, bf1);
+    store_b(cur ^ 1, br);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    read_a(cur ^ 1, afn); read_b(cur ^ 1, 0, bf0n);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(2, af, bf2);
+    __builtin_amdgcn_sched_barrier(0);
+    ar = an; br[0] = bn[0]; br[1] = bn[1];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) { af[mi][0] = afn[mi][0]; af[mi][1] = afn[mi][1]; }
+    bf0[0] = bf0n[0]; bf0[1] = bf0n[1];
   }
+  __syncthreads();
 
   const float dq = 1.f / (s_a * s_b);                   // powers of two: exact
   float* out = p.out + (size_t)split * p.Co * p.ld_out;
@@ -246,7 +265,7 @@ void wgrad3_set_tuning(int key, int value) { if (key == 0) g_w3 = value; else g_
 
 // shape test only (the workspace is sized without knowing whether the abs-max words will be there)
 bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
-  if (!g_w3 || ksize != 3 || stride != 1 || cin < 128 || cout < 128 || cin % 4 || cout % 4 || wd < 2) return false;
+  if (!g_w3 || ksize != 3 || stride != 1 || cin < 128 || cout < 128 || cin % 4 || cout % 4 || wd < 8 || h < 2) return false;
   const long long npix = (long long)n * h * wd;
   if (npix * (cin > cout ? cin : cout) * 4 >= 0x7FFFFFF0LL) return false;        // 32-bit byte offsets from the tensor base
   if ((long long)n * h * (wd + 1) >= 0x7FFFFFF0LL || npix < 1024) return false;
