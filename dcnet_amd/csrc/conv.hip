@@ -59,12 +59,16 @@ int launch_presplit(const float* src, float* dst, int64_t numel, const uint32_t*
   return DCN_OK;
 }
 
+int g_merge_classes = 1;    // dcn_set_tuning("merge", 0): stride-2 data gradients as four launches again
+
 void base_params(IgemmParams& p) {
   p = IgemmParams{};
   p.osy = p.osx = 1; p.isy = p.isx = 1; p.dense_out = 1;
 }
 
 }  // namespace
+
+void conv_set_merge(int v) { g_merge_classes = v; }
 
 extern "C" int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride) {
   const int pad = (ksize - 1) / 2;
@@ -144,8 +148,15 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
   p.accumulate = accumulate;
-  if (amax_dy && amax_w && igemm_will_presplit((long long)n * (stride == 1 ? h * wd : (h / 2) * (wd / 2)), cin, stride == 1 ? T : 1, cout)) {
-    // (stride 2: the four parity classes share one bank; the smallest class, with 1 tap, decides for all of them)
+  // four parity classes in one launch: measured (tools/bench_convs.py --ab merge=0) -8..-9 % on the 52/26-wide maps, whose
+  // classes fill 0.7-2.6 rounds of the chip each, and -7..+20 % on the larger ones (their classes are long grids already and
+  // the kernels there are issue-bound, not waiting for dY): only where a class has at most 64 K rows (g_merge_classes = 2: always)
+  const bool merged = stride == 2 && ksize == 3 && h >= 2 && wd >= 2 &&
+                      (g_merge_classes == 2 || (g_merge_classes == 1 && (long long)n * ((h + 1) / 2) * ((wd + 1) / 2) <= 65536));
+  if (amax_dy && amax_w && igemm_will_presplit((long long)n * (stride == 1 ? h * wd : ((h + 1) / 2) * ((wd + 1) / 2)), cin,
+                                               stride == 1 ? T : (merged ? 4 : 1), cout)) {
+    // (stride 2: the four parity classes share one bank; as separate launches the smallest class, with 1 tap, decides for all
+    //  of them; merged, the launch is sized by its largest class: 4 taps)
     const int64_t numel = (int64_t)cin * T * cout;
     if (wt_ready) {
       if (wt_split) { p.wt = wt_split; p.b_scale = wt_split + numel; }       // else: the tiles split the fp32 bank themselves
@@ -173,6 +184,33 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   }
   // stride 2: output pixels of parity class (a,b) only see taps with (a+pad-r), (b+pad-s) even.
   // Four dense sub-problems with 1/2/2/4 taps (3x3) instead of one 9-tap problem that is 3/4 zeros.
+  if (merged) {
+    // ... all in ONE launch (igemm.h ncls): block order (M-tile, class, N-tile) keeps the four classes of a region on one XCD
+    // at the same time, so dY is fetched from HBM once instead of once per tap (nine times a tensor that does not fit the
+    // Infinity Cache on the 416/208 maps), and the 13/26-wide maps fill the chip with one grid instead of four short ones.
+    IgemmParams q = p;
+    q.dense_out = 0; q.osy = q.osx = 2; q.ncls = 4; q.M = 0; q.ntaps = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        const int c = a * 2 + b;
+        q.cls_oy0[c] = a; q.cls_ox0[c] = b;
+        q.cls_Hs[c] = (h - a + 1) / 2; q.cls_Ws[c] = (wd - b + 1) / 2;
+        q.cls_M[c] = n * q.cls_Hs[c] * q.cls_Ws[c];
+        int nt = 0;
+        for (int r = 0; r < ksize; ++r)
+          for (int s = 0; s < ksize; ++s) {
+            if (((a + pad - r) & 1) || ((b + pad - s) & 1)) continue;
+            q.tap_dy[4 * c + nt] = (a + pad - r) / 2; q.tap_dx[4 * c + nt] = (b + pad - s) / 2;
+            q.tap_w[4 * c + nt] = (r * ksize + s) * cout;
+            ++nt;
+          }
+        q.cls_ntaps[c] = nt;
+        if (q.cls_M[c] > q.M) { q.M = q.cls_M[c]; q.Hs = q.cls_Hs[c]; q.Ws = q.cls_Ws[c]; }
+        if (nt > q.ntaps) q.ntaps = nt;
+      }
+    q.oy0 = q.ox0 = 0;
+    return igemm_launch(q, stream);
+  }
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 2; ++b) {
       IgemmParams q = p;

@@ -42,6 +42,10 @@ struct IgemmParams {
   int act; float slope;
   int accumulate, dense_out, c4;
   int tap_dy[IGEMM_MAX_TAPS], tap_dx[IGEMM_MAX_TAPS], tap_w[IGEMM_MAX_TAPS];
+  // ncls = 4: four sub-problems (the parity classes of a stride-2 data gradient) in one launch; class c has M / Hs / Ws / oy0 /
+  // ox0 / ntaps below and its taps at tap_*[4c ...]; M, ntaps above then hold the largest class (tile and grid sizing)
+  int ncls;
+  int cls_M[4], cls_Hs[4], cls_Ws[4], cls_oy0[4], cls_ox0[4], cls_ntaps[4];
 };
 
 // rows of the stats partial buffer (= number of M-blocks) the launch will use

@@ -148,10 +148,21 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int gn = (p.Co + BN - 1) / BN;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm = lin / gn, bn = lin - bm * gn;
+  // Sub-problem classes (ncls = 4: the parity classes of a stride-2 data gradient in ONE launch): block order (M-tile, class,
+  // N-tile), so the four classes of a region run side by side on one XCD and share its L2 — as four launches every class
+  // streamed dY from HBM again (9 tap reads of a tensor larger than the Infinity Cache).  Class c has its own output sub-grid
+  // and its taps at [4c, 4c + ntaps).
+  int bm, bn, M_ = p.M, Hs_ = p.Hs, Ws_ = p.Ws, oy0_ = p.oy0, ox0_ = p.ox0, ntaps_ = p.ntaps, tb_ = 0;
+  if (p.ncls) {
+    const int q = lin / gn, cls = q % p.ncls;
+    bn = lin - q * gn; bm = q / p.ncls;
+    M_ = p.cls_M[cls]; Hs_ = p.cls_Hs[cls]; Ws_ = p.cls_Ws[cls]; oy0_ = p.cls_oy0[cls]; ox0_ = p.cls_ox0[cls];
+    ntaps_ = p.cls_ntaps[cls]; tb_ = 4 * cls;
+  } else { bm = lin / gn; bn = lin - bm * gn; }
+  const int kiters_ = p.c4 ? p.kiters : ntaps_ * p.cpt;
   const int chunk = tid & (CPR - 1);     // which 16-B piece of the K-step row
   const int row0 = tid / CPR;            // rows row0 + RPP*j
-  const int hsws = p.Hs * p.Ws;
+  const int hsws = Hs_ * Ws_;
 
   // ---- descriptors (wave-uniform) ---------------------------------------------------------------
   const int n0 = (bm * BM) / hsws;                                   // image of the block's first row
@@ -169,20 +180,20 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   for (int j = 0; j < A_LD; ++j) {
     const int m = bm * BM + row0 + RPP * j;
     a_off[j] = 0; a_msk[j] = 0;
-    if (p.ntaps == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && !C4 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 && p.Ws == p.Wi && p.Hs == p.Hi) {
+    if (ntaps_ == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && !C4 && p.tap_dy[tb_ + 0] == 0 && p.tap_dx[tb_ + 0] == 0 && Ws_ == p.Wi && Hs_ == p.Hi) {
       // plain GEMM rows (1x1 convolutions, their data gradients, the co-attention products): row m IS pixel m — no divisions
-      if (m < p.M) { a_off[j] = (unsigned)((m - n0 * hsws) * p.ldi * 4 + chunk * 16); a_msk[j] = 1u; }
+      if (m < M_) { a_off[j] = (unsigned)((m - n0 * hsws) * p.ldi * 4 + chunk * 16); a_msk[j] = 1u; }
     } else
-    if (m < p.M) {
+    if (m < M_) {
       const int n = m / hsws, rem = m - n * hsws;
-      const int i = rem / p.Ws, jx = rem - i * p.Ws;
+      const int i = rem / Ws_, jx = rem - i * Ws_;
       const int iy0 = i * p.isy, ix0 = jx * p.isx;
       a_off[j] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * 4 + chunk * 16 * (C4 ? 0 : 1));
       unsigned msk = 0;
-      for (int t = 0; t < p.ntaps; ++t) {
+      for (int t = 0; t < ntaps_; ++t) {
         int dy, dx;
         if (C4) { const int r = t / 3; dy = r - 1; dx = t - 3 * r - 1; }
-        else { dy = p.tap_dy[t]; dx = p.tap_dx[t]; }
+        else { dy = p.tap_dy[tb_ + t]; dx = p.tap_dx[tb_ + t]; }
         if ((unsigned)(iy0 + dy) < (unsigned)p.Hi && (unsigned)(ix0 + dx) < (unsigned)p.Wi) msk |= 1u << t;
       }
       a_msk[j] = msk;
@@ -207,16 +218,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     for (int h = 0; h < C4_STEPS; ++h) {
       const int t = h * CPR + chunk, r = t / 3;
       c4_delta[h] = ((r - 1) * p.Wi + (t - 3 * r - 1)) * p.ldi * 4;
-      c4_bit[h] = t < p.ntaps ? 1u << t : 0u;
+      c4_bit[h] = t < ntaps_ ? 1u << t : 0u;
     }
   }
 
   // ---- wave-uniform K iterator: (tap, channel step) -> activation byte delta, weight byte offset ----
   int k_tap = 0, k_c = 0;
-  int a_delta = C4 ? 0 : (p.tap_dy[0] * p.Wi + p.tap_dx[0]) * p.ldi * 4;
+  int a_delta = C4 ? 0 : (p.tap_dy[tb_ + 0] * p.Wi + p.tap_dx[tb_ + 0]) * p.ldi * 4;
   unsigned tap_bit = 1u;
   unsigned a_soff = 0;                                  // channel offset inside the tap (bytes)
-  unsigned b_soff = C4 ? 0u : (unsigned)p.tap_w[0] * 4; // BMODE 0: K offset in the filter row; BMODE 1: k0*ldw
+  unsigned b_soff = C4 ? 0u : (unsigned)p.tap_w[tb_ + 0] * 4; // BMODE 0: K offset in the filter row; BMODE 1: k0*ldw
   int kbase = 0;                                        // BMODE 1: first k of the step (K tail masking)
 
   f32x4 a_reg[A_LD], b_reg[B_LD];
@@ -250,10 +261,10 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
       if (BMODE == 0) b_soff += BK * 4; else { b_soff += BK * p.ldw * 4; kbase += BK; }
       if (k_c == p.cpt) {
         k_c = 0; a_soff = 0; ++k_tap;
-        if (k_tap < p.ntaps) {
-          a_delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * 4;
+        if (k_tap < ntaps_) {
+          a_delta = (p.tap_dy[tb_ + k_tap] * p.Wi + p.tap_dx[tb_ + k_tap]) * p.ldi * 4;
           tap_bit = 1u << k_tap;
-          if (BMODE == 0) b_soff = (unsigned)p.tap_w[k_tap] * 4;
+          if (BMODE == 0) b_soff = (unsigned)p.tap_w[tb_ + k_tap] * 4;
         }
       }
     }
@@ -432,21 +443,21 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     };
     using T = std::true_type; using F = std::false_type;
     load_tiles_into(a_reg, b_reg, 0);
-    if (p.kiters > 1) load_tiles_into(a_reg2, b_reg2, 1);
+    if (kiters_ > 1) load_tiles_into(a_reg2, b_reg2, 1);
     store_tiles_from(a_reg, b_reg, 0);
     __syncthreads();
     int it = 0;
     using ST = std::conditional_t<ABL == 4, F, T>;      // (timing ablations: 3 = no global loads in the loop, 4 = no split / LDS stores)
-    for (; it + 2 < p.kiters; it += 2) {
+    for (; it + 2 < kiters_; it += 2) {
       // even step: LDS buffer 0 is current, stage 2 holds step it+1, stage 1 is free for step it+2
       if (ABL != 3) load_tiles_into(a_reg, b_reg, it + 2);
       step(0, a_reg2, b_reg2, ST{});
       __syncthreads();
-      if (ABL != 3) load_tiles_into(a_reg2, b_reg2, it + 3, it + 3 < p.kiters);
+      if (ABL != 3) load_tiles_into(a_reg2, b_reg2, it + 3, it + 3 < kiters_);
       step(1, a_reg, b_reg, ST{});
       __syncthreads();
     }
-    if (it + 1 < p.kiters) {      // two steps left: buffer 0 current, stage 2 holds the last step
+    if (it + 1 < kiters_) {      // two steps left: buffer 0 current, stage 2 holds the last step
       step(0, a_reg2, b_reg2, T{});
       __syncthreads();
       step(1, a_reg, b_reg, F{});
@@ -458,9 +469,9 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
-  for (int it = 0; it < p.kiters; ++it) {
+  for (int it = 0; it < kiters_; ++it) {
     const int cur = it & 1;
-    if (it + 1 < p.kiters) load_tiles(it + 1);
+    if (it + 1 < kiters_) load_tiles(it + 1);
     const float* a = As + cur * BM * LDS_LD + a_frag;
     const float* b = Bs + cur * B_TILE + b_frag;
 #pragma unroll
@@ -484,7 +495,7 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
           for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni][e], acc[mi][ni], 0, 0, 0);
     }
-    if (it + 1 < p.kiters) store_tiles(cur ^ 1);
+    if (it + 1 < kiters_) store_tiles(cur ^ 1);
     __syncthreads();
   }
   }
@@ -501,20 +512,20 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
   //     statistics and before scale/shift/activation (dX += ..., or a pre-filled per-image/per-position
   //     bias term of the fusion layer).
   if (p.accumulate) {
-    const int hsws0 = p.Hs * p.Ws;
+    const int hsws0 = Hs_ * Ws_;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = bm * BM + row;
-        if (m >= p.M) continue;
+        if (m >= M_) continue;
         size_t pix;
         if (p.dense_out) pix = (size_t)m;
         else {
           const int n = m / hsws0, rem = m - n * hsws0;
-          const int i = rem / p.Ws, jx = rem - i * p.Ws;
-          pix = ((size_t)n * p.Ho + p.oy0 + i * p.osy) * p.Wo + p.ox0 + jx * p.osx;
+          const int i = rem / Ws_, jx = rem - i * Ws_;
+          pix = ((size_t)n * p.Ho + oy0_ + i * p.osy) * p.Wo + ox0_ + jx * p.osx;
         }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -568,16 +579,16 @@ __global__ __launch_bounds__(256, OCC) void igemm_kernel(const IgemmParams p) {
     for (int r = 0; r < 16; ++r) {
       const int row = wm * (BM / WM) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int m = bm * BM + row;
-      if (m >= p.M) continue;
+      if (m >= M_) continue;
       size_t pix;
       if (p.dense_out) {
         pix = (size_t)m;
       } else {
         const int n = m / hsws, rem = m - n * hsws;
-        const int i = rem / p.Ws, jx = rem - i * p.Ws;
-        pix = ((size_t)n * p.Ho + p.oy0 + i * p.osy) * p.Wo + p.ox0 + jx * p.osx;
+        const int i = rem / Ws_, jx = rem - i * Ws_;
+        pix = ((size_t)n * p.Ho + oy0_ + i * p.osy) * p.Wo + ox0_ + jx * p.osx;
       }
-      const float rs = p.row_scale ? p.row_scale[(size_t)blockIdx.y * p.M + m] : 1.f;
+      const float rs = p.row_scale ? p.row_scale[(size_t)blockIdx.y * M_ + m] : 1.f;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         if (co_[ni] >= p.Co) continue;
@@ -602,7 +613,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   p.cpt = p.c4 ? 1 : p.Ci / BK;
   p.kiters = p.c4 ? 64 / BK : p.ntaps * p.cpt;
   constexpr int LDS_LD = BK + 4;
-  const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
+  const int gm = cdiv(p.M, BM) * (p.ncls ? p.ncls : 1), gn = cdiv(p.Co, BN);     // (classes: p.M = the largest class)
   constexpr int LD16 = (BK == 16 || F8) ? 16 : BK + 8;
   const size_t lds = SP ? (size_t)2 * NP * (BM * LD16 + (BMODE == 0 ? BN * LD16 : 2048) + (BPRE ? 32 : 0)) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
@@ -615,10 +626,14 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles
   const int tag = SP ? (F8 ? 23 : NP == 1 ? 19 : NP == 2 ? (BMODE == 1 ? 27 : BN == 64 ? 26 : 24) : BMODE == 1 ? 21 : BN == 64 ? 18 : 16) : p.M < 1024 ? 13 : (BM == 128 && BN == 128 && BMODE == 0 && BK == 32) ? 15 : BM == 64 ? (BMODE == 1 ? 7 : 6) : (BMODE == 1 ? (BN == 128 ? 3 : 4) : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
-  const double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
+  double k_alg = p.c4 ? 27.0 : (double)p.ntaps * (p.bmode == 1 && p.kvalid > 0 ? p.kvalid : p.Ci);
+  double mk = (double)p.M * k_alg;            // sum over classes of rows x K
+  if (p.ncls) { mk = 0; for (int c = 0; c < p.ncls; ++c) mk += (double)p.cls_M[c] * p.cls_ntaps[c] * p.Ci; k_alg = 9.0 * p.Ci; }
   // algorithmic bytes: the gathered tensor once (rows actually addressed: N*Hi*Wi pixels of Ci), the filter bank, the output
-  const double alg_bytes = 4.0 * nb * ((double)p.N * p.Hi * p.Wi * (p.c4 ? 4 : p.Ci) + (double)p.Co * k_alg + (double)p.M * p.Co);
-  const int pid = prof_begin(tag, 2.0 * nb * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  double m_out = p.M;
+  if (p.ncls) { m_out = 0; for (int c = 0; c < p.ncls; ++c) m_out += p.cls_M[c]; }
+  const double alg_bytes = 4.0 * nb * ((double)p.N * p.Hi * p.Wi * (p.c4 ? 4 : p.Ci) + (double)p.Co * k_alg + m_out * p.Co);
+  const int pid = prof_begin(tag, 2.0 * nb * mk * p.Co, stream, alg_bytes);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("igemm");
@@ -715,10 +730,12 @@ void wgrad_set_abl(int v);
 void wgrad_set_target(int v);
 void wgrad_set_target_small(int v);
 void wgrad3_set_tuning(int key, int value);
+void conv_set_merge(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"
   if (k == 'z') { wgrad_set_target_small(value); return DCN_OK; }   // "zwgsmall"
