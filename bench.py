@@ -51,6 +51,9 @@ def parse():
                          "exclusive duration (0 = skip, e.g. under rocprofv3 so its averages match the timed region)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the process group runs on gloo (RCCL refuses "
+                         "two ranks per device) — exercises broadcast, sharded seeds, the reducer and the max-over-ranks timing")
     ap.add_argument("--reducer", choices=["overlap", "ddp"], default="overlap",
                     help="multi-GPU gradient averaging: 'overlap' = dcnet_amd.parallel.OverlappedGradReducer (buckets all-reduced on a "
                          "communication stream while the backbone's backward is still running), 'ddp' = torch DDP wrapper")
@@ -139,6 +142,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or args.force_ddp
@@ -148,7 +153,10 @@ def main():
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if args.rehearse:
+            torch.distributed.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from dcnet_amd import losses
     from dcnet_amd.lib import lib
@@ -396,6 +404,9 @@ def main():
                                       f"pair semantics ({n_img} images/GPU/step), fwd + 5 losses + bwd + RMSprop",
                           "images_per_gpu": n_img, "parallelism": f"dp{world}"},
                "host_queue_ms_per_step": host_dt / args.steps * 1e3,
+               "memory": {"max_allocated_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                          "reserved_gb": torch.cuda.memory_reserved(dev) / 2 ** 30,
+                          "alloc_retries": torch.cuda.memory_stats(dev).get("num_alloc_retries", 0)},
                "loss": float(last.detach()), "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.size, args.frames, args.cpu_steps)
