@@ -597,7 +597,7 @@ int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int
 bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout);
 int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
-                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream);
+                  const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream);
 
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
@@ -642,9 +642,10 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   {
     const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
     const long long npix = (long long)n * h * wd;
-    if (g_wsplit == 4 && !g_wabl && amax_x && amax_dy && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
+    const bool f16 = g_wsplit == 4 && amax_x && amax_dy, b16 = g_wsplit == 2;      // (2: the bf16- and fp8-operand modes)
+    if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
-      return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, stream);
+      return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);
   }
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);

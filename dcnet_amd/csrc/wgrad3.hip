@@ -28,6 +28,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned OOBW = 0x80000000u;
 
 struct W3Params {
@@ -57,9 +59,14 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >>
 __device__ __forceinline__ int poff(int row, int c) { return 256 * row + 16 * ((c >> 3) ^ swz(row)) + 8 * ((c >> 2) & 1); }
 
 constexpr int A_PLANE = 16 * 256, B_PLANE = 18 * 256;
-constexpr int B_BASE = 2 * A_PLANE, BUF = 2 * A_PLANE + 2 * B_PLANE;
 
+// NP = 2: fp32-accurate f16 two-piece split (three MFMAs per product, per-tensor power-of-two scales from the abs-max words);
+// NP = 1: plain bf16 operands (round to nearest even, one MFMA per product) — the weight gradient of the bf16- and fp8-operand
+// modes (BASELINE.json configs[2] / [4]; ops.set_precision("bf16" | "fp8"))
+template <int NP>
 __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
+  constexpr int B_BASE = NP * A_PLANE, BUF = NP * A_PLANE + NP * B_PLANE;
+  typedef typename std::conditional<NP == 2, f16x8_t, bf16x8_t>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];       // [2 buffers][A: 2 planes x 16 rows | B: 2 planes x 18 rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;            // 64 filters x 32 channels per wave
@@ -74,7 +81,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   const int p_begin = split * p.kchunk;
   const int p_end = min(p.Mp, p_begin + p.kchunk);
   const int iters = (p_end - p_begin + 15) / 16;
-  const float s_a = pow2w(amax_read(p.amax_dy)), s_b = pow2w(amax_read(p.amax_x));
+  float s_a = 1.f, s_b = 1.f;
+  if constexpr (NP == 2) { s_a = pow2w(amax_read(p.amax_dy)); s_b = pow2w(amax_read(p.amax_x)); }
 
   const long long npix = (long long)p.N * p.H * p.W;
   const __amdgpu_buffer_rsrc_t a_rs = rsrcw(p.dy, ((npix - 1) * p.lddy + p.Co) * 4);
@@ -125,6 +133,11 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     }
   };
   auto split_store = [&](unsigned char* plane0, int plane_stride, int off, const f32x4 v, const float sc) {
+    if constexpr (NP == 1) {
+      const bf16x4_t b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, b);
+      return;
+    }
     const f32x4 t = v * sc;
     const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
     const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
@@ -164,25 +177,30 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   auto frag = [&](int byte0, int byte1) {
     const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(f16x8_t, v);
+    return __builtin_bit_cast(frag_t, v);
   };
 
-  auto read_a = [&](int buf, f16x8_t (*af)[2]) {
+  auto read_a = [&](int buf, frag_t (*af)[2]) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) af[mi][pl] = frag(buf * BUF + pl * A_PLANE + a_tr[mi][0], buf * BUF + pl * A_PLANE + a_tr[mi][1]);
+      for (int pl = 0; pl < NP; ++pl) af[mi][pl] = frag(buf * BUF + pl * A_PLANE + a_tr[mi][0], buf * BUF + pl * A_PLANE + a_tr[mi][1]);
   };
-  auto read_b = [&](int buf, int d, f16x8_t* bf) {
+  auto read_b = [&](int buf, int d, frag_t* bf) {
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) bf[pl] = frag(buf * BUF + pl * B_PLANE + b_tr[d][0], buf * BUF + pl * B_PLANE + b_tr[d][1]);
+    for (int pl = 0; pl < NP; ++pl) bf[pl] = frag(buf * BUF + pl * B_PLANE + b_tr[d][0], buf * BUF + pl * B_PLANE + b_tr[d][1]);
   };
-  auto mfma_tap = [&](int d, f16x8_t (*af)[2], const f16x8_t* bf) {      // smallest terms first: (l,h) (h,l) (h,h)
+  auto mfma_tap = [&](int d, frag_t (*af)[2], const frag_t* bf) {      // smallest terms first: (l,h) (h,l) (h,h)
+    if constexpr (NP == 1) {
 #pragma unroll
-    for (int term = 0; term < 3; ++term) {
-      const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
+      for (int mi = 0; mi < 2; ++mi) acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], bf[0], acc[mi][d], 0, 0, 0);
+    } else {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][qa], bf[qb], acc[mi][d], 0, 0, 0);
+      for (int term = 0; term < 3; ++term) {
+        const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi][d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][qa], bf[qb], acc[mi][d], 0, 0, 0);
+      }
     }
   };
 
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   // fragments of step it+1 (dY and tap 0) | 6 MFMAs of tap 2.  Every LDS read is issued >= 6 MFMAs before its use; every
   // load of the loop is unconditional (past the end of the split: zeros, igemm.hip).
   f32x4 ar, br[2];
-  f16x8_t af[2][2], bf0[2];
+  frag_t af[2][2], bf0[2];
   if (iters > 0) {
     load_into(ar, br);
     store_a(0, ar); store_b(0, br);
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   for (int it = 0; it < iters; ++it) {
     const int cur = it & 1;
     f32x4 an, bn[2];
-    f16x8_t bf1[2], bf2[2], afn[2][2], bf0n[2];
+    frag_t bf1[2], bf2[2], afn[2][2], bf0n[2];
     load_into(an, bn);                                  // step it+2
     read_b(cur, 1, bf1);
     __builtin_amdgcn_sched_barrier(0);
@@ -221,12 +239,15 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     __builtin_amdgcn_sched_barrier(0);
     ar = an; br[0] = bn[0]; br[1] = bn[1];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { af[mi][0] = afn[mi][0]; af[mi][1] = afn[mi][1]; }
-    bf0[0] = bf0n[0]; bf0[1] = bf0n[1];
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) af[mi][pl] = afn[mi][pl];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) bf0[pl] = bf0n[pl];
   }
   __syncthreads();
 
-  const float dq = 1.f / (s_a * s_b);                   // powers of two: exact
+  const float dq = 1.f / (s_a * s_b);                   // powers of two: exact (NP = 1: 1)
   float* out = p.out + (size_t)split * p.Co * p.ld_out;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -277,7 +298,7 @@ int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout) {
 }
 
 int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
-                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
+                  const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream) {
   const Plan3 pl = plan3(n, h, wd, cin, cout);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
   W3Params p{};
@@ -286,15 +307,17 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
   p.amax_dy = amax_dy; p.amax_x = amax_x;
-  const size_t lds = 2 * BUF;
+  const size_t lds = (size_t)2 * np * (A_PLANE + B_PLANE);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * (A_PLANE + B_PLANE));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_PLANE + B_PLANE));
     attr_done = true;
   }
   const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
-  const int pid = prof_begin(32, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);
-  hipLaunchKernelGGL(wgrad3_kernel, dim3(grid), dim3(512), lds, stream, p);
+  const int pid = prof_begin(np == 2 ? 32 : 20, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);
+  if (np == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(grid), dim3(512), lds, stream, p);
+  else hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad3");
   if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);

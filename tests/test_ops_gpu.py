@@ -765,6 +765,23 @@ def test_wgrad3_filter_row_kernel(dev, case):
             _close(alt, ref, 3e-5, f"wgrad3 target {target}")
     finally:
         lib().set_tuning(b"u3row", 1); lib().set_tuning(b"v3target", 512)
+    # bf16-operand mode (configs[2]; also the weight gradient of the fp8 mode): the same kernel with one bf16 plane per operand,
+    # against its exact model — the fp64 weight gradient of the bf16-rounded tensors
+    rb = lambda t: t.to(torch.bfloat16).double()
+    wgt16 = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(rb(x.cpu()).permute(0, 3, 1, 2), wgt16, padding=1).backward(rb(dy.cpu()).permute(0, 3, 1, 2))
+    ref16 = wgt16.grad.permute(0, 2, 3, 1)
+    try:
+        ops.set_precision("bf16")
+        got16 = ops.conv2d_bwd_weight(x, dy, 3, 1)
+        lib().set_tuning(b"u3row", 0)
+        old16 = ops.conv2d_bwd_weight(x, dy, 3, 1)
+    finally:
+        lib().set_tuning(b"u3row", 1)
+        ops.set_precision("fp32")
+    _close(got16, ref16, 3e-5, "wgrad3 bf16 operands vs exact model")
+    _close(old16, ref16, 3e-5, "per-tap bf16 operands vs exact model")
+    assert float((got16.double().cpu() - ref).abs().max()) > 1e-5 * max(1.0, float(ref.abs().max()))      # it IS reduced precision
     _close(new, ref, 3e-5, "wgrad3")
     _close(old, ref, 3e-5, "per-tap wgrad")
     _close(new, old, 3e-6, "wgrad3 vs per-tap")
