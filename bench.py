@@ -218,6 +218,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.prof_enable(0)
+    from dcnet_amd import ops as _ops_chk
+    _ops_chk.check_bilstm(dev)                  # the persistent BiLSTM's sticky error word: a timed-out hand-off must not pass as a result
     if use_ddp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -219,7 +219,7 @@ extern "C" int dcn_bilstm_fwd(const float* xg, const float* whh_fwd, const float
   DCN_CHECK_ARG(xg && whh_fwd && whh_rev && bhh_fwd && bhh_rev && out && hprev && cprev && acts && sync, "bilstm_fwd: null pointer");
   DCN_CHECK_ARG(hidden == LS_H, "bilstm_fwd: hidden size %d (built for %d)", hidden, LS_H);
   DCN_CHECK_ARG(n > 0 && n <= 64 * LS_MAXC && l > 0, "bilstm_fwd: %d rows (1..%d), %d steps", n, 64 * LS_MAXC, l);
-  if (hipMemsetAsync(sync, 0, 64, stream) != hipSuccess) { dcn_set_error("bilstm_fwd: memset failed"); return DCN_ERR_LAUNCH; }
+  if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_fwd: memset failed"); return DCN_ERR_LAUNCH; }   // the counters; the error word sync[8] is sticky
   const size_t lds = (size_t)32 * LS_H * sizeof(float) + 16;
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
@@ -235,7 +235,7 @@ extern "C" int dcn_bilstm_bwd(const float* dout, const float* whh_fwd, const flo
   DCN_CHECK_ARG(dout && whh_fwd && whh_rev && acts && cprev && dxg && sync, "bilstm_bwd: null pointer");
   DCN_CHECK_ARG(hidden == LS_H, "bilstm_bwd: hidden size %d (built for %d)", hidden, LS_H);
   DCN_CHECK_ARG(n > 0 && n <= 64 * LS_MAXC && l > 0, "bilstm_bwd: %d rows (1..%d), %d steps", n, 64 * LS_MAXC, l);
-  if (hipMemsetAsync(sync, 0, 64, stream) != hipSuccess) { dcn_set_error("bilstm_bwd: memset failed"); return DCN_ERR_LAUNCH; }
+  if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_bwd: memset failed"); return DCN_ERR_LAUNCH; }
   const size_t lds = (size_t)LS_UNITS * 4 * LS_H * sizeof(float) + 16;
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }

@@ -1004,8 +1004,15 @@ def bilstm_bwd(dout, whh_f, whh_r, acts, cprev, lens):
 
 
 def bilstm_sync_error(device) -> bool:
-    """True if a bounded spin of the last persistent launch on this stream gave up (host-synchronising: debugging only)."""
+    """True if a bounded spin of ANY persistent BiLSTM launch on this device gave up since the buffer was created (the
+    word is sticky: launches reset only their counters).  Host-synchronising: train.evaluate and bench.py call it once at the
+    end, so a hand-off that timed out cannot pass as a result."""
     return bool(_bilstm_sync(device)[8].item())
+
+
+def check_bilstm(device) -> None:
+    if bilstm_sync_error(device):
+        raise DcnError("persistent BiLSTM kernel: a grid hand-off spin timed out (the recurrence of some step is incomplete)")
 
 
 def colsum_rows(x2d):

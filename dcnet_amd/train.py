@@ -20,7 +20,7 @@ from typing import Dict, Iterable, Optional, Tuple
 
 import torch
 
-from . import losses
+from . import losses, ops
 
 
 def make_optimizer(model, lr: float = 1e-4, optimizer: str = "RMSprop"):
@@ -90,6 +90,10 @@ def _strip_module(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 def save_checkpoint(state: dict, is_best: bool, filename: str, directory: str = "./saved_models") -> str:
     """Writes ``<dir>/<filename>_checkpoint.pth.tar`` (+ ``_model_best`` copy), train_DCNet.py:255-263.
     ``state`` = {'epoch', 'state_dict', 'best_loss', 'optimizer'}."""
+    for t_ in state.get("state_dict", {}).values():
+        if torch.is_tensor(t_) and t_.is_cuda:
+            ops.check_bilstm(t_.device)         # (host-synchronising anyway: nothing is written after a timed-out BiLSTM hand-off)
+            break
     os.makedirs(directory, exist_ok=True)
     ckpt = os.path.join(directory, f"{filename}_checkpoint.pth.tar")
     torch.save(state, ckpt)
