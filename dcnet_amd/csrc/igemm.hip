@@ -667,8 +667,10 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // (the 256x64 tile is the same 64x64-per-wave body as 128x128 with 25 % more split work per MFMA)
     if ((p.f8 || (g_precision == 3 && p.amax_a && p.amax_b)) && ((BM == 128 && BN == 128) || (BM == 256 && BN == 64)) && rows >= 1024)
       return launch_bk<BM, BN, WM, WN, BMODE, C4, 32, true, 0, 1, 1, true>(p, stream);  // fp8 e4m3 operands
+    // (the 256x32 tile — data gradients towards 32 channels on the 416/208 maps — only where the K loop is long: 3x3 s1
+    //  64->32 @208 1.10 -> 0.74 ms, the stride-2 classes @416 1.94 -> 1.62 in sum; a 1-tap K = 32..64 launch loses 20 %)
     if (g_precision == 4 && p.amax_a && (p.amax_b || p.b_scale) && rows >= 1024 &&
-        ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || g_h2_narrow)) {
+        ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || (BM == 256 && BN == 32 && p.ntaps * p.Ci >= 128) || g_h2_narrow)) {
       // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
       if constexpr (BM == 128 && BN == 128) {
         if (p.b_scale && g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2, 2, 1, false, true>(p, stream);
