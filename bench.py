@@ -51,6 +51,7 @@ def parse():
                          "exclusive duration (0 = skip, e.g. under rocprofv3 so its averages match the timed region)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="wrap in DDP/RCCL even at world size 1 (exercises the hooks)")
+    ap.add_argument("--tune", type=str, default="", help="key=value[,key=value]: dcn_set_tuning knobs applied before the run (experiments)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: every rank uses cuda:0 and the process group runs on gloo (RCCL refuses "
                          "two ranks per device) — exercises broadcast, sharded seeds, the reducer and the max-over-ranks timing")
@@ -163,6 +164,9 @@ def main():
     from dcnet_amd.model import grounding_model
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs
 
+    for kv in [t for t in args.tune.split(",") if t]:
+        k_, v_ = kv.split("=")
+        lib().set_tuning(k_.encode(), int(v_))
     torch.manual_seed(1234)            # identical initial weights on every rank (DDP also broadcasts rank 0's)
     model = grounding_model(corpus=list(range(1000)), light=False, emb_size=512, coordmap=True,
                             bert_model="bert-base-uncased", dataset="vid", img_size=args.size,
