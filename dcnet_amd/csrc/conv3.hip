@@ -378,7 +378,7 @@ constexpr int A_LD_MAX = 4;   // strip loads per thread: S <= threads pixels.  (
 template <int WM, int WN>
 int launch3_ld(const IgemmParams& p, int gran, hipStream_t stream) { return launch3<WM, WN, A_LD_MAX>(p, gran, stream); }
 
-// tile choice: 256 pixels x 128 filters (8 waves) unless the grid would be too short to fill the chip
+// tile choice: 256 pixels x 128 filters (8 waves, one workgroup per CU) or 128 x 128 (4 waves, two per CU), see below
 int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
   int wmm = 4;
   const int wn = 2;
