@@ -286,7 +286,9 @@ void wgrad3_set_tuning(int key, int value) { if (key == 0) g_w3 = value; else g_
 
 // shape test only (the workspace is sized without knowing whether the abs-max words will be there)
 bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
-  if (!g_w3 || ksize != 3 || stride != 1 || cin < 128 || cout < 128 || cin % 4 || cout % 4 || wd < 8 || h < 2) return false;
+  if (!g_w3 || ksize != 3 || stride != 1 || cin < 64 || cout < 64 || (cin < 128 && cout < 128) || cin % 4 || cout % 4 || wd < 8 || h < 2) return false;
+  // (a 64-channel side leaves half of the 128-wide tile empty and still beats the per-tap narrow tile on the fp32 pipe: 64->128 @104
+  //  1.00 -> 0.58 ms, 128->64 @52 0.235 -> 0.154; with both sides below 128 it loses)
   const long long npix = (long long)n * h * wd;
   if (npix * (cin > cout ? cin : cout) * 4 >= 0x7FFFFFF0LL) return false;        // 32-bit byte offsets from the tensor base
   if ((long long)n * h * (wd + 1) >= 0x7FFFFFF0LL || npix < 1024) return false;

@@ -360,7 +360,7 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     geom = conv_geom(x.device, n, h, wd, ksize, stride)
-    if cin >= 128 and cout >= 128:          # the 128x128 weight-gradient tile is the one with a split mode
+    if cin >= 64 and cout >= 64 and (cin >= 128 or cout >= 128):      # the 128-wide weight-gradient tiles are the ones with a split mode
         amax_x = _amax_or_pass(x, amax_x); amax_dy = _amax_or_pass(dy, amax_dy)
     lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
                             n, h, wd, cin, cout, ksize, stride, _p(amax_x), _p(amax_dy), _s())
