@@ -730,6 +730,7 @@ int igemm_grid_m(int M, int Co, int ntaps) { return cdiv(M, tile_bm(M, Co, ntaps
 void wgrad_set_split(int v);
 void wgrad_set_abl(int v);
 void wgrad_set_target(int v);
+void wgrad_set_wide64(int v);
 void wgrad_set_target_small(int v);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
@@ -741,6 +742,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"
   if (k == 'z') { wgrad_set_target_small(value); return DCN_OK; }   // "zwgsmall"
+  if (k == 'c') { wgrad_set_wide64(value); return DCN_OK; }        // "cwide64"
   if (k == 'x') { wgrad_set_target(value); return DCN_OK; }   // "xwgtarget"
   if (k == 'w') { wgrad_set_split(value); return DCN_OK; }   // "wsplit": weight-gradient 128x128 tiles on the split-bf16 pipe
   if (k == 'p') { g_precision = value; wgrad_set_split(value == 3 ? 2 : value); return DCN_OK; }   // 3 (fp8): weight gradient with bf16 operands   // "precision": 0 native fp32 MFMA, 1 split-bf16 on the wide tiles

@@ -473,6 +473,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 struct Plan { int tm, tn, tiles_co, tiles_ci, T, splits, kchunk, M, ld_out; };
+int g_wide64 = 1;           // dcn_set_tuning("cwide64", 0): 64-channel sides back on the narrow fp32-pipe tiles
 int g_wg_target = 1024;    // dcn_set_tuning("xwgtarget", n): workgroups a 3x3 stride-1 weight-gradient launch aims for (split-K sizing)
 int g_wg_target_small = 512;   // dcn_set_tuning("zwgsmall", n): the same for 1x1 and stride-2 layers
 int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream);
@@ -486,6 +487,8 @@ Plan make_plan(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const int ci_axis = c4 ? 64 : cin;
   pl.tm = cout >= 128 ? 128 : (cout >= 64 ? 64 : 32);
   pl.tn = ci_axis >= 128 ? 128 : (ci_axis >= 64 ? 64 : 32);
+  // one side at 64 channels: the 128x128 tile, half empty, has the f16-split build (the narrow tiles run on the fp32 pipe)
+  if (g_wide64 && !c4 && cout >= 64 && ci_axis >= 64 && (cout >= 128 || ci_axis >= 128)) pl.tm = pl.tn = 128;
   pl.tiles_co = cdiv(cout, pl.tm); pl.tiles_ci = cdiv(ci_axis, pl.tn);
   pl.T = c4 ? 1 : ksize * ksize;
   pl.ld_out = c4 ? 64 : pl.T * cin;
@@ -569,6 +572,7 @@ int wgrad_split_mode() { return g_wsplit; }
 
 void wgrad_set_split(int v) { g_wsplit = v; }
 void wgrad_set_abl(int v) { g_wabl = v; }
+void wgrad_set_wide64(int v) { g_wide64 = v; }
 void wgrad_set_target(int v) { g_wg_target = v > 0 ? v : 1024; }
 void wgrad_set_target_small(int v) { g_wg_target_small = v > 0 ? v : 512; }
 
