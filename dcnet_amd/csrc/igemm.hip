@@ -653,6 +653,7 @@ int g_precision = 4;      // dcn_set_tuning("precision", 0..4): 0 = fp32 MFMA ev
                           // (configs[2], reduced precision); 3 = fp8 operands (configs[4]); 4 (default) = the f16 two-piece split
                           // (fp32 accuracy, three MFMAs per product) wherever the operands carry their abs-max, else as 1
 int g_h2_occ3 = 0;        // dcn_set_tuning("h2occ", 0): f16-split 128x128 tile built for 2 instead of 3 waves/SIMD
+int g_h2_k32 = 64;        // dcn_set_tuning("gk32", n): the 256x32 tile takes the f16 split from this K on
 int g_h2_narrow = 0;      // dcn_set_tuning("rnarrow", 1): the narrow NT tiles (128x64, 256x32, 64x128) on the f16 split as well
 int g_h2_bk = 16;         // dcn_set_tuning("qbk", 32): K-step of the f16-split tiles
 int g_h2_presplit = 1;    // dcn_set_tuning("ypresplit", 0): filter banks split inside every workgroup again
@@ -670,7 +671,7 @@ int launch_variant(const IgemmParams& p, hipStream_t stream) {
     // (the 256x32 tile — data gradients towards 32 channels on the 416/208 maps — only where the K loop is long: 3x3 s1
     //  64->32 @208 1.10 -> 0.74 ms, the stride-2 classes @416 1.94 -> 1.62 in sum; a 1-tap K = 32..64 launch loses 20 %)
     if (g_precision == 4 && p.amax_a && (p.amax_b || p.b_scale) && rows >= 1024 &&
-        ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || (BM == 256 && BN == 32 && p.ntaps * p.Ci >= 128) || g_h2_narrow)) {
+        ((BM == 128 && BN == 128) || (BM == 256 && BN == 64) || (BM == 256 && BN == 32 && p.ntaps * p.Ci >= g_h2_k32) || g_h2_narrow)) {
       // f16 two-piece split (fp32 accuracy, three MFMAs per product): launches whose operands carry their abs-max
       if constexpr (BM == 128 && BN == 128) {
         if (p.b_scale && g_abl == 2) return launch_bk<BM, BN, WM, WN, BMODE, C4, 16, true, 2, 2, 1, false, true>(p, stream);
@@ -751,6 +752,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   else if (k == 'n') g_nn_split = value;     // "nnsplit"
   else if (k == 'o') g_occ3 = value;         // "occ3"
   else if (k == 'h') g_h2_occ3 = value;      // "h2occ"
+  else if (k == 'g') g_h2_k32 = value;       // "gk32"
   else if (k == 'r') g_h2_narrow = value;    // "rnarrow"
   else if (k == 'q') g_h2_bk = value;        // "qbk"
   else if (k == 'y') g_h2_presplit = value;  // "ypresplit"
