@@ -653,7 +653,7 @@ int g_precision = 4;      // dcn_set_tuning("precision", 0..4): 0 = fp32 MFMA ev
                           // (configs[2], reduced precision); 3 = fp8 operands (configs[4]); 4 (default) = the f16 two-piece split
                           // (fp32 accuracy, three MFMAs per product) wherever the operands carry their abs-max, else as 1
 int g_h2_occ3 = 0;        // dcn_set_tuning("h2occ", 0): f16-split 128x128 tile built for 2 instead of 3 waves/SIMD
-int g_h2_k32 = 64;        // dcn_set_tuning("gk32", n): the 256x32 tile takes the f16 split from this K on
+int g_h2_k32 = 128;       // dcn_set_tuning("gk32", n): the 256x32 tile takes the f16 split from this K on
 int g_h2_narrow = 0;      // dcn_set_tuning("rnarrow", 1): the narrow NT tiles (128x64, 256x32, 64x128) on the f16 split as well
 int g_h2_bk = 16;         // dcn_set_tuning("qbk", 32): K-step of the f16-split tiles
 int g_h2_presplit = 1;    // dcn_set_tuning("ypresplit", 0): filter banks split inside every workgroup again
