@@ -250,8 +250,8 @@ def main():
     def extra_pass(precision: int):
         was = (_ops.WGRAD_SIDE, model.language_stream, model.sampling_stream)
         _ops.WGRAD_SIDE = False; model.language_stream = False; model.sampling_stream = False
-        L.set_tuning(b"precision", precision)
-        step(); barrier()
+        _ops.set_precision({v: k for k, v in _ops.PRECISIONS.items()}[precision])       # (the host side follows the mode: which
+        step(); barrier()                                                               #  operand banks / abs-max words it prepares)
         L.prof_enable(1)
         t1 = time.perf_counter()
         for _ in range(args.exclusive_steps):
@@ -260,7 +260,7 @@ def main():
         el = time.perf_counter() - t1
         L.prof_enable(0)
         _ops.WGRAD_SIDE, model.language_stream, model.sampling_stream = was
-        L.set_tuning(b"precision", 4)
+        _ops.set_precision("fp32")
         return collect() + (el / args.exclusive_steps * 1e3,)
 
     excl = native = bf16 = fp8 = bf16x3 = None
@@ -269,9 +269,7 @@ def main():
         bf16x3 = extra_pass(1)
         native = extra_pass(0)
         bf16 = extra_pass(2)
-        _ops._precision = "fp8"            # conv wrappers compute the operand scales in this mode
         fp8 = extra_pass(3)
-        _ops._precision = "fp32"
 
     if rank == 0:
         clips_total = args.clips * world * args.steps
@@ -300,10 +298,12 @@ def main():
                  28: "conv3_kernel<4,2,4>", 29: "conv3_kernel<2,2,4>",
                  30: "reduce_slabs_kernel", 31: "dA_kernel",
                  # 32: weight gradient of the 3x3 stride-1 layers, one filter row per workgroup (f16 split)
-                 32: "wgrad3_kernel"}
-        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32}
+                 32: "wgrad3_kernel",
+                 # 33: the strip kernel with bf16 operands (one plane, one MFMA per product): the bf16-operand mode's 3x3 layers
+                 33: "conv3_kernel<*,2,4,1> (bf16 operands)"}
+        flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33}
         peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32)
-                       else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
+                       else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}
 
         def table(c, m, w, nsteps):
             out = {}

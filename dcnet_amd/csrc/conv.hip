@@ -111,6 +111,9 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
         p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
       }
   }
+  if (w_split && w_split_ready == 2) {
+    p.wt16 = w_split;             // bf16-operand mode: the bank converted to bf16 (dcn_prepare_filters); read by the strip kernel only
+  } else
   if (w_split && amax_x && amax_w && !p.c4 && igemm_will_presplit(p.M, cout, p.ntaps, cin)) {
     // split the filter bank once (into the caller's scratch: cout*k*k*cin + 16 floats), not once per M-tile
     const int64_t numel = (int64_t)cout * p.ntaps * cin;
@@ -148,6 +151,9 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
   p.accumulate = accumulate;
+  if (wt_ready == 2) {            // bf16-operand mode: wt = transposed fp32 bank, wt_split = the same bank in bf16 (strip kernel only)
+    p.wt16 = wt_split; wt_split = nullptr;
+  }
   // four parity classes in one launch: measured (tools/bench_convs.py --ab merge=0) -8..-9 % on the 52/26-wide maps, whose
   // classes fill 0.7-2.6 rounds of the chip each, and -7..+20 % on the larger ones (their classes are long grids already and
   // the kernels there are issue-bound, not waiting for dY): only where a class has at most 64 K rows (g_merge_classes = 2: always)

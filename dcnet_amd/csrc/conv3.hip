@@ -49,21 +49,24 @@ __device__ __forceinline__ int row32(int pos, int half) { return pos * 32 + (((h
 
 // WM x WN waves, each a 64 x 64 sub-tile (2 x 2 accumulators of 32x32): BM = 64*WM pixels, BN = 64*WN filters.
 // A_LD: 16-B strip loads per thread and 16 channels (>= ceil(4*S / threads); excess loads are predicated off).
-template <int WM, int WN, int A_LD>
+// NP = 2: fp32-accurate f16 two-piece split (pre-split filter bank, three MFMAs per product).  NP = 1: bf16 operands, one plane,
+// one MFMA per product — the bf16-operand mode (BASELINE.json configs[2]); the filter bank arrives converted to bf16
+// (IgemmParams::wt16, dcn_prepare_filters), activations are rounded when the strip is staged.
+template <int WM, int WN, int A_LD, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParams p, const int S, const int gran) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
-  constexpr int B_LD = 4 * BN / NT;           // 16-B filter loads per thread and tap
-  static_assert((4 * BN) % NT == 0 && B_LD >= 1, "filter tile: whole loads per thread");
+  constexpr int CHB = 2 * NP;                 // 16-B chunks per filter row and tap (16 k: 64 B pre-split, 32 B bf16)
+  constexpr int B_LD = (BN * CHB + NT - 1) / NT;          // 16-B filter loads per thread and tap (the last may be predicated off)
   static_assert(A_LD % 2 == 0, "strip pieces are split in two halves (taps 0 and 1)");
   constexpr int PB = BN * 32;                 // bytes per filter plane of one tap
   // plane 1 sits 64 B past a multiple of 128: a ds_write_b128 wave-instruction stores the (plane 0, plane 1) chunks of the same
   // row side by side in lane order, and with planes a multiple of 128 B apart they fell on the same banks (PMC:
   // SQ_LDS_BANK_CONFLICT 23 % of SQ_LDS_IDX_ACTIVE)
-  constexpr int PB1 = PB + 64, SLOT = 2 * PB + 128;      // offset of plane 1 inside a tap slot / bytes per tap slot
+  constexpr int PB1 = PB + 64, SLOT = NP * PB + 128;     // offset of plane 1 inside a tap slot / bytes per tap slot (last 16 B: dump)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int PA = (S + 2) * 32;                // bytes per strip plane (+ the zero row at position S, + a dump row for predicated-off stores)
-  unsigned char* const Abase = smem3;                     // [2 buffers][2 planes][PA]
-  unsigned char* const Bbase = smem3 + 4 * PA;            // [2 buffers][3 taps][SLOT]
+  unsigned char* const Abase = smem3;                     // [2 buffers][NP planes][PA]
+  unsigned char* const Bbase = smem3 + 2 * NP * PA;       // [2 buffers][3 taps][SLOT]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, half = lane >> 5;
@@ -72,14 +75,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   const int bm = lin / gn, bn = lin - bm * gn;
   const int W = p.Wi, H = p.Hi, M = p.M;
   const int m0 = bm * BM;
-  const float sa = pow2_scale3(amax_read(p.amax_a)), sb = p.b_scale[0];
+  float sa = 1.f, sb = 1.f;
+  if constexpr (NP == 2) { sa = pow2_scale3(amax_read(p.amax_a)); sb = p.b_scale[0]; }
 
   // ---- descriptors ---------------------------------------------------------------------------------
   const int lin0 = m0 - W - 1;                                     // pixel of strip position 0
   const int base_px = lin0 > 0 ? lin0 : 0;
   const float* a_base = p.in + (long long)base_px * p.ldi;
   const __amdgpu_buffer_rsrc_t a_rs = rsrc3(a_base, ((long long)(M - base_px - 1) * p.ldi + p.Ci) * 4);
-  const __amdgpu_buffer_rsrc_t b_rs = rsrc3(p.wt, (long long)p.Co * p.ldw * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = NP == 2 ? rsrc3(p.wt, (long long)p.Co * p.ldw * 4)
+                                              : rsrc3(reinterpret_cast<const float*>(p.wt16), (long long)p.Co * p.ldw * 2);
+  constexpr int ESZ = NP == 2 ? 4 : 2;         // bytes per filter element in the bank
 
   // ---- per-thread staging state --------------------------------------------------------------------
   unsigned a_off[A_LD]; int a_st[A_LD];      // global byte offset (channel step 0) / LDS byte offset inside plane 0
@@ -93,10 +99,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   unsigned b_off[B_LD]; int b_st[B_LD];
 #pragma unroll
   for (int l = 0; l < B_LD; ++l) {
-    const int idx = tid + l * NT, row = idx >> 2, chunk = idx & 3;
+    const int idx = tid + l * NT, row = idx / CHB, chunk = idx % CHB;
     const int co = bn * BN + row;
-    b_off[l] = co < p.Co ? (unsigned)(co * p.ldw * 4 + chunk * 16) : OOB3;
-    b_st[l] = (chunk & 1) * PB1 + row32(row, chunk >> 1);           // chunk: plane = chunk & 1, k-half = chunk >> 1
+    const bool on = idx < BN * CHB;
+    b_off[l] = (on && co < p.Co) ? (unsigned)(co * p.ldw * ESZ + chunk * 16) : OOB3;
+    // pre-split: plane = chunk & 1, k-half = chunk >> 1; bf16: one plane, k-half = chunk; threads without a chunk: dump slot
+    b_st[l] = !on ? SLOT - 16 : (NP == 2 ? (chunk & 1) * PB1 + row32(row, chunk >> 1) : row32(row, chunk));
   }
   // rows of this lane (one per 32x32 block along M): in-image tap masks
   unsigned msk[2];
@@ -128,12 +136,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     const int cc = it / 3, g = it - 3 * cc;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const unsigned soff = (unsigned)(p.tap_w[3 * g + j] + cc * 16) * 4u;
+      const unsigned soff = (unsigned)(p.tap_w[3 * g + j] + cc * 16) * (unsigned)ESZ;
 #pragma unroll
       for (int l = 0; l < B_LD; ++l) br[j * B_LD + l] = ld16(b_rs, b_off[l], soff);
     }
   };
-  auto store_a_piece = [&](unsigned char* abuf, int j) {            // x*s = h + l, two f16 planes
+  auto store_a_piece = [&](unsigned char* abuf, int j) {            // x*s = h + l, two f16 planes (NP = 1: one bf16 plane)
+    if constexpr (NP == 1) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t b = {(__bf16)a_reg[j][0], (__bf16)a_reg[j][1], (__bf16)a_reg[j][2], (__bf16)a_reg[j][3]};
+      *reinterpret_cast<uint2*>(abuf + a_st[j]) = __builtin_bit_cast(uint2, b);
+      return;
+    }
     const f32x4 t = a_reg[j] * sa;
     const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
     const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   // ---- prologue --------------------------------------------------------------------------------------
-  if (tid < 8) {                              // the zero rows: [buffer][plane] x two 16-B halves
+  if (tid < 4 * NP) {                         // the zero rows: [buffer][plane] x two 16-B halves
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4*>(Abase + (tid >> 1) * PA + S * 32 + (tid & 1) * 16) = z;
   }
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   f16x8_t af[2][2][2], bf[2][2][2];          // [pipeline stage][block][plane]
   // fragments of tap J of the iteration with constants (G, CP, IP) into stage ST
   auto read_frags = [&](const int G, const int CP, const int IP, const int J, const int ST) {
-    const unsigned char* ab = Abase + CP * 2 * PA;
+    const unsigned char* ab = Abase + CP * NP * PA;
     const unsigned char* bb = Bbase + IP * 3 * SLOT;
     const int t = 3 * G + J;
     const int sh = (p.tap_dy[t] + 1) * W + p.tap_dx[t] + 1;
@@ -187,16 +201,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       const int pos = a_row0 + mi * 32 + sh;
       const int off = ((msk[mi] >> t) & 1) ? row32(pos, half) : S * 32;
       af[ST][mi][0] = *reinterpret_cast<const f16x8_t*>(ab + off);
-      af[ST][mi][1] = *reinterpret_cast<const f16x8_t*>(ab + PA + off);
+      if constexpr (NP == 2) af[ST][mi][1] = *reinterpret_cast<const f16x8_t*>(ab + PA + off);
     }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       bf[ST][ni][0] = *reinterpret_cast<const f16x8_t*>(bb + J * SLOT + b_fr[ni]);
-      bf[ST][ni][1] = *reinterpret_cast<const f16x8_t*>(bb + J * SLOT + PB1 + b_fr[ni]);
+      if constexpr (NP == 2) bf[ST][ni][1] = *reinterpret_cast<const f16x8_t*>(bb + J * SLOT + PB1 + b_fr[ni]);
     }
   };
   // one of the three cross terms, smallest first: (l,h) (h,l) (h,h)
   auto mfma_term = [&](const int ST, const int term) {
+    if constexpr (NP == 1) {                  // bf16 operands: the one product, in the slot of the (h,h) term
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      if (term != 2) return;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ST][mi][0]),
+                                                                __builtin_bit_cast(bf16x8_t, bf[ST][ni][0]), acc[mi][ni], 0, 0, 0);
+      return;
+    }
     const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       const bool in_b = it + 2 < iters;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const unsigned soff = (unsigned)(p.tap_w[3 * G2 + j] + (cc + C2) * 16) * 4u;
+        const unsigned soff = (unsigned)(p.tap_w[3 * G2 + j] + (cc + C2) * 16) * (unsigned)ESZ;
 #pragma unroll
         for (int l = 0; l < B_LD; ++l) bnew[j * B_LD + l] = ld16(b_rs, in_b ? b_off[l] : OOB3, in_b ? soff : 0u);
       }
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 #pragma unroll
       for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, in_a ? a_off[j] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
     }
-    unsigned char* an = Abase + (CP ^ 1) * 2 * PA;
+    unsigned char* an = Abase + (CP ^ 1) * NP * PA;
     unsigned char* bnx = Bbase + (IP ^ 1) * 3 * SLOT;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -353,21 +378,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 int g_conv3 = 1;          // dcn_set_tuning("3x3strip", 0): 3x3 stride-1 layers back on the implicit-GEMM tile
 int g_conv3_bm = 0;       // dcn_set_tuning("3bm", 128|256): force the strip kernel's M tile (0 = automatic)
 
-template <int WM, int WN, int A_LD>
+template <int WM, int WN, int A_LD, int NP = 2>
 int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   const int S = BM + 2 * p.Wi + 2;
-  const size_t lds = (size_t)4 * (S + 2) * 32 + (size_t)2 * 3 * (2 * BN * 32 + 128);
+  const size_t lds = (size_t)2 * NP * (S + 2) * 32 + (size_t)2 * 3 * (NP * BN * 32 + 128);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const double k_alg = 9.0 * p.Ci;
   const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co);
-  const int pid = prof_begin(WM == 4 ? 28 : 29, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
+  const int pid = prof_begin(NP == 1 ? 33 : (WM == 4 ? 28 : 29), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv3");
   return DCN_OK;
@@ -376,7 +401,10 @@ int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
 constexpr int A_LD_MAX = 4;   // strip loads per thread: S <= threads pixels.  (A 12-load build for the 104/208-wide maps with 64 filters
                               //  spilled registers and lost to the implicit-GEMM tile: 0.68 vs 0.55 ms, 1.24 vs 0.72 ms.)
 template <int WM, int WN>
-int launch3_ld(const IgemmParams& p, int gran, hipStream_t stream) { return launch3<WM, WN, A_LD_MAX>(p, gran, stream); }
+int launch3_ld(const IgemmParams& p, int gran, hipStream_t stream) {
+  if (p.wt16) return launch3<WM, WN, A_LD_MAX, 1>(p, gran, stream);       // bf16 operands
+  return launch3<WM, WN, A_LD_MAX>(p, gran, stream);
+}
 
 // tile choice: 256 pixels x 128 filters (8 waves, one workgroup per CU) or 128 x 128 (4 waves, two per CU), see below
 int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
@@ -401,7 +429,8 @@ void conv3_set_tuning(int key, int value) { if (key == 0) g_conv3 = value; else 
 
 // can this launch run on the strip kernel?  (gran = rows per statistics partial the caller sized its buffer for)
 bool conv3_applicable(const IgemmParams& p, int precision, int gran) {
-  if (!g_conv3 || precision != 4 || !p.b_scale || !p.amax_a || p.f8 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale) return false;
+  const bool f16 = precision == 4 && p.b_scale && p.amax_a && !p.wt16, b16 = precision == 2 && p.wt16;
+  if (!g_conv3 || !(f16 || b16) || p.f8 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale || p.ncls) return false;
   if (p.ntaps != 9 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1 || p.oy0 != 0 || p.ox0 != 0 || !p.dense_out) return false;
   if (p.Hs != p.Hi || p.Ws != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.M != p.N * p.Hi * p.Wi) return false;
   if (p.Ci % 32 != 0 || p.Co <= 64 || p.Wi < 2) return false;      // (64-filter layers only occur on the 104/208-wide maps: strip too long)

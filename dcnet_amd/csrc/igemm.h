@@ -18,6 +18,7 @@ struct IgemmParams {
   const float* f8;        // optional device {sA, sB}: power-of-two operand scales of the fp8 path (dcn_f8_scale); null = off
   const unsigned* amax_a; // optional device word: float bits of max|in| (f16 two-piece split: the kernel derives its power-of-two
   const unsigned* amax_b; //   scales from these); both needed, else the launch stays on the bf16 three-piece split
+  const void* wt16;       // non-null (bf16-operand mode): the filter bank converted to bf16, same [Co][ldw] layout (conv3.hip only)
   const float* b_scale;   // non-null: wt is pre-split (dcn_presplit_f16) with this power-of-two scale; igemm_will_presplit() says when
   unsigned* amax_out;     // optional device word: atomicMax of |stored values| (the abs-max of the tensor this launch produces)
   float* out;             // NHWC, pixel stride ldo

@@ -17,6 +17,8 @@ struct FilterJob {
   float* t;             // [ci][T][co] fp32, or null
   float* t_split;       // [ci][T][co] split, + 16 floats, or null
   unsigned* amax;       // DCN_AMAX_WORDS words (zeroed by the caller's memset)
+  void* ohwi_b16;       // [co][T][ci] bf16 (round to nearest even): the bank of the bf16-operand mode, or null
+  void* t_b16;          // [ci][T][co] bf16, or null
   int co, ci, T;
   int blk0;             // first block of this job in xform_kernel
   int ablk0;            // first block of this job in amax_kernel
@@ -103,6 +105,19 @@ __global__ __launch_bounds__(256) void filters_xform_kernel(const FilterJob* __r
   if (threadIdx.x < 128) {
     const int rr = threadIdx.x >> 2, g = (threadIdx.x & 3) * 8;
     float v[8];
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    if (job.ohwi_b16) {
+      bf16x8_t b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = (__bf16)tile[rr][g + e];
+      *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(job.ohwi_b16) + ((long long)(co0 + rr) * job.T + tap) * job.ci + ci0 + g) = b;
+    }
+    if (job.t_b16) {
+      bf16x8_t b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = (__bf16)tile[g + e][rr];
+      *reinterpret_cast<bf16x8_t*>(reinterpret_cast<__bf16*>(job.t_b16) + ((long long)(ci0 + rr) * job.T + tap) * job.co + co0 + g) = b;
+    }
     if (job.ohwi_split) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[rr][g + e];

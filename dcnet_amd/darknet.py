@@ -286,16 +286,16 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             x = out[op.src]; ax = amx.get(op.src)
             bank = banks.get(op.slot, p["w"]) if banks is not None else None
             if bank is not None:       # prepared for the whole network in one go (no per-layer transpose / abs-max / pre-split)
-                w, aw, wsp = bank["ohwi"], (bank["amax"] if am else None), bank["split"]
-                w._dcn_wt = (bank["t"], bank["tsplit"])
+                w, aw, wsp, w16 = bank["ohwi"], (bank["amax"] if am else None), bank["split"], bank["b16"]
+                w._dcn_wt = (bank["t"], bank["tsplit"]); w._dcn_wt16 = bank["tb16"]
             else:
-                w = ops.weight_to_ohwi(p["w"]); wsp = None
+                w = ops.weight_to_ohwi(p["w"]); wsp = w16 = None
                 aw = ops.absmax(p["w"]) if (am and op.cin > 4) else None
             ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
             if op.bn and training:
-                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp)
+                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp, w_b16=w16)
                 cnt = y.numel() // op.cout
                 mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
                 o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
@@ -309,13 +309,13 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     scale, shift = None, p["b"]
                 if save is None:      # inference: one kernel per layer, shortcut fused in the epilogue
                     o, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, residual=res, amax_x=ax, amax_w=aw, amax_out=ao,
-                                          w_split_ready=wsp)
+                                          w_split_ready=wsp, w_b16=w16)
                 else:                 # frozen-BN fine-tuning: keep the pre-shortcut activation for act'
                     if res is None:
-                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, amax_out=ao, w_split_ready=wsp)
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, amax_out=ao, w_split_ready=wsp, w_b16=w16)
                         o = a
                     else:
-                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, w_split_ready=wsp)
+                        a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, w_split_ready=wsp, w_b16=w16)
                         o = ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res, amax_out=ao)
                     save[op.slot] = (x, a, scale, w, ax, aw)
             out[op.dst] = o; amx[op.dst] = ao
@@ -407,10 +407,12 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
                 wtr = getattr(w, "_dcn_wt", None)      # the transposed banks of this step (ops.FilterBanks)
+                wt16 = getattr(w, "_dcn_wt16", None)
                 if cur is None:
-                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw, wt_ready=wtr)
+                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw, wt_ready=wtr, wt_b16=wt16)
                 else:
-                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr)
+                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr,
+                                        wt_b16=wt16)
             pg[op.slot] = d
             if sink is not None:
                 for k_, t_ in d.items():

@@ -223,7 +223,7 @@ def f8_scales(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
                residual=None, out=None, want_stats=False, accumulate=False, amax_x=None, amax_w=None, amax_out=None,
-               w_split_ready=None):
+               w_split_ready=None, w_b16=None):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
     where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats).
     amax_x / amax_w: abs-max words of the operands (computed here by a pass over the data when missing and the
@@ -247,14 +247,18 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
             wsplit = w_split_ready                                        # prepared for the whole network (FilterBanks)
         elif amax_w is not None and _precision == "fp32":
             wsplit = scratch(w_ohwi.numel() + 16, x.device, slot=5)       # the filter bank, split once per launch
+    ready = int(wsplit is not None and wsplit is w_split_ready)
+    if w_b16 is not None and cin != 4 and _precision == "bf16":
+        wsplit, ready = w_b16, 2                                          # the bank in bf16 (FilterBanks): the strip kernel's operand
     lib().conv2d_fwd(x.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
                      _p(scale), _p(shift), act, float(slope), _p(residual),
                      0 if residual is None else residual.stride(2), ldy, _p(stats), int(accumulate), _p(f8),
-                     _p(amax_x), _p(amax_w), _p(amax_out), _p(wsplit), int(wsplit is not None and wsplit is w_split_ready), _s())
+                     _p(amax_x), _p(amax_w), _p(amax_out), _p(wsplit), ready, _s())
     return out, stats
 
 
-def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None, wt_ready=None):
+def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None, wt_ready=None,
+                    wt_b16=None):
     """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin).
     wt_ready = (transposed fp32 bank, its split form | None) prepared by FilterBanks: nothing is converted here."""
     n, ho, wo, cout = dy.shape
@@ -270,9 +274,12 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
             wts = None
     else:
         wt, wts = scratch(w_ohwi.numel() + 16, dy.device, slot=1), None
+    ready = int(wt_ready is not None)
+    if wt_ready is not None and wt_b16 is not None and _precision == "bf16":
+        wts, ready = wt_b16, 2                                            # transposed bank in bf16 (FilterBanks)
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
                           n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w),
-                          int(wt_ready is not None), _p(wts), _s())
+                          ready, _p(wts), _s())
     return out
 
 
@@ -294,7 +301,7 @@ class FilterBanks:
               and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
         self.amax = torch.zeros(max(1, len(ok)) * AMAX_WORDS, dtype=torch.int32, device=self.device)
         rec = lib().filter_job_bytes()
-        assert rec == 6 * 8 + 6 * 4, rec
+        assert rec == 8 * 8 + 6 * 4, rec
         blob = bytearray()
         blk = ablk = 0
         self._ptrs = []
@@ -307,9 +314,11 @@ class FilterBanks:
             t = torch.empty(numel + 16, dtype=torch.float32, device=self.device)
             tsplit = torch.empty(numel + 16, dtype=torch.float32, device=self.device)
             am = self.amax[j * AMAX_WORDS:(j + 1) * AMAX_WORDS]
-            self.items[i] = dict(ohwi=ohwi, split=split, t=t, tsplit=tsplit, amax=am, shape=(co, ci, kh, kw))
-            blob += struct.pack("<6Q6i", w.data_ptr(), 0 if ohwi is None else ohwi.data_ptr(), split.data_ptr(), t.data_ptr(),
-                                tsplit.data_ptr(), am.data_ptr(), co, ci, T, blk, ablk, 0)
+            b16 = torch.empty(numel, dtype=torch.bfloat16, device=self.device)          # the banks of the bf16-operand mode
+            tb16 = torch.empty(numel, dtype=torch.bfloat16, device=self.device)
+            self.items[i] = dict(ohwi=ohwi, split=split, t=t, tsplit=tsplit, amax=am, b16=b16, tb16=tb16, shape=(co, ci, kh, kw))
+            blob += struct.pack("<8Q6i", w.data_ptr(), 0 if ohwi is None else ohwi.data_ptr(), split.data_ptr(), t.data_ptr(),
+                                tsplit.data_ptr(), am.data_ptr(), b16.data_ptr(), tb16.data_ptr(), co, ci, T, blk, ablk, 0)
             self._ptrs.append((i, w.data_ptr()))
             blk += T * (co // 32) * (ci // 32); ablk += (numel + 4095) // 4096
         self.njobs, self.blocks, self.ablocks = len(ok), blk, ablk

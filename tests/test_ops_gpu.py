@@ -688,6 +688,63 @@ def test_conv3_strip_kernel(dev, case):
         lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
 
 
+@pytest.mark.parametrize("case", [(8, 13, 13, 64, 128), (2, 52, 52, 32, 128), (2, 40, 24, 96, 160), (5, 17, 31, 64, 136),
+                                  (1, 104, 104, 32, 128)])
+def test_conv3_strip_kernel_bf16_operands(dev, case):
+    """bf16-operand mode (configs[2]) on the strip kernel: one bf16 plane per operand, the filter bank in bf16 from
+    ops.FilterBanks.  Against the exact model of the mode — fp64 convolution of the bf16-rounded tensors — forward with the
+    fused epilogue and BatchNorm sums, data gradient; and against the implicit-GEMM tile of the same mode."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout = case
+    cout_p = (cout + 31) // 32 * 32
+    x = _rand(n, h, w, cin, seed=31).to(dev)
+    w_oihw = torch.zeros(cout_p, cin, 3, 3)
+    w_oihw[:cout] = _rand(cout, cin, 3, 3, seed=32) / (cin * 9) ** 0.5
+    w_oihw = w_oihw.to(dev)
+    scale = (_rand(cout_p, seed=33).abs() + 0.5).to(dev); shift = _rand(cout_p, seed=34).to(dev)
+    dy = torch.zeros(n, h, w, cout_p); dy[..., :cout] = _rand(n, h, w, cout, seed=36) / 8
+    dy = dy.to(dev)
+    rb = lambda t: t.to(torch.bfloat16).double().cpu()
+    xd = rb(x).permute(0, 3, 1, 2).requires_grad_(True)
+    raw = F.conv2d(xd, rb(w_oihw), padding=1)
+    raw.backward(rb(dy).permute(0, 3, 1, 2))
+    rawl = raw.detach().permute(0, 2, 3, 1)
+    ref = F.leaky_relu(rawl * scale.double().cpu() + shift.double().cpu(), 0.1)
+    fb = ops.FilterBanks({0: w_oihw}, dev)
+    fb.refresh()
+    b = fb.get(0, w_oihw)
+    assert torch.equal(b["b16"].view(cout_p, 3, 3, cin), w_oihw.permute(0, 2, 3, 1).to(torch.bfloat16))
+    assert torch.equal(b["tb16"].view(cin, 3, 3, cout_p), w_oihw.permute(1, 2, 3, 0).to(torch.bfloat16))
+    try:
+        ops.set_precision("bf16")
+        lib().set_tuning(b"3x3strip", 0)
+        y0, _ = ops.conv2d_fwd(x, b["ohwi"], 3, 1, scale, shift, ops.ACT_LEAKY, 0.1, want_stats=True, w_b16=b["b16"])
+        d0 = ops.conv2d_bwd_data(dy, b["ohwi"], (h, w), 3, 1, wt_ready=(b["t"], b["tsplit"]), wt_b16=b["tb16"])
+        lib().set_tuning(b"3x3strip", 1)
+        for bm in (0, 128, 256):
+            lib().set_tuning(b"3bm", bm)
+            y1, st = ops.conv2d_fwd(x, b["ohwi"], 3, 1, scale, shift, ops.ACT_LEAKY, 0.1, want_stats=True, w_b16=b["b16"])
+            d1 = ops.conv2d_bwd_data(dy, b["ohwi"], (h, w), 3, 1, wt_ready=(b["t"], b["tsplit"]), wt_b16=b["tb16"])
+            _close(y1, ref, 2e-5, f"bf16 strip fwd bm={bm}")
+            _close(st[:, 0].double().sum(0), rawl.reshape(-1, cout_p).sum(0), 1e-4, "bf16 strip stats")
+            # (a data gradient with <= 64 input channels runs on the narrow fp32-operand tiles in every mode: closer to fp32 than
+            #  to the bf16 model)
+            _close(d1, xd.grad.permute(0, 2, 3, 1), 2e-5 if cin > 64 else 1e-2, f"bf16 strip dgrad bm={bm}")
+            _close(y1, y0, 2e-6, "bf16 strip vs tile fwd"); _close(d1, d0, 2e-6, "bf16 strip vs tile dgrad")
+        if w <= 64:
+            assert not torch.equal(y1, y0) or not torch.equal(d1, d0), "the strip kernel did not run"
+        # without the bf16 bank the mode stays on the implicit-GEMM tile: same exact model
+        y2, _ = ops.conv2d_fwd(x, b["ohwi"], 3, 1, scale, shift, ops.ACT_LEAKY, 0.1)
+        assert torch.equal(y2, y0)
+    finally:
+        lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
+        ops.set_precision("fp32")
+    # it IS reduced precision: the fp32-mode result differs from the bf16 model by far more than the tolerance above
+    yf, _ = ops.conv2d_fwd(x, b["ohwi"], 3, 1, scale, shift, ops.ACT_LEAKY, 0.1)
+    assert float((yf.double().cpu() - ref).abs().max()) > 1e-4
+
+
 def test_filter_banks_match_the_per_layer_preparation(dev):
     """ops.FilterBanks (dcn_prepare_filters: every filter bank of a network in three launches) writes the same OHWI bank,
     transposed bank, abs-max and f16-split banks as the per-layer kernels it replaces, and convolutions fed from it give
