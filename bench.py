@@ -300,7 +300,9 @@ def main():
                  # 32: weight gradient of the 3x3 stride-1 layers, one filter row per workgroup (f16 split)
                  32: "wgrad3_kernel",
                  # 33: the strip kernel with bf16 operands (one plane, one MFMA per product): the bf16-operand mode's 3x3 layers
-                 33: "conv3_kernel<*,2,4,1> (bf16 operands)"}
+                 33: "conv3_kernel<*,2,4,1> (bf16 operands)",
+                 # 34: the stem (4-channel image -> 32 filters) directly on the vector ALU, HBM-priced
+                 34: "stem_kernel"}
         flop_tags = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33}
         peak_of = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32)
                        else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33) else PEAK_FP32_MFMA_TFLOPS) for t in flop_tags}

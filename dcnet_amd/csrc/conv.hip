@@ -111,6 +111,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
         p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
       }
   }
+  if (p.c4 && stem_applicable(p, w_split)) return stem_launch(p, w_split, (hipStream_t)stream);      // (w_split: scratch of >= 27*32 floats)
   if (w_split && w_split_ready == 2) {
     p.wt16 = w_split;             // bf16-operand mode: the bank converted to bf16 (dcn_prepare_filters); read by the strip kernel only
   } else

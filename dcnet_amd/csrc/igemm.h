@@ -60,3 +60,8 @@ bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci);
 bool conv3_applicable(const IgemmParams& p, int precision, int gran);
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv3_set_tuning(int key, int value);
+
+// stem.hip: the 4-channel 3x3 stride-1 stem directly on the vector ALU (forward).  scratch: >= 27*32 floats.
+bool stem_applicable(const IgemmParams& p, const float* scratch);
+int stem_launch(const IgemmParams& p, float* scratch, hipStream_t stream);
+void stem_set_tuning(int v);

@@ -739,6 +739,7 @@ void conv_set_merge(int v);
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"

@@ -247,6 +247,8 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
             wsplit = w_split_ready                                        # prepared for the whole network (FilterBanks)
         elif amax_w is not None and _precision == "fp32":
             wsplit = scratch(w_ohwi.numel() + 16, x.device, slot=5)       # the filter bank, split once per launch
+    else:
+        wsplit = scratch(27 * 32 + 16, x.device, slot=5)                  # the stem kernel's re-ordered filter bank
     ready = int(wsplit is not None and wsplit is w_split_ready)
     if w_b16 is not None and cin != 4 and _precision == "bf16":
         wsplit, ready = w_b16, 2                                          # the bank in bf16 (FilterBanks): the strip kernel's operand

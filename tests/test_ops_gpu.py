@@ -70,6 +70,50 @@ def test_conv2d_fwd_fused_epilogue_and_stats(dev):
     _close(tot[1], (raw * raw).sum((0, 2, 3)), 1e-5, "stats sumsq")
 
 
+@pytest.mark.parametrize("n,h,w,cout", [(1, 32, 32, 32), (3, 19, 23, 32), (2, 40, 56, 16), (1, 5, 3, 32), (2, 64, 64, 24)])
+def test_stem_direct_kernel(dev, n, h, w, cout):
+    """csrc/stem.hip (the 4-channel 3x3 stem directly on the vector ALU, weights through the scalar cache) against fp64 and
+    against the implicit-GEMM c4 tile it replaces: plain, with BatchNorm partial sums (same [row][2][Co] layout: the caller
+    sizes the buffer before it knows which kernel runs), with the folded scale / shift / LeakyReLU epilogue and the abs-max
+    word, into a wider destination.  Image borders and the ragged last block of 256 pixels matter here."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    x = _rand(n, 3, h, w, seed=61); wt = _rand(cout, 3, 3, 3, seed=62, scale=27 ** -0.5)
+    scale = (_rand(cout, seed=63).abs() + 0.5); shift = _rand(cout, seed=64)
+    raw = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    ref = F.leaky_relu(raw * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1), 0.1)
+    xd = ops.nchw_to_nhwc(x.to(dev), 4); wd = ops.weight_to_ohwi(wt.to(dev))
+
+    def run():
+        out = {}
+        out["y"], out["stats"] = ops.conv2d_fwd(xd, wd, 3, 1, want_stats=True)
+        am = ops.amax_slot(dev)
+        buf = torch.zeros(n, h, w, cout + 8, device=dev)
+        ops.conv2d_fwd(xd, wd, 3, 1, scale.to(dev), shift.to(dev), ops.ACT_LEAKY, 0.1, out=buf[..., 4:4 + cout], amax_out=am)
+        out["buf"] = buf; out["amax"] = am.clone()
+        return out
+
+    try:
+        lib().set_tuning(b"jstem", 0)
+        old = run()
+        lib().set_tuning(b"jstem", 1)
+        new = run()
+    finally:
+        lib().set_tuning(b"jstem", 1)
+    for r, name in ((old, "c4 tile"), (new, "direct")):
+        _close(ops.nhwc_to_nchw(r["y"]), raw, 2e-5, f"stem {name}")
+        tot = r["stats"].sum(0).cpu().double()
+        _close(tot[0], raw.sum((0, 2, 3)), 1e-5, f"stem stats sum {name}")
+        _close(tot[1], (raw * raw).sum((0, 2, 3)), 1e-5, f"stem stats sumsq {name}")
+        _close(_nchw(r["buf"][..., 4:4 + cout]), ref, 2e-5, f"stem epilogue {name}")
+        assert float(r["buf"][..., :4].abs().max()) == 0 and float(r["buf"][..., 4 + cout:].abs().max()) == 0
+        assert float(r["amax"].view(torch.float32).max()) == float(r["buf"].abs().max())
+    assert new["stats"].shape == old["stats"].shape
+    _close(new["stats"].view(-1, 2 * cout), old["stats"].view(-1, 2 * cout), 1e-5, "stem stats rows")     # row by row
+    if cout % 4 == 0:
+        assert not torch.equal(new["y"], old["y"]), "the direct stem kernel did not run"
+
+
 def test_conv2d_fwd_into_concat_slice(dev):
     from dcnet_amd import ops
     n, h, w, cin, cout = 2, 10, 10, 64, 64

@@ -113,6 +113,8 @@ def main():
         print("%5d %5d %d %d %4d %3d %8.1f | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f" % (
             cin, cout, k, st, h, cnt, gf, tf, gf / tf, td, gf / td if td else 0, tw, gf / tw))
     for k in ("fwd", "dgrad", "wgrad"):
+        if not tot[k]:
+            continue
         print("total %-6s %8.2f ms  -> %6.1f TF/s" % (k, tot[k], tot["flop"] / 1e9 / tot[k]))
         if args.ab:
             print("   with %-12s %8.2f ms  -> %6.1f TF/s" % (args.ab, tot[k + "_b"], tot["flop"] / 1e9 / tot[k + "_b"]))
