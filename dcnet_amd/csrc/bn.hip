@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
   float vmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + r * c + ch));      // (not read again before the backward)
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const f32x4*>(scale + ch);
     if (shift) sh = *reinterpret_cast<const f32x4*>(shift + ch);
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
   float vmax = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(y + r * c + ch);
-    f32x4 d = *reinterpret_cast<const f32x4*>(dout + r * lddo + ch);
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + r * c + ch));      // last reads of both tensors
+    f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dout + r * lddo + ch));
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), is = *reinterpret_cast<const f32x4*>(invstd + ch);
     f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
     if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + ch);
