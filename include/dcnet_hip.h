@@ -101,12 +101,17 @@ int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, fl
                         int wt_ready, const float* wt_split, void* stream);
 /* w_split_ready / wt_ready / wt_split: the banks were prepared for the whole network by dcn_prepare_filters (below) — w_split
  * holds the split OHWI bank, wt the transposed fp32 bank and wt_split its split form; nothing is converted per call.
+ * Value 2 (bf16-operand mode, dcn_set_tuning("precision", 2)): w_split / wt_split point at the bank converted to bf16
+ * (ohwi_b16 / t_b16 of dcn_prepare_filters, same [Co][k*k*Ci] layout, 2 bytes per element); the 3x3 stride-1 strip kernel
+ * reads it, every other tile keeps rounding the fp32 bank itself.
+ * cin == 4 (the stem): w_split is plain scratch of >= 27*32 floats — the vector-ALU stem kernel re-orders the [Co][64] bank
+ * into [27][32] there; NULL keeps the stem on the implicit-GEMM tile.
  *
  * dcn_prepare_filters: every filter bank of a network in three launches (abs-max of each bank, then one LDS-tile pass that
  * writes, per job, any of: the OHWI bank, its f16-split form, the channel-transposed [Ci][T][Co] bank of the data gradient and
  * its split form; split banks carry their power-of-two scale in the float behind the bank, so they are numel + 16 floats).
  * jobs: device array of records {const float* src (OIHW); float* ohwi, *ohwi_split, *t, *t_split (NULL = not wanted);
- * uint32_t* amax; int co, ci, T, blk0, ablk0, pad} of dcn_filter_job_bytes() bytes each; co and ci multiples of 32; blk0 /
+ * uint32_t* amax; void* ohwi_b16, *t_b16 (the two banks in bf16, NULL = not wanted); int co, ci, T, blk0, ablk0, pad} of dcn_filter_job_bytes() bytes each; co and ci multiples of 32; blk0 /
  * ablk0 = ascending prefix sums of T*(co/32)*(ci/32) and ceil(co*ci*T/4096); amax_all/amax_words: the region that holds all
  * the jobs' abs-max words (zeroed here).  Replaces, per layer and step: the OIHW->OHWI transpose, dcn_absmax of the bank,
  * the pre-split and the data gradient's filter transpose (model/darknet.py:179-191 holds the parameters as OIHW). */
