@@ -111,6 +111,7 @@ class OverlappedGradReducer:
         self.bucket_bytes = int(bucket_bytes)
         self.group = group
         self._comm = None
+        self.always_collective = False   # tests: issue the all-reduce on a one-rank group as well (exercises the RCCL stream ordering)
         self._pushed = set()         # id(param) of the parameters whose gradient was reduced during the backward
         self._bufs = {}
         self.buckets_last_step = 0
@@ -154,9 +155,10 @@ class OverlappedGradReducer:
             for t in tensors:
                 views.append(flat[off:off + t.numel()].view(t.shape)); off += t.numel()
             torch._foreach_copy_(views, list(tensors))
-            if world > 1:
+            if world > 1 or (self.always_collective and dist.is_available() and dist.is_initialized()):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # (on a GPU: ordered on `comm` by ProcessGroupNCCL)
-                flat.div_(world)
+                if world > 1:
+                    flat.div_(world)
             torch._foreach_copy_(list(tensors), views)
             if comm is not None:
                 for t in tensors:

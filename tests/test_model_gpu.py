@@ -504,6 +504,13 @@ def test_overlapped_reducer_on_the_real_backbone_world_size_1(dev):
         got2 = step(red)                                                        # a second step reuses the bucket buffers
         for k in base:
             assert torch.equal(got2[k], base[k]), k
+        # the same with the all-reduce really issued (RCCL on one rank: the sum is the identity): every bucket goes through
+        # ProcessGroupNCCL from the autograd thread with the communication stream current — the calls of an N > 1 run
+        red.always_collective = True
+        for _ in range(2):
+            got3 = step(red)
+            for k in base:
+                assert torch.equal(got3[k], base[k]), k
     finally:
         m.visumodel.__dict__.pop("_grad_reducer", None)
         if created:
