@@ -129,7 +129,8 @@ void stem_set_tuning(int v) { g_stem_direct = v; }
 bool stem_applicable(const IgemmParams& p, const float* scratch) {
   return g_stem_direct && scratch && p.c4 && p.Co <= 32 && p.Co % 4 == 0 && p.ldo % 4 == 0 && !p.residual && !p.accumulate && !p.row_scale &&
          p.batch <= 1 && p.isy == 1 && p.isx == 1 && p.ldi == 4 && p.Hs == p.Hi && p.Ws == p.Wi && p.M == p.N * p.Hi * p.Wi &&
-         (long long)p.M * 16 < 0x7FFFFFF0LL && (p.act == DCN_ACT_NONE || p.act == DCN_ACT_LEAKY);
+         (long long)p.M * 16 < 0x7FFFFFF0LL && (p.act == DCN_ACT_NONE || p.act == DCN_ACT_LEAKY) &&
+         (((uintptr_t)p.out | (uintptr_t)p.in | (uintptr_t)p.scale | (uintptr_t)p.shift | (uintptr_t)scratch) & 15) == 0;      // 16-B accesses
 }
 
 // scratch: >= 27*32 floats (the re-ordered filter bank of this launch)

@@ -112,6 +112,11 @@ def test_stem_direct_kernel(dev, n, h, w, cout):
     _close(new["stats"].view(-1, 2 * cout), old["stats"].view(-1, 2 * cout), 1e-5, "stem stats rows")     # row by row
     if cout % 4 == 0:
         assert not torch.equal(new["y"], old["y"]), "the direct stem kernel did not run"
+    # a destination that is not 16-byte aligned stays on the implicit-GEMM tile (and is still right)
+    odd = torch.zeros(n, h, w, cout + 4, device=dev)
+    ops.conv2d_fwd(xd, wd, 3, 1, out=odd[..., 1:1 + cout])
+    _close(_nchw(odd[..., 1:1 + cout]), raw, 2e-5, "stem, unaligned destination")
+    assert float(odd[..., 0].abs().max()) == 0 and float(odd[..., 1 + cout:].abs().max()) == 0
 
 
 def test_conv2d_fwd_into_concat_slice(dev):
