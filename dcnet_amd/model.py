@@ -210,11 +210,14 @@ class grounding_model(nn.Module):
                                        nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
         self._pinned = {}
-        self._pin_event = None
+        self._spec = None          # draws made ahead for the next training forward (_presample_take)
         self._streams = {}
         # the two sampling heads (K9, K14) on their own stream under the head convs of scales 1 and 2 (forward()), and
         # their contrastive losses on that stream too (losses.total_loss), so that their backward overlaps as well
         self.sampling_stream = True
+        # a training forward also makes the draws of the NEXT one on its worker thread (used if Python's stream is still where
+        # they started from: _presample_take); False = every forward draws for itself
+        self.presample_ahead = True
         # the language branch (embedding, MLP, BiLSTM, mapping_lang, phrase attention) on its own stream under the backbone
         self.language_stream = True
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
@@ -317,18 +320,22 @@ class grounding_model(nn.Module):
         key = (n, hw, top_k, neg_n, neg_c)
         if key not in self._pinned:
             # page-locked staging so the upload is a true async copy (a pageable H2D would block the host
-            # until the queued backbone kernels drain).  Reuse is safe: the language branch of the next
-            # forward syncs the stream before these buffers are written again.
-            self._pinned[key] = (torch.empty((n // 2, top_k, neg_n), dtype=torch.int64).pin_memory(),
-                                 torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory(),
-                                 torch.empty(hw + 1, dtype=torch.int32).pin_memory(),
-                                 torch.empty(n * hw * neg_c, dtype=torch.int32).pin_memory())
-        k9, k14, csr_off, csr_src = self._pinned[key]
-        if self._pin_event is not None:
-            self._pin_event.synchronize()        # the previous forward's upload of these buffers has completed
+            # until the queued backbone kernels drain).  Two sets, used in turn: the draws of the NEXT forward are made
+            # (speculatively, see forward()) while the upload of this one may still be in flight.
+            mk = lambda: (torch.empty((n // 2, top_k, neg_n), dtype=torch.int64).pin_memory(),
+                          torch.empty((n, hw, neg_c), dtype=torch.int64).pin_memory(),
+                          torch.empty(hw + 1, dtype=torch.int32).pin_memory(),
+                          torch.empty(n * hw * neg_c, dtype=torch.int32).pin_memory())
+            self._pinned[key] = {"sets": [mk(), mk()], "events": [None, None], "turn": 0}
+        pin = self._pinned[key]
+        which = pin["turn"]; pin["turn"] ^= 1
+        k9, k14, csr_off, csr_src = pin["sets"][which]
+        if pin["events"][which] is not None:
+            pin["events"][which].synchronize()   # the upload of this set (two forwards ago) has completed
+            pin["events"][which] = None
         st, arr = _mt_state()
         L = lib()
-        box = {"err": None, "shape": (n, top_k, hw, neg_n, neg_c)}
+        box = {"err": None, "shape": (n, top_k, hw, neg_n, neg_c), "pin": pin, "which": which, "g0": g0}
 
         def work():
             try:
@@ -344,7 +351,21 @@ class grounding_model(nn.Module):
         th.start()
         return th, st, arr, (k9, k14, csr_off, csr_src), box
 
-    def _presample_join(self, handle, device):
+    def _presample_take(self, n, g0):
+        """The draws of this forward: the ones made ahead by the previous training forward if they are still valid — same
+        shapes, and nobody has touched Python's global stream since (its state is the one they started from) — else fresh
+        ones.  The K14 loop of the reference is O(N^2 HW) draws (11 M samples at 256 images: 0.4 s of one core, more than the
+        backbone's forward), all of which must be made to leave the stream where the reference leaves it; made ahead, they run
+        under the previous step's backward."""
+        spec, self._spec = self._spec, None
+        if spec is not None:
+            th, st, arr, bufs, box = spec
+            if box["shape"][0] == n and box["g0"] == g0 and random.getstate() == st:
+                return spec
+            th.join()                            # stale (re-seeded stream, other batch): let the worker finish, drop its draws
+        return self._presample_start(n, g0)
+
+    def _presample_join(self, handle, device, ahead=False):
         th, st, arr, (k9, k14, csr_off, csr_src), box = handle
         th.join()
         if box["err"] is not None:
@@ -360,11 +381,16 @@ class grounding_model(nn.Module):
             L.mt_sample_crossmodal_csr(k14.data_ptr(), n, hw, neg_c, csr_off.data_ptr(), csr_src.data_ptr())
         _mt_restore(st, arr)
         if device is None:                   # eval mode: the draws only advance the RNG stream, as in the reference
-            return None, None
+            return None
         out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True),
                "csr_off": csr_off.to(device, non_blocking=True), "csr_src": csr_src.to(device, non_blocking=True)}
         ev = torch.cuda.Event(); ev.record()
-        return out, ev
+        box["pin"]["events"][box["which"]] = ev
+        if ahead:
+            # the next training forward will most likely look the same: make its draws now, from the state the stream has
+            # after this one's (checked again when they are taken)
+            self._spec = self._presample_start(box["shape"][0], box["g0"])
+        return out
 
     def _interframe_sampling(self, fv0, presampled, top_k=30):
         """model/DCNet_model.py:381-430 on the NHWC scale-0 map (N,g,g,E): csrc/sample.hip."""
@@ -408,7 +434,7 @@ class grounding_model(nn.Module):
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
             flang_attn, flang_loc = self._phrases(context, embedded, word_id)    # :525-526, :556-557
-        handle = self._presample_start(N, image.shape[-1] // 32)                 # worker thread, under the backbone
+        handle = self._presample_take(N, image.shape[-1] // 32)                  # worker thread, under the backbone (or made ahead)
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
@@ -421,7 +447,7 @@ class grounding_model(nn.Module):
             # stream as soon as scale 0 is queued and run under the head convs of scales 1 and 2; autograd replays their
             # backward on the same stream, beside the heads' backward.  In eval mode the reference computes and discards
             # them: here only the RNG stream is advanced (the draws), the device work is skipped.
-            presampled, self._pin_event = self._presample_join(handle, image.device)
+            presampled = self._presample_join(handle, image.device, ahead=self.presample_ahead)
             samp = self._side_stream(image.device, "samp") if self.sampling_stream else main
             samp.wait_stream(main)
             with torch.cuda.stream(samp):

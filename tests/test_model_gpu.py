@@ -515,3 +515,37 @@ def test_overlapped_reducer_on_the_real_backbone_world_size_1(dev):
         m.visumodel.__dict__.pop("_grad_reducer", None)
         if created:
             dist.destroy_process_group()
+
+
+def test_draws_made_ahead_are_the_same_draws(dev):
+    """model.presample_ahead: a training forward makes the MT19937 draws of the next one on its worker thread (the K14 loop of
+    the reference is O(N^2 HW) draws: 0.4 s of one core at 256 images).  They are used only if Python's global stream is still
+    in the state they started from; the sampled negatives, the outputs and the state the stream is left in must be exactly those
+    of a model that draws for itself in every forward — over consecutive forwards, after a re-seed in between (stale draws
+    dropped), after draws by somebody else, and after a change of batch size."""
+    from dcnet_amd.utils.synth import synth_inputs
+    size = 256
+    sd = synth_sd(size)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(6, size, seed=41))
+
+    def run(ahead):
+        m = build_product(size, sd, dev).train()
+        m.presample_ahead = ahead
+        rec = []
+        random.seed(7)
+        for it in range(5):
+            n = 6 if it == 3 else 4                         # forward 3: another batch size
+            if it == 2:
+                random.seed(99)                             # the stream is re-seeded between forwards
+            if it == 4:
+                random.random()                             # ... or drawn from by somebody else
+            with torch.no_grad():
+                out = m(image[:n], word_id[:n], word_mask[:n])
+            rec.append((m.last_choices["k9_neg"].clone(), m.last_choices["k14_neg"].clone(), out[0][0].clone(), random.getstate()))
+        return rec
+
+    a, b = run(True), run(False)
+    for it, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), it
+        assert torch.equal(x[2], y[2]), it
+        assert x[3] == y[3], it
