@@ -14,7 +14,7 @@ void dcn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dcn_last_error(void) { return g_err; }
-extern "C" int dcn_version(void) { return 100; }
+extern "C" int dcn_version(void) { return DCN_ABI_VERSION; }
 
 // ---- streams ---------------------------------------------------------------------------------
 // level: -1 = highest, 0 = normal, +1 = lowest priority the device offers.  The weight-gradient GEMMs run
@@ -84,4 +84,20 @@ extern "C" int dcn_prof_collect(int64_t* counts, double* ms, double* work, doubl
     if (r.tag >= 0 && r.tag < DCN_PROF_TAGS) { counts[r.tag]++; ms[r.tag] += t; work[r.tag] += r.work; if (bytes) bytes[r.tag] += r.bytes; }
   }
   return DCN_OK;
+}
+
+// Per-launch records of the last window (host-synchronising): tag / milliseconds / algorithmic work / algorithmic bytes of up to
+// `max` launches in launch order.  Returns the number of records written (or a negative error).  Lets the caller price every
+// LAUNCH against the roofline that binds it (max of its MFMA time and its HBM time) instead of a per-tag average.
+extern "C" int dcn_prof_records(int32_t* tags, double* ms, double* work, double* bytes, int max) {
+  DCN_CHECK_ARG(tags && ms && work && bytes && max >= 0, "prof_records: null pointer");
+  int n = 0;
+  for (size_t i = 0; i < g_used && n < max; ++i) {
+    Rec& r = g_recs[i];
+    if (hipEventSynchronize(r.b) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    tags[n] = r.tag; ms[n] = t; work[n] = r.work; bytes[n] = r.bytes; ++n;
+  }
+  return n;
 }

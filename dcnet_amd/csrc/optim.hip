@@ -16,7 +16,8 @@ __device__ __forceinline__ void rms_update(float& p, const float g0, float& v, f
   p = p - lr * (g / (sqrtf(v) + eps));                   // param.addcdiv_(grad, square_avg.sqrt().add_(eps), value=-lr)
 }
 
-__global__ __launch_bounds__(256) void rmsprop_kernel(const RmsChunk c, float lr, float alpha, float eps, float wd) {
+__global__ __launch_bounds__(256) void rmsprop_kernel(const RmsChunk c, float lr, const float* __restrict__ lr_dev, float alpha, float eps, float wd) {
+  if (lr_dev) lr = lr_dev[0];                 // a captured step (hipGraph) reads its learning rate from device memory
   const int t = blockIdx.y;
   float* __restrict__ p = c.p[t]; const float* __restrict__ g = c.g[t]; float* __restrict__ v = c.v[t];
   const long long n = c.n[t];
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(const RmsChunk c, float lr
 }  // namespace
 
 extern "C" int dcn_rmsprop_step(float* const* params, const float* const* grads, float* const* square_avgs, const int64_t* numel,
-                                int count, float lr, float alpha, float eps, float weight_decay, void* stream) {
+                                int count, float lr, const float* lr_dev, float alpha, float eps, float weight_decay, void* stream) {
   DCN_CHECK_ARG(params && grads && square_avgs && numel && count > 0, "rmsprop_step: bad argument");
   for (int base = 0; base < count; base += RMS_CHUNK) {
     RmsChunk c{};
@@ -49,7 +50,7 @@ extern "C" int dcn_rmsprop_step(float* const* params, const float* const* grads,
     }
     long long bx = (biggest / 4 + 255) / 256;
     bx = bx < 1 ? 1 : (bx > 128 ? 128 : bx);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)bx, m), dim3(256), 0, (hipStream_t)stream, c, lr, alpha, eps, weight_decay);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)bx, m), dim3(256), 0, (hipStream_t)stream, c, lr, lr_dev, alpha, eps, weight_decay);
     DCN_CHECK_LAUNCH("rmsprop_step");
   }
   return DCN_OK;

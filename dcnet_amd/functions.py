@@ -389,8 +389,9 @@ class FusionConvBNAct(torch.autograd.Function):
         wd = weight.detach().view(co, -1)
         w1 = wd[:, :e].contiguous().view(co, e, 1, 1)
         w2, w3 = wd[:, e:2 * e], wd[:, 2 * e:]
-        coord2d = coord.reshape(h * w, -1)
-        y = (torch.matmul(flang.detach(), w2.t()).view(n, 1, co) + torch.matmul(coord2d, w3.t()).view(1, h * w, co)).view(n, h, w, co)
+        coord2d = coord.reshape(h * w, -1).contiguous()
+        # the pre-filled term W2.flang[n] + W3.coord[p] (csrc/fusion.hip; W2, W3 are column slices of the parameter: no copies)
+        y = ops.fusion_prefill(ops.gemm_nt(flang.detach().contiguous(), w2), coord2d, w3).view(n, h, w, co)
         wk = ops.weight_to_ohwi(w1)
         aw = ops.absmax(wk) if am else None
         if training:
@@ -432,13 +433,12 @@ class FusionConvBNAct(torch.autograd.Function):
         dw1 = ops.wgrad_on_side(corr, dy, 1, 1, (co, e, 1, 1), amax_x=ax, amax_dy=ady).view(co, e)      # overlaps with the data gradient
         dcorr = ops.conv2d_bwd_data(dy, wk, (h, w), 1, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
         ops.join_side(corr.device)
-        d_img = dy.sum((1, 2))                                  # (N,co): gradient of the per-image term
-        d_pos = dy.sum(0).view(h * w, co)                       # (HW,co): gradient of the per-position term
-        dflang = torch.matmul(d_img, wd[:, e:2 * e])
-        dw2 = torch.matmul(d_img.t(), flang.detach())
-        dw3 = torch.matmul(d_pos.t(), ctx.coord2d)
-        dweight = torch.cat([dw1, dw2, dw3], dim=1).view_as(weight)
-        return dcorr, dflang, None, dweight, dgamma, dbeta, None, None, None
+        # gradients of the per-image / per-position terms: one pass over dy (d_img, dW3), dW2 = d_img^T.flang, dflang = d_img.W2
+        dweight = torch.empty((co, wd.shape[1]), dtype=torch.float32, device=dy.device)
+        d_img = ops.fusion_bwd(dy, ctx.coord2d, flang.detach().contiguous(), dweight, e)
+        ops.copy_slice(dw1, dweight[:, :e])
+        dflang = ops.gemm_nn(d_img, wd[:, e:2 * e]) if ctx.needs_input_grad[1] else None
+        return dcorr, dflang, None, dweight.view_as(weight), dgamma, dbeta, None, None, None
 
 
 class CoAttentionPairs(torch.autograd.Function):
@@ -525,7 +525,7 @@ class LinearAct(torch.autograd.Function):
             dz = ops.act_bwd(out, dz, 0.0)
         dx = ops.gemm_nn(dz, weight.detach()) if ctx.needs_input_grad[0] else None
         dw = ops.gemm_tn(dz, x)
-        db = dz.sum(0) if ctx.has_bias else None
+        db = ops.colsum(dz) if ctx.has_bias else None
         return dx, dw, db, None
 
 
@@ -565,6 +565,23 @@ class BatchNormRowsAct(torch.autograd.Function):
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (a - beta) / gs).sum(0)
         return dx, dgamma, dbeta, None, None, None
+
+
+class Embedding(torch.autograd.Function):
+    """nn.Embedding (model/DCNet_model.py:168): row gather; the backward sums the rows of each vocabulary entry in token order
+    (deterministic, no sort / no atomics)."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        ids = ids.contiguous()
+        ctx.save_for_backward(ids)
+        ctx.vocab = table.shape[0]
+        return ops.embedding_fwd(ids, table.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        return None, ops.embedding_bwd(ids, dout.contiguous(), ctx.vocab)
 
 
 class BiLSTM(torch.autograd.Function):

@@ -1,0 +1,108 @@
+"""A training step of the hot path as ONE replayed hipGraph.
+
+The reference's step is a Python loop body (train_DCNet.py:580-646: forward, five losses, ``backward()``, RMSprop).  Eagerly
+that is ~1 300 kernel launches per step from one Python thread, which keeps that thread busy for most of the step's GPU time.
+``GraphedTrainStep`` captures the same launches once — forward of ``grounding_model``, ``losses.total_loss``, autograd's
+backward (with the weight-gradient / language / sampling side streams as forked branches of the graph) and the fused RMSprop
+update — and replays them with one ``hipGraphLaunch`` per step.  What stays on the host per step:
+
+  * the draws of the two sampling heads (Python's MT19937 stream must advance exactly as the reference's forward advances
+    it): made natively on a worker thread, uploaded into static device buffers the captured kernels read
+    (``grounding_model.draw_samples`` / ``static_samples``);
+  * the learning rate of the schedule (train_DCNet.py:244-253): one device scalar per parameter group that the captured
+    RMSprop kernel reads (``optim.RMSprop.device_lr``);
+  * new input data: ``copy_`` into the static ``image`` / ``word_id`` / ``bbox`` tensors.
+
+Data-parallel runs capture forward + backward only; the gradient all-reduce (one flat RCCL all-reduce,
+``parallel.FlatGradAllReduce``) and the optimiser step follow the replay eagerly — no collective is captured.
+
+Everything else is unchanged: the same kernels in the same order on the same streams, so a replayed step is bitwise equal to
+an eager one (tests/test_graph_gpu.py).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import losses, ops
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(model, optimizer, image, word_id, word_mask, bbox, size)`` then ``loss = step()`` per iteration.
+
+    ``image``/``word_id``/``word_mask``/``bbox`` become the static inputs (``step.image.copy_(new)`` to feed new data of the same
+    shape).  ``reducer``: a callable run after the replayed backward and before the optimiser step (data-parallel gradient
+    averaging); with a reducer the optimiser step runs eagerly after it.  ``warmup`` eager steps are run first (they populate the
+    library's caches: geometry tables, scratch buffers, function attributes) — they ARE training steps (parameters move)."""
+
+    def __init__(self, model, optimizer, image, word_id, word_mask, bbox, size: int, reducer=None, warmup: int = 2):
+        if not image.is_cuda:
+            raise RuntimeError("GraphedTrainStep: HIP only (no CPU path)")
+        self.model, self.opt, self.size, self.reducer = model, optimizer, size, reducer
+        self.core = model.module if hasattr(model, "module") else model
+        dev = image.device
+        self.image, self.word_id, self.bbox = image.clone(), word_id.clone(), bbox.clone()
+        self.word_mask = None if word_mask is None else word_mask.clone()
+        self.n = image.shape[0]
+        self.samples = self.core.sample_buffers(self.n, dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.loss = None
+        self.parts = None
+        self.replays = 0
+        if hasattr(optimizer, "device_lr"):
+            optimizer.device_lr = True
+            optimizer.sync_lr(dev)
+        model.train()
+        self.core.static_samples = self.samples
+        # warm-up on a side stream (torch.cuda.graph's documented recipe), then capture
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup)):
+                self.core.draw_samples(self.n, self.samples)
+                self._body(eager=True)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        optimizer.zero_grad(set_to_none=True)
+        self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.loss, self.parts = self._body(eager=False)
+        self.graph = g
+        ops._amax_pools.pop(dev.index, None)                  # the capture's private abs-max pool stays with the graph
+        self.replays = 0
+        # the capture pass itself does not execute kernels: run it once so that state (parameters, running statistics) is that
+        # of a step, with the draws made above
+        self._replay_device()
+
+    # ------------------------------------------------------------------------------------------------
+    def _body(self, eager: bool):
+        out = self.model(self.image, self.word_id, self.word_mask)
+        loss, parts = losses.total_loss(out, self.bbox, self.size)
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.reducer is None:
+            self.opt.step()
+        elif eager:
+            self.reducer()
+            self.opt.step()
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}
+
+    def _replay_device(self):
+        self.graph.replay()
+        if self.reducer is not None:
+            self.reducer()
+            self.opt.step()
+        elif hasattr(self.opt, "bump_steps") and self.replays > 0:
+            self.opt.bump_steps()
+        self.replays += 1
+
+    def __call__(self):
+        """One optimisation step.  Returns the (static) loss tensor of the step — reading it synchronises."""
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()
+        self.core.draw_samples(self.n, self.samples)
+        self._replay_device()
+        return self.loss

@@ -99,17 +99,25 @@ SIGNATURES = {
     "dcn_bilstm_sync_bytes": (L, []),
     "dcn_bilstm_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "dcn_bilstm_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
-    "dcn_rmsprop_step": (I, [P, P, P, P, I, F, F, F, F, P]),
+    "dcn_rmsprop_step": (I, [P, P, P, P, I, F, P, F, F, F, P]),
+    "dcn_fusion_prefill": (I, [P, P, P, I, P, I, I, I, P]),
+    "dcn_fusion_bwd_ws": (L, [I, I]),
+    "dcn_fusion_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dcn_row_lengths": (I, [P, I, I, P, P]),
+    "dcn_embedding_fwd": (I, [P, P, P, I, I, I, P]),
+    "dcn_embedding_bwd": (I, [P, P, P, I, I, I, P]),
     "dcn_set_tuning": (I, [c_char_p, I]),
     "dcn_stream_create": (P, [I]),
     "dcn_stream_destroy": (I, [P]),
     "dcn_stream_priority_range": (I, [P, P]),
     "dcn_prof_enable": (I, [I]),
     "dcn_prof_collect": (I, [P, P, P, P]),
+    "dcn_prof_records": (I, [P, P, P, P, I]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
-_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes"}      # int-returning value functions
+_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
+ABI_VERSION = 300        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):
@@ -134,6 +142,9 @@ class _Lib:
                 setattr(self, name[4:], self._checked(name, fn))
             else:
                 setattr(self, name[4:], fn)
+        if self._dll.dcn_version() != ABI_VERSION:
+            raise DcnError(f"{path} has ABI version {self._dll.dcn_version()}, this binding was written for {ABI_VERSION}: "
+                           "rebuild the library (python -m dcnet_amd.build --force)")
 
     def _checked(self, name, fn):
         def call(*a):

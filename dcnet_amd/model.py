@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from . import ops
 from .darknet import Darknet
 from .functions import (BatchNormRowsAct, BiLSTM, CoAttentionCenter, CoAttentionPairs, ConvBias, ConvBNAct, CrossModalSample,
-                        FusionConvBNAct, HeadTail, InterframeSample, L2Norm, LinearAct, NormAccumulate, NormScore, PhraseAttn, RowDot)
+                        Embedding, FusionConvBNAct, HeadTail, InterframeSample, L2Norm, LinearAct, NormAccumulate, NormScore, PhraseAttn, RowDot)
 from .lib import lib
 
 
@@ -96,9 +96,10 @@ class RNNEncoder(nn.Module):
         # themselves.  The reference trims the batch to its longest row first (model/DCNet_model.py:474-475);
         # computing the padded steps instead changes nothing that is consumed (padded outputs are zero,
         # PhraseAttention renormalises over the valid positions, the sentence vector is read at len-1).
-        lengths = (input_labels != 0).sum(1)
+        input_labels = input_labels.contiguous()
+        lengths = ops.row_lengths(input_labels)                                             # :150 (ids != 0).sum(1)
         n, L = input_labels.shape
-        emb = self.input_dropout(self.embedding(input_labels))                              # :168-169
+        emb = self.input_dropout(Embedding.apply(input_labels, self.embedding.weight))      # :168-169
         lin = self.mlp[0]
         embedded = LinearAct.apply(emb.view(n * L, -1), lin.weight, lin.bias, True).view(n, L, -1)     # :170
         r = self.rnn
@@ -211,6 +212,9 @@ class grounding_model(nn.Module):
         self._coord_cache = {}
         self._pinned = {}
         self._spec = None          # draws made ahead for the next training forward (_presample_take)
+        # device tensors (sample_buffers) that already hold this forward's draws (draw_samples): the forward then neither
+        # draws nor uploads — a captured training step reads its draws from these static buffers
+        self.static_samples = None
         self._streams = {}
         # the two sampling heads (K9, K14) on their own stream under the head convs of scales 1 and 2 (forward()), and
         # their contrastive losses on that stream too (losses.total_loss), so that their backward overlaps as well
@@ -246,7 +250,7 @@ class grounding_model(nn.Module):
         z = ml[3](z)
         z = LinearAct.apply(z, ml[4].weight, ml[4].bias, False)
         z = BatchNormRowsAct.apply(z, ml[5].weight, ml[5].bias, ml[5], self.training, True)
-        flang = F.normalize(z, p=2, dim=1)                                      # :485-487
+        flang = L2Norm.apply(z)                                                 # :485-487 F.normalize(dim=1), csrc/score.hip
         return word_id, flang, context, embedded
 
     def _fusion_head(self, s: int, corr, flang):
@@ -365,7 +369,23 @@ class grounding_model(nn.Module):
             th.join()                            # stale (re-seeded stream, other batch): let the worker finish, drop its draws
         return self._presample_start(n, g0)
 
-    def _presample_join(self, handle, device, ahead=False):
+    def sample_buffers(self, n: int, device, top_k=30, neg_n=10, neg_c=5) -> dict:
+        """Device tensors with the shapes of one training forward's draws (n images): the static buffers of a captured step."""
+        hw = (self.img_size // 32) ** 2
+        return {"k9": torch.zeros((n // 2, top_k, neg_n), dtype=torch.int64, device=device),
+                "k14": torch.zeros((n, hw, neg_c), dtype=torch.int64, device=device),
+                "csr_off": torch.zeros(hw + 1, dtype=torch.int32, device=device),
+                "csr_src": torch.zeros(n * hw * neg_c, dtype=torch.int32, device=device)}
+
+    def draw_samples(self, n: int, into: dict) -> dict:
+        """Make the draws of ONE training forward on ``n`` images — Python's global MT19937 stream advances exactly as that
+        forward would advance it — and upload them into the device tensors ``into`` (sample_buffers) on the current stream.
+        With ``self.static_samples = into`` the forward then reads them instead of drawing itself: the host half of a step
+        whose device half is a replayed hipGraph (dcnet_amd.graph.GraphedTrainStep)."""
+        handle = self._presample_take(n, self.img_size // 32)
+        return self._presample_join(handle, into["k9"].device, ahead=self.presample_ahead, into=into)
+
+    def _presample_join(self, handle, device, ahead=False, into=None):
         th, st, arr, (k9, k14, csr_off, csr_src), box = handle
         th.join()
         if box["err"] is not None:
@@ -382,8 +402,13 @@ class grounding_model(nn.Module):
         _mt_restore(st, arr)
         if device is None:                   # eval mode: the draws only advance the RNG stream, as in the reference
             return None
-        out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True),
-               "csr_off": csr_off.to(device, non_blocking=True), "csr_src": csr_src.to(device, non_blocking=True)}
+        if into is not None:
+            for k_, src in (("k9", k9), ("k14", k14), ("csr_off", csr_off), ("csr_src", csr_src)):
+                into[k_].copy_(src, non_blocking=True)
+            out = into
+        else:
+            out = {"k9": k9.to(device, non_blocking=True), "k14": k14.to(device, non_blocking=True),
+                   "csr_off": csr_off.to(device, non_blocking=True), "csr_src": csr_src.to(device, non_blocking=True)}
         ev = torch.cuda.Event(); ev.record()
         box["pin"]["events"][box["which"]] = ev
         if ahead:
@@ -429,12 +454,15 @@ class grounding_model(nn.Module):
         # kernels) goes on a side stream: it runs under the backbone, and autograd replays its backward on the
         # same side stream under the backbone's backward.
         main = torch.cuda.current_stream()
+        if ops.use_amax():
+            ops.amax_begin_step(image.device)        # (before any stream forks: the step's abs-max words are zeroed on `main`)
         side = self._side_stream(image.device) if self.language_stream else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
             flang_attn, flang_loc = self._phrases(context, embedded, word_id)    # :525-526, :556-557
-        handle = self._presample_take(N, image.shape[-1] // 32)                  # worker thread, under the backbone (or made ahead)
+        static = self.static_samples if self.training else None
+        handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
@@ -447,7 +475,7 @@ class grounding_model(nn.Module):
             # stream as soon as scale 0 is queued and run under the head convs of scales 1 and 2; autograd replays their
             # backward on the same stream, beside the heads' backward.  In eval mode the reference computes and discards
             # them: here only the RNG stream is advanced (the draws), the device work is skipped.
-            presampled = self._presample_join(handle, image.device, ahead=self.presample_ahead)
+            presampled = static if static is not None else self._presample_join(handle, image.device, ahead=self.presample_ahead)
             samp = self._side_stream(image.device, "samp") if self.sampling_stream else main
             samp.wait_stream(main)
             with torch.cuda.stream(samp):
@@ -478,6 +506,8 @@ class grounding_model(nn.Module):
             raise ValueError("batch must be a multiple of n_frame (model/test_DCNet_model.py:287)")
         B = image.size(0) // n_frame
         main = torch.cuda.current_stream()
+        if ops.use_amax():
+            ops.amax_begin_step(image.device)
         side = self._side_stream(image.device) if self.language_stream else main
         side.wait_stream(main)
         with torch.cuda.stream(side):

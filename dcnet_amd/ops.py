@@ -42,8 +42,8 @@ def get_precision() -> str:
 
 # ---- abs-max words of GEMM operands (the f16 two-piece split derives its power-of-two scales from them) --------------
 # A word holds the float bits of max|tensor| and is written with order-independent atomic maxima by the kernels that
-# produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool and are
-# used once, so a saved activation keeps its word for the backward whatever runs in between.
+# produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool (one quarter of
+# it per training step, amax_begin_step) and are used once per step, so a saved activation keeps its word for the backward.
 AMAX_WORDS = 64          # DCN_AMAX_WORDS: the waves of a producer spread their atomic maxima over this many words
 _amax_pools = {}
 _amax_consts = {}
@@ -55,14 +55,54 @@ def use_amax() -> bool:
     return _precision in ("fp32", "fp8")
 
 
+AMAX_SLOTS = 8192        # slots of the shared pool, handed out in four quarters (one per training step in flight)
+_AMAX_Q = AMAX_SLOTS // 4
+
+
+def _amax_new_pool(device):
+    """[pool tensor, cursor (slots), end of the current quarter (slots)], zero-filled on the current stream; the device is
+    synchronised ONCE here (pool creation) so that no stream can see the memset land after its first atomic maximum."""
+    t = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device)
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(device)
+    return [t, 0, _AMAX_Q]
+
+
+def amax_begin_step(device) -> None:
+    """Call at the start of a forward, on the stream every other stream of the step forks from: moves the slot cursor to the
+    next quarter of the pool and zeroes that quarter there, so the words a step hands out are zero before any of its kernels
+    (on whichever stream) updates them, and the words of the previous three steps stay untouched (a saved activation keeps
+    its word for the backward).  Under hipGraph capture the step gets a pool of its own whose memset is part of the graph:
+    every replay starts from zeroed words."""
+    key = torch.device(device).index
+    if torch.cuda.is_current_stream_capturing():
+        _amax_pools[key] = [torch.zeros(_AMAX_Q * AMAX_WORDS, dtype=torch.int32, device=device), 0, _AMAX_Q, True]
+        return
+    pool = _amax_pools.get(key)
+    if pool is None or len(pool) > 3:          # (no pool yet, or the private pool of a finished capture)
+        _amax_pools[key] = _amax_new_pool(device)
+        return
+    q = (pool[2] // _AMAX_Q) % 4               # next quarter
+    pool[0][q * _AMAX_Q * AMAX_WORDS:(q + 1) * _AMAX_Q * AMAX_WORDS].zero_()
+    pool[1], pool[2] = q * _AMAX_Q, (q + 1) * _AMAX_Q
+
+
 def amax_slot(device) -> torch.Tensor:
     key = torch.device(device).index
     pool = _amax_pools.get(key)
-    if pool is None or pool[1] + AMAX_WORDS > pool[0].numel():
-        pool = [torch.zeros(1024 * AMAX_WORDS, dtype=torch.int32, device=device), 0]
+    if pool is None or (len(pool) > 3 and not torch.cuda.is_current_stream_capturing()):
+        pool = _amax_new_pool(device)
         _amax_pools[key] = pool
-    t = pool[0][pool[1]:pool[1] + AMAX_WORDS]
-    pool[1] += AMAX_WORDS
+    if pool[1] >= pool[2]:
+        # the quarter is used up (op-level tests that never call amax_begin_step, or a step with > 2048 GEMM operands): take a
+        # fresh pool — the old one stays alive through the slots that reference it
+        if len(pool) > 3:
+            pool = [torch.zeros(_AMAX_Q * AMAX_WORDS, dtype=torch.int32, device=device), 0, _AMAX_Q, True]
+        else:
+            pool = _amax_new_pool(device)
+        _amax_pools[key] = pool
+    t = pool[0][pool[1] * AMAX_WORDS:(pool[1] + 1) * AMAX_WORDS]
+    pool[1] += 1
     return t
 
 
@@ -620,6 +660,52 @@ def colsum(x2d):
     return out
 
 
+# ---- fusion layer constants, small language-branch ops (csrc/fusion.hip) ------------------------------------------------
+def fusion_prefill(a_img, coord2d, w3):
+    """out (n,hw,co) = a_img[n,None,:] + coord2d (hw,8) @ w3 (co,8 view, row-strided)^T."""
+    n, co = a_img.shape
+    hw = coord2d.shape[0]
+    _chk(a_img, "fusion_prefill A"); _chk(coord2d, "fusion_prefill coord")
+    assert w3.shape == (co, 8) and w3.stride(1) == 1
+    out = torch.empty((n, hw, co), dtype=torch.float32, device=a_img.device)
+    lib().fusion_prefill(a_img.data_ptr(), coord2d.data_ptr(), w3.data_ptr(), w3.stride(0), out.data_ptr(), n, hw, co, _s())
+    return out
+
+
+def fusion_bwd(dy, coord2d, flang, dweight, e):
+    """dy (n,h,w,co) contiguous.  Writes dW2 / dW3 into columns [e, 2e) / [2e, 2e+8) of ``dweight`` (co, 2e+8) and returns d_img (n,co)."""
+    n, co = dy.shape[0], dy.shape[-1]
+    hw = dy.numel() // (n * co)
+    _chk(dy, "fusion_bwd dy"); _chk(flang, "fusion_bwd flang"); _chk(dweight, "fusion_bwd dweight")
+    d_img = torch.empty((n, co), dtype=torch.float32, device=dy.device)
+    ws = scratch(lib().fusion_bwd_ws(n, co), dy.device, slot=0)
+    ld = dweight.stride(0)
+    lib().fusion_bwd(dy.data_ptr(), coord2d.data_ptr(), flang.data_ptr(), ws.data_ptr(), d_img.data_ptr(),
+                     dweight[:, e:].data_ptr(), dweight[:, 2 * e:].data_ptr(), ld, n, hw, co, e, _s())
+    return d_img
+
+
+def row_lengths(ids):
+    n, L = ids.shape
+    out = torch.empty(n, dtype=torch.int64, device=ids.device)
+    lib().row_lengths(ids.data_ptr(), n, L, out.data_ptr(), _s())
+    return out
+
+
+def embedding_fwd(ids, table):
+    v, e = table.shape
+    out = torch.empty(tuple(ids.shape) + (e,), dtype=torch.float32, device=table.device)
+    lib().embedding_fwd(ids.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), e, v, _s())
+    return out
+
+
+def embedding_bwd(ids, dout, vocab):
+    e = dout.shape[-1]
+    dt = torch.empty((vocab, e), dtype=torch.float32, device=dout.device)
+    lib().embedding_bwd(ids.data_ptr(), dout.data_ptr(), dt.data_ptr(), ids.numel(), e, vocab, _s())
+    return dt
+
+
 # ---- cross-scale head tail -------------------------------------------------------------------------------
 import ctypes as _ct
 
@@ -1015,10 +1101,19 @@ def bilstm_bwd(dout, whh_f, whh_r, acts, cprev, lens):
 
 
 def bilstm_sync_error(device) -> bool:
-    """True if a bounded spin of ANY persistent BiLSTM launch on this device gave up since the buffer was created (the
-    word is sticky: launches reset only their counters).  Host-synchronising: train.evaluate and bench.py call it once at the
-    end, so a hand-off that timed out cannot pass as a result."""
-    return bool(_bilstm_sync(device)[8].item())
+    """True if a bounded spin of ANY persistent BiLSTM launch on this device — on whichever stream it ran (the model launches
+    it on its language side stream) — gave up since that stream's buffer was created (the word is sticky: launches reset only
+    their counters; a captured step re-creates its buffer on every replay, so there it speaks about the last replay).
+    Host-synchronising (the whole device): bench.py, train.evaluate and train.save_checkpoint call it, so a hand-off that
+    timed out cannot pass as a result."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    bufs = [t for (d, _s), t in _lstm_sync.items() if d == idx]
+    if not bufs:
+        return False
+    torch.cuda.synchronize(idx)
+    return any(bool(t[8].item()) for t in bufs)
 
 
 def check_bilstm(device) -> None:

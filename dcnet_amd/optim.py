@@ -22,6 +22,29 @@ class RMSprop(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or alpha < 0 or weight_decay < 0:
             raise ValueError("invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay, momentum=0.0, centered=False))
+        # device_lr: the step reads each group's learning rate from a device scalar (refreshed by sync_lr()) instead of a kernel
+        # argument — what a step captured into a hipGraph needs to follow a schedule (dcnet_amd.graph.GraphedTrainStep)
+        self.device_lr = False
+        self._lr_dev = {}
+        self._stepped = []           # the "step" counters touched by the last step() (bump_steps: replays of a captured step)
+
+    def sync_lr(self, device=None) -> None:
+        """Copy every group's current ``lr`` into its device scalar (async, from page-locked memory)."""
+        for gi, group in enumerate(self.param_groups):
+            ent = self._lr_dev.get(gi)
+            if ent is None:
+                dev = device if device is not None else next(p.device for p in group["params"] if p.is_cuda)
+                ent = (torch.empty(1, dtype=torch.float32).pin_memory(), torch.empty(1, dtype=torch.float32, device=dev))
+                self._lr_dev[gi] = ent
+            if float(ent[0][0]) != float(group["lr"]) or not getattr(self, "_lr_uploaded", False):
+                ent[0][0] = float(group["lr"])
+                ent[1].copy_(ent[0], non_blocking=True)
+        self._lr_uploaded = True
+
+    def bump_steps(self) -> None:
+        """Advance the per-parameter ``step`` counters once more (a replay of a captured step ran the device update)."""
+        if self._stepped:
+            torch._foreach_add_(self._stepped, 1)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -30,7 +53,10 @@ class RMSprop(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = lib()
-        for group in self.param_groups:
+        self._stepped = []
+        if self.device_lr and not self._lr_dev:
+            raise RuntimeError("dcnet_amd.optim.RMSprop: device_lr is set but sync_lr() was never called")
+        for gi, group in enumerate(self.param_groups):
             ps, gs, vs, ns, keep = [], [], [], [], []
             for p in group["params"]:
                 if p.grad is None:
@@ -42,6 +68,7 @@ class RMSprop(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["square_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                self._stepped.append(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); vs.append(st["square_avg"].data_ptr()); ns.append(p.numel())
                 keep.append(g)          # (a contiguous copy may be freed right after the launch: same-stream reuse is ordered)
@@ -49,6 +76,7 @@ class RMSprop(torch.optim.Optimizer):
                 continue
             n = len(ps)
             A = ctypes.c_void_p * n
-            L.rmsprop_step(A(*ps), A(*gs), A(*vs), (ctypes.c_int64 * n)(*ns), n, float(group["lr"]), float(group["alpha"]),
+            lr_dev = self._lr_dev[gi][1].data_ptr() if self.device_lr else 0
+            L.rmsprop_step(A(*ps), A(*gs), A(*vs), (ctypes.c_int64 * n)(*ns), n, float(group["lr"]), lr_dev, float(group["alpha"]),
                            float(group["eps"]), float(group["weight_decay"]), torch.cuda.current_stream().cuda_stream)
         return loss

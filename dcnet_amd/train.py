@@ -79,6 +79,7 @@ def evaluate(model, image, word_id, word_mask, bbox, size: int, n_frame: Optiona
         outbox = model(image, word_id, word_mask, n_frame)[0]
     boxes = losses.decode_boxes(list(outbox), size)
     iou = losses.bbox_iou(boxes, torch.clamp(bbox, min=0, max=size - 1))
+    ops.check_bilstm(image.device)              # (evaluation results are read by the host anyway: one device synchronisation)
     return (iou > 0.5).float().mean(), iou.mean(), boxes
 
 

@@ -35,6 +35,11 @@ extern "C" {
 #define DCN_ACT_NONE 0
 #define DCN_ACT_LEAKY 1       /* y = x > 0 ? x : slope*x   (slope 0 == ReLU) */
 
+/* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
+ * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
+ * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
+#define DCN_ABI_VERSION 300
+
 const char* dcn_last_error(void);
 int dcn_version(void);
 
@@ -427,13 +432,34 @@ int dcn_set_tuning(const char* key, int value);
  * g += weight_decay*p;  v = alpha*v + (1-alpha)*g*g;  p -= lr*g/(sqrt(v)+eps)   — torch.optim.RMSprop with
  * momentum = 0, centered = False (train_DCNet.py:528-534), which the reference steps at train_DCNet.py:646. */
 int dcn_rmsprop_step(float* const* params, const float* const* grads, float* const* square_avgs, const int64_t* numel,
-                     int count, float lr, float alpha, float eps, float weight_decay, void* stream);
+                     int count, float lr, const float* lr_dev /* device scalar that overrides lr when non-NULL: a step captured into a
+                     hipGraph then follows the caller's learning-rate schedule (train_DCNet.py:244-253) without re-capture */,
+                     float alpha, float eps, float weight_decay, void* stream);
 /* Keys: "precision" 4 (default): the wide tiles of the conv engine and of the weight-gradient GEMM run the f16 two-piece
  *         split (see dcn_absmax) wherever both operands carry their abs-max word, and as 1 otherwise;
  *         1: the bf16 matrix pipe with every fp32 operand cut into three bf16 pieces (exact) and the six cross terms
  *         >= 2^-16 accumulated in fp32 — measured error against fp64 is at or below that of v_mfma_f32_32x32x2_f32;
  *         0: v_mfma_f32_32x32x2_f32 everywhere; 2: bf16 operands; 3: fp8 operands (dcn_f8_scale).
  *       "bm", "k": tile / K-step overrides; "split" 16|32, "wsplit" 1: force the split pipe on every NT / TN tile. */
+
+/* ---- the fusion layer's constant terms, and small language-branch ops ------------------------------------------ */
+/* The first fcn_emb convolution (model/DCNet_model.py:491-505) convolves [corr | tile(flang) | coord] with W = [W1|W2|W3]; the
+ * last two groups are constant over positions / images, so conv = W1.corr[n,p] + W2.flang[n] + W3.coord[p].
+ * dcn_fusion_prefill: out[n][p][c] = A[n][c] + sum_k coord[p][k] * w3[c*ldw + k]  (A = flang.W2^T, e.g. from dcn_gemm_nt; w3 = the
+ *   last 8 columns of the layer's [co][2e+8] filter matrix, ldw its row stride); dcn_conv2d_fwd then accumulates W1.corr onto it.
+ * dcn_fusion_bwd: from dy[n][hw][co] (the gradient of that convolution's raw output), in one pass: d_img[n][c] = sum_p dy,
+ *   dw3[c*ldd + k] = sum_{n,p} dy[n][p][c] * coord[p][k], then dw2[c*ldd + j] = sum_n d_img[n][c] * flang[n][j]; ws = dcn_fusion_bwd_ws
+ *   floats.  Fixed summation order (no atomics).  These replace five torch.matmul and two .sum() of the round-2 host code. */
+int dcn_fusion_prefill(const float* A, const float* coord, const float* w3, int ldw, float* out, int n, int hw, int co, void* stream);
+int64_t dcn_fusion_bwd_ws(int n, int co);
+int dcn_fusion_bwd(const float* dy, const float* coord, const float* flang, float* ws, float* d_img, float* dw2, float* dw3,
+                   int ldd, int n, int hw, int co, int e, void* stream);
+/* lengths[r] = #{l : ids[r][l] != 0}  (model/DCNet_model.py:150 `(input_labels != 0).sum(1)`). */
+int dcn_row_lengths(const int64_t* ids, int n, int L, int64_t* out, void* stream);
+/* nn.Embedding forward (row gather) and its backward as a deterministic per-vocabulary-row sum (model/DCNet_model.py:168; torch's
+ * backward sorts the indices). */
+int dcn_embedding_fwd(const int64_t* ids, const float* table, float* out, int tokens, int e, int vocab, void* stream);
+int dcn_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int tokens, int e, int vocab, void* stream);
 
 /* ---- streams with a dispatch priority ------------------------------------------------------- */
 /* level -1 / 0 / +1 = highest / normal / lowest priority of the device.  Returns a hipStream_t (NULL on
@@ -454,6 +480,9 @@ int dcn_stream_priority_range(int* least, int* greatest);
  * the launch count, the summed kernel milliseconds and the summed algorithmic work (FLOP or bytes). */
 int dcn_prof_enable(int on);
 int dcn_prof_collect(int64_t* counts, double* ms, double* work, double* bytes /* algorithmic HBM bytes of the FLOP-priced tags; may be NULL */);
+/* The same window launch by launch (up to `max` records, launch order): returns the number written.  bench.py prices each launch
+ * against the roofline that binds it: max(work / MFMA peak of its arithmetic, bytes / HBM peak). */
+int dcn_prof_records(int32_t* tags, double* ms, double* work, double* bytes, int max);
 
 /* ---- host-side negative sampling (CPU; bit-exact with Python's random.sample) -------------- */
 /* state = the 625 uint32 of random.getstate()[1], advanced in place.

@@ -27,7 +27,8 @@ def test_header_symbols_are_exported_and_bound():
         assert n in SIGNATURES, f"{n} has no ctypes signature in dcnet_amd/lib.py"
     assert set(SIGNATURES) <= set(names), sorted(set(SIGNATURES) - set(names))
     L = lib()
-    assert L.version() >= 100
+    from dcnet_amd.lib import ABI_VERSION
+    assert L.version() == ABI_VERSION
     assert L.conv2d_stats_rows(2, 13, 13, 128, 3, 1) in (3, 6)     # 338 rows in 128- or 64-row tiles: pure host arithmetic
     assert L.channel_stats_rows(1000) == 8
     assert L.conv2d_geom_size(2, 13, 13, 3, 1) == 2 * 13 * 13 + 128          # one entry per output pixel + prefetch slack

@@ -1,0 +1,84 @@
+"""The captured training step (dcnet_amd.graph.GraphedTrainStep: forward + five losses + backward + RMSprop as one hipGraph)
+against the eager step it was captured from: same kernels, same order, same streams -> the same bits.  The oracle-level parity of
+the step itself is tests/test_model_gpu.py::test_train_forward_backward_matches_oracle; this file pins the replay to it."""
+import random
+
+import pytest
+import torch
+
+from util import build_product, synth_sd
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, size, n, seed):
+    from dcnet_amd.parallel import freeze_gradless
+    from dcnet_amd.train import make_optimizer
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    m = build_product(size, synth_sd(size), dev)
+    freeze_gradless(m)
+    opt = make_optimizer(m, 1e-4)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n, size, seed=seed))
+    bbox = synth_boxes(n, size, seed=seed).to(dev)
+    return m, opt, image, word_id, word_mask, bbox
+
+
+def test_replayed_steps_equal_eager_steps_bitwise(dev):
+    """Five optimisation steps, once eagerly (train.train_step) and once as one eager warm-up step + the captured pass + three
+    replays under a learning-rate schedule: identical losses, parameters, running statistics, optimiser state and Python RNG
+    position."""
+    from dcnet_amd.graph import GraphedTrainStep
+    from dcnet_amd.train import adjust_learning_rate, train_step
+    size, n, steps = 256, 4, 5
+    lr_of = lambda it: 1e-4 if it < 2 else 1e-4 * (1 - it / 10.0)     # the constructor's two steps run at the initial rate
+    m1, o1, image, word_id, word_mask, bbox = _setup(dev, size, n, 21)
+    random.seed(99)
+    ref_losses = []
+    for it in range(steps):
+        adjust_learning_rate(o1, 0, lr_of(it), 1, 0.9)
+        loss, _ = train_step(m1, o1, image, word_id, word_mask, bbox, size)
+        ref_losses.append(float(loss))
+    rng_after = random.getstate()
+
+    m2, o2, image, word_id, word_mask, bbox = _setup(dev, size, n, 21)
+    random.seed(99)
+    step = GraphedTrainStep(m2, o2, image, word_id, word_mask, bbox, size, warmup=1)      # steps 0 (eager) and 1 (captured pass)
+    got = [None, float(step.loss)]
+    for it in range(2, steps):
+        adjust_learning_rate(o2, 0, lr_of(it), 1, 0.9)
+        got.append(float(step()))
+    assert got[1:] == ref_losses[1:], (got, ref_losses)
+    assert random.getstate() == rng_after
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k]), k
+    s1, s2 = o1.state_dict()["state"], o2.state_dict()["state"]
+    assert s1.keys() == s2.keys()
+    for k in s1:
+        assert torch.equal(s1[k]["square_avg"], s2[k]["square_avg"]), k
+        assert float(s1[k]["step"]) == float(s2[k]["step"]) == steps, (k, float(s1[k]["step"]), float(s2[k]["step"]))
+
+
+def test_new_inputs_reach_the_captured_step(dev):
+    """copy_ into the static inputs changes what the next replay computes (loss equals an eager model's loss on that batch)."""
+    from dcnet_amd import losses
+    from dcnet_amd.graph import GraphedTrainStep
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n = 256, 2
+    m, opt, image, word_id, word_mask, bbox = _setup(dev, size, n, 5)
+    for g in opt.param_groups:
+        g["lr"] = 0.0                                   # parameters stay put: losses depend on the batch and the draws only
+        g["weight_decay"] = 0.0
+    random.seed(3)
+    step = GraphedTrainStep(m, opt, image, word_id, word_mask, bbox, size, warmup=1)
+    img2, wid2, _ = (t.to(dev) for t in synth_inputs(n, size, seed=6))
+    box2 = synth_boxes(n, size, seed=6).to(dev)
+    step.image.copy_(img2); step.word_id.copy_(wid2); step.bbox.copy_(box2)
+    st = random.getstate()
+    a = float(step())
+    # the same batch, the same draws, eagerly on the same model (BatchNorm in train mode uses batch statistics; lr = 0)
+    random.setstate(st)
+    m.static_samples = None
+    out = m(img2, wid2, word_mask)
+    b = float(losses.total_loss(out, box2, size)[0])
+    assert a == b, (a, b)

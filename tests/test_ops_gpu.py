@@ -342,6 +342,29 @@ def test_bilstm_matches_torch_packed_lstm(dev, ragged, n):
         _close(p.grad, getattr(ref, nm).grad.float(), 1e-4, nm)
 
 
+def test_bilstm_error_word_is_seen_from_another_stream(dev):
+    """The model launches the persistent BiLSTM on its language side stream and callers check on the main stream: the check
+    must look at the sync buffer of EVERY stream of the device (round-2 advisor finding: it created a fresh zeroed buffer for
+    the caller's stream and always reported 'no error')."""
+    from dcnet_amd import ops
+    from dcnet_amd.functions import BiLSTM
+    torch.manual_seed(2)
+    L, I, H, n = 20, 512, 512, 4
+    params = [(torch.randn(s_) * 0.05).to(dev) for s_ in ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,)) * 2]
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        BiLSTM.apply(_rand(n, L, I, seed=72).to(dev), torch.full((n,), L, device=dev), *params)
+    key = (dev.index if dev.index is not None else 0, side.cuda_stream)
+    assert key in ops._lstm_sync, "the launch on the side stream must own a sync buffer"
+    assert not ops.bilstm_sync_error(dev)
+    ops._lstm_sync[key][8] = 1                        # what a timed-out spin leaves behind
+    assert ops.bilstm_sync_error(dev), "a sticky error word on another stream's buffer must be reported"
+    with pytest.raises(ops.DcnError):
+        ops.check_bilstm(dev)
+    ops._lstm_sync[key][8] = 0
+
+
 def test_location_module_core(dev):
     from dcnet_amd.functions import LocModule
     n, p, c = 3, 341, 512

@@ -13,11 +13,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench done"; tail -c 600 "$OUT/bench.json"; echo
-BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --exclusive-steps 0"
+BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 1"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats done"
-BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --exclusive-steps 0"
+BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --alt-steps 0 --profile-steps 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_fetch.err"
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_write.err"

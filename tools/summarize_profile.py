@@ -62,10 +62,13 @@ def main():
     stats = find(os.path.join(a.dir, "stats"), "*kernel_stats.csv")
     bench_json = os.path.join(a.dir, "bench_under_rocprof.json")
     dominant = None
+    match = None
     if os.path.exists(bench_json) and os.path.getsize(bench_json):
         with open(bench_json) as f:
             line = [l for l in f if l.startswith("{")][-1]
-        dominant = json.loads(line)["roofline"]["kernel"]
+        rf = json.loads(line)["roofline"]
+        dominant = rf["kernel"]
+        match = rf.get("rocprof_match")
     if stats:
         with open(stats, newline="") as f:
             rows = list(csv.DictReader(f))
@@ -90,12 +93,12 @@ def main():
         print(f"-- {counter} (KB): kernel, launches, sum, avg/launch")
         print("\n".join(lines[:6]))
     if dominant and len(tables) == 2:
-        want = norm(dominant).rstrip(">")      # rocprof prints defaulted template arguments too
-        hit = [k for k in tables["fetch"] if want in norm(k)]
+        wants = [w.replace(" ", "") for w in match] if match else [norm(dominant).rstrip(">")]      # rocprof prints defaulted template arguments too
+        hit = [k for k in tables["fetch"] if any(w in norm(k) for w in wants)]
         if hit:
-            k = hit[0]
-            nf, sf = tables["fetch"][k]
-            nw, sw = tables["write"].get(k, [1, 0.0])
+            k = " + ".join(h[:80] for h in hit)
+            nf = sum(tables["fetch"][h][0] for h in hit); sf = sum(tables["fetch"][h][1] for h in hit)
+            nw = sum(tables["write"].get(h, [0, 0.0])[0] for h in hit); sw = sum(tables["write"].get(h, [0, 0.0])[1] for h in hit)
             fetch_kb, write_kb = sf / nf, sw / max(nw, 1)
             rec = {"round": a.round, "kernel": dominant, "rocprof_name": k, "launches_in_pass": nf,
                    "FETCH_SIZE_KB_avg_per_launch": fetch_kb, "WRITE_SIZE_KB_avg_per_launch": write_kb,
@@ -103,7 +106,7 @@ def main():
                                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
                    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
                    "command": "tools/gpu_profile.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 "
-                              "bench.py --steps 1 --warmup 0 --no-cpu-baseline --exclusive-steps 0 (second pass: --pmc WRITE_SIZE)",
+                              "bench.py --steps 1 --warmup 0 --no-cpu-baseline --alt-steps 0 --profile-steps 1 (second pass: --pmc WRITE_SIZE)",
                    "note": "Infinity-Cache hits are counted in FETCH_SIZE, so this is an upper bound on HBM bytes"}
             print(json.dumps(rec, indent=1))
             if not a.no_copy:
