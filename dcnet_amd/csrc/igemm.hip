@@ -738,6 +738,7 @@ void conv_set_merge(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : 0, value); return DCN_OK; }   // "1x1dma" (0/1), "1stages" (3/4/5)
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
@@ -792,6 +793,8 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
     // 3x3 stride-1 launches with a pre-split filter bank: the strip kernel of conv3.hip (activations staged once per 16 channels)
     const int gran = tile_bm(p.M, p.Co, p.ntaps, 32);
     if (conv3_applicable(p, g_precision, gran)) return conv3_launch(p, gran, stream);
+    // 1x1 layers and their data gradients (plain GEMM rows, pre-split bank): both tiles by LDS-DMA, conv1.hip
+    if (gran == 128 && conv1_applicable(p, g_precision)) return conv1_launch(p, stream);
   }
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);

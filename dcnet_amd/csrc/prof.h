@@ -11,6 +11,6 @@
 //       30 reduce_slabs (split-K slabs of the weight gradient), 31 dA (co-attention backward, elementwise over E),
 //       32 wgrad3 (3x3 stride-1 weight gradient by filter rows, f16 split),
 //       28 / 29 conv3 (3x3 stride-1 strip kernel, f16 split): 256x128 / 128x128 tile, 33 conv3 with bf16 operands,
-//       34 stem (direct 3x3 conv of the 4-channel image, HBM-priced)
+//       34 stem (direct 3x3 conv of the 4-channel image, HBM-priced), 35 conv1 (1x1 layers, both tiles by LDS-DMA, f16 split)
 int prof_begin(int tag, double work, hipStream_t s, double bytes = 0.0);   // returns a record id or -1 (disabled / full); bytes: algorithmic HBM bytes of a FLOP-priced launch
 void prof_end(int id, hipStream_t s);

@@ -164,7 +164,7 @@ def main():
     print(f"bn calibration: {len(calib)} buffers -> {calib_path}")
     del cm
     report = {}
-    for size, N in ((256, 2), (416, 2), (256, 4)):
+    for size, N in ((256, 2), (416, 2), (256, 4), (416, 4)):
         P = _P(size)
         ref_train_mod = _ref_model_module("DCNet_model", P)
         model = ref_train_mod.grounding_model(corpus=corpus, light=False, emb_size=512, coordmap=True,
@@ -179,7 +179,7 @@ def main():
         model.load_state_dict(sd, strict=True)
         _zero_dropout(model)
         image, word_id, word_mask = synth_inputs(N, size, seed=size + N,
-                                                 n_words=10 if (size, N) == (416, 2) else None)
+                                                 n_words=10 if (size, N) == (416, 2) else None)      # (416, 4): the benchmark geometry, train mode (round-3: verdict item 9)
         tag = f"S{size}_N{N}"
 
         # ---- 1. eval forward (4-tuple) ------------------------------------------------
