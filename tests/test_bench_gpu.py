@@ -1,0 +1,53 @@
+"""bench.py as the driver runs it: ONE JSON line on stdout, short enough to survive a tail capture (< 2 KB), carrying the
+roofline / cpu_baseline objects; and `--gpus N` without a launcher spawns its own ranks (rehearsed here with two ranks on the
+one GPU of the box over gloo: broadcast, per-rank seeds, flat gradient all-reduce, max-over-ranks timing, barrier before the
+line)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, timeout=420):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 2048, len(lines[0])
+    return json.loads(lines[0]), r.stderr
+
+
+def test_single_gpu_line_is_compact_and_complete():
+    res, _ = _run(["--steps", "2", "--warmup", "1", "--clips", "2", "--frames", "2", "--size", "256", "--alt-steps", "1", "--cpu-steps", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    assert res["n_gpus"] == 1 and res["steps"] == 2 and res["dtype"] == "f32" and res["vs_baseline"] is None
+    assert "workload" in res["config"] and "hipGraph" in res["config"]["step"]
+    rf = res["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step"):
+        assert k in rf, k
+    assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["gpu_vs_oracle_max_abs_err"] < 1e-3
+    assert abs(res["value"] - 2 * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-9      # clips / s from the same clock
+    assert os.path.exists(os.path.join(ROOT, "profiles", "bench_full_latest.json"))
+
+
+def test_gpus_2_self_launch_rehearsal():
+    """No launcher environment: bench.py must start its own two ranks (children of torch.distributed.run), not exit."""
+    res, err = _run(["--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "1", "--clips", "1", "--frames", "2", "--size", "256",
+                     "--no-cpu-baseline", "--alt-steps", "0", "--profile-steps", "0"])
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["config"]["reducer"] == "flat" and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 1 * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-9   # whole-job clips / s
+    assert "spawning 2 ranks" in err

@@ -81,13 +81,15 @@ def test_nframe_forward_matches_oracle_and_golden(dev, size, b, t):
     assert float(O.bbox_iou_xyxy(boxes, torch.from_numpy(gold["boxes"])).min()) > 0.999
 
 
-def test_train_forward_backward_matches_oracle(dev):
+@pytest.mark.parametrize("size,n", [(256, 4), (416, 4)])
+def test_train_forward_backward_matches_oracle(dev, size, n):
     """Train mode (batch-stat BN, p_dropout = 0), N = 4 (the well-conditioned golden case): the 11
-    outputs, the five losses, the sampled indices, BN running stats and parameter gradients."""
+    outputs, the five losses, the sampled indices, BN running stats and parameter gradients.  416x416 is the benchmark
+    geometry (BASELINE.json configs[1]: 13/26/52 grids, 169-position sampling heads) against the reference's own train-mode
+    fixture ``train_S416_N4.npz``."""
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs
     from oracle import dcnet_oracle as O
     from oracle import train_oracle as TO
-    size, n = 256, 4
     sd = synth_sd(size)
     image, word_id, word_mask = synth_inputs(n, size, seed=size + n)
     bbox = synth_boxes(n, size, seed=size + n)

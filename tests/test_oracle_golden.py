@@ -51,11 +51,13 @@ def test_oracle_nframe_matches_reference_outputs():
         assert maxdiff(o["loc_score"][s], torch.from_numpy(gold[f"loc{s}"])) < 2e-4
 
 
-def test_oracle_train_losses_indices_and_grads_match_reference():
+@pytest.mark.parametrize("tag", ["S256_N4", "S416_N4"])
+def test_oracle_train_losses_indices_and_grads_match_reference(tag):
+    """S416_N4 = the benchmark geometry (416x416: 13/26/52 grids, P = 3549) in train mode, 4 images."""
     from dcnet_amd.utils.synth import synth_boxes
     from oracle import dcnet_oracle as O
     from oracle import train_oracle as TO
-    gold = np.load(os.path.join(GOLD, "train_S256_N4.npz"), allow_pickle=True)
+    gold = np.load(os.path.join(GOLD, f"train_{tag}.npz"), allow_pickle=True)
     size, n, (image, word_id, _) = _inputs(gold)
     sd = synth_sd(size)
     nograd = set(str(k) for k in gold["nograd"])
