@@ -90,6 +90,10 @@ def parse():
     ap.add_argument("--alt-steps", "--exclusive-steps", type=int, default=2, dest="alt_steps",
                     help="untimed steps per alternative pass (side streams off: per-kernel exclusive durations; bf16x3 / native "
                          "fp32 / bf16 / fp8 arithmetic).  0 = skip, e.g. under rocprofv3 so its averages speak about the timed step")
+    ap.add_argument("--schedules", type=int, default=0,
+                    help="N > 0: after the timed region capture the step under three stream schedules (no side streams; the default: "
+                         "weight gradient beside the data-gradient chain; weight gradient queued behind its layer's data gradient) "
+                         "and time N replays of each — the table goes to the full JSON (`schedules`)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="process group + reducer even at world size 1 (exercises the hooks)")
     ap.add_argument("--tune", type=str, default="", help="key=value[,key=value]: dcn_set_tuning knobs applied before the run (experiments)")
@@ -193,6 +197,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    # stdout carries exactly ONE line: libraries that print there (gloo's connection banner, RCCL without NCCL_DEBUG_FILE, ...) are
+    # sent to stderr for the whole run; the JSON line goes to a duplicate of the original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -370,6 +379,28 @@ def main():
         r = collect(); r["ms_per_step"] = el / nsteps * 1e3; r["steps"] = nsteps
         return r
 
+    sched = None
+    if args.schedules > 0 and not use_dist:
+        from dcnet_amd.graph import GraphedTrainStep
+        sched = {}
+        for name, (ws, ls, ss, after) in {"no_side_streams": (False, False, False, False), "default_wgrad_beside_dgrad": (True, True, True, False),
+                                          "wgrad_behind_its_dgrad": (True, True, True, True)}.items():
+            was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD)
+            ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = ws, ls, ss, after
+            g_ = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=1)
+            g_(); barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.schedules):
+                g_()
+            barrier()
+            sched[name] = (time.perf_counter() - t1) / args.schedules * 1e3
+            ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = was
+            del g_
+            model.static_samples = None
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+        if hasattr(opt, "device_lr"):
+            opt.device_lr = False
     prof = run_pass(args.profile_steps) if args.profile_steps > 0 else None
     alts = {}
     if args.alt_steps > 0:
@@ -412,6 +443,9 @@ def main():
                           "reducer": reducer_name, "step": graph_note},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4)}
         full = {"bench_line": None, "timed": {"ms_per_step": res["ms_per_step"], "step": graph_note}}
+        if sched:
+            full["schedules_ms_per_step"] = sched
+            print("schedules (graph replay, ms/step):", json.dumps(sched), file=sys.stderr, flush=True)
         if prof is not None:
             mm_tags = sorted(FLOP_TAGS - {13, 14})
             # time-dominant kernel (family) of the step among the conv-engine launches; the FLOP-dominant one beside it
@@ -495,8 +529,8 @@ def main():
                 break
             res.pop(drop, None)
             line = json.dumps(res, separators=(",", ":"))
-        sys.stdout.write(line + "\n")
         sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

@@ -1,4 +1,6 @@
-// 1x1 convolution / plain NT GEMM (forward and data gradient of every 1x1 layer) with both operand tiles brought in by LDS-DMA.
+// Implicit-GEMM convolution with both operand tiles brought in by LDS-DMA: every 1x1 layer (forward and data gradient), and the
+// multi-tap launches that have no strip form — stride-2 3x3 layers, the parity classes of their data gradients, 3x3 layers with
+// 32 / 64 filters on the 104..416-wide maps.
 //
 // Why a kernel of its own: the 1x1 layers are the time-dominant launches of the step (round-2 verdict: 26 % of it at 0.12-0.16 of
 // the MFMA ceiling) and they are NOT matrix-pipe work — 256->128 channels on the 52x52 maps is 43 FLOP/B against a machine balance
@@ -25,10 +27,9 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int C1_BM = 128, C1_BN = 128;
-constexpr int C1_ASTAGE = C1_BM * 64;            // [128 rows][16 k fp32]: 64-B rows, 16-B chunks XOR-swizzled by (row >> 2) & 3
-constexpr int C1_BPLANE = C1_BN * 32;            // [128 filters][16 k f16]: 32-B rows, halves swapped in rows 8-15 (mod 16)
-constexpr unsigned C1_OOB = 0x80000000u;
+// A tile of a K-step: [BM rows][16 k fp32] — 64-B rows, 16-B chunks XOR-swizzled by (row >> 2) & 3.
+// B tile: 2 planes (h, l) of [BN filters][16 k f16] — 32-B rows, halves swapped in rows 8-15 (mod 16).
+constexpr unsigned C1_OOB = 0x80000000u;         // beyond every descriptor: an LDS-DMA lane with this offset writes ZEROS (tools/ldsdma_oob_probe.hip)
 
 __device__ __forceinline__ float c1_pow2_scale(unsigned amax_bits) {      // = igemm.hip pow2_scale
   const int be = (int)((amax_bits >> 23) & 0xFF);
@@ -38,119 +39,170 @@ __device__ __forceinline__ float c1_pow2_scale(unsigned amax_bits) {      // = i
   return __uint_as_float((unsigned)(e + 127) << 23);
 }
 
-// SA / SB: ring depths (K-steps) of the activation / filter tiles.  The loads are WAVE-SPECIALISED — waves 0-1 bring in the eight
+// SA / SB: ring depths (K-steps) of the activation / filter tiles.  The loads are WAVE-SPECIALISED — waves 0-1 bring in the
 // 1-KiB pieces of an A tile, waves 2-3 those of a B tile — because `s_waitcnt vmcnt` retires a wave's loads in issue order: a
-// wave that loaded both kinds could keep only as many A tiles in flight as B tiles.  A comes from HBM (deep ring: SA - 1 tiles
-// of 8 KB in flight per workgroup), B from L2 (the bank of this filter tile is shared by every M-tile: a shallow ring).
-template <int SA, int SB>
+// wave that loaded both kinds could keep only as many A tiles in flight as B tiles.  A comes from HBM, B from L2 (the bank of this
+// filter tile is shared by every M-tile).  MI x NI: 32x32 accumulator blocks per wave — tile BM = 128 MI rows (four waves stacked
+// along M), BN = 32 NI filters: (1,4) wide layers, (1,2) / (2,2) 64 filters, (2,1) 32 filters.
+// K runs over (tap, 16-channel step); a tap that leaves the image for a row is that lane's out-of-range offset (zeros), exactly
+// like the buffer loads of igemm.hip: per row a byte offset and a bit mask of in-image taps, computed once.
+template <int SA, int SB, int NI, int MI>
 __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
+  constexpr int BM = 128 * MI, BN = 32 * NI;
+  constexpr int ASTAGE = BM * 64, BPLANE = BN * 32, BSTAGE = 2 * BPLANE;
+  constexpr int AP = 4 * MI;                      // A pieces per loader wave and K-step (16 rows each)
+  constexpr int NLD = AP > NI ? AP : NI;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem1[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gn = p.Co / C1_BN;
+  const int gn = p.Co / BN;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = lin / gn, bn = lin - bm * gn;
-  const int M = p.M, m0 = bm * C1_BM;
-  const int kiters = p.Ci >> 4;
+  const int M = p.M, m0 = bm * BM;
+  const int cpt = p.Ci >> 4;                      // 16-channel steps per tap
+  const int kiters = p.ntaps * cpt;
+  const int hsws = p.Hs * p.Ws;
+  const bool plain = p.ntaps == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 &&
+                     p.Ws == p.Wi && p.Hs == p.Hi;            // GEMM rows: row m IS pixel m (no divisions)
 
   const float sa = c1_pow2_scale(amax_read(p.amax_a)), sb = p.b_scale[0];
 
   // ---- descriptors ------------------------------------------------------------------------------------------------
-  const float* a_base = p.in + (long long)m0 * p.ldi;
-  const long long a_bytes = ((long long)(M - m0 - 1) * p.ldi + p.Ci) * 4;
+  const int n0 = m0 / hsws;                                           // image of the tile's first row
+  const long long img = (long long)p.Hi * p.Wi * p.ldi;               // floats per image of the gathered tensor
+  const float* a_base = p.in + (long long)n0 * img;
+  const long long a_bytes = ((long long)(p.N - n0) * img - p.ldi + p.Ci) * 4;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0 : (int)a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, (int)((long long)p.Co * p.ldw * 4), 0x00020000);
 
-  // ---- per-lane source offsets of this wave's four 1-KiB LDS-DMA pieces per K-step (waves 0-1: A, waves 2-3: B) --------------
+  // ---- per-lane source offsets of this wave's 1-KiB LDS-DMA pieces per K-step (waves 0-1: A, waves 2-3: B) --------------------
   // A piece j (16 rows): LDS position (row, c') = (16 j + lane / 4, lane % 4) holds the row's chunk c = c' ^ ((row >> 2) & 3).
-  // Rows past M are clamped to the last row (finite values; the epilogue masks them).
-  // B piece j: plane = j >> 2, 32 filters: LDS position (row, halfpos) = (32 (j & 3) + lane / 2, lane & 1) holds k-half
-  // kh = halfpos ^ ((row >> 3) & 1) of plane `plane`: bank chunk 2 kh + plane of the K-step's 64 bytes.
+  // B piece (plane = wave & 1, e): 32 filters: LDS position (row, halfpos) = (32 e + lane / 2, lane & 1) holds k-half
+  // kh = halfpos ^ ((row >> 3) & 1) of that plane: bank chunk 2 kh + plane of the K-step's 64 bytes.
   const bool loads_a = wave < 2;
-  unsigned voff[4];
-  int dst[4];
+  unsigned voff[NLD], msk[NLD];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int j = 4 * (wave & 1) + e;
-    if (loads_a) {
+  for (int e = 0; e < NLD; ++e) { voff[e] = C1_OOB; msk[e] = 0; }
+  if (loads_a) {
+#pragma unroll
+    for (int e = 0; e < AP; ++e) {
+      const int j = AP * (wave & 1) + e;
       const int row = 16 * j + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
-      int m = m0 + row; m = m < M ? m : M - 1;
-      voff[e] = (unsigned)((m - m0) * p.ldi * 4 + c * 16);
-      dst[e] = j * 1024;
-    } else {
-      const int plane = j >> 2, rr = 32 * (j & 3) + (lane >> 1), kh = (lane & 1) ^ ((rr >> 3) & 1);
-      voff[e] = (unsigned)((bn * C1_BN + rr) * p.ldw * 4 + (2 * kh + plane) * 16);
-      dst[e] = SA * C1_ASTAGE + plane * C1_BPLANE + (j & 3) * 1024;
+      const int m = m0 + row;
+      if (m < M) {
+        if (plain) { voff[e] = (unsigned)((m - n0 * hsws) * p.ldi * 4 + c * 16); msk[e] = 1u; }
+        else {
+          const int n = m / hsws, rem = m - n * hsws;
+          const int i = rem / p.Ws, jx = rem - i * p.Ws;
+          const int iy0 = i * p.isy, ix0 = jx * p.isx;
+          voff[e] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * 4 + c * 16);
+          unsigned mk = 0;
+          for (int t = 0; t < p.ntaps; ++t)
+            if ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.Hi && (unsigned)(ix0 + p.tap_dx[t]) < (unsigned)p.Wi) mk |= 1u << t;
+          msk[e] = mk;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int plane = wave & 1, rr = 32 * e + (lane >> 1), kh = (lane & 1) ^ ((rr >> 3) & 1);
+      voff[e] = (unsigned)((bn * BN + rr) * p.ldw * 4 + (2 * kh + plane) * 16);
+      msk[e] = 0xFFFFu;
     }
   }
-  const unsigned b_k0 = (unsigned)p.tap_w[0] * 4;
   const __amdgpu_buffer_rsrc_t my_rs = loads_a ? a_rs : b_rs;
+  const int my_dst = loads_a ? AP * (wave & 1) * 1024 : SA * ASTAGE + (wave & 1) * BPLANE;   // first piece of this wave inside a ring slot
+  const int my_n = loads_a ? AP : NI;
 
-  auto issue = [&](int it) {               // this wave's four pieces of K-step `it` (past the end: no-ops that still count in vmcnt)
-    const int kt = loads_a ? it + SA - 1 : it + SB - 1;          // the K-step whose ring slot the previous iteration freed
-    const bool live = kt < kiters;
-    const unsigned soff = live ? (unsigned)kt * 64u + (loads_a ? 0u : b_k0) : 0u;
-    unsigned char* st = smem1 + (loads_a ? (kt % SA) * C1_ASTAGE : (kt % SB) * 2 * C1_BPLANE);
+  // wave-uniform K iterator of this wave's loads: (tap, channel step) of the next K-step to issue
+  int k_tap = 0, k_c = 0, k_done = 0;
+  auto issue = [&]() {                     // this wave's pieces of its next K-step (past the end: no-ops that still count in vmcnt)
+    const bool live = k_done < kiters;
+    const unsigned bit = 1u << k_tap;
+    int delta = 0; unsigned soff = 0;
+    if (live) {
+      if (loads_a) { delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * 4; soff = (unsigned)k_c * 64u; }
+      else soff = (unsigned)(p.tap_w[k_tap] + k_c * 16) * 4u;
+    }
+    unsigned char* st = smem1 + (loads_a ? (k_done % SA) * ASTAGE : (k_done % SB) * BSTAGE) + my_dst;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(my_rs, (lds_void*)(st + dst[e]), 16, live ? voff[e] : C1_OOB, soff, 0, 0);
+    for (int e = 0; e < NLD; ++e)
+      if (e < my_n)
+        // (explicit int casts: with unsigned arguments hipcc 7.2 silently drops the instantiation of the whole kernel template)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(my_rs, (lds_void*)(st + e * 1024), 16,
+                                                 (int)((live && (msk[e] & bit)) ? voff[e] + (unsigned)delta : C1_OOB), (int)soff, 0, 0);
+    ++k_done; ++k_c;
+    if (k_c == cpt) { k_c = 0; ++k_tap; }
   };
 
   // ---- fragment addresses ----------------------------------------------------------------------------------------------
-  const int ar = wave * 32 + (lane & 31), kh = lane >> 5;
-  const int a_rd0 = ar * 64 + (((2 * kh) ^ ((ar >> 2) & 3)) << 4);
-  const int a_rd1 = ar * 64 + (((2 * kh + 1) ^ ((ar >> 2) & 3)) << 4);
-  int b_rd[4];
+  const int kh = lane >> 5;
+  int a_rd0[MI], a_rd1[MI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
+  for (int mi = 0; mi < MI; ++mi) {
+    const int ar = (wave * MI + mi) * 32 + (lane & 31);
+    a_rd0[mi] = ar * 64 + (((2 * kh) ^ ((ar >> 2) & 3)) << 4);
+    a_rd1[mi] = ar * 64 + (((2 * kh + 1) ^ ((ar >> 2) & 3)) << 4);
+  }
+  int b_rd[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
     const int row = ni * 32 + (lane & 31);
-    b_rd[ni] = SA * C1_ASTAGE + row * 32 + (((kh ^ (row >> 3)) & 1) << 4);
+    b_rd[ni] = SA * ASTAGE + row * 32 + (((kh ^ (row >> 3)) & 1) << 4);
   }
 
-  f32x16 acc[4];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   // ---- prologue: SA - 1 activation tiles / SB - 1 filter tiles in flight --------------------------------------------------
-  for (int s = -(loads_a ? SA : SB) + 1; s < 0; ++s) issue(s);
+  for (int s = 0; s < (loads_a ? SA : SB) - 1; ++s) issue();
 
   for (int it = 0; it < kiters; ++it) {
-    // this wave's pieces of K-step `it` have landed (all but the younger K-steps' 4 loads each), then everybody's
-    if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SA - 2) * 4) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SB - 2) * 4) : "memory");
+    // this wave's pieces of K-step `it` have landed (all but the younger K-steps' loads), then everybody's
+    if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SA - 2) * AP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SB - 2) * NI) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // the slots read during the previous iteration are free (every wave has passed the barrier): refill them
-    issue(it);
-    const unsigned char* st = smem1 + (it % SA) * C1_ASTAGE;
-    const unsigned char* sb_ = smem1 + (it % SB) * 2 * C1_BPLANE;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_rd0), x1 = *reinterpret_cast<const f32x4*>(st + a_rd1);
-    f16x8_t bh[4], bl[4];
+    issue();
+    const unsigned char* st = smem1 + (it % SA) * ASTAGE;
+    const unsigned char* sb_ = smem1 + (it % SB) * BSTAGE;
+    f16x8_t bh[NI], bl[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
       bh[ni] = *reinterpret_cast<const f16x8_t*>(sb_ + b_rd[ni]);
-      bl[ni] = *reinterpret_cast<const f16x8_t*>(sb_ + C1_BPLANE + b_rd[ni]);
+      bl[ni] = *reinterpret_cast<const f16x8_t*>(sb_ + BPLANE + b_rd[ni]);
     }
-    // x * s = h + l, two f16 (round to nearest): 11 + 11 significant bits
-    const f32x4 t0 = x0 * sa, t1 = x1 * sa;
-    f16x8_t ah, al;
+    f16x8_t ah[MI], al[MI];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ah[e] = (_Float16)t0[e]; ah[4 + e] = (_Float16)t1[e];
-    }
+    for (int mi = 0; mi < MI; ++mi) {
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_rd0[mi]), x1 = *reinterpret_cast<const f32x4*>(st + a_rd1[mi]);
+      // x * s = h + l, two f16 (round to nearest): 11 + 11 significant bits
+      const f32x4 t0 = x0 * sa, t1 = x1 * sa;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      al[e] = (_Float16)(t0[e] - (float)ah[e]); al[4 + e] = (_Float16)(t1[e] - (float)ah[4 + e]);
+      for (int e = 0; e < 4; ++e) { ah[mi][e] = (_Float16)t0[e]; ah[mi][4 + e] = (_Float16)t1[e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { al[mi][e] = (_Float16)(t0[e] - (float)ah[mi][e]); al[mi][4 + e] = (_Float16)(t1[e] - (float)ah[mi][4 + e]); }
     }
     // smallest terms first: (l,h) (h,l) (h,h)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ni], acc[ni], 0, 0, 0);
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ni], acc[ni], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[ni], 0, 0, 0);
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
   }
   // the no-op pieces issued past the end may still be pending LDS writes: drain before LDS is reused / the workgroup ends
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,120 +210,170 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
 
   const float dq = 1.f / (sa * sb);           // powers of two: exact
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) acc[ni] *= dq;
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= dq;
 
-  // ---- epilogue (igemm.hip's; output pixel = row m; rows >= M are duplicates of row M-1 and masked) ------------------------
+  // ---- epilogue (igemm.hip's) -------------------------------------------------------------------------------------------
   float* __restrict__ gout = p.out;
-  const int rbase = m0 + wave * 32 + 4 * kh;         // row of register r: rbase + (r & 3) + 8 * (r >> 2)
+  // output pixel of accumulator register r of block mi: row m = rbase(mi) + (r & 3) + 8 (r >> 2)
+  auto out_pix = [&](int m) -> size_t {
+    if (p.dense_out) return (size_t)m;
+    const int n = m / hsws, rem = m - n * hsws;
+    const int i = rem / p.Ws, jx = rem - i * p.Ws;
+    return ((size_t)n * p.Ho + p.oy0 + i * p.osy) * p.Wo + p.ox0 + jx * p.osx;
+  };
   if (p.accumulate) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = rbase + (r & 3) + 8 * (r >> 2);
-      if (m >= M) continue;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[ni][r] += gout[(size_t)m * p.ldo + bn * C1_BN + ni * 32 + (lane & 31)];
-    }
-  }
-  if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem1);      // [2][4 waves][128]
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      float s = 0.f, ss = 0.f;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = rbase + (r & 3) + 8 * (r >> 2);
-        const float v = m < M ? acc[ni][r] : 0.f;
-        s += v; ss += v * v;
+        const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+        if (m >= M) continue;
+        const size_t pix = out_pix(m);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] += gout[pix * p.ldo + bn * BN + ni * 32 + (lane & 31)];
       }
+  }
+  if (p.stats) {                                         // one partial row per BM output rows (rows >= M gathered zeros)
+    float* red = reinterpret_cast<float*>(smem1);      // [2][4 waves][BN]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s += v; ss += v * v; }
       s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
       if (lane < 32) {
-        red[(0 * 4 + wave) * C1_BN + ni * 32 + lane] = s;
-        red[(1 * 4 + wave) * C1_BN + ni * 32 + lane] = ss;
+        red[(0 * 4 + wave) * BN + ni * 32 + lane] = s;
+        red[(1 * 4 + wave) * BN + ni * 32 + lane] = ss;
       }
     }
     __syncthreads();
-    {
-      const int which = tid >> 7, col = tid & 127;
+    for (int idx = tid; idx < 2 * BN; idx += 256) {
+      const int which = idx / BN, col = idx - which * BN;
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) t += red[(which * 4 + w) * C1_BN + col];
-      p.stats[((size_t)bm * 2 + which) * p.Co + bn * C1_BN + col] = t;
+      for (int w = 0; w < 4; ++w) t += red[(which * 4 + w) * BN + col];
+      p.stats[((size_t)bm * 2 + which) * p.Co + bn * BN + col] = t;
     }
   }
-  float sc[4], sh[4];
+  float sc[NI], sh[NI];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int co = bn * C1_BN + ni * 32 + (lane & 31);
+  for (int ni = 0; ni < NI; ++ni) {
+    const int co = bn * BN + ni * 32 + (lane & 31);
     sc[ni] = p.scale ? p.scale[co] : 1.f;
     sh[ni] = p.shift ? p.shift[co] : 0.f;
   }
   float vmax = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = rbase + (r & 3) + 8 * (r >> 2);
-    if (m >= M) continue;
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int co = bn * C1_BN + ni * 32 + (lane & 31);
-      float v = acc[ni][r] * sc[ni] + sh[ni];
-      if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-      if (p.residual) v += p.residual[(size_t)m * p.ldr + co];
-      gout[(size_t)m * p.ldo + co] = v;
-      vmax = fmaxf(vmax, fabsf(v));
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+      if (m >= M) continue;
+      const size_t pix = out_pix(m);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int co = bn * BN + ni * 32 + (lane & 31);
+        float v = acc[mi][ni][r] * sc[ni] + sh[ni];
+        if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        if (p.residual) v += p.residual[pix * p.ldr + co];
+        gout[pix * p.ldo + co] = v;
+        vmax = fmaxf(vmax, fabsf(v));
+      }
     }
-  }
   if (p.amax_out) {
     vmax = wave_max(vmax);
     if (lane == 0) amax_update(p.amax_out, vmax, blockIdx.x * 4 + wave);
   }
 }
 
-int g_conv1 = 1;          // dcn_set_tuning("1x1dma", 0): 1x1 layers back on the implicit-GEMM tile
-int g_conv1_stages = 32;  // dcn_set_tuning("1stages", 10 * SA + SB): ring depths.  Default 3 activation + 2 filter K-steps = 40 KB: FOUR workgroups per CU (measured per layer, tools/bench_convs.py --set 1stages=..: 32 < 33 < 42 < 44 ~ 63 << 84: occupancy beats ring depth)
+int g_conv1 = 1;          // dcn_set_tuning("1x1dma", 0): back on the implicit-GEMM tiles of igemm.hip; 2: 1x1 launches only
+int g_conv1_stages = 32;  // dcn_set_tuning("1stages", 10 * SA + SB): ring depths.  Default 3 activation + 2 filter K-steps = 40 KB at the 128 x 128 tile:
+                          // FOUR workgroups per CU (measured per layer, tools/bench_convs.py --set 1stages=..: 32 < 33 < 42 < 44 ~ 63 << 84: occupancy beats ring depth)
 
-template <int SA, int SB>
+template <int SA, int SB, int NI, int MI>
 int launch1(const IgemmParams& p, hipStream_t stream) {
+  constexpr int BM = 128 * MI, BN = 32 * NI;
   static bool attr_done = false;
-  const size_t lds = (size_t)SA * C1_ASTAGE + (size_t)SB * 2 * C1_BPLANE;
+  const size_t lds = (size_t)SA * BM * 64 + (size_t)SB * 2 * BN * 32;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_kernel<SA, SB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_kernel<SA, SB, NI, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  const int gm = cdiv(p.M, C1_BM), gn = p.Co / C1_BN;
-  const double alg_bytes = 4.0 * ((double)p.M * p.Ci + (double)p.Co * p.Ci + (double)p.M * p.Co);
-  const int pid = prof_begin(35, 2.0 * (double)p.M * p.Co * p.Ci, stream, alg_bytes);
-  hipLaunchKernelGGL((conv1_kernel<SA, SB>), dim3(gm * gn), dim3(256), lds, stream, p);
+  const int gm = cdiv(p.M, BM), gn = p.Co / BN;
+  const double k_alg = (double)p.ntaps * p.Ci;
+  // algorithmic bytes: the gathered tensor once (its N*Hi*Wi pixels of Ci), the filter bank, the output
+  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co);
+  const int pid = prof_begin(35, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  hipLaunchKernelGGL((conv1_kernel<SA, SB, NI, MI>), dim3(gm * gn), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv1");
   return DCN_OK;
+}
+
+template <int NI, int MI>
+int launch1_ring(const IgemmParams& p, hipStream_t stream) {
+  if constexpr (NI == 4 && MI == 1) {
+    switch (g_conv1_stages) {
+      case 33: return launch1<3, 3, NI, MI>(p, stream);
+      case 42: return launch1<4, 2, NI, MI>(p, stream);
+      case 44: return launch1<4, 4, NI, MI>(p, stream);
+      case 63: return launch1<6, 3, NI, MI>(p, stream);
+      default: break;
+    }
+  }
+  return launch1<3, 2, NI, MI>(p, stream);
+}
+
+// (MI, NI) for a launch, 0 = not on this kernel.  gran = rows per BatchNorm partial the caller sized its buffer for (128 | 256).
+int conv1_shape(const IgemmParams& p, int gran) {
+  const int ni = p.Co % 128 == 0 ? 4 : (p.Co % 64 == 0 ? 2 : (p.Co % 32 == 0 ? 1 : 0));
+  if (!ni) return 0;
+  int mi;
+  if (p.stats) { mi = gran == 128 ? 1 : (gran == 256 ? 2 : 0); }
+  else mi = ni == 4 ? 1 : 2;
+  if (!mi || mi * ni > 4 || (mi == 1 && ni == 1)) return 0;
+  return mi * 10 + ni;
 }
 
 }  // namespace
 
 void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else g_conv1_stages = value; }
 
-// plain NT GEMM rows with a pre-split B bank and an abs-max word for A: the 1x1 convolutions and their data gradients
-bool conv1_applicable(const IgemmParams& p, int precision) {
-  if (!g_conv1 || precision != 4 || !p.b_scale || !p.amax_a || p.wt16 || p.f8 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale || p.ncls)
-    return false;
-  if (p.ntaps != 1 || p.tap_dy[0] != 0 || p.tap_dx[0] != 0 || p.isy != 1 || p.isx != 1 || !p.dense_out) return false;
-  if (p.Hs != p.Hi || p.Ws != p.Wi || (long long)p.M != (long long)p.N * p.Hi * p.Wi) return false;
-  if (p.Co % C1_BN != 0 || p.Ci % 16 != 0 || p.Ci < 32 || p.M < 1024) return false;
-  if ((long long)C1_BM * p.ldi * 4 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 4 >= 0x7FFFFFF0LL) return false;
+// shape part of the decision.  The kernel only takes launches that igemm.hip would run on its f16-split tiles WITH the pre-split
+// bank (b_scale set by conv.hip under igemm_will_presplit): the arithmetic — which products, in which order — is then the same and
+// the results are bitwise those of the tile it replaces.  (Taking the 32 / 64-filter 1x1 layers and parity classes from the
+// fp32-pipe narrow tiles as well measured -0.2 ms per step; it changes their rounding, and with it which LeakyReLU kinks the
+// ill-conditioned N = 4 gradient test sits on.)  Multi-tap launches: stride-2 layers and the parity classes of their data
+// gradients; the 3x3 stride-1 layers re-gather every pixel nine times here and belong to the strip kernel / the 256 x 64 tile
+// (measured: 32 -> 64 @208 forward 0.745 vs 0.731 ms, data gradient 0.778 vs 0.722).
+bool conv1_will_take(long long rows, int Co, int ntaps, int Ci) {
+  if (!g_conv1 || rows < 1024 || Co % 64 != 0 || Ci % 16 != 0 || Ci < 32 || ntaps < 1 || ntaps > 16) return false;
+  if (g_conv1 == 2 && ntaps != 1) return false;
   return true;
 }
 
-int conv1_launch(const IgemmParams& p, hipStream_t stream) {
-  switch (g_conv1_stages) {
-    case 33: return launch1<3, 3>(p, stream);
-    case 32: return launch1<3, 2>(p, stream);
-    case 42: return launch1<4, 2>(p, stream);
-    case 44: return launch1<4, 4>(p, stream);
-    case 43: return launch1<4, 3>(p, stream);
-    case 53: return launch1<5, 3>(p, stream);
-    case 84: return launch1<8, 4>(p, stream);
-    case 64: return launch1<6, 4>(p, stream);
-    case 63: return launch1<6, 3>(p, stream);
-    default: return launch1<3, 2>(p, stream);
+// NT launches with a pre-split B bank and an abs-max word for A: 1x1 convolutions and their data gradients (plain GEMM rows), and
+// gathered multi-tap launches (stride-2 layers, parity classes of their data gradients, narrow 3x3 layers)
+bool conv1_applicable(const IgemmParams& p, int precision, int gran) {
+  if (!g_conv1 || precision != 4 || !p.b_scale || !p.amax_a || p.wt16 || p.f8 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale || p.ncls)
+    return false;
+  if (!conv1_will_take(p.M, p.Co, p.ntaps, p.Ci)) return false;
+  if (p.ntaps > 1 && p.isy == 1 && p.osy == 1) return false;            // stride-1 multi-tap: strip kernel / 256 x 64 tile
+  if ((long long)p.M != (long long)p.N * p.Hs * p.Ws) return false;
+  if (p.Hs * p.Ws < 1 || (256 / (p.Hs * p.Ws) + 2) * (long long)p.Hi * p.Wi * p.ldi * 4 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 4 >= 0x7FFFFFF0LL) return false;
+  return conv1_shape(p, gran) != 0;
+}
+
+int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
+  switch (conv1_shape(p, gran)) {
+    case 14: return launch1_ring<4, 1>(p, stream);
+    case 12: return launch1_ring<2, 1>(p, stream);
+    case 22: return launch1_ring<2, 2>(p, stream);
+    case 21: return launch1_ring<1, 2>(p, stream);
+    default: dcn_set_error("conv1: no tile for this launch"); return DCN_ERR_ARG;
   }
 }

@@ -61,10 +61,12 @@ bool conv3_applicable(const IgemmParams& p, int precision, int gran);
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv3_set_tuning(int key, int value);
 
-// conv1.hip: 1x1 convolutions / plain NT GEMM rows with both tiles by LDS-DMA (f16 split, pre-split filter bank, 128-row tiles)
-bool conv1_applicable(const IgemmParams& p, int precision);
-int conv1_launch(const IgemmParams& p, hipStream_t stream);
+// conv1.hip: NT launches with both tiles by LDS-DMA (f16 split, pre-split filter bank): 1x1 layers, stride-2 layers, the parity
+// classes of their data gradients, narrow 3x3 layers.  gran = output rows per BatchNorm partial row (128 | 256).
+bool conv1_applicable(const IgemmParams& p, int precision, int gran);
+int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv1_set_tuning(int key, int value);
+
 
 // stem.hip: the 4-channel 3x3 stride-1 stem directly on the vector ALU (forward).  scratch: >= 27*32 floats.
 bool stem_applicable(const IgemmParams& p, const float* scratch);

@@ -794,7 +794,7 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
     const int gran = tile_bm(p.M, p.Co, p.ntaps, 32);
     if (conv3_applicable(p, g_precision, gran)) return conv3_launch(p, gran, stream);
     // 1x1 layers and their data gradients (plain GEMM rows, pre-split bank): both tiles by LDS-DMA, conv1.hip
-    if (gran == 128 && conv1_applicable(p, g_precision)) return conv1_launch(p, stream);
+    if (conv1_applicable(p, g_precision, gran)) return conv1_launch(p, gran, stream);
   }
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);

@@ -402,7 +402,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 ady = None            # (frozen-BN path: the GEMMs below compute the abs-max of dy themselves)
             if op.res is not None:
                 add(op.res, dout)
-            d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)     # overlaps with the data gradient below
+            if not ops.WGRAD_AFTER_DGRAD:
+                d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)     # overlaps with the data gradient below
             if op.need_dx:
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
@@ -413,6 +414,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 else:
                     ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr,
                                         wt_b16=wt16)
+            if ops.WGRAD_AFTER_DGRAD:      # (schedule experiment: queued behind the data gradient, beside the next layer's BatchNorm passes)
+                d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)
             pg[op.slot] = d
             if sink is not None:
                 for k_, t_ in d.items():

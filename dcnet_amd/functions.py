@@ -58,8 +58,11 @@ class ConvBNAct(torch.autograd.Function):
             z = y if slope == 0 else torch.where(y > 0, y, y / slope)
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
-        dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
+        if not ops.WGRAD_AFTER_DGRAD:
+            dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
         dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
+        if ops.WGRAD_AFTER_DGRAD:
+            dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
         ops.join_side(x.device)
         return dx, dwt, dgamma, dbeta, None, None, None, None, None
 

@@ -142,6 +142,11 @@ class _Lib:
                 setattr(self, name[4:], self._checked(name, fn))
             else:
                 setattr(self, name[4:], fn)
+        # experiments: DCN_TUNE="key=value,key=value" applies dcn_set_tuning knobs at load time (e.g. to run a test under a knob)
+        for kv in [t for t in os.environ.get("DCN_TUNE", "").split(",") if t]:
+            k_, v_ = kv.split("=")
+            if self._dll.dcn_set_tuning(k_.encode(), int(v_)) != 0:
+                raise DcnError(f"DCN_TUNE: unknown knob {k_!r}")
         if self._dll.dcn_version() != ABI_VERSION:
             raise DcnError(f"{path} has ABI version {self._dll.dcn_version()}, this binding was written for {ABI_VERSION}: "
                            "rebuild the library (python -m dcnet_amd.build --force)")

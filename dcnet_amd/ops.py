@@ -442,6 +442,8 @@ def side_stream(device) -> "torch.cuda.Stream":
 
 SIDE_PRIORITY = 0      # 0: a normal torch stream; +1 (lowest dispatch priority, dcn_stream_create) measured 20 % slower
 WGRAD_SIDE = True      # A/B switch: False runs the weight gradient on the caller's stream
+WGRAD_AFTER_DGRAD = False   # schedule experiment (bench.py --schedules): the side stream waits for the layer's DATA gradient as well, so
+                            # a weight gradient starts beside the next layer's HBM-bound BatchNorm passes instead of beside its own dgrad
 
 
 def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):

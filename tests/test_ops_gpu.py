@@ -760,51 +760,67 @@ def test_conv3_strip_kernel(dev, case):
         lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
 
 
-@pytest.mark.parametrize("case", [(2, 26, 26, 512, 256), (8, 13, 13, 1024, 512), (1, 37, 29, 32, 128), (2, 52, 52, 256, 128),
-                                  (1, 33, 32, 96, 384), (8, 13, 13, 64, 128)])
+@pytest.mark.parametrize("case", [(2, 26, 26, 512, 256, 1, 1), (8, 13, 13, 1024, 512, 1, 1), (1, 37, 29, 32, 128, 1, 1), (2, 52, 52, 256, 128, 1, 1),
+                                  (1, 33, 32, 96, 384, 1, 1), (8, 13, 13, 64, 128, 1, 1), (2, 40, 36, 64, 32, 1, 1), (3, 30, 26, 128, 64, 1, 1),
+                                  (2, 52, 50, 32, 64, 3, 2), (2, 45, 47, 64, 128, 3, 2), (1, 64, 60, 32, 64, 3, 1), (2, 37, 41, 64, 64, 3, 1),
+                                  (8, 26, 26, 128, 256, 3, 2)])
 def test_conv1_lds_dma_kernel(dev, case):
-    """The 1x1 kernel with both tiles by LDS-DMA (csrc/conv1.hip: a ring of K-steps in flight across raw barriers, the f16 split
-    done on the fragment) against fp64 and against the implicit-GEMM tile it replaces: forward with the fused epilogue, BatchNorm
-    partial sums, shortcut add, concat-slice destination, accumulate, abs-max word; data gradient plain and accumulating.  Ring
-    depths 3 / 4 / 5; K loops shorter than the ring (32 channels = 2 K-steps), M tails (rows % 128 != 0), several filter tiles."""
+    """The implicit-GEMM kernel with both tiles by LDS-DMA (csrc/conv1.hip: rings of K-steps in flight across raw barriers, the f16
+    split done on the fragment) against fp64 and against the implicit-GEMM tiles it replaces: 1x1 layers (plain GEMM rows), 3x3
+    stride-2 layers and the four parity classes of their data gradients, 3x3 stride-1 layers with 32 / 64 filters; forward with the
+    fused epilogue, BatchNorm partial sums, shortcut add, concat-slice destination, accumulate, abs-max word; data gradient plain
+    and accumulating.  Several ring depths; K loops shorter than the ring, M tails, odd image sizes (borders), every tile shape."""
     from dcnet_amd import ops
     from dcnet_amd.lib import lib
-    n, h, w, cin, cout = case
+    n, h, w, cin, cout, k, st = case
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
     x = _rand(n, h, w, cin, seed=41).to(dev)
-    wt = (_rand(cout, 1, 1, cin, seed=42) / cin ** 0.5).to(dev)
+    wt = (_rand(cout, k, k, cin, seed=42) / (cin * k * k) ** 0.5).to(dev)
     scale = (_rand(cout, seed=43).abs() + 0.5).to(dev); shift = _rand(cout, seed=44).to(dev)
-    res = _rand(n, h, w, cout, seed=45).to(dev)
-    xd = x.double().cpu().requires_grad_(True)
-    raw = xd.reshape(-1, cin) @ wt.view(cout, cin).double().cpu().t()
-    dy = _rand(n, h, w, cout, seed=46) / 8
-    raw.backward(dy.reshape(-1, cout).double())
-    rawl = raw.detach().view(n, h, w, cout)
+    res = _rand(n, ho, wo, cout, seed=45).to(dev)
+    xd = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    raw = F.conv2d(xd, wt.permute(0, 3, 1, 2).double().cpu(), stride=st, padding=pad)
+    dy = _rand(n, ho, wo, cout, seed=46) / 8
+    raw.backward(dy.permute(0, 3, 1, 2).double())
+    rawl = raw.detach().permute(0, 2, 3, 1)
+    dxref = xd.grad.permute(0, 2, 3, 1)
     ref = F.leaky_relu(rawl * scale.double().cpu() + shift.double().cpu(), 0.1) + res.double().cpu()
     dyd = dy.to(dev)
     base = _rand(n, h, w, cin, seed=47).to(dev)
-    dgrad_ok = cin % 128 == 0            # the data gradient is a 1x1 GEMM towards cin "filters": on this kernel when cin % 128 == 0
 
     def run():
         out = {}
-        out["y"], out["stats"] = ops.conv2d_fwd(x, wt, 1, 1, scale, shift, ops.ACT_LEAKY, 0.1, residual=res, want_stats=True)
-        buf = torch.zeros(n, h, w, cout + 64, device=dev)
+        out["y"], out["stats"] = ops.conv2d_fwd(x, wt, k, st, scale, shift, ops.ACT_LEAKY, 0.1, residual=res, want_stats=True)
+        buf = torch.zeros(n, ho, wo, cout + 64, device=dev)
         am = ops.amax_slot(dev)
-        ops.conv2d_fwd(x, wt, 1, 1, out=buf[..., 32:32 + cout], amax_out=am)
+        ops.conv2d_fwd(x, wt, k, st, out=buf[..., 32:32 + cout], amax_out=am)
         out["slice"] = buf; out["amax"] = am.clone()
         acc = rawl.float().to(dev).clone()
-        _, out["acc_stats"] = ops.conv2d_fwd(x, wt, 1, 1, out=acc, accumulate=True, want_stats=True)
+        _, out["acc_stats"] = ops.conv2d_fwd(x, wt, k, st, out=acc, accumulate=True, want_stats=True)
         out["acc"] = acc
-        out["dx"] = ops.conv2d_bwd_data(dyd, wt, (h, w), 1, 1)
+        out["dx"] = ops.conv2d_bwd_data(dyd, wt, (h, w), k, st)
         dx2 = base.clone()
-        ops.conv2d_bwd_data(dyd, wt, (h, w), 1, 1, out=dx2, accumulate=True)
+        ops.conv2d_bwd_data(dyd, wt, (h, w), k, st, out=dx2, accumulate=True)
         out["dx_acc"] = dx2
         return out
+
+    import ctypes
+
+    def launches():
+        lib().prof_enable(1)
+        run()
+        lib().prof_enable(0)
+        c = (ctypes.c_int64 * 40)(); m = (ctypes.c_double * 40)(); wk = (ctypes.c_double * 40)()
+        lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
+        return c[35]
 
     try:
         lib().set_tuning(b"1x1dma", 0)
         old = run()
+        assert launches() == 0
         lib().set_tuning(b"1x1dma", 1)
-        for stages in (33, 32, 44, 63):
+        for stages in (32, 33, 44, 63):
             lib().set_tuning(b"1stages", stages)
             new = run()
             _close(new["y"], ref, 2e-5, f"conv1 fwd epilogue stages={stages}")
@@ -816,19 +832,15 @@ def test_conv1_lds_dma_kernel(dev, case):
             assert float(new["amax"].view(torch.float32).max()) == float(new["slice"].abs().max())
             _close(new["acc"], 2 * rawl, 2e-5, "conv1 accumulate")
             _close(new["acc_stats"][:, 0].double().sum(0), 2 * rawl.reshape(-1, cout).sum(0), 1e-4, "conv1 accumulate stats (raw + content)")
-            _close(new["dx"], xd.grad, 2e-5, "conv1 dgrad")
-            _close(new["dx_acc"], xd.grad + base.double().cpu(), 2e-5, "conv1 dgrad accumulate")
-            for k in ("y", "dx"):        # the same split arithmetic: agreement far inside the fp64 tolerance
-                _close(new[k], old[k], 2e-6, f"conv1 vs tile {k}")
-        # (both kernels add the three cross terms of every 16-deep K-step in the same order: their results are bitwise equal, so
-        #  "it ran" is read off the library's launch records: tag 35 = conv1_kernel)
-        import ctypes
-        lib().prof_enable(1)
-        run()
-        lib().prof_enable(0)
-        c = (ctypes.c_int64 * 40)(); m = (ctypes.c_double * 40)(); wk = (ctypes.c_double * 40)()
-        lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
-        assert c[35] >= (5 if dgrad_ok else 3), f"the LDS-DMA kernel ran {c[35]} times"
+            _close(new["dx"], dxref, 2e-5, "conv1 dgrad")
+            _close(new["dx_acc"], dxref + base.double().cpu(), 2e-5, "conv1 dgrad accumulate")
+            for kk in ("y", "dx"):        # the same split arithmetic (another summation order over taps at most)
+                _close(new[kk], old[kk], 2e-6, f"conv1 vs tile {kk}")
+        # (for plain GEMM rows both kernels add the three cross terms of every 16-deep K-step in the same order: bitwise equal
+        #  results, so "it ran" is read off the library's launch records: tag 35 = conv1_kernel)
+        if cout % 128 == 0 and (k == 1 or st == 2):
+            assert launches() >= 3, "the LDS-DMA kernel did not take the forward launches"
+        # (32 / 64 filters on the fp32-pipe narrow tiles and 3x3 stride-1 launches stay where they were: csrc/conv1.hip conv1_will_take)
     finally:
         lib().set_tuning(b"1x1dma", 1); lib().set_tuning(b"1stages", 32)
 
