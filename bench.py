@@ -88,12 +88,14 @@ def parse():
                     help="untimed eager steps AFTER the timed region, same streams, with a HIP event pair around every conv-engine "
                          "launch: the per-kernel durations of the roofline object (0 = skip)")
     ap.add_argument("--alt-steps", "--exclusive-steps", type=int, default=2, dest="alt_steps",
-                    help="untimed steps per alternative pass (side streams off: per-kernel exclusive durations; bf16x3 / native "
+                    help="untimed eager steps per alternative-arithmetic pass, side streams off (bf16x3 / native "
                          "fp32 / bf16 / fp8 arithmetic).  0 = skip, e.g. under rocprofv3 so its averages speak about the timed step")
     ap.add_argument("--schedules", type=int, default=0,
                     help="N > 0: after the timed region capture the step under three stream schedules (no side streams; the default: "
                          "weight gradient beside the data-gradient chain; weight gradient queued behind its layer's data gradient) "
                          "and time N replays of each — the table goes to the full JSON (`schedules`)")
+    ap.add_argument("--no-side-streams", action="store_true",
+                    help="weight gradients, language branch and sampling heads on the main stream (every kernel alone on the GPU)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="process group + reducer even at world size 1 (exercises the hooks)")
     ap.add_argument("--tune", type=str, default="", help="key=value[,key=value]: dcn_set_tuning knobs applied before the run (experiments)")
@@ -244,6 +246,8 @@ def main():
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs
 
     L = lib()
+    if args.no_side_streams:
+        ops.WGRAD_SIDE = False
     for kv in [t for t in args.tune.split(",") if t]:
         k_, v_ = kv.split("=")
         L.set_tuning(k_.encode(), int(v_))
@@ -252,6 +256,8 @@ def main():
                             bert_model="bert-base-uncased", dataset="vid", img_size=args.size,
                             config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None).to(dev)
     model.train()
+    if args.no_side_streams:
+        model.language_stream = False; model.sampling_stream = False
     # parameters that never receive a gradient in the reference either (dead YOLO heads F7, feature_map F8):
     # freezing them gives a static graph instead of find_unused_parameters=True (train_DCNet.py:483)
     from dcnet_amd.parallel import FlatGradAllReduce, attach_overlapped_reducer, broadcast_parameters, freeze_gradless, wrap_ddp
@@ -383,8 +389,9 @@ def main():
     if args.schedules > 0 and not use_dist:
         from dcnet_amd.graph import GraphedTrainStep
         sched = {}
-        for name, (ws, ls, ss, after) in {"no_side_streams": (False, False, False, False), "default_wgrad_beside_dgrad": (True, True, True, False),
-                                          "wgrad_behind_its_dgrad": (True, True, True, True)}.items():
+        for name, (ws, ls, ss, after) in {"no_side_streams": (False, False, False, False), "wgrad_beside_dgrad": (True, True, True, False),
+                                          "wgrad_behind_its_dgrad": (True, True, True, True),
+                                          "wgrad_on_main_small_branches_aside": (False, True, True, False)}.items():
             was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD)
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = ws, ls, ss, after
             g_ = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=1)
@@ -401,10 +408,14 @@ def main():
             torch.cuda.empty_cache()
         if hasattr(opt, "device_lr"):
             opt.device_lr = False
-    prof = run_pass(args.profile_steps) if args.profile_steps > 0 else None
+    # Per-launch HIP event pairs, side streams off: every kernel ALONE on the GPU — the one regime an eager pass can reproduce (a
+    # replayed graph keeps all streams fed, the eager host does not; events recorded inside a captured graph cannot be read back:
+    # tools/graph_event_probe.hip).  `rocprofv3 -- python3 bench.py --graph off --no-side-streams` shows the same averages.  The
+    # in-step durations of the replayed step (weight gradients beside the data-gradient chain) come from the committed rocprofv3
+    # summary of the default command (profiles/in_step_latest.json) and are quoted beside them.
+    prof = run_pass(args.profile_steps, 4, False) if args.profile_steps > 0 else None
     alts = {}
     if args.alt_steps > 0:
-        alts["exclusive"] = run_pass(args.alt_steps, 4, False)
         alts["fp32_bf16x3"] = run_pass(args.alt_steps, 1, False)
         alts["native_fp32"] = run_pass(args.alt_steps, 0, False)
         alts["bf16_operands"] = run_pass(args.alt_steps, 2, False)
@@ -477,17 +488,23 @@ def main():
                         "avg_launch_ms": e["avg_launch_ms"], "ms_per_step": e["ms_per_step"], "launches_per_step": e["launches_per_step"],
                         "alg_bytes_per_launch": e["alg_bytes_per_launch"], "hbm_frac_algorithmic": e["hbm_frac_algorithmic"],
                         "binding_frac": e["binding_frac"],
-                        "note": "time-dominant conv-engine kernel of an untimed profiled pass (same streams as the timed step); "
-                                "binding_frac = sum over launches of max(FLOP/838.9T, bytes/8TB/s) / measured time"}
-            if "exclusive" in alts:
-                x = entry(alts["exclusive"], dom)
-                roofline["exclusive_frac"] = x["frac"] if x else None
+                        "note": "time-dominant conv-engine kernel; HIP event pair per launch, untimed eager pass, kernels alone on the GPU "
+                                "(side streams off); in_step = inside the replayed step, from the committed rocprofv3 summary; "
+                                "binding_frac = sum over launches of max(FLOP/838.9T, bytes/8TB/s) / time"}
+            ins_file = os.path.join(ROOT, "profiles", "in_step_latest.json")
+            if os.path.exists(ins_file):     # launch durations inside the replayed step (rocprofv3 of this command, committed profile)
+                with open(ins_file) as f:
+                    ins = json.load(f)
+                key = {28: "conv3", 29: "conv3", 32: "wgrad3", 35: "conv1", 25: "wgrad<128,128>", 24: "igemm<128,128> NT"}.get(dom)
+                k_ = ins.get("kernels", {}).get(key)
+                if k_:
+                    fl_per_launch = fam_sum(prof, dom, "work") / fam_sum(prof, dom, "c")
+                    roofline["in_step"] = {"avg_launch_ms": round(k_["avg_launch_ms"], 4),
+                                           "frac": round(fl_per_launch / (k_["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_OF[dom], 4),
+                                           "source": ins.get("source")}
             res["roofline"] = roofline
             fe = entry(prof, fdom)
             res["flop_dominant"] = {k: fe[k] for k in ("kernel", "frac", "ms_per_step", "binding_frac")}
-            if "exclusive" in alts:
-                x = entry(alts["exclusive"], fdom)
-                res["flop_dominant"]["exclusive_frac"] = x["frac"] if x else None
             if prof["c"][8]:
                 rate = prof["work"][8] / (prof["ms"][8] * 1e-3) / 1e9
                 res["hbm_scoring"] = {"kernel": NAMES[8], "achieved": round(rate, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -500,9 +517,9 @@ def main():
                                   "tflops_over_step_wall": round(mfma_work / prof["steps"] / 1e12 / (dt / args.steps), 1)}
             bn = sum(prof["ms"][t] for t in (10, 11, 22)) / prof["steps"]
             res["bn_passes_ms_per_step"] = round(bn, 2)
-            full["profiled_pass"] = {"ms_per_step": prof["ms_per_step"], "kernels": table(prof)}
+            full["profiled_pass_kernels_alone"] = {"ms_per_step": prof["ms_per_step"], "kernels": table(prof)}
         if alts:
-            res["alt"] = {"exclusive_ms": round(alts["exclusive"]["ms_per_step"], 1), "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
+            res["alt"] = {"exclusive_ms": round(prof["ms_per_step"], 1) if prof else None, "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
                           "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1),
                           "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1),
                           "note": "eager steps, side streams off, untimed; bf16/fp8 = reduced-precision operand modes, never `value`"}

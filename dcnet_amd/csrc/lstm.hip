@@ -211,6 +211,20 @@ __global__ __launch_bounds__(256) void bilstm_bwd_kernel(const float* __restrict
 
 extern "C" int64_t dcn_bilstm_sync_bytes(void) { return 64; }
 
+namespace {
+// All 128 workgroups of a pass must be resident at once (they hand h_t to each other through global memory): checked once per
+// process against the device's occupancy answer for this kernel and LDS size, so that a partitioned / smaller GPU fails with a
+// message instead of spinning every hand-off to its timeout (round-2 advisor finding).  (-1: the query itself failed.)
+template <typename K>
+int resident_blocks(K kernel, size_t lds) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) return -1;
+  return per_cu * prop.multiProcessorCount;
+}
+}  // namespace
+
 // sync: 64 bytes of device memory (zeroed here by a memset node on the stream before the launch).
 extern "C" int dcn_bilstm_fwd(const float* xg, const float* whh_fwd, const float* whh_rev, const float* bhh_fwd, const float* bhh_rev,
                               const int64_t* lens, float* out, float* hprev, float* cprev, float* acts, void* sync,
@@ -222,7 +236,14 @@ extern "C" int dcn_bilstm_fwd(const float* xg, const float* whh_fwd, const float
   if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_fwd: memset failed"); return DCN_ERR_LAUNCH; }   // the counters; the error word sync[8] is sticky
   const size_t lds = (size_t)32 * LS_H * sizeof(float) + 16;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  static int resident = 0;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    resident = resident_blocks(bilstm_fwd_kernel, lds);
+    attr_done = true;
+  }
+  DCN_CHECK_ARG(resident < 0 || resident >= 2 * (LS_H / LS_UNITS), "bilstm_fwd: the device keeps %d workgroups of this kernel resident, the "
+                "persistent recurrence needs all %d at once (use the per-step dcn_lstm_cell_* path)", resident, 2 * (LS_H / LS_UNITS));
   hipLaunchKernelGGL(bilstm_fwd_kernel, dim3(LS_H / LS_UNITS, 2), dim3(256), lds, stream, xg, whh_fwd, whh_rev, bhh_fwd, bhh_rev, lens, out, hprev, cprev, acts,
                      (unsigned*)sync, n, l);
   DCN_CHECK_LAUNCH("bilstm_fwd");
@@ -238,7 +259,14 @@ extern "C" int dcn_bilstm_bwd(const float* dout, const float* whh_fwd, const flo
   if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_bwd: memset failed"); return DCN_ERR_LAUNCH; }
   const size_t lds = (size_t)LS_UNITS * 4 * LS_H * sizeof(float) + 16;
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  static int resident = 0;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    resident = resident_blocks(bilstm_bwd_kernel, lds);
+    attr_done = true;
+  }
+  DCN_CHECK_ARG(resident < 0 || resident >= 2 * (LS_H / LS_UNITS), "bilstm_bwd: the device keeps %d workgroups of this kernel resident, the "
+                "persistent recurrence needs all %d at once", resident, 2 * (LS_H / LS_UNITS));
   hipLaunchKernelGGL(bilstm_bwd_kernel, dim3(LS_H / LS_UNITS, 2), dim3(256), lds, stream, dout, whh_fwd, whh_rev, acts, cprev, lens, dxg,
                      (unsigned*)sync, n, l);
   DCN_CHECK_LAUNCH("bilstm_bwd");

@@ -108,7 +108,9 @@ class RNNEncoder(nn.Module):
                               r.weight_ih_l0_reverse, r.weight_hh_l0_reverse, r.bias_ih_l0_reverse, r.bias_hh_l0_reverse)
         embedded = embedded * (torch.arange(L, device=embedded.device)[None, :]
                                < lengths[:, None]).unsqueeze(2).to(embedded.dtype)              # :178 pad_packed zeros
-        sent = output[torch.arange(output.size(0), device=output.device), lengths - 1]
+        # sentence vector = output[i, len_i - 1] (:185-188).  torch.gather: its backward is a scatter-add on unique rows — advanced
+        # indexing (`output[arange, len - 1]`) would put a rocprim radix sort into the backward of every step
+        sent = output.gather(1, (lengths - 1).clamp(min=0).view(n, 1, 1).expand(n, 1, output.size(2))).squeeze(1)
         return sent, output, embedded
 
 
@@ -279,6 +281,9 @@ class grounding_model(nn.Module):
     def _scale_nframe(self, s: int, raw_s, flang, flang_attn, B: int, n_frame: int):
         """Scale s of the inference model: centre frame vs every other frame, mean of the normalised
         correspondence features (model/test_DCNet_model.py:299-332), then the shared head."""
+        if self.training and torch.is_grad_enabled() and raw_s.requires_grad:
+            raise NotImplementedError("the n_frame (inference) model is forward-only — its centre-frame co-attention has no backward "
+                                      "kernels; run it under torch.no_grad(), train with the pair-semantics forward(image, word_id, word_mask)")
         one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None
         fv = L2Norm.apply(self.mapping_visu[s](raw_s, self.visumodel._tap_amax[s]))
         _, h, w, e = fv.shape

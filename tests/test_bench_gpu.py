@@ -34,7 +34,7 @@ def test_single_gpu_line_is_compact_and_complete():
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["dtype"] == "f32" and res["vs_baseline"] is None
     assert "workload" in res["config"] and "hipGraph" in res["config"]["step"]
     rf = res["roofline"]
-    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step", "binding_frac"):
         assert k in rf, k
     assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = res["cpu_baseline"]

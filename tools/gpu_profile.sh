@@ -11,13 +11,19 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+cp "$ROOT/gpurun_out/bench_full_latest.json" "$OUT/bench_full.json" 2>/dev/null || true
 echo "bench done"; tail -c 600 "$OUT/bench.json"; echo
-BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 1"
+# the default command (graph replays; no eager profiled pass, so every traced step runs with the replay's stream concurrency)
+BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats done"
-BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --alt-steps 0 --profile-steps 1"
+# the eager step with the per-launch event pairs (what bench.py's live roofline numbers are taken from): its averages must agree with them
+BENCHE="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 2 --graph off --no-side-streams"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o bench -- python3 $BENCHE > "$OUT/bench_eager_under_rocprof.json" 2> "$OUT/stats_eager.err"
+echo "eager stats done"
+BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --alt-steps 0 --profile-steps 1 --graph off"      # (counter collection serialises dispatches: the eager step)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_fetch.err"
 echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_write.err"

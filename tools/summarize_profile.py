@@ -63,12 +63,16 @@ def main():
     bench_json = os.path.join(a.dir, "bench_under_rocprof.json")
     dominant = None
     match = None
-    if os.path.exists(bench_json) and os.path.getsize(bench_json):
-        with open(bench_json) as f:
-            line = [l for l in f if l.startswith("{")][-1]
-        rf = json.loads(line)["roofline"]
-        dominant = rf["kernel"]
-        match = rf.get("rocprof_match")
+    eager_json = os.path.join(a.dir, "bench_eager_under_rocprof.json")
+    for cand in (bench_json, eager_json, os.path.join(a.dir, "bench.json")):      # (the graph-replay run carries no live roofline)
+        if os.path.exists(cand) and os.path.getsize(cand):
+            with open(cand) as f:
+                line = [l for l in f if l.startswith("{")][-1]
+            rf = json.loads(line).get("roofline")
+            if rf:
+                dominant = rf["kernel"]
+                match = rf.get("rocprof_match")
+                break
     if stats:
         with open(stats, newline="") as f:
             rows = list(csv.DictReader(f))
@@ -79,6 +83,34 @@ def main():
             shutil.copy(stats, os.path.join(prof, f"{tag}_{a.name}_kernel_stats.csv"))
             if os.path.exists(bench_json):
                 shutil.copy(bench_json, os.path.join(prof, f"{tag}_{a.name}_under_rocprof.json"))
+            est = find(os.path.join(a.dir, "stats_eager"), "*kernel_stats.csv")
+            if est:     # the eager, side-streams-off run: the regime of bench.py's live per-launch event pairs
+                shutil.copy(est, os.path.join(prof, f"{tag}_{a.name}_eager_kernel_stats.csv"))
+                if os.path.exists(eager_json):
+                    shutil.copy(eager_json, os.path.join(prof, f"{tag}_{a.name}_eager_under_rocprof.json"))
+            for extra in ("bench.json", "bench_full.json"):
+                if os.path.exists(os.path.join(a.dir, extra)):
+                    shutil.copy(os.path.join(a.dir, extra), os.path.join(prof, f"{tag}_{extra}"))
+    # in-step launch durations of the replayed graph (real stream concurrency), per kernel family: bench.py cannot time launches
+    # inside a hipGraph (events recorded in a captured graph cannot be read: tools/graph_event_probe.hip), so it quotes these beside
+    # its live event-pair numbers
+    if stats and not a.no_copy:
+        fam = {"conv3": ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], "conv3<4,2,4>": ["conv3_kernel<4,2,4,2>"], "conv3<2,2,4>": ["conv3_kernel<2,2,4,2>"],
+               "wgrad3": ["wgrad3_kernel<2>"], "conv1": ["conv1_kernel<"], "wgrad<128,128>": ["wgrad_kernel<128,128,16,true,0,2>"],
+               "igemm<128,128> NT": ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], "scale_act": ["scale_act_kernel"],
+               "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel"], "channel_partials": ["channel_partials_kernel"],
+               "l2norm_score_fwd": ["l2norm_score_fwd_kernel"]}
+        out = {"round": a.round, "source": f"profiles/{tag}_{a.name}_kernel_stats.csv", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
+               "--warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0 (graph replays only)", "kernels": {}}
+        for k_, pats in fam.items():
+            calls = 0; tot = 0.0
+            for r in rows:
+                if any(p_ in norm(r["Name"]) for p_ in pats):
+                    calls += int(r["Calls"]); tot += float(r["TotalDurationNs"])
+            if calls:
+                out["kernels"][k_] = {"calls": calls, "avg_launch_ms": tot / calls / 1e6}
+        with open(os.path.join(prof, "in_step_latest.json"), "w") as f:
+            json.dump(out, f, indent=1)
     tables = {}
     for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         cc = find(os.path.join(a.dir, f"pmc_{which}"), "*counter_collection.csv")
