@@ -389,11 +389,13 @@ def main():
     if args.schedules > 0 and not use_dist:
         from dcnet_amd.graph import GraphedTrainStep
         sched = {}
-        for name, (ws, ls, ss, after) in {"no_side_streams": (False, False, False, False), "wgrad_beside_dgrad": (True, True, True, False),
-                                          "wgrad_behind_its_dgrad": (True, True, True, True),
-                                          "wgrad_on_main_small_branches_aside": (False, True, True, False)}.items():
+        for name, (ws, ls, ss, after, prio) in {"no_side_streams": (False, False, False, False, 0), "wgrad_beside_dgrad": (True, True, True, False, 0),
+                                                "wgrad_behind_its_dgrad": (True, True, True, True, 0),
+                                                "wgrad_beside_dgrad_low_priority": (True, True, True, False, 1),
+                                                "wgrad_behind_its_dgrad_low_priority": (True, True, True, True, 1)}.items():
             was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD)
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = ws, ls, ss, after
+            ops.SIDE_PRIORITY = prio
             g_ = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=1)
             g_(); barrier()
             t1 = time.perf_counter()
@@ -402,6 +404,7 @@ def main():
             barrier()
             sched[name] = (time.perf_counter() - t1) / args.schedules * 1e3
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = was
+            ops.SIDE_PRIORITY = 0
             del g_
             model.static_samples = None
             opt.zero_grad(set_to_none=True)

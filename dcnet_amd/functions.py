@@ -15,16 +15,26 @@ class ConvBNAct(torch.autograd.Function):
     + ReLU.  x may carry zero-padded channels beyond the weight's Cin (K-padding to 32)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float, amax_x=None):
-        """Returns (out, amax_out): amax_* are the abs-max words of ops.amax_* (None outside the f16-split precision)."""
-        w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3])
+    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float, amax_x=None, bank=None):
+        """Returns (out, amax_out): amax_* are the abs-max words of ops.amax_* (None outside the f16-split precision).
+        bank: this layer's entry of an ops.FilterBanks table refreshed this step (OHWI / split / transposed banks + abs-max word):
+        nothing is transposed, measured or split per launch then."""
         cout = weight.shape[0]
         am = ops.use_amax()
+        if bank is not None and x.shape[3] != weight.shape[1]:
+            bank = None                    # (K-padded input: the per-launch path pads the bank)
+        wsp = wtr = None
+        if bank is not None:
+            w, wsp, wtr = bank["ohwi"], bank["split"], (bank["t"], bank["tsplit"])
+            aw = bank["amax"] if am else None
+        else:
+            w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3])
+            aw = ops.absmax(weight.detach()) if am else None
         ax = (amax_x if amax_x is not None else ops.absmax(x)) if am else None
-        aw = ops.absmax(weight.detach()) if am else None
         ao = ops.amax_slot(x.device) if am else None
+        ctx.wtr = wtr
         if training:
-            y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True, amax_x=ax, amax_w=aw)
+            y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp)
             mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                  bn.running_mean, bn.running_var)
             bn.num_batches_tracked += 1
@@ -32,7 +42,7 @@ class ConvBNAct(torch.autograd.Function):
             ctx.save_for_backward(x, y, mi, w, gamma, beta)
         else:
             ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
-            out, _ = ops.conv2d_fwd(x, w, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, amax_x=ax, amax_w=aw, amax_out=ao)
+            out, _ = ops.conv2d_fwd(x, w, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, amax_x=ax, amax_w=aw, amax_out=ao, w_split_ready=wsp)
             ctx.save_for_backward(x, out, ss, w, gamma, beta)
         ctx.meta = (ksize, training, slope, tuple(weight.shape))
         ctx.amax = (ax, aw)
@@ -60,11 +70,11 @@ class ConvBNAct(torch.autograd.Function):
             dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
         if not ops.WGRAD_AFTER_DGRAD:
             dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
-        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
+        dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw, wt_ready=ctx.wtr) if ctx.needs_input_grad[0] else None
         if ops.WGRAD_AFTER_DGRAD:
             dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
         ops.join_side(x.device)
-        return dx, dwt, dgamma, dbeta, None, None, None, None, None
+        return dx, dwt, dgamma, dbeta, None, None, None, None, None, None
 
 
 class ConvBias(torch.autograd.Function):

@@ -70,7 +70,7 @@ class ConvBatchNormReLU(nn.Sequential):
         """``amax`` / the ``_dcn_amax`` attribute of the input: abs-max word of x (ops.amax_*); the output carries its own."""
         amax = amax if amax is not None else getattr(x_nhwc, "_dcn_amax", None)
         out, a = ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
-                                 self.conv.kernel_size[0], self.training, self.slope, amax)
+                                 self.conv.kernel_size[0], self.training, self.slope, amax, self.__dict__.get("_dcn_bank"))
         out._dcn_amax = a
         return out
 
@@ -237,6 +237,33 @@ class grounding_model(nn.Module):
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
+
+    def _head_filter_banks(self):
+        """The filter banks of the head's ConvBatchNormReLU blocks (mapping_visu, corr_conv, fcn_emb, fcn_out) in their GEMM forms,
+        refreshed by ONE dcn_prepare_filters call per forward — as the backbone's (Darknet._filter_banks): per layer and step that
+        replaces an OIHW->OHWI transpose, an abs-max pass and a pre-split in the forward and a filter transpose + pre-split in the
+        backward (~150 launches of 5-10 us).  The first fcn_emb block (1032 input channels: the fusion layer) keeps its own path."""
+        if not ops.FILTER_BANKS or not ops.use_amax():
+            for blk in self._head_blocks():
+                blk.__dict__["_dcn_bank"] = None
+            return
+        blocks = self._head_blocks()
+        ws = {i: b.conv.weight for i, b in enumerate(blocks)}
+        fb = self.__dict__.get("_hbanks")
+        if fb is None or not fb.valid_for(ws):
+            fb = ops.FilterBanks({i: w.detach() for i, w in ws.items()}, next(iter(ws.values())).device)
+            self.__dict__["_hbanks"] = fb
+        fb.refresh()
+        for i, b in enumerate(blocks):
+            b.__dict__["_dcn_bank"] = fb.get(i, b.conv.weight)
+
+    def _head_blocks(self):
+        out = []
+        for seq in (self.mapping_visu, self.corr_conv, self.fcn_emb, self.fcn_out):
+            for m in seq.modules():
+                if isinstance(m, ConvBatchNormReLU):
+                    out.append(m)
+        return out
 
     def _coord(self, h, w, device):
         key = (h, w, str(device))
@@ -469,6 +496,7 @@ class grounding_model(nn.Module):
         static = self.static_samples if self.training else None
         handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
+        self._head_filter_banks()
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)
@@ -519,6 +547,7 @@ class grounding_model(nn.Module):
             word_id, flang, context, embedded = self._language(word_id)
             flang_attn, flang_loc = self._phrases(context, embedded, word_id)
         raw = self.visumodel.forward_nhwc(image)
+        self._head_filter_banks()
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)

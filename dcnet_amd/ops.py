@@ -442,8 +442,10 @@ def side_stream(device) -> "torch.cuda.Stream":
 
 SIDE_PRIORITY = 0      # 0: a normal torch stream; +1 (lowest dispatch priority, dcn_stream_create) measured 20 % slower
 WGRAD_SIDE = True      # A/B switch: False runs the weight gradient on the caller's stream
-WGRAD_AFTER_DGRAD = False   # schedule experiment (bench.py --schedules): the side stream waits for the layer's DATA gradient as well, so
-                            # a weight gradient starts beside the next layer's HBM-bound BatchNorm passes instead of beside its own dgrad
+WGRAD_AFTER_DGRAD = True    # the side stream also waits for the layer's DATA gradient (queued first: the critical chain), so a weight
+                            # gradient starts beside the NEXT layer's HBM-bound BatchNorm passes instead of beside its own data gradient:
+                            # 110.2-112.0 vs 111.0-112.9 ms per replayed step in three same-process comparisons (bench.py --schedules;
+                            # False = round 2's order; a lowest-priority side stream: +-0)
 
 
 def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
