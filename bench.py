@@ -274,7 +274,7 @@ def main():
         else:
             if world > 1:
                 broadcast_parameters(model, 0)
-            flat = FlatGradAllReduce(model.parameters())
+            flat = FlatGradAllReduce(model.parameters()).bind()       # gradients live in one flat buffer: no per-parameter copies
     from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
     opt = make_optimizer(model, 1e-4)
 
@@ -288,7 +288,10 @@ def main():
     def eager_step():
         out = net(image, word_id, word_mask)
         loss, _ = losses.total_loss(out, bbox, args.size)
-        opt.zero_grad(set_to_none=True)
+        if flat is not None:
+            flat.zero()
+        else:
+            opt.zero_grad(set_to_none=True)
         if red is not None:
             red.begin_step()
         loss.backward()

@@ -64,7 +64,7 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
-        optimizer.zero_grad(set_to_none=True)
+        self._zero_grads()
         self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
@@ -78,10 +78,17 @@ class GraphedTrainStep:
         self._replay_device()
 
     # ------------------------------------------------------------------------------------------------
+    def _zero_grads(self):
+        r = self.reducer
+        if r is not None and getattr(r, "bound", False):
+            r.zero()                         # gradients are views of the reducer's flat buffer: one memset, views stay attached
+        else:
+            self.opt.zero_grad(set_to_none=True)
+
     def _body(self, eager: bool):
         out = self.model(self.image, self.word_id, self.word_mask)
         loss, parts = losses.total_loss(out, self.bbox, self.size)
-        self.opt.zero_grad(set_to_none=True)
+        self._zero_grads()
         loss.backward()
         if self.reducer is None:
             self.opt.step()

@@ -82,6 +82,20 @@ def _worker_backbone(rank, world, port, out):
         res[f"local{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
         FlatGradAllReduce(m.parameters())()
         res[f"flat{it}"] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # bound form (the graph-replayed data-parallel step): gradients are views of ONE flat buffer, zeroed by one memset, reduced in place
+    m3 = _Backbone(); m3.load_state_dict(m.state_dict())
+    for i in (3, 17):
+        m3.ws[i].requires_grad_(False)
+    for p in m3.dead:
+        p.requires_grad_(False)
+    fl = FlatGradAllReduce(m3.parameters()).bind()
+    ptrs = {k: p.grad.data_ptr() for k, p in m3.named_parameters() if p.grad is not None}
+    for it in range(2):
+        fl.zero()
+        ((m3(data[idx]) - tgt[idx]) ** 2).mean().backward()
+        fl()
+        res[f"bound{it}"] = {k: p.grad.clone() for k, p in m3.named_parameters() if p.grad is not None}
+    res["bound_views_kept"] = all(p.grad.data_ptr() == ptrs[k] for k, p in m3.named_parameters() if k in ptrs)
     m2 = _Backbone(); m2.load_state_dict(m.state_dict())
     for i in (3, 17):
         m2.ws[i].requires_grad_(False)
@@ -111,7 +125,9 @@ def test_two_rank_allreduce_with_a_single_node_backbone(tmp_path):
             for i in range(world):
                 assert torch.allclose(r[i][f"flat{it}"][k], mean, atol=1e-6), (it, k)
                 assert torch.allclose(r[i][f"ddp{it}"][k], mean, atol=1e-6), (it, k)
+                assert torch.allclose(r[i][f"bound{it}"][k], mean, atol=1e-6), (it, k)      # (same parameters: the model state is not stepped)
     assert all(gr is None for gr in r[0]["frozen_grads"])
+    assert r[0]["bound_views_kept"] and r[1]["bound_views_kept"], "autograd replaced a gradient view of the flat buffer"
 
 
 class _PushingGrads(torch.autograd.Function):
