@@ -331,6 +331,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if use_graph and step is not eager_step:
+        step.host_launch_s = step.host_sampler_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
@@ -459,6 +461,11 @@ def main():
                           "parallelism": f"dp{world}", "ranks_seen": dist.get_world_size() if use_dist else 1,
                           "reducer": reducer_name, "step": graph_note},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4)}
+        if step is not eager_step:
+            # what the host does per replayed step: launching (graph + optimiser-side calls) vs waiting for the native sampler thread
+            # (the reference's O(N^2 HW) random.sample loop, serial by construction; it runs under the previous replay)
+            res["host_ms_per_step"] = {"launch": round(step.host_launch_s / args.steps * 1e3, 2),
+                                       "sampler_wait": round(step.host_sampler_s / args.steps * 1e3, 2)}
         full = {"bench_line": None, "timed": {"ms_per_step": res["ms_per_step"], "step": graph_note}}
         if sched:
             full["schedules_ms_per_step"] = sched

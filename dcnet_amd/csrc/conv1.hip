@@ -329,9 +329,16 @@ int launch1_ring(const IgemmParams& p, hipStream_t stream) {
 }
 
 // (MI, NI) for a launch, 0 = not on this kernel.  gran = rows per BatchNorm partial the caller sized its buffer for (128 | 256).
+int g_conv1_fill = 0;     // dcn_set_tuning("1fill", n): grids of fewer 128 x 128 workgroups than n take 128 x 64 tiles (twice the workgroups).
+                          // Measured on the 13x13 maps (340 workgroups for 1024 slots), tools/bench_convs.py --ab 1fill=0 --ab-default 512:
+                          // 1024->512 0.058 -> 0.064 ms, 512->512 data gradient 0.039 -> 0.048: half the MFMAs per barrier costs more than
+                          // the second round of workgroups brings; off.
+
 int conv1_shape(const IgemmParams& p, int gran) {
-  const int ni = p.Co % 128 == 0 ? 4 : (p.Co % 64 == 0 ? 2 : (p.Co % 32 == 0 ? 1 : 0));
+  int ni = p.Co % 128 == 0 ? 4 : (p.Co % 64 == 0 ? 2 : (p.Co % 32 == 0 ? 1 : 0));
   if (!ni) return 0;
+  // (experiment knob, off by default — see g_conv1_fill)
+  if (ni == 4 && (!p.stats || gran == 128) && (long long)cdiv(p.M, 128) * (p.Co / 128) < g_conv1_fill) ni = 2;
   int mi;
   if (p.stats) { mi = gran == 128 ? 1 : (gran == 256 ? 2 : 0); }
   else mi = ni == 4 ? 1 : 2;
@@ -341,7 +348,7 @@ int conv1_shape(const IgemmParams& p, int gran) {
 
 }  // namespace
 
-void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else g_conv1_stages = value; }
+void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else g_conv1_fill = value; }
 
 // shape part of the decision.  The kernel only takes launches that igemm.hip would run on its f16-split tiles WITH the pre-split
 // bank (b_scale set by conv.hip under igemm_will_presplit): the arithmetic — which products, in which order — is then the same and

@@ -21,6 +21,7 @@ an eager one (tests/test_graph_gpu.py).
 """
 from __future__ import annotations
 
+import time
 from typing import Optional
 
 import torch
@@ -50,6 +51,8 @@ class GraphedTrainStep:
         self.loss = None
         self.parts = None
         self.replays = 0
+        self.host_launch_s = 0.0         # host time spent launching (graph replay, reducer, optimiser step, learning-rate upload)
+        self.host_sampler_s = 0.0        # host time spent waiting for / uploading the draws of the sampling heads (worker thread)
         if hasattr(optimizer, "device_lr"):
             optimizer.device_lr = True
             optimizer.sync_lr(dev)
@@ -108,8 +111,13 @@ class GraphedTrainStep:
 
     def __call__(self):
         """One optimisation step.  Returns the (static) loss tensor of the step — reading it synchronises."""
+        t0 = time.perf_counter()
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()
+        t1 = time.perf_counter()
         self.core.draw_samples(self.n, self.samples)
+        t2 = time.perf_counter()
         self._replay_device()
+        t3 = time.perf_counter()
+        self.host_launch_s += (t1 - t0) + (t3 - t2); self.host_sampler_s += t2 - t1
         return self.loss
