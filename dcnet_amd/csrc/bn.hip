@@ -67,21 +67,41 @@ __global__ __launch_bounds__(256) void sums_finalize_kernel(const double* __rest
 // the two-stage pair, on the critical path between every conv and its BatchNorm apply.  MODE 0: BatchNorm statistics
 // (same arithmetic as bn_finalize_kernel); MODE 1: the two backward sums.
 constexpr int FUSED_ROWS_MAX = 4096;
+// Block = 256 threads = 32 row lanes x RF_CH channels (round 3; was 1024 threads = 32 x 32): under the replayed step the kernel's few
+// 16-wave blocks waited for a CU with 16 free wave slots beside the weight-gradient stream (42.8 us per launch on the critical
+// chain of the backward instead of 9-13); 4-wave blocks find a slot at once.  Rows per lane and the order of the 32 lane sums
+// are unchanged: bitwise the same result.
+constexpr int RF_CH = 8;
 template <int MODE>
-__global__ __launch_bounds__(1024) void reduce_finalize_kernel(const float* __restrict__ stats, int rows, int c, double inv_count,
-                                                               double unbias, const float* gamma, const float* beta, float eps,
-                                                               float momentum, float* running_mean, float* running_var,
-                                                               float* mean, float* invstd, float* scale, float* shift,
-                                                               float* sums) {
-  __shared__ double red[2][32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + tx;
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float* __restrict__ stats, int rows, int c, double inv_count,
+                                                              double unbias, const float* gamma, const float* beta, float eps,
+                                                              float momentum, float* running_mean, float* running_var,
+                                                              float* mean, float* invstd, float* scale, float* shift,
+                                                              float* sums) {
+  __shared__ double red[2][32][RF_CH + 1];
+  const int tx = threadIdx.x & (RF_CH - 1), ty = threadIdx.x / RF_CH;
+  const int ch = blockIdx.x * RF_CH + tx;
   double s = 0.0, ss = 0.0;
-  if (ch < c)
-    for (int r = ty; r < rows; r += 32) {
+  if (ch < c) {
+    // eight rows (sixteen independent loads) in flight per thread, summed in the same order as the plain loop: the kernel sits on
+    // the critical path between every convolution and its BatchNorm apply and is pure load latency (42 dependent-free iterations
+    // of two loads each took 12.7 us on the 52x52 layers)
+    int r = ty;
+    for (; r + 7 * 32 < rows; r += 8 * 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a[k] = stats[((size_t)(r + 32 * k) * 2 + 0) * c + ch];
+        b[k] = stats[((size_t)(r + 32 * k) * 2 + 1) * c + ch];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s += (double)a[k]; ss += (double)b[k]; }
+    }
+    for (; r < rows; r += 32) {
       s += (double)stats[((size_t)r * 2 + 0) * c + ch];
       ss += (double)stats[((size_t)r * 2 + 1) * c + ch];
     }
+  }
   red[0][ty][tx] = s; red[1][ty][tx] = ss;
   __syncthreads();
   if (ty != 0 || ch >= c) return;
@@ -269,7 +289,7 @@ extern "C" int dcn_bn_finalize(const float* stats, int rows, int c, int64_t coun
   DCN_CHECK_ARG(((uintptr_t)ws & 7) == 0, "bn_finalize: ws must be 8-byte aligned");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   if (rows <= FUSED_ROWS_MAX) {
-    hipLaunchKernelGGL((reduce_finalize_kernel<0>), dim3(cdiv(c, 32)), dim3(1024), 0, stream, stats, rows, c, 1.0 / (double)count,
+    hipLaunchKernelGGL((reduce_finalize_kernel<0>), dim3(cdiv(c, RF_CH)), dim3(256), 0, stream, stats, rows, c, 1.0 / (double)count,
                        unbias, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, (float*)nullptr);
     DCN_CHECK_LAUNCH("bn_reduce_finalize");
     return DCN_OK;
@@ -336,7 +356,7 @@ extern "C" int dcn_bn_bwd_sums(const float* stats, int rows, int c, float* sums,
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(stats && sums && ws && rows > 0 && c > 0, "bn_bwd_sums: bad argument");
   if (rows <= FUSED_ROWS_MAX) {
-    hipLaunchKernelGGL((reduce_finalize_kernel<1>), dim3(cdiv(c, 32)), dim3(1024), 0, stream, stats, rows, c, 0.0, 0.0,
+    hipLaunchKernelGGL((reduce_finalize_kernel<1>), dim3(cdiv(c, RF_CH)), dim3(256), 0, stream, stats, rows, c, 0.0, 0.0,
                        (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, sums);
     DCN_CHECK_LAUNCH("bn_reduce_sums");
