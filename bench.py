@@ -94,6 +94,9 @@ def parse():
                     help="N > 0: after the timed region capture the step under three stream schedules (no side streams; the default: "
                          "weight gradient beside the data-gradient chain; weight gradient queued behind its layer's data gradient) "
                          "and time N replays of each — the table goes to the full JSON (`schedules`)")
+    ap.add_argument("--schedule-tunes", type=str, default="",
+                    help="with --schedules: extra variants of the default schedule under dcn_set_tuning knobs, 'k=v+k=v;k=v' "
+                         "(one variant per ';', knobs joined by '+', restored afterwards: give the default as the 3rd field k=v=default)")
     ap.add_argument("--no-side-streams", action="store_true",
                     help="weight gradients, language branch and sampling heads on the main stream (every kernel alone on the GPU)")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -322,7 +325,6 @@ def main():
             if args.graph == "on":
                 raise
             print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
-            model.static_samples = None
             if hasattr(opt, "device_lr"):
                 opt.device_lr = False
             torch.cuda.synchronize()
@@ -397,10 +399,17 @@ def main():
         for name, (ws, ls, ss, after, prio) in {"no_side_streams": (False, False, False, False, 0), "wgrad_beside_dgrad": (True, True, True, False, 0),
                                                 "wgrad_behind_its_dgrad": (True, True, True, True, 0),
                                                 "wgrad_beside_dgrad_low_priority": (True, True, True, False, 1),
-                                                "wgrad_behind_its_dgrad_low_priority": (True, True, True, True, 1)}.items():
+                                                "wgrad_behind_its_dgrad_low_priority": (True, True, True, True, 1),
+                                                **{"tune:" + t: (True, True, True, True, 0) for t in args.schedule_tunes.split(";") if t}}.items():
             was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD)
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = ws, ls, ss, after
             ops.SIDE_PRIORITY = prio
+            restore = []
+            if name.startswith("tune:"):
+                for kv in name[5:].split("+"):
+                    parts_ = kv.split("=")
+                    L.set_tuning(parts_[0].encode(), int(parts_[1]))
+                    restore.append((parts_[0], int(parts_[2]) if len(parts_) > 2 else 0))
             g_ = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=1)
             g_(); barrier()
             t1 = time.perf_counter()
@@ -410,6 +419,8 @@ def main():
             sched[name] = (time.perf_counter() - t1) / args.schedules * 1e3
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = was
             ops.SIDE_PRIORITY = 0
+            for k_, v_ in restore:
+                L.set_tuning(k_.encode(), v_)
             del g_
             model.static_samples = None
             opt.zero_grad(set_to_none=True)

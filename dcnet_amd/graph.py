@@ -57,7 +57,6 @@ class GraphedTrainStep:
             optimizer.device_lr = True
             optimizer.sync_lr(dev)
         model.train()
-        self.core.static_samples = self.samples
         # warm-up on a side stream (torch.cuda.graph's documented recipe), then capture
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -89,7 +88,13 @@ class GraphedTrainStep:
             self.opt.zero_grad(set_to_none=True)
 
     def _body(self, eager: bool):
-        out = self.model(self.image, self.word_id, self.word_mask)
+        # the forward reads this step's draws from the static buffers (draw_samples filled them); only for this call — an eager
+        # forward of the same model elsewhere keeps drawing for itself
+        self.core.static_samples = self.samples
+        try:
+            out = self.model(self.image, self.word_id, self.word_mask)
+        finally:
+            self.core.static_samples = None
         loss, parts = losses.total_loss(out, self.bbox, self.size)
         self._zero_grads()
         loss.backward()

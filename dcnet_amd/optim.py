@@ -54,8 +54,11 @@ class RMSprop(torch.optim.Optimizer):
                 loss = closure()
         L = lib()
         self._stepped = []
-        if self.device_lr and not self._lr_dev:
-            raise RuntimeError("dcnet_amd.optim.RMSprop: device_lr is set but sync_lr() was never called")
+        if self.device_lr:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_lr()           # an eager step always sees the groups' current learning rates (a captured one: sync_lr() before the replay)
+            elif not self._lr_dev:
+                raise RuntimeError("dcnet_amd.optim.RMSprop: device_lr is set but sync_lr() was never called before the capture")
         for gi, group in enumerate(self.param_groups):
             ps, gs, vs, ns, keep = [], [], [], [], []
             for p in group["params"]:
