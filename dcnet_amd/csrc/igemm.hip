@@ -735,11 +735,14 @@ void wgrad_set_wide64(int v);
 void wgrad_set_target_small(int v);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
+void score_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : 0), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'e') { score_set_tuning(0, value); return DCN_OK; }    // "e2rpw": rows per wave of l2norm_score_fwd
+  if (k == 'f') { score_set_tuning(1, value); return DCN_OK; }    // "f2nt": non-temporal loads there
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)

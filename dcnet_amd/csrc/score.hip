@@ -10,47 +10,59 @@ namespace {
 
 constexpr int MAX_V4 = 4;   // c <= 1024
 
-// Each wave normalises RPW rows at once: all their 16-B loads are issued before the first reduction, which
-// keeps 2*RPW KiB in flight per wave (one row per wave measured 4.9 TB/s, two rows 5.4+).
-constexpr int RPW = 2;
+// Each wave normalises RPW rows at once: all their 16-B loads are issued before the first reduction, which keeps RPW * c * 4
+// bytes in flight per wave (tools/bench_score.py, 64 x 52 x 52 x 512: one or two rows 5.1 TB/s, four 4.9, eight 4.4).
+// V4 = 16-B loads per lane and row (c <= 256 V4): registers are sized for the launch's channel count, not for the maximum.
+// NT: x is read with non-temporal loads (it is not read again before the backward; `out` is, by the kernels that follow):
+// 5.1 -> 5.6 TB/s on the same shape, a device copy of the same bytes runs at 5.5.
+template <int V4, int RPW, bool NT>
 __global__ __launch_bounds__(256) void l2norm_score_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int ldo,
                                                                float* __restrict__ norm, const float* __restrict__ q,
                                                                float* __restrict__ score, float* __restrict__ score_flip,
                                                                int64_t rows, int rpi, int c, float out_scale, int accumulate) {
   const int lane = threadIdx.x & 63;
-  const int64_t nimg = rows / rpi;
+  const int nimg = (int)(rows / rpi);
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= rows) return;
-  f32x4 v[RPW][MAX_V4];
+  f32x4 v[RPW][V4];
   float ss[RPW];
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int64_t row = row0 + r < rows ? row0 + r : rows - 1;       // tail: recompute the last row, store is guarded
 #pragma unroll
-    for (int k = 0; k < MAX_V4; ++k) {
+    for (int k = 0; k < V4; ++k) {
       const int ch = (lane + 64 * k) * 4;
       v[r][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ch < c) v[r][k] = *reinterpret_cast<const f32x4*>(x + row * ldx + ch);
+      if (ch < c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + row * ldx + ch);
+        v[r][k] = NT ? __builtin_nontemporal_load(src) : *src;
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_V4; ++k) s += v[r][k][0] * v[r][k][0] + v[r][k][1] * v[r][k][1] + v[r][k][2] * v[r][k][2] + v[r][k][3] * v[r][k][3];
+    for (int k = 0; k < V4; ++k)           // explicit fma chain: every instantiation rounds alike
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(v[r][k][j], v[r][k][j], s);
     ss[r] = wave_sum(s);
   }
+  // image of the wave's first row: one division per wave, then a compare per row (rows of a wave are consecutive)
+  int img = (int)(row0 / rpi);
+  int64_t img_end = (int64_t)(img + 1) * rpi;
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const int64_t row = row0 + r;
     if (row >= rows) break;
+    if (row >= img_end) { ++img; img_end += rpi; }
     const float nrm = sqrtf(ss[r]);
     const float inv = 1.f / fmaxf(nrm, 1e-12f);
-    const float* qq = q ? q + (row / rpi) * c : nullptr;
-    const float* qf = (q && score_flip) ? q + (nimg - 1 - row / rpi) * c : nullptr;     // the language vector of image N-1-n
+    const float* qq = q ? q + (int64_t)img * c : nullptr;
+    const float* qf = (q && score_flip) ? q + (int64_t)(nimg - 1 - img) * c : nullptr;     // the language vector of image N-1-n
     float dot = 0.f, dotf = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_V4; ++k) {
+    for (int k = 0; k < V4; ++k) {
       const int ch = (lane + 64 * k) * 4;
       if (ch < c) {
         const f32x4 o = v[r][k] * inv;
@@ -59,11 +71,13 @@ __global__ __launch_bounds__(256) void l2norm_score_fwd_kernel(const float* __re
         *reinterpret_cast<f32x4*>(out + row * ldo + ch) = st;
         if (qq) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(qq + ch);
-          dot += o[0] * w[0] + o[1] * w[1] + o[2] * w[2] + o[3] * w[3];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dot = fmaf(o[j], w[j], dot);
         }
         if (qf) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(qf + ch);
-          dotf += o[0] * w[0] + o[1] * w[1] + o[2] * w[2] + o[3] * w[3];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dotf = fmaf(o[j], w[j], dotf);
         }
       }
     }
@@ -75,6 +89,20 @@ __global__ __launch_bounds__(256) void l2norm_score_fwd_kernel(const float* __re
       if (qf) score_flip[row] = dotf;
     }
   }
+}
+
+int g_l2_rpw = 2;      // dcn_set_tuning("e2rpw", 1|2|4|8): rows per wave of l2norm_score_fwd (tools/bench_score.py)
+int g_l2_nt = 1;       // dcn_set_tuning("f2nt", 0|1): non-temporal loads of x
+
+template <int V4>
+void launch_l2fwd(const float* x, int ldx, float* out, int ldo, float* norm, const float* q, float* score, float* score_flip,
+                  int64_t rows, int rpi, int c, float out_scale, int accumulate, hipStream_t stream) {
+#define L2F(R, N) hipLaunchKernelGGL((l2norm_score_fwd_kernel<V4, R, N>), dim3(cdiv(rows, 4 * R)), dim3(256), 0, stream, \
+                                     x, ldx, out, ldo, norm, q, score, score_flip, rows, rpi, c, out_scale, accumulate)
+  const int r = (g_l2_rpw == 8 && V4 > 2) ? 4 : g_l2_rpw;          // (8 rows x 1024 channels: 128 data registers)
+  if (g_l2_nt) { if (r == 1) L2F(1, true); else if (r == 2) L2F(2, true); else if (r == 8) L2F(8, true); else L2F(4, true); }
+  else { if (r == 1) L2F(1, false); else if (r == 2) L2F(2, false); else if (r == 8) L2F(8, false); else L2F(4, false); }
+#undef L2F
 }
 
 // g = dout + dscore*q ;  dx = (g - out*<g,out>) / max(norm, eps)
@@ -177,8 +205,10 @@ extern "C" int dcn_l2norm_score_fwd(const float* x, int ldx, float* out, int ldo
   if (ldo <= 0) ldo = c;
   // algorithmic bytes: read x, write out (+ norm, score)
   const int pid = prof_begin(8, (double)rows * (2.0 * c * 4 + 8), (hipStream_t)stream);
-  hipLaunchKernelGGL(l2norm_score_fwd_kernel, dim3(cdiv(rows, 4 * RPW)), dim3(256), 0, (hipStream_t)stream,
-                     x, ldx, out, ldo, norm, q, score, score_flip, rows, rows_per_image > 0 ? rows_per_image : 1, c, out_scale, accumulate);
+  const int rpi_ = rows_per_image > 0 ? rows_per_image : 1;
+  if (c <= 256) launch_l2fwd<1>(x, ldx, out, ldo, norm, q, score, score_flip, rows, rpi_, c, out_scale, accumulate, (hipStream_t)stream);
+  else if (c <= 512) launch_l2fwd<2>(x, ldx, out, ldo, norm, q, score, score_flip, rows, rpi_, c, out_scale, accumulate, (hipStream_t)stream);
+  else launch_l2fwd<4>(x, ldx, out, ldo, norm, q, score, score_flip, rows, rpi_, c, out_scale, accumulate, (hipStream_t)stream);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("l2norm_score_fwd");
   return DCN_OK;
@@ -231,3 +261,5 @@ extern "C" int dcn_rowdot_bwd(const float* x, int ldx, const float* q, int flip,
   }
   return DCN_OK;
 }
+
+void score_set_tuning(int key, int value) { if (key == 0) g_l2_rpw = value; else g_l2_nt = value; }
