@@ -140,11 +140,12 @@ template <int MODE>
 __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dout,
                                                                int lddo, const float* mean, const float* invstd,
                                                                const float* gamma, const float* beta, int act, float slope,
-                                                               int64_t rows, int c, float* __restrict__ stats) {
+                                                               int64_t rows, int c, float* __restrict__ stats, int rev) {
   __shared__ float red[2][16][64];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int ch = blockIdx.y * 64 + tx * 4;
-  const int64_t r0 = (int64_t)blockIdx.x * 128;
+  const int bx = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;      // (sweep direction: see g_bn_rev)
+  const int64_t r0 = (int64_t)bx * 128;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
   if (ch < c) {
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f}, g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) acc += red[which][k][t];
-      stats[((size_t)blockIdx.x * 2 + which) * c + cc] = acc;
+      stats[((size_t)bx * 2 + which) * c + cc] = acc;
     }
   }
 }
@@ -194,11 +195,12 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const float* __re
 __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int act, float slope,
                                                         const float* __restrict__ residual, float* __restrict__ out,
-                                                        int64_t rows, int c, int ldo, unsigned* __restrict__ amax) {
+                                                        int64_t rows, int c, int ldo, unsigned* __restrict__ amax, int rev) {
   const int c4 = c >> 2;
   const int64_t total = rows * c4;
   float vmax = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+    const int64_t i = rev ? total - 1 - j : j;
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
     f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + r * c + ch));      // (not read again before the backward)
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -224,11 +226,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                                const float* mean, const float* invstd, const float* gamma,
                                                                const float* beta, int act, float slope, const float* sums,
                                                                float inv_count, int64_t rows, int c, float* __restrict__ dy,
-                                                               unsigned* __restrict__ amax) {
+                                                               unsigned* __restrict__ amax, int rev) {
   const int c4 = c >> 2;
   const int64_t total = rows * c4;
   float vmax = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < total; j += (int64_t)gridDim.x * 256) {
+    const int64_t i = rev ? total - 1 - j : j;
     const int64_t r = i / c4; const int ch = (int)(i - r * c4) * 4;
     const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + r * c + ch));      // last reads of both tensors
     f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dout + r * lddo + ch));
@@ -269,6 +272,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// dcn_set_tuning("dbnrev", mask): sweep direction of the streaming passes (1 scale_act, 2 backward partials, 4 backward apply run
+// from the last row to the first): a pass that starts where its producer stopped finds the producer's last lines in the
+// memory-side cache.
+int g_bn_rev = 0;
+
 inline int stream_grid(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -276,6 +284,8 @@ inline int stream_grid(int64_t work_items) {
 inline int row_slices(int rows) { int rs = (rows + 63) / 64; return rs < 1 ? 1 : (rs > RS_MAX ? RS_MAX : rs); }
 
 }  // namespace
+
+void bn_set_tuning(int v) { g_bn_rev = v; }
 
 extern "C" int64_t dcn_bn_ws(int c) { return (int64_t)RS_MAX * 2 * c * 2; }   // doubles stored in a float-typed scratch
 
@@ -319,7 +329,7 @@ extern "C" int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, fl
   DCN_CHECK_ARG(x && stats && rows > 0 && c > 0, "channel_stats: bad argument");
   DCN_CHECK_ARG(c % 4 == 0 && (ld <= 0 || ld % 4 == 0) && ((uintptr_t)x & 15) == 0, "channel_stats: c=%d / ld=%d must be multiples of 4 floats, x 16-byte aligned", c, ld);
   hipLaunchKernelGGL((channel_partials_kernel<0>), dim3(cdiv(rows, 128), cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream,
-                     x, ld > 0 ? ld : c, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, rows, c, stats);
+                     x, ld > 0 ? ld : c, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0.f, rows, c, stats, 0);
   DCN_CHECK_LAUNCH("channel_stats");
   return DCN_OK;
 }
@@ -332,7 +342,7 @@ extern "C" int dcn_scale_act(const float* y, const float* scale, const float* sh
   const int pid = prof_begin(10, (double)rows * c * 4.0 * (residual ? 3 : 2), (hipStream_t)stream);
   // (with an abs-max word: at most 1024 workgroups, i.e. 1024 atomics over 64 words; they all finish together)
   hipLaunchKernelGGL(scale_act_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, scale, shift, act, slope, residual, out, rows, c, ldo, amax);
+                     y, scale, shift, act, slope, residual, out, rows, c, ldo, amax, g_bn_rev & 1);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("scale_act");
   return DCN_OK;
@@ -346,7 +356,7 @@ extern "C" int dcn_bn_act_bwd_reduce(const float* y, const float* dout, int lddo
                 "bn_act_bwd_reduce: c=%d / lddo=%d must be multiples of 4 floats, pointers 16-byte aligned", c, lddo);
   const int pid = prof_begin(22, 8.0 * (double)rows * c, (hipStream_t)stream);
   hipLaunchKernelGGL((channel_partials_kernel<1>), dim3(cdiv(rows, 128), cdiv(c, 64)), dim3(256), 0, (hipStream_t)stream,
-                     y, c, dout, lddo > 0 ? lddo : c, mean, invstd, gamma, beta, act, slope, rows, c, stats);
+                     y, c, dout, lddo > 0 ? lddo : c, mean, invstd, gamma, beta, act, slope, rows, c, stats, (g_bn_rev >> 1) & 1);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_reduce");
   return DCN_OK;
@@ -377,7 +387,7 @@ extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo,
   if (lddo <= 0) lddo = c;
   const int pid = prof_begin(11, (double)rows * c * 4.0 * 3, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax);
+                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax, (g_bn_rev >> 2) & 1);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply");
   return DCN_OK;

@@ -736,11 +736,15 @@ void wgrad_set_target_small(int v);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
 void score_set_tuning(int key, int value);
+void bn_set_tuning(int v);
+void wgrad9_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : 0), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"
+  if (k == 'd') { bn_set_tuning(value); return DCN_OK; }          // "dbnrev": sweep direction of the BatchNorm streaming passes (bn.hip)
   if (k == 'e') { score_set_tuning(0, value); return DCN_OK; }    // "e2rpw": rows per wave of l2norm_score_fwd
   if (k == 'f') { score_set_tuning(1, value); return DCN_OK; }    // "f2nt": non-temporal loads there
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)

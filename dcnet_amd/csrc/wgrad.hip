@@ -603,9 +603,19 @@ int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout);
 int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
                   const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream);
 
+// wgrad9.hip: the 3x3 layers with 32 input channels and 64 filters, nine taps per workgroup (f16 split)
+bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int64_t wgrad9_ws(int n, int h, int wd, int stride);
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int stride,
+                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream);
+
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  if (wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride)) {
+    const int64_t w9 = wgrad9_ws(n, h, wd, stride);
+    if (w9 > ws) ws = w9;
+  }
   if (wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride)) {       // (which kernel runs depends on the abs-max words: size for both)
     const int64_t w3 = wgrad3_ws(n, h, wd, cin, cout);
     if (w3 > ws) ws = w3;
@@ -647,6 +657,8 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
     const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
     const long long npix = (long long)n * h * wd;
     const bool f16 = g_wsplit == 4 && amax_x && amax_dy, b16 = g_wsplit == 2;      // (2: the bf16- and fp8-operand modes)
+    if (f16 && !g_wabl && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0)
+      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, stride, amax_x, amax_dy, stream);
     if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
       return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);

@@ -1,0 +1,288 @@
+// Weight gradient of the 3x3 layers with 32 input channels and 64 filters — the 32 -> 64 stride-2 layer on the 416x416 map and the
+// 32 -> 64 layer of the first residual block on the 208x208 map (yolov3.cfg) — ALL NINE taps per workgroup, f16 two-piece split.
+//
+//   dW[co][r][s][ci] = sum_q dY[q][co] * X[S*oy + r - 1][S*ox + s - 1][ci]          q = (n, oy, ox), S = stride
+//
+// wgrad.hip runs these layers as nine per-tap launches' worth of 64 x 32 tiles on the fp32 MFMA pipe: dY (0.7 GB) and X (0.35 / 1.4 GB)
+// are read nine times through L2 and the pipe runs at 1/16 of the f16 rate (1.4 ms per layer against 0.2-0.4 ms of HBM traffic).
+// With 64 x 32 x 9 = 18 432 accumulators the whole filter bank fits one workgroup: six waves, wave (cb, r) owns 32 filters x 32
+// channels x the three taps of filter row r.  K runs over PADDED positions as in wgrad3.hip: q counts rows of Wo + 1 entries whose
+// last entry is a pad (dY = 0), and X is addressed as X_pad[S*q + s] in rows of S*(Wo + 1) entries whose entry u is image column
+// u - 1 (u = 0 and u > W are zero) — then the left / right taps of the border columns read zeros without a mask, for both strides,
+// and the top / bottom filter rows are zeroed when their image row is loaded.  Per K-step of 32 positions a workgroup stages dY
+// (32 x 64) and, per filter row, the S*31 + 3 entries of X_pad its three taps touch (stride 2: even and odd entries in separate
+// planes, so that every tap reads consecutive rows); both are split into f16 pieces on the way to LDS and the MFMA operands come
+// from ds_read_b64_tr_b16 (wgrad.hip).  Split-K over positions into slabs summed in a fixed order (reduce_slabs_kernel):
+// bitwise reproducible.  Roofline: HBM (dY + X once: 1.06 / 2.13 GB per launch at N = 64) — the MFMA work is 0.12 ms at 838.9.
+#include "common.h"
+#include "prof.h"
+
+int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream);
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB9 = 0x80000000u;
+
+struct W9Params {
+  const float* x; const float* dy; float* out;
+  int N, H, W, Ho, Wo, ldx, lddy;
+  int Mp, kchunk, splits;          // padded positions N*Ho*(Wo+1); per split (multiple of 32)
+  const unsigned* amax_dy; const unsigned* amax_x;
+};
+
+__device__ __forceinline__ f32x4 ld9(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc9(const float* base, long long bytes) {
+  const unsigned n = bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0u : (unsigned)(bytes < 0 ? 0 : bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, n, 0x00020000);
+}
+__device__ __forceinline__ float pow2_9(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xFF);
+  if (be == 0 || be == 255) return 1.f;
+  int e = 14 - (be - 126);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
+
+constexpr int KS = 32;                    // dY positions per K-step (two MFMA K-steps per barrier)
+constexpr int A_PLANE9 = KS * 128;        // [32 positions][64 filters] f16
+// dY plane: 128-B rows, the two 64-B halves swap on rows 2, 3 (mod 4): four consecutive rows of one half sit in four different
+// 64-B bank groups (a half-wave of the transposed read takes 4 rows x 64 B)
+__device__ __forceinline__ int a_off(int row, int c) { return 128 * row + 64 * ((c >> 5) ^ ((row >> 1) & 1)) + 2 * (c & 31); }
+
+// X planes of one filter row: S = 1: [34 entries][32 channels] f16 (64-B rows).  S = 2: even entries (33 rows) then odd entries
+// (32 rows) starting 128 B (mod 256) further, so that a store of entries 4j..4j+3 (two even, two odd rows) spreads over all banks.
+template <int S> struct XLay;
+template <> struct XLay<1> { static constexpr int NU = 34, ROWB = 34 * 64; };
+template <> struct XLay<2> { static constexpr int NU = 65, ODD = 34 * 64, ROWB = 34 * 64 + 32 * 64; };
+template <int S> __device__ __forceinline__ int x_off(int s) {          // entry s of the staged range (U = S*q0 + s)
+  if constexpr (S == 1) return 64 * s;
+  else return (s & 1) ? XLay<2>::ODD + 64 * (s >> 1) : 64 * (s >> 1);
+}
+template <int S> __device__ __forceinline__ int x_tap(int k, int d) {   // LDS row of position k (0..31), tap d
+  if constexpr (S == 1) return 64 * (k + d);
+  else return d == 1 ? XLay<2>::ODD + 64 * k : 64 * (k + (d >> 1));
+}
+
+template <int S>
+__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad9_kernel(const W9Params p) {
+  constexpr int NU = XLay<S>::NU, ROWB = XLay<S>::ROWB, B_PLANE = 3 * ROWB;
+  constexpr int B_BASE = 2 * A_PLANE9, BUF = 2 * A_PLANE9 + 2 * B_PLANE;
+  constexpr int NA = KS * 16, NX = 3 * NU * 8, NSLOT = (NA + NX + 383) / 384;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm9[];     // [2 buffers][dY: 2 planes | X: 2 planes x 3 filter rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = wave & 1, r = wave >> 1;                                 // 32 filters x 32 channels x filter row r
+  const int split = xcd_remap(blockIdx.x, gridDim.x);
+  const int Wp = p.Wo + 1, RL = S * Wp;
+  const int p_begin = split * p.kchunk;
+  const int p_end = min(p.Mp, p_begin + p.kchunk);
+  const int iters = (p_end - p_begin + KS - 1) / KS;
+  const float s_a = pow2_9(amax_read(p.amax_dy)), s_b = pow2_9(amax_read(p.amax_x));
+
+  const __amdgpu_buffer_rsrc_t a_rs = rsrc9(p.dy, (((long long)p.N * p.Ho * p.Wo - 1) * p.lddy + 64) * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrc9(p.x, (((long long)p.N * p.H * p.W - 1) * p.ldx + 32) * 4);
+
+  // ---- load slots: element e = slot*384 + tid of the K-step's staging list (dY pieces first, then X pieces) ----------------
+  // dY piece: position q0 + idx, filters c..c+3;  X piece: filter row fr, entry idx of the staged range, channels c..c+3.
+  // NA is a multiple of 64, so a slot is one kind for a whole wave (is_a: scalar — the two kinds use different buffer
+  // descriptors and must not meet in one load); elements past the end of the list repeat the last X piece (same bytes, same place).
+  // meta = fr << 2 | c << 4 | idx << 10.  The step's first position q0 = (row g_row = n*Ho + oy, column g_col) is the same for
+  // the whole workgroup (scalar registers); a slot adds its idx and wraps into the next row at most once.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int meta[NSLOT], st_off[NSLOT];
+  bool is_a[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    const int e = j * 384 + tid;
+    is_a[j] = j * 384 + 64 * wave_u < NA;
+    if (is_a[j]) {
+      const int pos = e >> 4, c = (e & 15) * 4;
+      meta[j] = (c << 4) | (pos << 10); st_off[j] = a_off(pos, c);
+    } else {
+      const int x = min(e - NA, NX - 1);
+      const int fr = x / (NU * 8), rem = x - fr * (NU * 8);
+      const int s = rem >> 3, c = (rem & 7) * 4;
+      meta[j] = (fr << 2) | (c << 4) | (s << 10); st_off[j] = B_BASE + fr * ROWB + x_off<S>(s) + 2 * c;
+    }
+  }
+  int q_step = p_begin;                                   // first position of the step being LOADED
+  int g_row = p_begin / Wp, g_col = p_begin - g_row * Wp;
+  int g_nb = (g_row / p.Ho) * p.H, g_oy = g_row % p.Ho;
+  const int rows_x = p.N * p.H;
+
+  auto load_step = [&](f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      unsigned off = OOB9;
+      const int c = (meta[j] >> 4) & 63, idx = meta[j] >> 10;
+      if (is_a[j]) {
+        int col = g_col + idx, row = g_row;
+        if (col >= Wp) { col -= Wp; ++row; }
+        if (col < p.Wo && q_step + idx < p_end) off = (unsigned)(((row * p.Wo + col) * p.lddy + c) * 4);      // (< 2^31: checked by the launcher)
+        v[j] = ld9(a_rs, off);
+      } else {
+        int u = S * g_col + idx, oy = g_oy, nb = g_nb;
+        if (u >= RL) { u -= RL; if (++oy == p.Ho) { oy = 0; nb += p.H; } }
+        const int iy = S * oy + ((meta[j] >> 2) & 3) - 1, ix = u - 1;
+        if ((unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H && nb < rows_x)
+          off = (unsigned)((((nb + iy) * p.W + ix) * p.ldx + c) * 4);
+        v[j] = ld9(b_rs, off);
+      }
+    }
+    q_step += KS; g_col += KS;
+    if (g_col >= Wp) { g_col -= Wp; ++g_row; if (++g_oy == p.Ho) { g_oy = 0; g_nb += p.H; } }
+  };
+  auto store_step = [&](int buf, const f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      const f32x4 t = v[j] * (is_a[j] ? s_a : s_b);
+      const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+      const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                         (_Float16)(t[3] - (float)h[3])};
+      unsigned char* dst = sm9 + buf * BUF + st_off[j];
+      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h);
+      *reinterpret_cast<uint2*>(dst + (is_a[j] ? A_PLANE9 : B_PLANE)) = __builtin_bit_cast(uint2, l);
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[d][q] = 0.f;
+
+  // transposed-read addresses (wgrad.hip): 16-lane group (hh, gg): K rows 8hh + 4r2 + q, channels 16gg + 4pp of the wave's block
+  const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+  int a_tr[2][2], b_tr[2][3][2];                           // [MFMA K-step][..][r2]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int k = 16 * ks + 8 * hh + 4 * r2 + qq;
+      a_tr[ks][r2] = a_off(k, cb * 32 + 16 * gg + 4 * pp);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) b_tr[ks][d][r2] = B_BASE + r * ROWB + x_tap<S>(k, d) + 2 * (16 * gg + 4 * pp);
+    }
+  auto tr_read = [&](int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm9 + byte_off));
+  };
+  auto frag = [&](int byte0, int byte1) {
+    const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+  auto k_step = [&](int buf, int ks) {
+    f16x8_t af[2], bf[3][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) af[pl] = frag(buf * BUF + pl * A_PLANE9 + a_tr[ks][0], buf * BUF + pl * A_PLANE9 + a_tr[ks][1]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bf[d][pl] = frag(buf * BUF + pl * B_PLANE + b_tr[ks][d][0], buf * BUF + pl * B_PLANE + b_tr[ks][d][1]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {                           // smallest terms first: (l,h) (h,l) (h,h)
+      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[d][0], acc[d], 0, 0, 0);
+      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[d][1], acc[d], 0, 0, 0);
+      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[d][0], acc[d], 0, 0, 0);
+    }
+  };
+
+  // One register set for the staged pieces: step it+1 is split and stored between the two MFMA K-steps of step it, and the loads
+  // of step it+2 are issued right behind the stores — they fly under the second K-step, the barrier and the first K-step of
+  // the next iteration (a second set cost 50 registers and the second workgroup per CU with them).
+  f32x4 cur[NSLOT];
+  if (iters > 0) {
+    load_step(cur);
+    store_step(0, cur);
+    load_step(cur);                                          // step 1 (past the end of the split: dY masked to zero)
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    const int b = it & 1;
+    k_step(b, 0);
+    store_step(b ^ 1, cur);                                  // step it + 1
+    load_step(cur);                                          // step it + 2
+    k_step(b, 1);
+    __syncthreads();
+  }
+
+  const float dq = 1.f / (s_a * s_b);                        // powers of two: exact
+  float* out = p.out + (size_t)split * 64 * 288;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int co = cb * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+    const int ci = lane & 31;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) out[(size_t)co * 288 + (3 * r + d) * 32 + ci] = acc[d][q] * dq;
+  }
+}
+
+int g_w9 = 1;             // dcn_set_tuning("9tap", 0): these layers back on the per-tap kernel of wgrad.hip
+int g_w9_target = 512;    // dcn_set_tuning("9target", n): workgroups (= split-K slabs) per launch
+
+struct Plan9 { int splits, kchunk, Mp; };
+Plan9 plan9(int n, int ho, int wo) {
+  Plan9 pl;
+  pl.Mp = n * ho * (wo + 1);
+  int splits = g_w9_target;
+  const int max_splits = pl.Mp / 256 > 0 ? pl.Mp / 256 : 1;
+  if (splits > max_splits) splits = max_splits;
+  pl.kchunk = cdiv(cdiv(pl.Mp, splits), KS) * KS;
+  pl.splits = cdiv(pl.Mp, pl.kchunk);
+  return pl;
+}
+
+template <int S> size_t lds9() { return (size_t)2 * (2 * A_PLANE9 + 2 * 3 * XLay<S>::ROWB); }
+
+}  // namespace
+
+void wgrad9_set_tuning(int key, int value) { if (key == 0) g_w9 = value; else g_w9_target = value > 0 ? value : 512; }
+
+// shape test only (the workspace is sized without knowing whether the abs-max words will be there)
+bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  if (!g_w9 || ksize != 3 || (stride != 1 && stride != 2) || cin != 32 || cout != 64) return false;
+  if (h % stride || wd % stride || wd / stride < KS || h / stride < 2) return false;       // (one row wrap per K-step at most)
+  const long long npix = (long long)n * h * wd, opix = (long long)n * (h / stride) * (wd / stride);
+  if (npix * 32 * 4 >= 0x7FFFFFF0LL || opix * 64 * 4 >= 0x7FFFFFF0LL) return false;        // 32-bit byte offsets from the tensor bases (dense)
+  if ((long long)n * (h / stride) * (wd / stride + 1) * stride >= 0x7FFFFFF0LL || npix < 4096) return false;
+  return true;
+}
+int64_t wgrad9_ws(int n, int h, int wd, int stride) {
+  const Plan9 pl = plan9(n, h / stride, wd / stride);
+  return pl.splits > 1 ? (int64_t)pl.splits * 64 * 288 : 0;
+}
+
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int stride,
+                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
+  const int ho = h / stride, wo = wd / stride;
+  const Plan9 pl = plan9(n, ho, wo);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
+  DCN_CHECK_ARG((long long)n * ho * wo * lddy * 4 < 0x7FFFFFF0LL && (long long)n * h * wd * ldx * 4 < 0x7FFFFFF0LL,
+                "conv2d_bwd_weight: a sliced operand of %lld bytes exceeds the 32-bit byte offsets of the nine-tap kernel",
+                (long long)n * h * wd * ldx * 4);
+  W9Params p{};
+  p.x = x; p.dy = dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ho = ho; p.Wo = wo; p.ldx = ldx; p.lddy = lddy;
+  p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.amax_dy = amax_dy; p.amax_x = amax_x;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<1>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<2>());
+    attr_done = true;
+  }
+  // HBM-priced: dY and X once, the slabs written
+  const double bytes = 4.0 * ((double)n * ho * wo * 64 + (double)n * h * wd * 32 + (double)pl.splits * 64 * 288);
+  const int pid = prof_begin(36, 2.0 * (double)n * ho * wo * 64 * 288.0, stream, bytes);
+  if (stride == 1) hipLaunchKernelGGL(wgrad9_kernel<1>, dim3(pl.splits), dim3(384), lds9<1>(), stream, p);
+  else hipLaunchKernelGGL(wgrad9_kernel<2>, dim3(pl.splits), dim3(384), lds9<2>(), stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("wgrad9");
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)64 * 288 / 4, pl.splits, stream);
+  return DCN_OK;
+}

@@ -940,6 +940,66 @@ def test_filter_banks_match_the_per_layer_preparation(dev):
     assert torch.equal(ops.conv2d_fwd(x1, b["ohwi"], 1, 1)[0], ops.conv2d_fwd(x1, b["ohwi"], 1, 1, amax_w=b["amax"], w_split_ready=b["split"])[0])
 
 
+def _prof_launches(tag):
+    """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
+    import ctypes
+    from dcnet_amd.lib import lib
+    c = (ctypes.c_int64 * 40)(); m = (ctypes.c_double * 40)(); wk = (ctypes.c_double * 40)()
+    lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
+    return c[tag]
+
+
+W9_CASES = [
+    # n, h, w, stride   (3x3, 32 input channels, 64 filters; output rows of >= 32 pixels)
+    (2, 64, 64, 1),
+    (2, 40, 70, 1),      # rows that are no multiple of the 32-position K-step
+    (1, 35, 131, 1),     # odd map
+    (4, 33, 33, 1),      # shortest rows (34 padded entries: a wrap in every K-step), image-to-image wrap
+    (2, 64, 64, 2),      # 32-pixel output rows
+    (1, 72, 136, 2),
+    (3, 66, 96, 2),
+]
+
+
+@pytest.mark.parametrize("case", W9_CASES)
+def test_wgrad9_nine_tap_kernel(dev, case):
+    """csrc/wgrad9.hip (weight gradient of the 32 -> 64 3x3 layers of the 416 / 208 maps, stride 1 and 2, all nine taps per
+    workgroup, K over padded positions) against fp64 and against the per-tap kernel it replaces: image borders (pads must read as
+    zero, top / bottom filter rows masked), the stride-2 even / odd planes, split-K slabs and a dY that is a slice of a wider
+    tensor."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, st = case
+    x = _rand(n, h, w, 32, seed=51).to(dev)
+    wide = (_rand(n, h // st, w // st, 96, seed=52) / 8).to(dev)
+    dy = wide[..., 16:80]                                          # pixel stride 96
+    xd = x.permute(0, 3, 1, 2).double().cpu()
+    wgt = torch.zeros(64, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, wgt, padding=1, stride=st).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = wgt.grad.permute(0, 2, 3, 1)                             # OHWI
+    try:
+        lib().set_tuning(b"9tap", 0)
+        old = ops.conv2d_bwd_weight(x, dy, 3, st)
+        lib().set_tuning(b"9tap", 1)
+        lib().prof_enable(1)
+        new = ops.conv2d_bwd_weight(x, dy, 3, st)
+        lib().prof_enable(0)
+        ran = _prof_launches(36)
+        new_c = ops.conv2d_bwd_weight(x, dy.contiguous(), 3, st)
+        for target in (1, 7, 4096):                                # one slab ... as many as the positions allow
+            lib().set_tuning(b"9target", target)
+            alt = ops.conv2d_bwd_weight(x, dy, 3, st)
+            _close(alt, ref, 3e-5, f"wgrad9 target {target}")
+    finally:
+        lib().set_tuning(b"9tap", 1); lib().set_tuning(b"9target", 512); lib().prof_enable(0)
+    assert ran == 1, "the nine-tap kernel did not run"
+    _close(new, ref, 3e-5, "wgrad9")
+    _close(old, ref, 3e-5, "per-tap wgrad")
+    assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
+    again = ops.conv2d_bwd_weight(x, dy, 3, st)
+    assert torch.equal(new, again)                                 # fixed summation order
+
+
 W3_CASES = [
     # n, h, w, cin, cout   (3x3 stride 1, >= 128 channels both sides, >= 1024 pixels)
     (8, 13, 13, 128, 256),
