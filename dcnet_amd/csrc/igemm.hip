@@ -744,6 +744,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : 0), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"
+  if (k == 'N') { nconv_set_tuning(value); return DCN_OK; }       // "Nconv": register-bank kernels of the 32 <-> 64 channel layers (nconv.hip)
   if (k == 'd') { bn_set_tuning(value); return DCN_OK; }          // "dbnrev": sweep direction of the BatchNorm streaming passes (bn.hip)
   if (k == 'e') { score_set_tuning(0, value); return DCN_OK; }    // "e2rpw": rows per wave of l2norm_score_fwd
   if (k == 'f') { score_set_tuning(1, value); return DCN_OK; }    // "f2nt": non-temporal loads there
@@ -771,6 +772,8 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   else { dcn_set_error("set_tuning: unknown key"); return DCN_ERR_ARG; }
   return DCN_OK;
 }
+
+int igemm_precision() { return g_precision; }
 
 bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci) {
   if (g_precision != 4 || !g_h2_presplit || g_split || rows < 1024 || Co <= 32) return false;

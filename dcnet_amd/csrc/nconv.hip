@@ -1,0 +1,260 @@
+// Data gradient of the 32 -> 64 3x3 stride-2 layer of the 416x416 map (yolov3.cfg: the first down-sampling convolution), i.e. a
+// transposed convolution from 64 channels (dY, 208x208) to 32 channels (dX, 416x416), f16 two-piece split.
+//
+//   dX[2r+a][2c+b][ci] = sum over the taps (ky, kx) of parity class (a, b), over co:  dY[r + (ky==0)][c + (kx==0)][co] * W[co][ky][kx][ci]
+//   class (a, b): ky = 1 for a = 0, ky in {0, 2} for a = 1 (kx likewise): 1 / 2 / 2 / 4 taps
+//
+// igemm.hip runs the four classes as implicit GEMMs on 256 x 32 tiles: K loops of 4-16 steps, dY gathered from L2 once per tap, the
+// 1-tap class on the fp32 pipe — 1.8 ms against 0.4 ms of HBM traffic (0.7 GB read, 1.4 GB written).  Here the filter bank
+// (32 x 9 x 64: 73 KB) lives in REGISTERS: one persistent workgroup per CU (four waves, one per SIMD, up to 512 registers each) walks
+// a contiguous range of dY positions in chunks of 64; wave (mb, role) owns 32 positions and the taps of two classes (role 0: the
+// 4-tap class and the 1-tap class, role 1: the two 2-tap classes — 20 / 16 MFMA triples per chunk), whose B fragments it split
+// once.  Per chunk the workgroup stages two row strips of dY (rows r and r+1, 65 entries x 64 channels, split into f16 pieces on
+// the way to LDS, double buffered); every A fragment is one ds_read_b128 at (strip, entry + 0|1).  Positions are PADDED as in
+// wgrad3.hip (rows of Wo + 1 entries, the last one a pad that is staged as zero), so the right neighbour of the last column and
+// the row below the last row read zeros without masks in the loop.  All four classes of a chunk are stored by the workgroup that
+// computed them: full 128-byte pixels.  Roofline: HBM.
+#include "common.h"
+#include "prof.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned OOBN = 0x80000000u;
+
+struct D2Params {
+  const float* dy; const float* wt; float* dx;      // wt: transposed bank [32 ci][9 taps][64 co] fp32
+  int N, Ho, Wo, lddy, ldo;
+  int Mp, nchunks, per_wg;                          // padded positions N*Ho*(Wo+1); chunks of 64; chunks per workgroup
+  const unsigned* amax_dy; const unsigned* amax_w;
+};
+
+__device__ __forceinline__ f32x4 ldn(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float pow2n(unsigned amax_bits) {
+  const int be = (int)((amax_bits >> 23) & 0xFF);
+  if (be == 0 || be == 255) return 1.f;
+  int e = 14 - (be - 126);
+  e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  return __uint_as_float((unsigned)(e + 127) << 23);
+}
+
+constexpr int CH = 64;                    // positions per chunk
+constexpr int NE = CH + 1;                // entries per strip (the right neighbour of the last position)
+constexpr int STRIP = NE * 128;           // [entry][64 channels] f16
+constexpr int PLANE = 2 * STRIP;          // both strips of one f16 piece
+constexpr int BUFB = 2 * PLANE;           // high + low pieces
+// 128-byte rows; the 16-byte chunk index is XORed with (entry / 2) % 8: the 16 lanes of a ds_read_b128 pass (consecutive entries,
+// one chunk) land in 16 different 16-byte bank groups
+__device__ __forceinline__ int s_off(int strip, int e, int co) { return strip * STRIP + 128 * e + 16 * ((co >> 3) ^ ((e >> 1) & 7)) + 2 * (co & 7); }
+
+// taps of a role: (ky, kx, accumulator).  role 0: class (1,1) <- (0,0) (0,2) (2,0) (2,2), class (0,0) <- (1,1);
+// role 1: class (0,1) <- (1,0) (1,2), class (1,0) <- (0,1) (2,1)
+template <int ROLE> struct Taps;
+template <> struct Taps<0> {
+  static constexpr int N = 5;
+  static constexpr int ky[5] = {0, 0, 2, 2, 1}, kx[5] = {0, 2, 0, 2, 1}, ac[5] = {0, 0, 0, 0, 1};
+  static constexpr int ca[2] = {1, 0}, cb[2] = {1, 0};        // parity class (a, b) of each accumulator
+};
+template <> struct Taps<1> {
+  static constexpr int N = 4;
+  static constexpr int ky[4] = {1, 1, 0, 2}, kx[4] = {0, 2, 1, 1}, ac[4] = {0, 0, 1, 1};
+  static constexpr int ca[2] = {0, 1}, cb[2] = {1, 0};
+};
+
+// scalar walker over padded positions: (row = n*Ho + r, column in [0, Wp), r)
+struct Walk { int row, col, r; };
+__device__ __forceinline__ void walk_to(Walk& w, int q, int Wp, int Ho) { w.row = q / Wp; w.col = q - w.row * Wp; w.r = w.row % Ho; }
+__device__ __forceinline__ void walk_step(Walk& w, int Wp, int Ho) {      // + CH (< Wp: one wrap at most)
+  w.col += CH;
+  if (w.col >= Wp) { w.col -= Wp; ++w.row; if (++w.r == Ho) w.r = 0; }
+}
+
+template <int ROLE>
+__device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm) {
+  typedef Taps<ROLE> T;
+  constexpr int NT = T::N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mb = wave & 1;
+  const int m = lane & 31, kg = lane >> 5;
+  const int Wp = p.Wo + 1, NR = p.N * p.Ho, W = 2 * p.Wo;
+  const float s_a = pow2n(amax_read(p.amax_dy)), s_b = pow2n(amax_read(p.amax_w));
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0,
+      (unsigned)((((long long)NR * p.Wo - 1) * p.lddy + 64) * 4), 0x00020000);
+
+  // ---- the wave's filter fragments, split once: B[k = co][n = ci = lane % 32], 8 consecutive co per lane ------------------
+  f16x8_t bh[NT][4], bl[NT][4];
+  auto load_b = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float* src = p.wt + ((size_t)(m * 9 + T::ky[i] * 3 + T::kx[i]) * 64 + kk * 16 + 8 * kg);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s_b, v1 = *reinterpret_cast<const f32x4*>(src + 4) * s_b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bh[i][kk][e] = (_Float16)v0[e]; bh[i][kk][4 + e] = (_Float16)v1[e];
+        bl[i][kk][e] = (_Float16)(v0[e] - (float)bh[i][kk][e]); bl[i][kk][4 + e] = (_Float16)(v1[e] - (float)bh[i][kk][4 + e]);
+      }
+    }
+  };
+  load_b(std::integral_constant<int, 0>{}); load_b(std::integral_constant<int, 1>{}); load_b(std::integral_constant<int, 2>{});
+  load_b(std::integral_constant<int, 3>{});
+  if constexpr (NT > 4) load_b(std::integral_constant<int, 4>{});
+
+  // ---- staging list of a chunk: 2 strips x 65 entries x 16 pieces of 4 channels = 2080 pieces: 8 per thread + 32 more (wave 0) ----
+  constexpr int NSLOT = 9;
+  const bool last_on = __builtin_amdgcn_readfirstlane(wave) == 0;           // slot 8: lanes 32..63 repeat piece 2079
+  int meta[NSLOT], st_off[NSLOT];                                              // meta = strip | entry << 1 | co << 8
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    int idx = j * 256 + tid;
+    if (idx > 2 * NE * 16 - 1) idx = 2 * NE * 16 - 1;
+    const int strip = idx / (NE * 16), rem = idx - strip * (NE * 16);
+    const int e = rem >> 4, co = (rem & 15) * 4;
+    meta[j] = strip | (e << 1) | (co << 8);
+    st_off[j] = s_off(strip, e, co);
+  }
+
+  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
+  Walk wl, wc;                                       // chunk being LOADED / being computed
+  walk_to(wl, c_begin * CH, Wp, p.Ho); wc = wl;
+
+  auto load_chunk = [&](f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      if (j == NSLOT - 1 && !last_on) continue;
+      const int strip = meta[j] & 1, e = (meta[j] >> 1) & 127, co = meta[j] >> 8;
+      int col = wl.col + e, row = wl.row, r = wl.r;
+      if (col >= Wp) { col -= Wp; ++row; if (++r == p.Ho) r = 0; }
+      unsigned off = OOBN;
+      if (col < p.Wo && row < NR && (strip == 0 || r + 1 < p.Ho)) off = (unsigned)((((row + strip) * p.Wo + col) * p.lddy + co) * 4);
+      v[j] = ldn(a_rs, off);
+    }
+    walk_step(wl, Wp, p.Ho);
+  };
+  auto store_chunk = [&](int buf, const f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+      if (j == NSLOT - 1 && !last_on) continue;
+      const f32x4 t = v[j] * s_a;
+      const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+      const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                         (_Float16)(t[3] - (float)h[3])};
+      unsigned char* dst = sm + buf * BUFB + st_off[j];
+      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h);
+      *reinterpret_cast<uint2*>(dst + PLANE) = __builtin_bit_cast(uint2, l);
+    }
+  };
+
+  // A fragment of (strip dyo, entry mb*32 + m + dxo, K-step kk): 8 channels from kk*16 + 8*kg
+  int a_addr[2][2][4];                               // [dyo][dxo][kk]
+#pragma unroll
+  for (int dyo = 0; dyo < 2; ++dyo)
+#pragma unroll
+    for (int dxo = 0; dxo < 2; ++dxo)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a_addr[dyo][dxo][kk] = s_off(dyo, mb * 32 + m + dxo, kk * 16 + 8 * kg);
+
+  const float dq = 1.f / (s_a * s_b);                // powers of two: exact
+  f32x4 stage[NSLOT];
+  if (c_begin < c_end) {
+    load_chunk(stage);
+    store_chunk(0, stage);
+    load_chunk(stage);                                // chunk c_begin + 1 (past the range: unused)
+  }
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][q] = 0.f;
+    auto tap = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int dyo = T::ky[i] == 0 ? 1 : 0, dxo = T::kx[i] == 0 ? 1 : 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + a_addr[dyo][dxo][kk]);
+        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + a_addr[dyo][dxo][kk]);
+        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][kk], acc[T::ac[i]], 0, 0, 0);      // smallest terms first
+        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][kk], acc[T::ac[i]], 0, 0, 0);
+        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][kk], acc[T::ac[i]], 0, 0, 0);
+      }
+    };
+    tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
+    store_chunk(buf ^ 1, stage);                      // chunk c + 1
+    load_chunk(stage);                                // chunk c + 2
+    tap(std::integral_constant<int, 2>{}); tap(std::integral_constant<int, 3>{});
+    if constexpr (NT > 4) tap(std::integral_constant<int, 4>{});
+
+    // ---- store: D[m = position][n = ci]; register q <-> position mb*32 + (q & 3) + 8 (q >> 2) + 4 kg ---------------------------
+    const int q0 = c * CH;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+      int col = wc.col + pos, row = wc.row;
+      if (col >= Wp) { col -= Wp; ++row; }
+      if (col >= p.Wo || q0 + pos >= p.Mp) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const size_t pix = (size_t)(2 * row + T::ca[a]) * W + 2 * col + T::cb[a];
+        p.dx[pix * p.ldo + m] = acc[a][q] * dq;
+      }
+    }
+    walk_step(wc, Wp, p.Ho);
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dgrad2_kernel(const D2Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smn[];       // [2 buffers][high | low][strip r | strip r+1]
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0>(p, smn);
+  else dgrad2_body<1>(p, smn);
+}
+
+int g_nconv = 1;          // dcn_set_tuning("Nconv", 0): these layers back on the implicit-GEMM tiles
+int g_ncus = 0;
+
+}  // namespace
+
+void nconv_set_tuning(int v) { g_nconv = v; }
+
+// the 32 -> 64 3x3 stride-2 layer's data gradient (dY 64 channels -> dX 32 channels), dense dX
+bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int stride, int accumulate) {
+  if (!g_nconv || ksize != 3 || stride != 2 || cin != 32 || cout != 64 || accumulate) return false;
+  if ((h & 1) || (wd & 1) || wd / 2 < CH || h < 4) return false;                       // (one row wrap per chunk at most)
+  if ((long long)n * h * wd * 32 * 4 >= 0x7FFFFFF0LL || (long long)n * (h / 2) * (wd / 2 + 1) >= 0x7FFFFFF0LL) return false;
+  return (long long)n * h * wd >= 65536;                                               // (a persistent grid wants work for every CU)
+}
+
+int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd,
+                  const uint32_t* amax_dy, const uint32_t* amax_w, hipStream_t stream) {
+  DCN_CHECK_ARG((long long)n * (h / 2) * (wd / 2) * lddy * 4 < 0x7FFFFFF0LL, "conv2d_bwd_data: dY slice exceeds 32-bit byte offsets");
+  if (!g_ncus) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
+    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  D2Params p{};
+  p.dy = dy; p.wt = wt; p.dx = dx; p.N = n; p.Ho = h / 2; p.Wo = wd / 2; p.lddy = lddy; p.ldo = 32;
+  p.Mp = n * p.Ho * (p.Wo + 1);
+  p.nchunks = cdiv(p.Mp, CH);
+  int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
+  p.per_wg = cdiv(p.nchunks, grid);
+  grid = cdiv(p.nchunks, p.per_wg);
+  p.amax_dy = amax_dy; p.amax_w = amax_w;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUFB);
+    attr_done = true;
+  }
+  const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * 64 + (double)n * h * wd * 32 + 32.0 * 9 * 64);
+  const int pid = prof_begin(37, 2.0 * (double)n * p.Ho * p.Wo * 64 * 9.0 * 32, stream, bytes);
+  hipLaunchKernelGGL(dgrad2_kernel, dim3(grid), dim3(256), 2 * BUFB, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("dgrad2");
+  return DCN_OK;
+}
