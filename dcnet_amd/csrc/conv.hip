@@ -147,10 +147,10 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
                        w, wt, cout, T, cin);
     DCN_CHECK_LAUNCH("transpose_filter");
   }
-  // the 32 -> 64 stride-2 layer of the 416x416 map: all four parity classes from one pass over dY, filter bank in registers (nconv.hip)
+  // the stride-2 layers of the 416x416 / 208x208 maps: all four parity classes from one pass over dY, filter bank in registers (nconv.hip)
   if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && igemm_precision() == 4 &&
       dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, accumulate))
-    return dgrad2_launch(dy, lddy, wt, dx, n, h, wd, amax_dy, amax_w, stream);
+    return dgrad2_launch(dy, lddy, wt, dx, n, h, wd, cin, accumulate, amax_dy, amax_w, stream);
   IgemmParams p; base_params(p);
   p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx; p.amax_a = amax_dy; p.amax_b = amax_w;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;

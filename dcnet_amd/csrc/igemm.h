@@ -73,9 +73,9 @@ bool stem_applicable(const IgemmParams& p, const float* scratch);
 int stem_launch(const IgemmParams& p, float* scratch, hipStream_t stream);
 void stem_set_tuning(int v);
 
-// nconv.hip: the data gradient of the 32 -> 64 3x3 stride-2 layer with the filter bank in registers (persistent workgroups, f16 split)
+// nconv.hip: the data gradients of the 32 -> 64 and 64 -> 128 3x3 stride-2 layers with the filter bank in registers (persistent workgroups, f16 split)
 bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int stride, int accumulate);
-int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd,
+int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
                   const uint32_t* amax_dy, const uint32_t* amax_w, hipStream_t stream);
 void nconv_set_tuning(int v);
 int igemm_precision();       // dcn_set_tuning("precision"): 4 = f16 two-piece split (the default)

@@ -1,16 +1,17 @@
-// Data gradient of the 32 -> 64 3x3 stride-2 layer of the 416x416 map (yolov3.cfg: the first down-sampling convolution), i.e. a
-// transposed convolution from 64 channels (dY, 208x208) to 32 channels (dX, 416x416), f16 two-piece split.
+// Data gradient of the first two 3x3 stride-2 layers (yolov3.cfg: 32 -> 64 on the 416x416 map, 64 -> 128 on the 208x208 map), i.e.
+// transposed convolutions from CK = 64 | 128 channels (dY) to CN = 32 | 64 channels (dX), f16 two-piece split.
 //
 //   dX[2r+a][2c+b][ci] = sum over the taps (ky, kx) of parity class (a, b), over co:  dY[r + (ky==0)][c + (kx==0)][co] * W[co][ky][kx][ci]
 //   class (a, b): ky = 1 for a = 0, ky in {0, 2} for a = 1 (kx likewise): 1 / 2 / 2 / 4 taps
 //
 // igemm.hip runs the four classes as implicit GEMMs on 256 x 32 tiles: K loops of 4-16 steps, dY gathered from L2 once per tap, the
-// 1-tap class on the fp32 pipe — 1.8 ms against 0.4 ms of HBM traffic (0.7 GB read, 1.4 GB written).  Here the filter bank
-// (32 x 9 x 64: 73 KB) lives in REGISTERS: one persistent workgroup per CU (four waves, one per SIMD, up to 512 registers each) walks
-// a contiguous range of dY positions in chunks of 64; wave (mb, role) owns 32 positions and the taps of two classes (role 0: the
-// 4-tap class and the 1-tap class, role 1: the two 2-tap classes — 20 / 16 MFMA triples per chunk), whose B fragments it split
-// once.  Per chunk the workgroup stages two row strips of dY (rows r and r+1, 65 entries x 64 channels, split into f16 pieces on
-// the way to LDS, double buffered); every A fragment is one ds_read_b128 at (strip, entry + 0|1).  Positions are PADDED as in
+// 1-tap class on the fp32 pipe — 1.8 ms (32 <- 64) and 1.0 ms (64 <- 128) against 0.4 / 0.2 ms of HBM traffic.  Here the filter
+// bank (73 | 295 KB) lives in REGISTERS: one persistent workgroup per CU (four waves, one per SIMD, up to 512 registers each) walks
+// a contiguous range of dY positions in chunks of 64 (CN = 32) or 32 (CN = 64); a wave owns 32 positions x 32 output channels and the
+// taps of two classes (role 0: the 4-tap class and the 1-tap class, role 1: the two 2-tap classes — 5 / 4 taps x CK/16 MFMA
+// triples per chunk), whose B fragments it split once (160 | 320 registers).  Per chunk the workgroup stages two row strips of dY
+// (rows r and r+1, chunk + 1 entries x CK channels, split into f16 pieces on the way to LDS, double buffered); every A fragment is
+// one ds_read_b128 at (strip, entry + 0|1).  Positions are PADDED as in
 // wgrad3.hip (rows of Wo + 1 entries, the last one a pad that is staged as zero), so the right neighbour of the last column and
 // the row below the last row read zeros without masks in the loop.  All four classes of a chunk are stored by the workgroup that
 // computed them: full 128-byte pixels.  Roofline: HBM.
@@ -25,8 +26,8 @@ typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned OOBN = 0x80000000u;
 
 struct D2Params {
-  const float* dy; const float* wt; float* dx;      // wt: transposed bank [32 ci][9 taps][64 co] fp32
-  int N, Ho, Wo, lddy, ldo;
+  const float* dy; const float* wt; float* dx;      // wt: transposed bank [CN ci][9 taps][CK co] fp32
+  int N, Ho, Wo, lddy, ldo, accumulate;
   int Mp, nchunks, per_wg;                          // padded positions N*Ho*(Wo+1); chunks of 64; chunks per workgroup
   const unsigned* amax_dy; const unsigned* amax_w;
 };
@@ -42,14 +43,25 @@ __device__ __forceinline__ float pow2n(unsigned amax_bits) {
   return __uint_as_float((unsigned)(e + 127) << 23);
 }
 
-constexpr int CH = 64;                    // positions per chunk
-constexpr int NE = CH + 1;                // entries per strip (the right neighbour of the last position)
-constexpr int STRIP = NE * 128;           // [entry][64 channels] f16
-constexpr int PLANE = 2 * STRIP;          // both strips of one f16 piece
-constexpr int BUFB = 2 * PLANE;           // high + low pieces
-// 128-byte rows; the 16-byte chunk index is XORed with (entry / 2) % 8: the 16 lanes of a ds_read_b128 pass (consecutive entries,
-// one chunk) land in 16 different 16-byte bank groups
-__device__ __forceinline__ int s_off(int strip, int e, int co) { return strip * STRIP + 128 * e + 16 * ((co >> 3) ^ ((e >> 1) & 7)) + 2 * (co & 7); }
+// LDS geometry for CK dY channels and CN dX channels
+template <int CK, int CN> struct Geo {
+  static constexpr int MBS = CN == 32 ? 2 : 1;         // 32-position blocks per chunk (the four waves: MBS x 2 roles x CN/32 channel blocks)
+  static constexpr int CH = 32 * MBS;                  // positions per chunk
+  static constexpr int NE = CH + 1;                    // entries per strip (the right neighbour of the last position)
+  static constexpr int ROW = 2 * CK;                   // bytes of an entry in one f16 plane
+  static constexpr int STRIP = NE * ROW;
+  static constexpr int PLANE = 2 * STRIP;              // both strips of one f16 piece
+  static constexpr int BUFB = 2 * PLANE;               // high + low pieces
+  static constexpr int PIECES = 2 * NE * (CK / 4);     // 16-byte pieces staged per chunk
+  static constexpr int NSLOT = (PIECES + 255) / 256;
+  // the 16-byte chunk index of an entry is XORed with a function of the entry so that the 16 lanes of a ds_read_b128 pass
+  // (consecutive entries, one chunk) land in 16 different 16-byte bank groups: 128-byte rows: bank group = 8 (e & 1) + chunk,
+  // 256-byte rows: bank group = chunk
+  static __device__ __forceinline__ int off(int strip, int e, int co) {
+    const int x = CK == 64 ? ((e >> 1) & 7) : (e & 15);
+    return strip * STRIP + ROW * e + 16 * ((co >> 3) ^ x) + 2 * (co & 7);
+  }
+};
 
 // taps of a role: (ky, kx, accumulator).  role 0: class (1,1) <- (0,0) (0,2) (2,0) (2,2), class (0,0) <- (1,1);
 // role 1: class (0,1) <- (1,0) (1,2), class (1,0) <- (0,1) (2,1)
@@ -68,30 +80,33 @@ template <> struct Taps<1> {
 // scalar walker over padded positions: (row = n*Ho + r, column in [0, Wp), r)
 struct Walk { int row, col, r; };
 __device__ __forceinline__ void walk_to(Walk& w, int q, int Wp, int Ho) { w.row = q / Wp; w.col = q - w.row * Wp; w.r = w.row % Ho; }
-__device__ __forceinline__ void walk_step(Walk& w, int Wp, int Ho) {      // + CH (< Wp: one wrap at most)
-  w.col += CH;
+__device__ __forceinline__ void walk_step(Walk& w, int step, int Wp, int Ho) {      // + step (< Wp: one wrap at most)
+  w.col += step;
   if (w.col >= Wp) { w.col -= Wp; ++w.row; if (++w.r == Ho) w.r = 0; }
 }
 
-template <int ROLE>
+template <int ROLE, int CK, int CN>
 __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm) {
   typedef Taps<ROLE> T;
-  constexpr int NT = T::N;
+  typedef Geo<CK, CN> G;
+  constexpr int NT = T::N, KS = CK / 16, CH = G::CH, NE = G::NE, PLANE = G::PLANE, BUFB = G::BUFB, NSLOT = G::NSLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mb = wave & 1;
+  const int mb = CN == 32 ? (wave & 1) : 0, nb = CN == 32 ? 0 : (wave & 1);
   const int m = lane & 31, kg = lane >> 5;
   const int Wp = p.Wo + 1, NR = p.N * p.Ho, W = 2 * p.Wo;
   const float s_a = pow2n(amax_read(p.amax_dy)), s_b = pow2n(amax_read(p.amax_w));
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0,
-      (unsigned)((((long long)NR * p.Wo - 1) * p.lddy + 64) * 4), 0x00020000);
+      (unsigned)((((long long)NR * p.Wo - 1) * p.lddy + CK) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0,
+      (unsigned)((((long long)NR * 4 * p.Wo - 1) * p.ldo + CN) * 4), 0x00020000);
 
   // ---- the wave's filter fragments, split once: B[k = co][n = ci = lane % 32], 8 consecutive co per lane ------------------
-  f16x8_t bh[NT][4], bl[NT][4];
+  f16x8_t bh[NT][KS], bl[NT][KS];
   auto load_b = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const float* src = p.wt + ((size_t)(m * 9 + T::ky[i] * 3 + T::kx[i]) * 64 + kk * 16 + 8 * kg);
+    for (int kk = 0; kk < KS; ++kk) {
+      const float* src = p.wt + ((size_t)((nb * 32 + m) * 9 + T::ky[i] * 3 + T::kx[i]) * CK + kk * 16 + 8 * kg);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s_b, v1 = *reinterpret_cast<const f32x4*>(src + 4) * s_b;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -104,18 +119,18 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   load_b(std::integral_constant<int, 3>{});
   if constexpr (NT > 4) load_b(std::integral_constant<int, 4>{});
 
-  // ---- staging list of a chunk: 2 strips x 65 entries x 16 pieces of 4 channels = 2080 pieces: 8 per thread + 32 more (wave 0) ----
-  constexpr int NSLOT = 9;
-  const bool last_on = __builtin_amdgcn_readfirstlane(wave) == 0;           // slot 8: lanes 32..63 repeat piece 2079
+  // ---- staging list of a chunk: 2 strips x NE entries x CK/4 pieces of 4 channels (2080 | 2112): 8 per thread + a rest for wave 0
+  static_assert(G::PIECES > 8 * 256 && G::PIECES <= 8 * 256 + 64, "the ninth slot is one wave");
+  const bool last_on = __builtin_amdgcn_readfirstlane(wave) == 0;           // slot 8: lanes past the list repeat its last piece
   int meta[NSLOT], st_off[NSLOT];                                              // meta = strip | entry << 1 | co << 8
 #pragma unroll
   for (int j = 0; j < NSLOT; ++j) {
     int idx = j * 256 + tid;
-    if (idx > 2 * NE * 16 - 1) idx = 2 * NE * 16 - 1;
-    const int strip = idx / (NE * 16), rem = idx - strip * (NE * 16);
-    const int e = rem >> 4, co = (rem & 15) * 4;
+    if (idx > G::PIECES - 1) idx = G::PIECES - 1;
+    const int strip = idx / (NE * (CK / 4)), rem = idx - strip * (NE * (CK / 4));
+    const int e = rem / (CK / 4), co = (rem % (CK / 4)) * 4;
     meta[j] = strip | (e << 1) | (co << 8);
-    st_off[j] = s_off(strip, e, co);
+    st_off[j] = G::off(strip, e, co);
   }
 
   const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
@@ -133,7 +148,7 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       if (col < p.Wo && row < NR && (strip == 0 || r + 1 < p.Ho)) off = (unsigned)((((row + strip) * p.Wo + col) * p.lddy + co) * 4);
       v[j] = ldn(a_rs, off);
     }
-    walk_step(wl, Wp, p.Ho);
+    walk_step(wl, CH, Wp, p.Ho);
   };
   auto store_chunk = [&](int buf, const f32x4* v) {
 #pragma unroll
@@ -149,14 +164,16 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     }
   };
 
-  // A fragment of (strip dyo, entry mb*32 + m + dxo, K-step kk): 8 channels from kk*16 + 8*kg
-  int a_addr[2][2][4];                               // [dyo][dxo][kk]
+  // A fragment of (strip dyo, entry mb*32 + m + dxo, K-step kk): 8 channels from kk*16 + 8*kg.  The swizzle only depends on the
+  // entry, so a K-step moves the 16-byte chunk index by two: chunk (2 kk + kg) ^ x
+  int a_base[2][2], a_x[2];                          // [dyo][dxo]: row base; [dxo]: the entry's XOR term
 #pragma unroll
-  for (int dyo = 0; dyo < 2; ++dyo)
+  for (int dxo = 0; dxo < 2; ++dxo) {
+    const int e = mb * 32 + m + dxo;
+    a_x[dxo] = CK == 64 ? ((e >> 1) & 7) : (e & 15);
 #pragma unroll
-    for (int dxo = 0; dxo < 2; ++dxo)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) a_addr[dyo][dxo][kk] = s_off(dyo, mb * 32 + m + dxo, kk * 16 + 8 * kg);
+    for (int dyo = 0; dyo < 2; ++dyo) a_base[dyo][dxo] = dyo * G::STRIP + G::ROW * e;
+  }
 
   const float dq = 1.f / (s_a * s_b);                // powers of two: exact
   f32x4 stage[NSLOT];
@@ -177,12 +194,15 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       constexpr int i = decltype(ic)::value;
       constexpr int dyo = T::ky[i] == 0 ? 1 : 0, dxo = T::kx[i] == 0 ? 1 : 0;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + a_addr[dyo][dxo][kk]);
-        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + a_addr[dyo][dxo][kk]);
+      for (int kk = 0; kk < KS; ++kk) {
+        const int ao = a_base[dyo][dxo] + 16 * ((2 * kk + kg) ^ a_x[dxo]);
+        const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + ao);
+        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + ao);
         acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][kk], acc[T::ac[i]], 0, 0, 0);      // smallest terms first
         acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][kk], acc[T::ac[i]], 0, 0, 0);
         acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][kk], acc[T::ac[i]], 0, 0, 0);
+        // (320 filter registers at CK = 128: keep the scheduler from reading all eight K-steps' fragments ahead of the MFMAs)
+        if constexpr (KS > 4) { if (kk & 1) __builtin_amdgcn_sched_barrier(0); }
       }
     };
     tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
@@ -200,19 +220,23 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       if (col >= Wp) { col -= Wp; ++row; }
       if (col >= p.Wo || q0 + pos >= p.Mp) continue;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const size_t pix = (size_t)(2 * row + T::ca[a]) * W + 2 * col + T::cb[a];
-        p.dx[pix * p.ldo + m] = acc[a][q] * dq;
+      for (int a = 0; a < 2; ++a) {               // (32-bit byte offsets through a buffer descriptor: one address register per store)
+        const int pix = (2 * row + T::ca[a]) * W + 2 * col + T::cb[a];
+        const int off = (pix * p.ldo + nb * 32 + m) * 4;
+        float v = acc[a][q] * dq;
+        if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rs, off, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, off, 0, 0);
       }
     }
-    walk_step(wc, Wp, p.Ho);
+    walk_step(wc, CH, Wp, p.Ho);
   }
 }
 
+template <int CK, int CN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dgrad2_kernel(const D2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smn[];       // [2 buffers][high | low][strip r | strip r+1]
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0>(p, smn);
-  else dgrad2_body<1>(p, smn);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN>(p, smn);
+  else dgrad2_body<1, CK, CN>(p, smn);
 }
 
 int g_nconv = 1;          // dcn_set_tuning("Nconv", 0): these layers back on the implicit-GEMM tiles
@@ -222,15 +246,31 @@ int g_ncus = 0;
 
 void nconv_set_tuning(int v) { g_nconv = v; }
 
-// the 32 -> 64 3x3 stride-2 layer's data gradient (dY 64 channels -> dX 32 channels), dense dX
+// data gradients of the 32 -> 64 and 64 -> 128 3x3 stride-2 layers (dY 64 | 128 channels -> dX 32 | 64 channels), dense dX
 bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int stride, int accumulate) {
-  if (!g_nconv || ksize != 3 || stride != 2 || cin != 32 || cout != 64 || accumulate) return false;
-  if ((h & 1) || (wd & 1) || wd / 2 < CH || h < 4) return false;                       // (one row wrap per chunk at most)
-  if ((long long)n * h * wd * 32 * 4 >= 0x7FFFFFF0LL || (long long)n * (h / 2) * (wd / 2 + 1) >= 0x7FFFFFF0LL) return false;
+  if (!g_nconv || ksize != 3 || stride != 2 || !((cin == 32 && cout == 64) || (cin == 64 && cout == 128 && g_nconv != 2))) return false;
+  (void)accumulate;
+  if ((h & 1) || (wd & 1) || wd / 2 < 64 || h < 4) return false;                       // (one row wrap per chunk at most)
+  if ((long long)n * h * wd * cin * 4 >= 0x7FFFFFF0LL || (long long)n * (h / 2) * (wd / 2 + 1) >= 0x7FFFFFF0LL) return false;
   return (long long)n * h * wd >= 65536;                                               // (a persistent grid wants work for every CU)
 }
 
-int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd,
+template <int CK, int CN>
+int launch_d2(D2Params& p, int grid, double flop, double bytes, hipStream_t stream) {
+  typedef Geo<CK, CN> G;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
+    attr_done = true;
+  }
+  const int pid = prof_begin(37, flop, stream, bytes);
+  hipLaunchKernelGGL((dgrad2_kernel<CK, CN>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("dgrad2");
+  return DCN_OK;
+}
+
+int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
                   const uint32_t* amax_dy, const uint32_t* amax_w, hipStream_t stream) {
   DCN_CHECK_ARG((long long)n * (h / 2) * (wd / 2) * lddy * 4 < 0x7FFFFFF0LL, "conv2d_bwd_data: dY slice exceeds 32-bit byte offsets");
   if (!g_ncus) {
@@ -238,23 +278,16 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
     g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  const int ch = cin == 32 ? 64 : 32, ck = 2 * cin;
   D2Params p{};
-  p.dy = dy; p.wt = wt; p.dx = dx; p.N = n; p.Ho = h / 2; p.Wo = wd / 2; p.lddy = lddy; p.ldo = 32;
+  p.dy = dy; p.wt = wt; p.dx = dx; p.N = n; p.Ho = h / 2; p.Wo = wd / 2; p.lddy = lddy; p.ldo = cin; p.accumulate = accumulate;
   p.Mp = n * p.Ho * (p.Wo + 1);
-  p.nchunks = cdiv(p.Mp, CH);
+  p.nchunks = cdiv(p.Mp, ch);
   int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
   p.per_wg = cdiv(p.nchunks, grid);
   grid = cdiv(p.nchunks, p.per_wg);
   p.amax_dy = amax_dy; p.amax_w = amax_w;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUFB);
-    attr_done = true;
-  }
-  const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * 64 + (double)n * h * wd * 32 + 32.0 * 9 * 64);
-  const int pid = prof_begin(37, 2.0 * (double)n * p.Ho * p.Wo * 64 * 9.0 * 32, stream, bytes);
-  hipLaunchKernelGGL(dgrad2_kernel, dim3(grid), dim3(256), 2 * BUFB, stream, p);
-  prof_end(pid, stream);
-  DCN_CHECK_LAUNCH("dgrad2");
-  return DCN_OK;
+  const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * ck + (double)n * h * wd * cin * (accumulate ? 2 : 1) + (double)cin * 9 * ck);
+  const double flop = 2.0 * (double)n * p.Ho * p.Wo * ck * 9.0 * cin;
+  return cin == 32 ? launch_d2<64, 32>(p, grid, flop, bytes, stream) : launch_d2<128, 64>(p, grid, flop, bytes, stream);
 }

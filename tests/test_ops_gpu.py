@@ -941,33 +941,38 @@ def test_filter_banks_match_the_per_layer_preparation(dev):
 
 
 D2_CASES = [
-    # n, h, w   (32 -> 64 3x3 stride 2: dY (n, h/2, w/2, 64) -> dX (n, h, w, 32); >= 65536 input pixels, output rows of >= 64)
-    (4, 128, 128),
-    (2, 130, 256),
-    (3, 132, 176),      # 89 padded entries per row: a chunk of 64 wraps in most steps, images wrap too
-    (1, 264, 256),
+    # n, h, w, cin   (cin -> 2 cin 3x3 stride 2: dY (n, h/2, w/2, 2 cin) -> dX (n, h, w, cin); >= 65536 input pixels, output rows of >= 64)
+    (4, 128, 128, 32),
+    (2, 130, 256, 32),
+    (3, 132, 176, 32),      # 89 padded entries per row: a chunk of 64 wraps in most steps, images wrap too
+    (1, 264, 256, 32),
+    (4, 128, 128, 64),
+    (3, 132, 176, 64),
+    (1, 264, 258, 64),
 ]
 
 
 @pytest.mark.parametrize("case", D2_CASES)
 def test_dgrad2_register_bank_kernel(dev, case):
-    """csrc/nconv.hip (data gradient of the 32 -> 64 stride-2 layer: four parity classes from one pass over dY, filter bank in
-    registers, persistent workgroups) against fp64 and against the implicit-GEMM launch it replaces: image borders (the row below
-    the last dY row and the column right of the last column read zeros), chunk / row / image wraps, a dY that is a slice of a
-    wider tensor, with and without the prepared banks."""
+    """csrc/nconv.hip (data gradients of the 32 -> 64 and 64 -> 128 stride-2 layers: four parity classes from one pass over dY,
+    filter bank in registers, persistent workgroups) against fp64 and against the implicit-GEMM launch it replaces: image borders
+    (the row below the last dY row and the column right of the last column read zeros), chunk / row / image wraps, a dY that is a
+    slice of a wider tensor, accumulation into an existing gradient, with and without the prepared banks."""
     from dcnet_amd import ops
     from dcnet_amd.lib import lib
-    n, h, w = case
-    wgt = (_rand(64, 32, 3, 3, seed=61) / 6)
-    wide = _rand(n, h // 2, w // 2, 96, seed=62).to(dev)
-    dy = wide[..., 16:80]                                          # pixel stride 96
-    xd = torch.zeros(n, 32, h, w, dtype=torch.float64, requires_grad=True)
+    n, h, w, cin = case
+    cout = 2 * cin
+    wgt = (_rand(cout, cin, 3, 3, seed=61) / 6)
+    wide = _rand(n, h // 2, w // 2, cout + 32, seed=62).to(dev)
+    dy = wide[..., 16:16 + cout]                                   # pixel stride cout + 32
+    xd = torch.zeros(n, cin, h, w, dtype=torch.float64, requires_grad=True)
     F.conv2d(xd, wgt.double(), padding=1, stride=2).backward(dy.permute(0, 3, 1, 2).double().cpu())
     ref = xd.grad.permute(0, 2, 3, 1)
     w_ohwi = wgt.permute(0, 2, 3, 1).contiguous().to(dev)
     wdev = wgt.to(dev)
     fb = ops.FilterBanks([wdev], dev); fb.refresh()
     b = fb.get(0, wdev)
+    base = _rand(n, h, w, cin, seed=63).to(dev)
     try:
         lib().set_tuning(b"Nconv", 0)
         old = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2)
@@ -978,11 +983,14 @@ def test_dgrad2_register_bank_kernel(dev, case):
         ran = _prof_launches(37)
         new_c = ops.conv2d_bwd_data(dy.contiguous(), w_ohwi, (h, w), 3, 2)
         new_b = ops.conv2d_bwd_data(dy, b["ohwi"], (h, w), 3, 2, amax_w=b["amax"], wt_ready=(b["t"], b["tsplit"]))
+        acc = base.clone()
+        ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2, out=acc, accumulate=True)
     finally:
         lib().set_tuning(b"Nconv", 1); lib().prof_enable(0)
     assert ran == 1, "the register-bank kernel did not run"
     _close(new, ref, 2e-5, "dgrad2")
     _close(old, ref, 2e-5, "implicit-GEMM classes")
+    _close(acc, ref + base.double().cpu(), 2e-5, "dgrad2 accumulate")
     assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
     assert torch.equal(new, new_b)                                 # nor do the prepared banks
     assert torch.equal(new, ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2))
