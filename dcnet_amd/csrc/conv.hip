@@ -112,6 +112,11 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
       }
   }
   if (p.c4 && stem_applicable(p, w_split)) return stem_launch(p, w_split, (hipStream_t)stream);      // (w_split: scratch of >= 27*32 floats)
+  // the 32 -> 64 3x3 layers of the 416x416 / 208x208 maps, raw result + BatchNorm partial sums: filter bank in registers (nconv.hip)
+  if (amax_x && amax_w && !amax_y && !f8_scales && !scale && !shift && !residual && act == DCN_ACT_NONE && !accumulate &&
+      w_split_ready != 2 && igemm_precision() == 4 && nconv1_applicable(0, n, h, wd, cin, cout, ksize, stride))
+    return nconv1_launch(0, x, cin, w, y, p.ldo, stats, stats ? dcn_conv2d_stats_rows(n, h, wd, cout, ksize, stride) : 0,
+                         n, h, wd, stride, amax_x, amax_w, (hipStream_t)stream);
   if (w_split && w_split_ready == 2) {
     p.wt16 = w_split;             // bf16-operand mode: the bank converted to bf16 (dcn_prepare_filters); read by the strip kernel only
   } else
@@ -151,6 +156,9 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && igemm_precision() == 4 &&
       dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, accumulate))
     return dgrad2_launch(dy, lddy, wt, dx, n, h, wd, cin, accumulate, amax_dy, amax_w, stream);
+  if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && !accumulate && igemm_precision() == 4 &&
+      nconv1_applicable(1, n, h, wd, cin, cout, ksize, stride))
+    return nconv1_launch(1, dy, lddy, wt, dx, cin, nullptr, 0, n, h, wd, 1, amax_dy, amax_w, stream);
   IgemmParams p; base_params(p);
   p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx; p.amax_a = amax_dy; p.amax_b = amax_w;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;

@@ -122,15 +122,18 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   // ---- staging list of a chunk: 2 strips x NE entries x CK/4 pieces of 4 channels (2080 | 2112): 8 per thread + a rest for wave 0
   static_assert(G::PIECES > 8 * 256 && G::PIECES <= 8 * 256 + 64, "the ninth slot is one wave");
   const bool last_on = __builtin_amdgcn_readfirstlane(wave) == 0;           // slot 8: lanes past the list repeat its last piece
-  int meta[NSLOT], st_off[NSLOT];                                              // meta = strip | entry << 1 | co << 8
+  // per piece: meta = strip | entry << 1, its LDS offset, and the chunk-independent part of its global byte offset: the chunk's
+  // first entry sits at dY pixel (row + strip)*Wo + col + e, minus one when the entry wrapped into the next padded row
+  int meta[NSLOT], st_off[NSLOT], k_off[NSLOT];
 #pragma unroll
   for (int j = 0; j < NSLOT; ++j) {
     int idx = j * 256 + tid;
     if (idx > G::PIECES - 1) idx = G::PIECES - 1;
     const int strip = idx / (NE * (CK / 4)), rem = idx - strip * (NE * (CK / 4));
     const int e = rem / (CK / 4), co = (rem % (CK / 4)) * 4;
-    meta[j] = strip | (e << 1) | (co << 8);
+    meta[j] = strip | (e << 1);
     st_off[j] = G::off(strip, e, co);
+    k_off[j] = ((strip * p.Wo + e) * p.lddy + co) * 4;
   }
 
   const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
@@ -141,11 +144,12 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       if (j == NSLOT - 1 && !last_on) continue;
-      const int strip = meta[j] & 1, e = (meta[j] >> 1) & 127, co = meta[j] >> 8;
-      int col = wl.col + e, row = wl.row, r = wl.r;
-      if (col >= Wp) { col -= Wp; ++row; if (++r == p.Ho) r = 0; }
-      unsigned off = OOBN;
-      if (col < p.Wo && row < NR && (strip == 0 || r + 1 < p.Ho)) off = (unsigned)((((row + strip) * p.Wo + col) * p.lddy + co) * 4);
+      const int strip = meta[j] & 1, e = meta[j] >> 1;
+      const int t = wl.col + e;                                       // == Wo: the pad entry; beyond: the next padded row
+      const int r = t > p.Wo ? (wl.r + 1 == p.Ho ? 0 : wl.r + 1) : wl.r;
+      const int base = (wl.row * p.Wo + wl.col) * p.lddy * 4;         // (scalar)
+      unsigned off = (unsigned)(base + k_off[j] - (t > p.Wo ? p.lddy * 4 : 0));
+      if (t == p.Wo || (strip == 1 && r + 1 >= p.Ho)) off = OOBN;     // (rows past the tensor: out of the descriptor's range, read as zero)
       v[j] = ldn(a_rs, off);
     }
     walk_step(wl, CH, Wp, p.Ho);
@@ -212,16 +216,18 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     if constexpr (NT > 4) tap(std::integral_constant<int, 4>{});
 
     // ---- store: D[m = position][n = ci]; register q <-> position mb*32 + (q & 3) + 8 (q >> 2) + 4 kg ---------------------------
+    // dX pixel of position pos, class (a, b): (2 row + a)*W + 2 (col + pos) + b; behind the pad entry the position sits in the next
+    // padded row: +2W - 2 Wp = -2 pixels ... +2W
     const int q0 = c * CH;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
-      int col = wc.col + pos, row = wc.row;
-      if (col >= Wp) { col -= Wp; ++row; }
-      if (col >= p.Wo || q0 + pos >= p.Mp) continue;
+      const int t = wc.col + pos;
+      if (t == p.Wo || q0 + pos >= p.Mp) continue;
+      const int pbase = 2 * wc.row * W + 2 * t + (t > p.Wo ? 2 * W - 2 * Wp : 0);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {               // (32-bit byte offsets through a buffer descriptor: one address register per store)
-        const int pix = (2 * row + T::ca[a]) * W + 2 * col + T::cb[a];
+        const int pix = pbase + T::ca[a] * W + T::cb[a];
         const int off = (pix * p.ldo + nb * 32 + m) * 4;
         float v = acc[a][q] * dq;
         if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rs, off, 0, 0));
@@ -237,6 +243,227 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) unsigned char smn[];       // [2 buffers][high | low][strip r | strip r+1]
   if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN>(p, smn);
   else dgrad2_body<1, CK, CN>(p, smn);
+}
+
+// =====================================================================================================================
+// 3x3 layers between 32 and 64 channels with the filter bank in registers: the 32 -> 64 layer of the first residual block on the
+// 208x208 map (S = 1, forward, and its data gradient 64 -> 32) and the forward of the 32 -> 64 stride-2 layer on the 416x416 map
+// (S = 2).  igemm.hip runs them on 256 x 64 / 256 x 32 tiles that gather every tap from L2: 0.75-0.93 ms against 0.2-0.4 ms of
+// HBM traffic.  Same scheme as dgrad2_kernel: one persistent workgroup per CU walks padded OUTPUT positions (rows of Wo + 1 entries)
+// in chunks of 64 and stages, per chunk, the three input rows the taps touch as strips of X_pad[S*q + kx] entries (rows of
+// S*(Wo+1) entries whose entry u is image column u - 1: the left / right borders read zeros without masks; the top / bottom rows
+// are zeroed when staged; S = 2: even and odd entries in separate planes, so that every tap reads consecutive rows).  The four
+// waves are (position block, channel block): CN = 64: wave (mb, nb) owns 32 positions x 32 filters and all of K = 32;
+// CN = 32 (the data gradient): wave (mb, kh) owns 32 positions x 32 channels and HALF of K = 64 — the two halves meet in LDS
+// before the store.  Either way a wave keeps 9 taps x 2 K-steps of split filter fragments (144 registers).  The forward also
+// produces the BatchNorm partial sums: one row per workgroup (accumulated over its chunks), the caller's remaining rows are zeroed.
+struct N1Params {
+  const float* x; const float* w; float* y; float* stats;   // w: [CN][9][CK] fp32 (OHWI bank, or the transposed bank of the data gradient)
+  int N, Ho, Wo, ldi, ldo;                                    // Ho x Wo: OUTPUT grid; input (S*Ho) x (S*Wo)
+  int Mp, nchunks, per_wg;
+  const unsigned* amax_x; const unsigned* amax_w;
+};
+
+template <int S, int CK> struct Geo1 {
+  static constexpr int CH = 64;
+  static constexpr int NE = S * (CH - 1) + 3;            // entries per strip: 66 | 129
+  static constexpr int NEV = S == 1 ? NE : CH + 1;       // S = 2: rows of the even plane (65), then CH rows of the odd plane
+  static constexpr int ROW = 2 * CK;                     // bytes of an entry in one f16 plane: 64 | 128
+  static constexpr int STRIP = NE * ROW;
+  static constexpr int PLANE = 3 * STRIP;                // three input rows
+  static constexpr int BUFB = 2 * PLANE;                 // high + low pieces
+  static constexpr int PIECES = 3 * NE * (CK / 4);
+  static constexpr int NSLOT = (PIECES + 255) / 256;
+  static __device__ __forceinline__ int row_of(int e) { return S == 1 ? e : ((e & 1) ? NEV + (e >> 1) : (e >> 1)); }    // LDS row of entry e
+  // 16-byte chunk swizzle: 64-byte rows: chunk ^ (row / 4) % 4; 128-byte rows: chunk ^ (row / 2) % 8 (16 consecutive rows of one
+  // chunk -> 16 different 16-byte bank groups)
+  static __device__ __forceinline__ int off(int strip, int row, int c) {
+    const int x = CK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+    return strip * STRIP + ROW * row + 16 * ((c >> 3) ^ x) + 2 * (c & 7);
+  }
+};
+
+template <int S, int CK, int CN, bool FLIP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nconv1_kernel(const N1Params p) {
+  typedef Geo1<S, CK> G;
+  constexpr int CH = G::CH, NE = G::NE, PLANE = G::PLANE, BUFB = G::BUFB, NSLOT = G::NSLOT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];       // [2 buffers][high | low][3 strips]  (+ CN = 32: the K-halves' exchange)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mb = wave & 1, hb = wave >> 1;               // hb: channel block (CN = 64) or K half (CN = 32)
+  const int nb = CN == 64 ? hb : 0, kofs = CN == 64 ? 0 : hb * 32;
+  const int m = lane & 31, kg = lane >> 5;
+  const int Wp = p.Wo + 1, RL = S * Wp, NR = p.N * p.Ho, W = S * p.Wo, H = S * p.Ho;
+  const float s_a = pow2n(amax_read(p.amax_x)), s_b = pow2n(amax_read(p.amax_w));
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0,
+      (unsigned)((((long long)p.N * H * W - 1) * p.ldi + CK) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0,
+      (unsigned)((((long long)NR * p.Wo - 1) * p.ldo + CN) * 4), 0x00020000);
+
+  // ---- the wave's filter fragments (tap t = 3 j + kx of strip j, entry offset kx; FLIP: the data gradient reads bank tap 8 - t) ----
+  f16x8_t bh[9][2], bl[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const float* src = p.w + ((size_t)((nb * 32 + m) * 9 + (FLIP ? 8 - t : t)) * CK + kofs + kk * 16 + 8 * kg);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s_b, v1 = *reinterpret_cast<const f32x4*>(src + 4) * s_b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bh[t][kk][e] = (_Float16)v0[e]; bh[t][kk][4 + e] = (_Float16)v1[e];
+        bl[t][kk][e] = (_Float16)(v0[e] - (float)bh[t][kk][e]); bl[t][kk][4 + e] = (_Float16)(v1[e] - (float)bh[t][kk][4 + e]);
+      }
+    }
+
+  // ---- staging list of a chunk: 3 strips x NE entries x CK/4 pieces; the last slot is a partial one (whole waves) --------------
+  constexpr int FULL = G::PIECES / 256, REST = G::PIECES - FULL * 256;            // REST pieces in slot FULL: waves 0 .. ceil(REST/64)-1
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool last_on = REST > 0 && wave_u * 64 < REST;
+  // per piece: meta = strip | entry << 2, its LDS offset, and the part of its global byte offset that does not depend on the chunk:
+  // the chunk's first entry sits at input pixel (S*row + strip - 1)*W + S*col - 1 + e, plus S*W - RL when the entry wrapped into the
+  // next padded row
+  int meta[NSLOT], st_off[NSLOT], k_off[NSLOT];
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) {
+    int idx = j * 256 + tid;
+    if (idx > G::PIECES - 1) idx = G::PIECES - 1;                              // (lanes past the list repeat its last piece)
+    const int strip = idx / (NE * (CK / 4)), rem = idx - strip * (NE * (CK / 4));
+    const int e = rem / (CK / 4), c = (rem % (CK / 4)) * 4;
+    meta[j] = strip | (e << 2);
+    st_off[j] = G::off(strip, G::row_of(e), c);
+    k_off[j] = ((((strip - 1) * W + e - 1) * p.ldi) + c) * 4;
+  }
+  const int wrap_delta = (S * W - RL) * p.ldi * 4;          // an output row further: S input rows on, one padded row of entries back
+
+  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
+  Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy, column, oy)
+  walk_to(wl, c_begin * CH, Wp, p.Ho); wc = wl;
+
+  // scalar state of the chunk being loaded (all derived from the walker): byte offset of its first entry, the entry index from which
+  // entries wrap into the next padded row, and whether strip 0 / strip 2 lie outside the image before / after the wrap
+  auto load_slot = [&](int j, f32x4* v) {
+    if (j >= FULL && !last_on) return;
+    const int strip = meta[j] & 3, e = meta[j] >> 2;
+    const int u0 = S * wl.col;
+    const bool wrapped = e >= RL - u0;
+    const int u = u0 + e - (wrapped ? RL : 0);                      // entry within its padded row: image column u - 1
+    const int oy = wrapped ? (wl.r + 1 == p.Ho ? 0 : wl.r + 1) : wl.r;
+    const bool row_out = (strip == 0 && oy == 0) || (S == 1 && strip == 2 && oy == p.Ho - 1);
+    const int base = (S * wl.row * W + u0) * p.ldi * 4;             // (scalar)
+    unsigned off = (unsigned)(base + k_off[j] + (wrapped ? wrap_delta : 0));
+    if ((unsigned)(u - 1) >= (unsigned)W || row_out) off = OOBN;    // (rows past the tensor: out of the descriptor's range, read as zero)
+    v[j] = ldn(a_rs, off);
+  };
+  auto store_slot = [&](int j, int buf, const f32x4* v) {
+    if (j >= FULL && !last_on) return;
+    const f32x4 t = v[j] * s_a;
+    const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+    const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                       (_Float16)(t[3] - (float)h[3])};
+    unsigned char* dst = sm + buf * BUFB + st_off[j];
+    *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(dst + PLANE) = __builtin_bit_cast(uint2, l);
+  };
+  auto load_chunk = [&](f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) load_slot(j, v);
+    walk_step(wl, CH, Wp, p.Ho);
+  };
+  auto store_chunk = [&](int buf, const f32x4* v) {
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) store_slot(j, buf, v);
+  };
+
+  // A fragment of (strip j, tap column kx, K-step kk): LDS row of entry S*(mb*32 + m) + kx, 8 channels from kofs + kk*16 + 8*kg
+  int a_addr[3][2];                                  // [kx][kk], strip 0
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) a_addr[kx][kk] = G::off(0, G::row_of(S * (mb * 32 + m) + kx), kofs + kk * 16 + 8 * kg);
+
+  const float dq = 1.f / (s_a * s_b);                // powers of two: exact
+  float st_s = 0.f, st_ss = 0.f;                     // BatchNorm partial sums of this lane's filter over the workgroup's positions
+  f32x4 stage[NSLOT];
+  if (c_begin < c_end) {
+    load_chunk(stage);
+    store_chunk(0, stage);
+    load_chunk(stage);                                // chunk c_begin + 1 (past the range: unused)
+  }
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    __syncthreads();
+    // Two accumulators (one per K-step of a tap): a wave is alone on its SIMD, and 54 MFMAs chained through ONE accumulator wait
+    // for each other's results.  The staging of chunk c + 1 (split + LDS store of the pieces loaded during the previous chunk)
+    // and the loads of chunk c + 2 are spread over the taps, slot by slot, so that their vector-ALU work runs under the MFMAs.
+    f32x16 acc, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[q] = 0.f; acc1[q] = 0.f; }
+    constexpr int PER_TAP = (NSLOT + 8) / 9;          // slots handled behind each tap
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int j = t / 3, kx = t - 3 * j;
+      {
+        const int ao = buf * BUFB + j * G::STRIP + a_addr[kx][0];
+        const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + ao);
+        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + ao + PLANE);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t][0], acc, 0, 0, 0);      // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][0], acc, 0, 0, 0);
+      }
+      {
+        const int ao = buf * BUFB + j * G::STRIP + a_addr[kx][1];
+        const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + ao);
+        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + ao + PLANE);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t][1], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t][1], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][1], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < PER_TAP; ++k) {
+        const int sl = t * PER_TAP + k;
+        if (sl < NSLOT) { store_slot(sl, buf ^ 1, stage); load_slot(sl, stage); }
+      }
+    }
+    walk_step(wl, CH, Wp, p.Ho);                      // (the loads above were chunk c + 2)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] += acc1[q];
+
+    if constexpr (CN == 32) {                         // the two K halves of a position block meet in LDS (behind the staging buffers)
+      float* xch = reinterpret_cast<float*>(sm + 2 * BUFB) + mb * 16 * 64;
+      if (hb == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xch[q * 64 + lane] = acc[q];
+      }
+      __syncthreads();
+      if (hb == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += xch[q * 64 + lane];
+      }
+    }
+    // ---- store: D[m = position][n = channel]; register q <-> position mb*32 + (q & 3) + 8 (q >> 2) + 4 kg -------------------
+    if (CN == 64 || hb == 0) {
+      // output pixel of position pos: row*Wo + col + pos, minus one behind the pad entry (col + pos == Wo: the pad itself, no pixel)
+      const int q0 = c * CH;
+      const int obase = ((wc.row * p.Wo + wc.col) * p.ldo + nb * 32 + m) * 4;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+        const int t = wc.col + pos;
+        if (t == p.Wo || q0 + pos >= p.Mp) continue;
+        const float v = acc[q] * dq;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, obase + (pos - (t > p.Wo ? 1 : 0)) * p.ldo * 4, 0, 0);
+        st_s += v; st_ss += v * v;
+      }
+    }
+    walk_step(wc, CH, Wp, p.Ho);
+  }
+  if (p.stats) {                                      // one partial row per workgroup: [2][CN]
+    st_s += __shfl_xor(st_s, 32); st_ss += __shfl_xor(st_ss, 32);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sm);       // [mb][2][CN]
+    if (kg == 0 && (CN == 64 || hb == 0)) { red[(mb * 2 + 0) * CN + nb * 32 + m] = st_s; red[(mb * 2 + 1) * CN + nb * 32 + m] = st_ss; }
+    __syncthreads();
+    if (tid < 2 * CN) p.stats[(size_t)blockIdx.x * 2 * CN + tid] = red[tid] + red[2 * CN + tid];
+  }
 }
 
 int g_nconv = 1;          // dcn_set_tuning("Nconv", 0): these layers back on the implicit-GEMM tiles
@@ -290,4 +517,64 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
   const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * ck + (double)n * h * wd * cin * (accumulate ? 2 : 1) + (double)cin * 9 * ck);
   const double flop = 2.0 * (double)n * p.Ho * p.Wo * ck * 9.0 * cin;
   return cin == 32 ? launch_d2<64, 32>(p, grid, flop, bytes, stream) : launch_d2<128, 64>(p, grid, flop, bytes, stream);
+}
+
+// ---- 3x3 layers between 32 and 64 channels (forward S = 1 | 2, data gradient S = 1) ---------------------------------------------
+// mode 0: forward 32 -> 64 (stride 1 | 2);  mode 1: data gradient of the stride-1 layer (dY 64 channels -> dX 32 channels)
+bool nconv1_applicable(int mode, int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  if (!g_nconv || g_nconv == 3 || ksize != 3 || cin != 32 || cout != 64) return false;
+  if (mode == 1 && stride != 1) return false;
+  if (stride != 1 && stride != 2) return false;
+  if ((h % stride) || (wd % stride) || wd / stride < 64 || h / stride < 2) return false;      // (one row wrap per chunk at most)
+  const long long opix = (long long)n * (h / stride) * (wd / stride);
+  if ((long long)n * h * wd * (mode == 0 ? 32 : 64) * 4 >= 0x7FFFFFF0LL || opix * (mode == 0 ? 64 : 32) * 4 >= 0x7FFFFFF0LL) return false;   // 32-bit byte offsets (dense)
+  return (long long)n * (h / stride) * (wd / stride) >= 65536;                                // (a persistent grid wants work for every CU)
+}
+
+template <int S, int CK, int CN, bool FLIP>
+int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stream) {
+  typedef Geo1<S, CK> G;
+  const int lds = 2 * G::BUFB + (CN == 32 ? 2 * 16 * 64 * 4 : 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const int pid = prof_begin(38, flop, stream, bytes);
+  hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP>), dim3(grid), dim3(256), lds, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("nconv1");
+  return DCN_OK;
+}
+
+// x: the gathered tensor (forward: input (n, h, wd, 32); data gradient: dY (n, h, wd, 64)), w: fp32 bank [CN][9][CK], y: the output
+// (forward: (n, h/s, wd/s, 64) with pixel stride ldo; data gradient: dX (n, h, wd, 32)), stats: [stats_rows][2][64] or null
+int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, int ldo, float* stats, int stats_rows,
+                  int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, hipStream_t stream) {
+  if (!g_ncus) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("nconv1: device query failed"); return DCN_ERR_LAUNCH; }
+    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int ck = mode == 0 ? 32 : 64, cn = mode == 0 ? 64 : 32;
+  DCN_CHECK_ARG((long long)n * h * wd * ldi * 4 < 0x7FFFFFF0LL && (long long)n * (h / stride) * (wd / stride) * ldo * 4 < 0x7FFFFFF0LL,
+                "conv2d: a sliced operand exceeds the 32-bit byte offsets of the register-bank kernel");
+  N1Params p{};
+  p.x = x; p.w = w; p.y = y; p.stats = stats; p.N = n; p.Ho = h / stride; p.Wo = wd / stride; p.ldi = ldi; p.ldo = ldo;
+  p.Mp = n * p.Ho * (p.Wo + 1);
+  p.nchunks = cdiv(p.Mp, 64);
+  int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
+  p.per_wg = cdiv(p.nchunks, grid);
+  grid = cdiv(p.nchunks, p.per_wg);
+  p.amax_x = amax_x; p.amax_w = amax_w;
+  if (stats) {
+    DCN_CHECK_ARG(stats_rows >= grid, "conv2d_fwd: %d statistics rows for %d workgroups", stats_rows, grid);
+    if (stats_rows > grid && hipMemsetAsync(stats + (size_t)grid * 2 * cn, 0, (size_t)(stats_rows - grid) * 2 * cn * sizeof(float), stream) != hipSuccess) {
+      dcn_set_error("conv2d_fwd: memset of the statistics rows failed"); return DCN_ERR_LAUNCH;
+    }
+  }
+  const double bytes = 4.0 * ((double)n * h * wd * ck + (double)n * p.Ho * p.Wo * cn + 64.0 * 9 * 32);
+  const double flop = 2.0 * (double)n * p.Ho * p.Wo * 64 * 9.0 * 32;
+  if (mode == 1) return launch_n1<1, 64, 32, true>(p, grid, flop, bytes, stream);
+  return stride == 1 ? launch_n1<1, 32, 64, false>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false>(p, grid, flop, bytes, stream);
 }

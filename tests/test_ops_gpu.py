@@ -996,6 +996,75 @@ def test_dgrad2_register_bank_kernel(dev, case):
     assert torch.equal(new, ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2))
 
 
+N1_CASES = [
+    # mode, stride, n, h, w   (input size; 32 <-> 64 channels, 3x3; >= 65536 output pixels, output rows of >= 64)
+    ("fwd", 1, 4, 128, 128),
+    ("fwd", 1, 3, 132, 176),
+    ("fwd", 1, 1, 258, 255),     # odd width: 256 padded entries per row
+    ("fwd", 2, 4, 256, 256),
+    ("fwd", 2, 3, 264, 352),
+    ("fwd", 2, 2, 520, 260),
+    ("dgrad", 1, 4, 128, 128),
+    ("dgrad", 1, 3, 132, 176),
+    ("dgrad", 1, 1, 258, 255),
+]
+
+
+@pytest.mark.parametrize("case", N1_CASES)
+def test_nconv1_register_bank_kernels(dev, case):
+    """csrc/nconv.hip nconv1_kernel (32 -> 64 3x3 forward at stride 1 and 2 with BatchNorm partial sums, and the stride-1 data
+    gradient 64 -> 32; filter bank in registers, persistent workgroups over padded output positions) against fp64 and against the
+    implicit-GEMM tiles they replace: image borders, chunk / row / image wraps, the stride-2 even / odd planes, sliced outputs."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    mode, st, n, h, w = case
+    wgt = (_rand(64, 32, 3, 3, seed=71) / 6)
+    w_ohwi = wgt.permute(0, 2, 3, 1).contiguous().to(dev)
+    if mode == "fwd":
+        x = _rand(n, h, w, 32, seed=72).to(dev)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wgt.double(), padding=1, stride=st).permute(0, 2, 3, 1)
+        ho, wo = ref.shape[1], ref.shape[2]
+
+        def run():
+            y, stats = ops.conv2d_fwd(x, w_ohwi, 3, st, want_stats=True)
+            buf = torch.zeros(n, ho, wo, 128, device=dev)
+            ops.conv2d_fwd(x, w_ohwi, 3, st, out=buf[..., 32:96])
+            return y, stats, buf
+    else:
+        wide = _rand(n, h, w, 96, seed=73).to(dev)
+        dy = wide[..., 16:80]
+        xd = torch.zeros(n, 32, h, w, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xd, wgt.double(), padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+        ref = xd.grad.permute(0, 2, 3, 1)
+
+        def run():
+            return ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 1), None, ops.conv2d_bwd_data(dy.contiguous(), w_ohwi, (h, w), 3, 1)
+    try:
+        lib().set_tuning(b"Nconv", 0)
+        old = run()
+        lib().set_tuning(b"Nconv", 1)
+        lib().prof_enable(1)
+        new = run()
+        lib().prof_enable(0)
+        ran = _prof_launches(38)
+    finally:
+        lib().set_tuning(b"Nconv", 1); lib().prof_enable(0)
+    assert ran == 2, "the register-bank kernel did not run"
+    _close(new[0], ref, 2e-5, f"nconv1 {mode}")
+    _close(old[0], ref, 2e-5, "implicit-GEMM tile")
+    if mode == "fwd":
+        rawl = ref.reshape(-1, 64)
+        _close(new[1][:, 0].double().sum(0), rawl.sum(0), 1e-4, "nconv1 stats sum")
+        _close(new[1][:, 1].double().sum(0), (rawl * rawl).sum(0), 1e-4, "nconv1 stats sumsq")
+        assert new[1].shape == old[1].shape
+        assert torch.equal(new[2][..., 32:96], new[0])
+        assert float(new[2][..., :32].abs().max()) == 0 and float(new[2][..., 96:].abs().max()) == 0
+    else:
+        assert torch.equal(new[0], new[2])                          # the pixel stride of dY changes nothing
+    again = run()
+    assert torch.equal(new[0], again[0]) and (mode != "fwd" or torch.equal(new[1], again[1]))
+
+
 def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
