@@ -412,7 +412,10 @@ def main():
             if name.startswith("tune:"):
                 for kv in name[5:].split("+"):
                     parts_ = kv.split("=")
-                    L.set_tuning(parts_[0].encode(), int(parts_[1]))
+                    if parts_[0].startswith("ops."):          # a Python-level switch of dcnet_amd.ops (e.g. ops.STEM_FUSED_BWD=0=1)
+                        setattr(ops, parts_[0][4:], int(parts_[1]))
+                    else:
+                        L.set_tuning(parts_[0].encode(), int(parts_[1]))
                     restore.append((parts_[0], int(parts_[2]) if len(parts_) > 2 else 0))
             g_ = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=1)
             g_(); barrier()
@@ -424,7 +427,10 @@ def main():
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = was
             ops.SIDE_PRIORITY = 0
             for k_, v_ in restore:
-                L.set_tuning(k_.encode(), v_)
+                if k_.startswith("ops."):
+                    setattr(ops, k_[4:], v_)
+                else:
+                    L.set_tuning(k_.encode(), v_)
             del g_
             model.static_samples = None
             opt.zero_grad(set_to_none=True)

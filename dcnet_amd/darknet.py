@@ -378,6 +378,21 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
             shape = tuple(p["w"].shape)
             d = {}
             ady = ops.amax_slot(dout.device) if ops.use_amax() else None
+            if (op.bn and training and not op.need_dx and ops.STEM_FUSED_BWD and x.shape[3] == 4 and op.cout == 32 and op.k == 3
+                    and op.stride == 1 and op.res is None and y.is_contiguous() and x.shape[2] >= 32):
+                # the stem: nothing but its weight gradient reads dy, so dy is formed inside that kernel and never written
+                mi = aux
+                dw, d["gamma"], d["beta"] = ops.stem_bwd_weight_bn(x, y, dout, mi[0], mi[1], p["gamma"], p["beta"],
+                                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1)
+                d["w"] = ops.weight_grad_to_oihw(dw, shape)
+                pg[op.slot] = d
+                if sink is not None:
+                    for k_, t_ in d.items():
+                        if t_ is not None:
+                            pending.append((op.slot, k_, t_)); pending_bytes += t_.numel() * 4
+                    if pending_bytes >= bucket_bytes:
+                        sink(pending); pending = []; pending_bytes = 0
+                continue
             if op.bn and training:
                 mi = aux
                 dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], p["gamma"], p["beta"],

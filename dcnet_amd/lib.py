@@ -33,6 +33,8 @@ SIGNATURES = {
     "dcn_conv2d_geom": (I, [P, I, I, I, I, I, P]),
     "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
+    "dcn_stem_bwd_weight_bn": (I, [P, P, P, I, P, P, P, P, I, F, P, L, I, I, I, I, P, P, P]),
+    "dcn_stem_bwd_weight_bn_ws": (L, [I, I, I]),
     "dcn_bn_ws": (L, [I]),
     "dcn_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
     "dcn_bn_fold": (I, [P, P, P, P, F, I, P, P, P]),
@@ -117,7 +119,7 @@ SIGNATURES = {
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
-ABI_VERSION = 300        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+ABI_VERSION = 301        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

@@ -536,6 +536,31 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None):
     return dy, sums[1], sums[0]
 
 
+def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope):
+    """The stem's weight gradient with its BatchNorm + activation backward applied on the fly (csrc/stem.hip): x (N,H,W,4),
+    y (N,H,W,32) the raw convolution output, dout the gradient w.r.t. act(bn(y)).  Returns (dw (32, 64) in the c4 layout of
+    conv2d_bwd_weight, dgamma, dbeta) — what bn_act_bwd + conv2d_bwd_weight return, without writing dy."""
+    n, h, wd, c = y.shape
+    rows = n * h * wd
+    dev = y.device
+    r = lib().channel_stats_rows(rows)
+    part = scratch(r * 2 * c, dev, slot=0)
+    lddo = dout.stride(-2)
+    lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+                            act, float(slope), rows, c, part.data_ptr(), _s())
+    sums = torch.empty((2, c), dtype=torch.float32, device=dev)
+    ws = scratch(lib().bn_ws(c), dev, slot=2)
+    lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
+    dw = torch.empty((c, 64), dtype=torch.float32, device=dev)
+    slabs = scratch(lib().stem_bwd_weight_bn_ws(n, h, wd), dev, slot=0)          # (the partials in slot 0 have been reduced)
+    lib().stem_bwd_weight_bn(x.data_ptr(), y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+                             act, float(slope), sums.data_ptr(), rows, n, h, wd, c, dw.data_ptr(), slabs.data_ptr(), _s())
+    return dw, sums[1], sums[0]
+
+
+STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
+
+
 def act_bwd(out, dout, slope):
     c = out.shape[-1]
     rows = out.numel() // c

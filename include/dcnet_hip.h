@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 300
+#define DCN_ABI_VERSION 301
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -139,6 +139,18 @@ int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, fl
                           int n, int h, int wd, int cin, int cout, int ksize, int stride,
                           const uint32_t* amax_x, const uint32_t* amax_dy, void* stream);
 int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+/* The stem's weight gradient with its BatchNorm + LeakyReLU backward applied on the fly (the stem has no data gradient, so its
+ * dY is never written): x (n,h,wd,4) the padded image, y (n,h,wd,32) the raw output of dcn_conv2d_fwd, dout the gradient w.r.t.
+ * act(bn(y)) with pixel stride lddo, mean / invstd of dcn_bn_finalize, sums [2][32] of dcn_bn_bwd_sums over dcn_bn_act_bwd_reduce
+ * (= dbeta, dgamma), count = n*h*wd.  dw: [32][64], k = tap*4 + channel (the c4 layout dcn_conv2d_bwd_weight writes for cin == 4);
+ * ws: dcn_stem_bwd_weight_bn_ws(n, h, wd) floats.  Same result as dcn_bn_act_bwd_apply followed by dcn_conv2d_bwd_weight, to
+ * rounding.  Replaces autograd of nn.Conv2d(3, 32, 3) + nn.BatchNorm2d + LeakyReLU at model/darknet.py:179-191 (first block of
+ * model/yolov3.cfg), reached from loss.backward() at train_DCNet.py:645. */
+int dcn_stem_bwd_weight_bn(const float* x, const float* y, const float* dout, int lddo,
+                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int act, float slope, const float* sums, int64_t count,
+                           int n, int h, int wd, int cout, float* dw, float* ws, void* stream);
+int64_t dcn_stem_bwd_weight_bn_ws(int n, int h, int wd);
 
 /* ---- BatchNorm (train mode) + activation + shortcut ---------------------------------- */
 /* Scratch (floats, 8-byte aligned) needed by dcn_bn_finalize / dcn_bn_bwd_sums for c channels. */

@@ -1065,6 +1065,42 @@ def test_nconv1_register_bank_kernels(dev, case):
     assert torch.equal(new[0], again[0]) and (mode != "fwd" or torch.equal(new[1], again[1]))
 
 
+@pytest.mark.parametrize("case", [(2, 40, 52), (1, 33, 32), (3, 64, 100), (2, 17, 257)])
+def test_stem_bwd_weight_bn_fused(dev, case):
+    """csrc/stem.hip stem_wgrad_bn_kernel (the stem's weight gradient with BatchNorm + LeakyReLU backward formed on the fly, fp32
+    MFMA over padded positions) against the two calls it replaces (dcn_bn_act_bwd_apply + dcn_conv2d_bwd_weight) and against fp64
+    autograd of conv -> batch norm (batch statistics) -> LeakyReLU."""
+    from dcnet_amd import ops
+    n, h, w = case
+    img = _rand(n, 3, h, w, seed=91)
+    wgt = (_rand(32, 3, 3, 3, seed=92) / 3)
+    gamma = (torch.rand(32, generator=torch.Generator().manual_seed(93)) + 0.5); beta = _rand(32, seed=94) / 4
+    dout_c = _rand(n, 32, h, w, seed=95)
+    # fp64 truth
+    wd_ = wgt.double().requires_grad_(True); g_ = gamma.double().requires_grad_(True); b_ = beta.double().requires_grad_(True)
+    yd = F.conv2d(img.double(), wd_, padding=1)
+    out = F.leaky_relu(F.batch_norm(yd, None, None, g_, b_, True, 0.1, 1e-5), 0.1)
+    out.backward(dout_c.double())
+    # device: forward pieces, then the two backward paths
+    x = ops.nchw_to_nhwc(img.to(dev), 4)
+    w_ohwi = ops.weight_to_ohwi(wgt.to(dev))
+    y, stats = ops.conv2d_fwd(x, w_ohwi, 3, 1, want_stats=True)
+    rm = torch.zeros(32, device=dev); rv = torch.ones(32, device=dev)
+    mi = ops.bn_finalize(stats, n * h * w, gamma.to(dev), beta.to(dev), 1e-5, 0.1, rm, rv)
+    dout = _nhwc(dout_c).to(dev)
+    dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], gamma.to(dev), beta.to(dev), ops.ACT_LEAKY, 0.1)
+    dw_old = ops.conv2d_bwd_weight(x, dy, 3, 1)
+    dw_new, dgamma2, dbeta2 = ops.stem_bwd_weight_bn(x, y, dout, mi[0], mi[1], gamma.to(dev), beta.to(dev), ops.ACT_LEAKY, 0.1)
+    assert dw_new.shape == dw_old.shape == (32, 64)
+    assert torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2)
+    _close(dw_new, dw_old, 2e-5, "fused vs apply + wgrad")
+    assert float(dw_new[:, 36:].abs().max()) == 0 and float(dw_new[:, :36].view(32, 9, 4)[..., 3].abs().max()) == 0
+    got = ops.weight_grad_to_oihw(dw_new, (32, 3, 3, 3))
+    _close(got, wd_.grad, 1e-4, "fused stem weight gradient vs fp64 autograd")
+    _close(dgamma2, g_.grad, 1e-4, "dgamma"); _close(dbeta2, b_.grad, 1e-4, "dbeta")
+    assert torch.equal(dw_new, ops.stem_bwd_weight_bn(x, y, dout, mi[0], mi[1], gamma.to(dev), beta.to(dev), ops.ACT_LEAKY, 0.1)[0])
+
+
 def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
