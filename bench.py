@@ -62,7 +62,8 @@ NAMES = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,
          33: "conv3_kernel<*,2,4,1> (bf16 operands)", 34: "stem_kernel", 35: "conv1_kernel (1x1, f16 split)",
          36: "wgrad9_kernel (32 -> 64 3x3 layers, nine taps per workgroup, f16 split)",
          37: "dgrad2_kernel (stride-2 data gradients 64 -> 32 / 128 -> 64 channels, filter bank in registers, f16 split)",
-         38: "nconv1_kernel (3x3 layers between 32 and 64 channels, filter bank in registers, f16 split)"}
+         38: "nconv1_kernel (3x3 layers between 32 and 64 channels, filter bank in registers, f16 split)",
+         39: "stem_wgrad_bn_kernel (stem weight gradient + BatchNorm backward, fp32 MFMA)"}
 FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38}
 PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38)
                else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}

@@ -62,9 +62,11 @@ int dcn_ohwi_to_oihw(const float* src, float* dst, int co, int ci, int kh, int k
  * (model/DCNet_model.py:491-499 tiles them as 520 extra input channels instead).
  * scale/shift/residual may be NULL.  y has pixel stride ldy >= cout (lets a layer write
  * straight into a channel slice of a route-concat buffer); residual has pixel stride ldr.
- * stats (optional, [grid_m][2][cout] floats, grid_m = dcn_conv2d_stats_rows(...)): per
- * 128/256-row block partial sum and sum-of-squares of the RAW conv result (before
- * scale/shift/act) per output channel — the batch statistics of train-mode BatchNorm.
+ * stats (optional, [grid_m][2][cout] floats, grid_m = dcn_conv2d_stats_rows(...)): partial
+ * sums and sums-of-squares of the RAW conv result (before scale/shift/act) per output channel —
+ * the batch statistics of train-mode BatchNorm.  All grid_m rows are written and their column sums
+ * are the statistics; how the pixels are dealt to the rows is the kernel's business (one row per
+ * 128/256-row tile; the persistent kernels of nconv.hip fill one row per workgroup and zero the rest).
  * Replaces nn.Conv2d (+ eval-mode BatchNorm2d + LeakyReLU/ReLU + shortcut add):
  * model/darknet.py:179-191,403-405 and ConvBatchNormReLU model/darknet.py:131-153. */
 int dcn_conv2d_fwd(const float* x, const float* w, float* y,
@@ -435,8 +437,13 @@ int dcn_upsample2_nhwc_bwd(const float* ddst, int ldd, float* dsrc, int lds, int
 /* strided copy / accumulate of a [rows][c] channel slice: dst (+)= src. */
 int dcn_copy_slice(const float* src, int lds, float* dst, int ldd, int64_t rows, int c, int accumulate, void* stream);
 
-/* Experiment knob of the conv engine's tile heuristic ("bm": force the M tile to 64 or 128, 0 = automatic).
- * Used by tools/bench_convs.py for in-process A/B runs (a 128x256 tile measured 10-25 % slower and was dropped). */
+/* Experiment knobs (in-process A/B runs: tools/bench_convs.py --ab, bench.py --schedule-tunes, the DCN_TUNE environment variable).
+ * The key's first characters select the knob; the ones that switch a kernel family off and on (1 = default):
+ *   "precision" 0..4 (see above) | "1x1dma" conv1.hip | "3x3strip" conv3.hip | "Nconv" nconv.hip (0 off, 2: 32 -> 64 stride-2 data
+ *   gradient only, 3: dgrad2 only) | "9tap" wgrad9.hip | "u3row" wgrad3.hip | "jstem" the stem's direct forward | "merge" parity
+ *   classes of a stride-2 data gradient in one launch | "bm" force the M tile (64 / 128, 0 = automatic).
+ * Sizing knobs: "1stages", "9target", "v3target", "xwgtarget", "zwgsmall", "e2rpw" / "f2nt" (scoring pass), "dbnrev" (sweep
+ * direction of the BatchNorm passes).  Unknown keys are ignored by design of the A/B tools; none changes results beyond rounding. */
 int dcn_set_tuning(const char* key, int value);
 
 /* ---- optimiser ---------------------------------------------------------------------------------

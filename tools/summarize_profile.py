@@ -99,7 +99,8 @@ def main():
                "wgrad3": ["wgrad3_kernel<2>"], "conv1": ["conv1_kernel<"], "wgrad<128,128>": ["wgrad_kernel<128,128,16,true,0,2>"],
                "igemm<128,128> NT": ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], "scale_act": ["scale_act_kernel"],
                "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel"], "channel_partials": ["channel_partials_kernel"],
-               "l2norm_score_fwd": ["l2norm_score_fwd_kernel"]}
+               "l2norm_score_fwd": ["l2norm_score_fwd_kernel"], "dgrad2": ["dgrad2_kernel<"], "nconv1": ["nconv1_kernel<"],
+               "wgrad9": ["wgrad9_kernel<"], "stem_wgrad_bn": ["stem_wgrad_bn_kernel"]}
         out = {"round": a.round, "source": f"profiles/{tag}_{a.name}_kernel_stats.csv", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
                "--warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0 (graph replays only)", "kernels": {}}
         for k_, pats in fam.items():
