@@ -132,11 +132,44 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   return igemm_launch(p, (hipStream_t)stream);
 }
 
+namespace {
+int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                  int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                  int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                  int wt_ready, const float* wt_split, const DcnBnTap* tap, int* tap_rows, hipStream_t stream);
+}
+
 extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, float* dx,
                                    int n, int h, int wd, int cin, int cout, int ksize, int stride,
                                    int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
                                    int wt_ready, const float* wt_split, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  return bwd_data_impl(dy, lddy, w, wt, dx, n, h, wd, cin, cout, ksize, stride, accumulate, f8_scales, amax_dy, amax_w, wt_ready, wt_split,
+                       nullptr, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int dcn_conv2d_bwd_data_tap(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                                       int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                                       int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                                       int wt_ready, const float* wt_split,
+                                       const float* tap_y, const float* tap_mean, const float* tap_invstd, const float* tap_gamma,
+                                       const float* tap_beta, int tap_act, float tap_slope, float* tap_stats, int tap_stats_rows,
+                                       int* tap_rows, void* stream_) {
+  DCN_CHECK_ARG(tap_rows, "conv2d_bwd_data_tap: tap_rows is where the number of statistics rows written comes back");
+  *tap_rows = 0;
+  DcnBnTap tap{tap_y, tap_mean, tap_invstd, tap_gamma, tap_beta, tap_act, tap_slope, tap_stats, tap_stats_rows};
+  return bwd_data_impl(dy, lddy, w, wt, dx, n, h, wd, cin, cout, ksize, stride, accumulate, f8_scales, amax_dy, amax_w, wt_ready, wt_split,
+                       (tap_y && tap_stats) ? &tap : nullptr, tap_rows, (hipStream_t)stream_);
+}
+
+extern "C" int dcn_conv2d_bwd_data_tap_rows(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  return (cin == 32 && dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, 0)) ? dgrad2_grid(n, h, wd, cin) : 0;
+}
+
+namespace {
+int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                  int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                  int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                  int wt_ready, const float* wt_split, const DcnBnTap* tap, int* tap_rows, hipStream_t stream) {
   DCN_CHECK_ARG(ksize == 1 || ksize == 3, "conv2d_bwd_data: ksize=%d", ksize);
   DCN_CHECK_ARG(stride == 1 || stride == 2, "conv2d_bwd_data: stride=%d", stride);
   DCN_CHECK_ARG(cout % 32 == 0, "conv2d_bwd_data: cout=%d must be a multiple of 32 (pad the filter bank)", cout);
@@ -154,8 +187,12 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
   }
   // the stride-2 layers of the 416x416 / 208x208 maps: all four parity classes from one pass over dY, filter bank in registers (nconv.hip)
   if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && igemm_precision() == 4 &&
-      dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, accumulate))
-    return dgrad2_launch(dy, lddy, wt, dx, n, h, wd, cin, accumulate, amax_dy, amax_w, stream);
+      dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, accumulate)) {
+    if (tap && (cin != 32 || tap->stats_rows < dgrad2_grid(n, h, wd, cin))) tap = nullptr;      // (64-channel form / too few rows: the caller reduces by itself)
+    const int rc = dgrad2_launch(dy, lddy, wt, dx, n, h, wd, cin, accumulate, amax_dy, amax_w, tap, stream);
+    if (rc == DCN_OK && tap && tap_rows) *tap_rows = dgrad2_grid(n, h, wd, cin);
+    return rc;
+  }
   if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && !accumulate && igemm_precision() == 4 &&
       nconv1_applicable(1, n, h, wd, cin, cout, ksize, stride))
     return nconv1_launch(1, dy, lddy, wt, dx, cin, nullptr, 0, n, h, wd, 1, amax_dy, amax_w, stream);
@@ -255,3 +292,5 @@ extern "C" int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, fl
     }
   return DCN_OK;
 }
+}  // namespace
+

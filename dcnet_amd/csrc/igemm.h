@@ -75,8 +75,12 @@ void stem_set_tuning(int v);
 
 // nconv.hip: the data gradients of the 32 -> 64 and 64 -> 128 3x3 stride-2 layers with the filter bank in registers (persistent workgroups, f16 split)
 bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int stride, int accumulate);
+// tap (optional): the BatchNorm + activation in front of this convolution — the kernel also writes the partial sums its backward starts with
+struct DcnBnTap { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; int act; float slope;
+                  float* stats; int stats_rows; };
+int dgrad2_grid(int n, int h, int wd, int cin);      // workgroups (= statistics rows of a tap) of a launch, -1: device query failed
 int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
-                  const uint32_t* amax_dy, const uint32_t* amax_w, hipStream_t stream);
+                  const uint32_t* amax_dy, const uint32_t* amax_w, const DcnBnTap* tap, hipStream_t stream);
 void nconv_set_tuning(int v);
 int igemm_precision();       // dcn_set_tuning("precision"): 4 = f16 two-piece split (the default)
 // ... and the 3x3 layers between 32 and 64 channels: mode 0 = forward 32 -> 64 (stride 1 | 2, BatchNorm partial sums), mode 1 = data

@@ -15,7 +15,7 @@
 // wgrad3.hip (rows of Wo + 1 entries, the last one a pad that is staged as zero), so the right neighbour of the last column and
 // the row below the last row read zeros without masks in the loop.  All four classes of a chunk are stored by the workgroup that
 // computed them: full 128-byte pixels.  Roofline: HBM.
-#include "common.h"
+#include "igemm.h"
 #include "prof.h"
 #include <type_traits>
 
@@ -30,6 +30,10 @@ struct D2Params {
   int N, Ho, Wo, lddy, ldo, accumulate;
   int Mp, nchunks, per_wg;                          // padded positions N*Ho*(Wo+1); chunks of 64; chunks per workgroup
   const unsigned* amax_dy; const unsigned* amax_w;
+  // optional tap: dX is the gradient w.r.t. act(bn(y_prev)) — the output of the layer in front; its BatchNorm backward starts with
+  // sum(g) and sum(g * xhat) per channel, g = dX * act'(.), which this kernel can form while it still holds dX in registers
+  const float* tap_y; const float* tap_mean; const float* tap_invstd; const float* tap_gamma; const float* tap_beta;
+  int tap_act; float tap_slope; float* tap_stats;   // tap_stats: [gridDim.x][2][CN]
 };
 
 __device__ __forceinline__ f32x4 ldn(__amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -85,7 +89,7 @@ __device__ __forceinline__ void walk_step(Walk& w, int step, int Wp, int Ho) {  
   if (w.col >= Wp) { w.col -= Wp; ++w.row; if (++w.r == Ho) w.r = 0; }
 }
 
-template <int ROLE, int CK, int CN>
+template <int ROLE, int CK, int CN, bool TAP>
 __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm) {
   typedef Taps<ROLE> T;
   typedef Geo<CK, CN> G;
@@ -180,6 +184,15 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   }
 
   const float dq = 1.f / (s_a * s_b);                // powers of two: exact
+  constexpr bool tapped = TAP;                        // (a build of its own: the constants and sums cost registers the 128-channel form does not have)
+  float t_mu = 0.f, t_is = 1.f, t_ga = 1.f, t_be = 0.f, t_s = 0.f, t_ss = 0.f;      // this lane's channel nb*32 + m of the layer in front
+  if constexpr (tapped) {
+    t_mu = p.tap_mean[nb * 32 + m]; t_is = p.tap_invstd[nb * 32 + m];
+    if (p.tap_gamma) t_ga = p.tap_gamma[nb * 32 + m];
+    if (p.tap_beta) t_be = p.tap_beta[nb * 32 + m];
+  }
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tapped ? p.tap_y : p.dx), 0,
+      (unsigned)(((long long)NR * 4 * p.Wo) * CN * 4), 0x00020000);
   f32x4 stage[NSLOT];
   if (c_begin < c_end) {
     load_chunk(stage);
@@ -209,6 +222,23 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
         if constexpr (KS > 4) { if (kk & 1) __builtin_amdgcn_sched_barrier(0); }
       }
     };
+    const int q0 = c * CH;
+    auto pix_of = [&](int q, int a, bool& ok) {
+      const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
+      const int t = wc.col + pos;
+      ok = t != p.Wo && q0 + pos < p.Mp;
+      return 2 * wc.row * W + 2 * t + (t > p.Wo ? 2 * W - 2 * Wp : 0) + T::ca[a] * W + T::cb[a];
+    };
+    float ty[tapped ? 2 : 1][tapped ? 16 : 1];
+    if constexpr (tapped) {                         // all 32 loads of y issued in front of the chunk's MFMAs (one by one, behind each
+#pragma unroll                                      // store, every load's latency was exposed: the tap cost more than the pass it replaces)
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          bool ok; const int pix = pix_of(q, a, ok);
+          ty[a][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(y_rs, ok ? (pix * CN + nb * 32 + m) * 4 : (int)OOBN, 0, 0));
+        }
+    }
     tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
     store_chunk(buf ^ 1, stage);                      // chunk c + 1
     load_chunk(stage);                                // chunk c + 2
@@ -218,31 +248,47 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     // ---- store: D[m = position][n = ci]; register q <-> position mb*32 + (q & 3) + 8 (q >> 2) + 4 kg ---------------------------
     // dX pixel of position pos, class (a, b): (2 row + a)*W + 2 (col + pos) + b; behind the pad entry the position sits in the next
     // padded row: +2W - 2 Wp = -2 pixels ... +2W
-    const int q0 = c * CH;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
-      const int t = wc.col + pos;
-      if (t == p.Wo || q0 + pos >= p.Mp) continue;
-      const int pbase = 2 * wc.row * W + 2 * t + (t > p.Wo ? 2 * W - 2 * Wp : 0);
 #pragma unroll
       for (int a = 0; a < 2; ++a) {               // (32-bit byte offsets through a buffer descriptor: one address register per store)
-        const int pix = pbase + T::ca[a] * W + T::cb[a];
+        bool ok; const int pix = pix_of(q, a, ok);
+        if (!ok) continue;
         const int off = (pix * p.ldo + nb * 32 + m) * 4;
         float v = acc[a][q] * dq;
         if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rs, off, 0, 0));
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, off, 0, 0);
+        if constexpr (tapped) {                   // the terms of channel_partials_kernel<1> (bn.hip), on the value just stored
+          const float xh = (ty[a][q] - t_mu) * t_is;
+          const float g = (p.tap_act == DCN_ACT_LEAKY && t_ga * xh + t_be <= 0.f) ? v * p.tap_slope : v;
+          t_s += g; t_ss += g * xh;
+        }
       }
     }
     walk_step(wc, CH, Wp, p.Ho);
   }
+  if constexpr (tapped) {                             // one partial row per workgroup: [2][CN]
+    t_s += __shfl_xor(t_s, 32); t_ss += __shfl_xor(t_ss, 32);
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(sm);       // [wave][2][32]
+    if (kg == 0) { red[(wave * 2 + 0) * 32 + m] = t_s; red[(wave * 2 + 1) * 32 + m] = t_ss; }
+    __syncthreads();
+    if (tid < 2 * CN) {
+      const int which = tid / CN, ch = tid - which * CN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (CN == 32 || (w & 1) == (ch >> 5)) t += red[(w * 2 + which) * 32 + (ch & 31)];      // (CN = 64: wave & 1 is its channel block)
+      p.tap_stats[((size_t)blockIdx.x * 2 + which) * CN + ch] = t;
+    }
+  }
 }
 
-template <int CK, int CN>
+template <int CK, int CN, bool TAP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dgrad2_kernel(const D2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smn[];       // [2 buffers][high | low][strip r | strip r+1]
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN>(p, smn);
-  else dgrad2_body<1, CK, CN>(p, smn);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN, TAP>(p, smn);
+  else dgrad2_body<1, CK, CN, TAP>(p, smn);
 }
 
 // =====================================================================================================================
@@ -482,23 +528,34 @@ bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int s
   return (long long)n * h * wd >= 65536;                                               // (a persistent grid wants work for every CU)
 }
 
-template <int CK, int CN>
+template <int CK, int CN, bool TAP>
 int launch_d2(D2Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo<CK, CN> G;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN, TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
     attr_done = true;
   }
   const int pid = prof_begin(37, flop, stream, bytes);
-  hipLaunchKernelGGL((dgrad2_kernel<CK, CN>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
+  hipLaunchKernelGGL((dgrad2_kernel<CK, CN, TAP>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("dgrad2");
   return DCN_OK;
 }
 
+int dgrad2_grid(int n, int h, int wd, int cin) {
+  if (!g_ncus) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int nchunks = cdiv((long long)n * (h / 2) * (wd / 2 + 1), cin == 32 ? 64 : 32);
+  const int grid = g_ncus < nchunks ? g_ncus : nchunks;
+  return cdiv(nchunks, cdiv(nchunks, grid));
+}
+
 int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
-                  const uint32_t* amax_dy, const uint32_t* amax_w, hipStream_t stream) {
+                  const uint32_t* amax_dy, const uint32_t* amax_w, const DcnBnTap* tap, hipStream_t stream) {
   DCN_CHECK_ARG((long long)n * (h / 2) * (wd / 2) * lddy * 4 < 0x7FFFFFF0LL, "conv2d_bwd_data: dY slice exceeds 32-bit byte offsets");
   if (!g_ncus) {
     int dev = 0; hipDeviceProp_t prop;
@@ -514,9 +571,17 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
   p.per_wg = cdiv(p.nchunks, grid);
   grid = cdiv(p.nchunks, p.per_wg);
   p.amax_dy = amax_dy; p.amax_w = amax_w;
-  const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * ck + (double)n * h * wd * cin * (accumulate ? 2 : 1) + (double)cin * 9 * ck);
+  if (tap) {
+    DCN_CHECK_ARG(cin == 32, "conv2d_bwd_data: the BatchNorm tap exists for the 32-channel form only");
+    DCN_CHECK_ARG(tap->y && tap->mean && tap->invstd && tap->stats && tap->stats_rows >= grid,
+                  "conv2d_bwd_data: BatchNorm tap needs y, mean, invstd and %d statistics rows (%d given)", grid, tap->stats_rows);
+    p.tap_y = tap->y; p.tap_mean = tap->mean; p.tap_invstd = tap->invstd; p.tap_gamma = tap->gamma; p.tap_beta = tap->beta;
+    p.tap_act = tap->act; p.tap_slope = tap->slope; p.tap_stats = tap->stats;
+  }
+  const double bytes = 4.0 * ((double)n * p.Ho * p.Wo * ck + (double)n * h * wd * cin * ((accumulate ? 2 : 1) + (tap ? 1 : 0)) + (double)cin * 9 * ck);
   const double flop = 2.0 * (double)n * p.Ho * p.Wo * ck * 9.0 * cin;
-  return cin == 32 ? launch_d2<64, 32>(p, grid, flop, bytes, stream) : launch_d2<128, 64>(p, grid, flop, bytes, stream);
+  if (cin == 32) return tap ? launch_d2<64, 32, true>(p, grid, flop, bytes, stream) : launch_d2<64, 32, false>(p, grid, flop, bytes, stream);
+  return launch_d2<128, 64, false>(p, grid, flop, bytes, stream);
 }
 
 // ---- 3x3 layers between 32 and 64 channels (forward S = 1 | 2, data gradient S = 1) ---------------------------------------------

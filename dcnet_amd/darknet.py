@@ -356,6 +356,17 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
         if gt is not None:
             add(t, gt.clone(memory_format=torch.contiguous_format))   # never accumulate into autograd's tensor
     pg: Dict[int, dict] = {}
+    # BatchNorm taps: the data gradient that completes the gradient of a conv + BN + activation output (= the FIRST consumer of that
+    # output in plan order, processed last) can form the partial sums that layer's BatchNorm backward starts with (ops.conv2d_bwd_data)
+    producer = {op.dst: op for op in plan if isinstance(op, _ConvOp)}
+    first_use: Dict[int, int] = {}
+    for i, op in enumerate(plan):
+        ins = (op.src, op.res) if isinstance(op, _ConvOp) else (op.up_src, op.lat_src) if isinstance(op, _UpCatOp) else (op.src,)
+        for s_ in ins:
+            if s_ is not None:
+                first_use.setdefault(s_, i)
+    index_of = {id(op): i for i, op in enumerate(plan)}
+    tapped: Dict[int, torch.Tensor] = {}
     for op in reversed(plan):
         dout = g.pop(op.dst, None)
         if dout is None:
@@ -383,7 +394,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 # the stem: nothing but its weight gradient reads dy, so dy is formed inside that kernel and never written
                 mi = aux
                 dw, d["gamma"], d["beta"] = ops.stem_bwd_weight_bn(x, y, dout, mi[0], mi[1], p["gamma"], p["beta"],
-                                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1)
+                                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1,
+                                                                   part=tapped.pop(op.slot, None))
                 d["w"] = ops.weight_grad_to_oihw(dw, shape)
                 pg[op.slot] = d
                 if sink is not None:
@@ -396,7 +408,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
             if op.bn and training:
                 mi = aux
                 dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], p["gamma"], p["beta"],
-                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1, amax_out=ady)
+                                                   ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1, amax_out=ady,
+                                                   part=tapped.pop(op.slot, None))
                 d["gamma"], d["beta"] = dgamma, dbeta
             else:
                 # frozen statistics: y holds act(scale*conv+shift) before the shortcut add
@@ -424,11 +437,22 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 hw = (x.shape[1], x.shape[2])
                 wtr = getattr(w, "_dcn_wt", None)      # the transposed banks of this step (ops.FilterBanks)
                 wt16 = getattr(w, "_dcn_wt16", None)
+                tap = None
+                prev = producer.get(op.src)
+                if (ops.BN_TAP and training and prev is not None and prev.bn and first_use.get(op.src) == index_of[id(op)]
+                        and prev.slot in save and x.shape[3] == 32 and op.stride == 2 and op.k == 3):
+                    _, y_prev, mi_prev = save[prev.slot][:3]
+                    if torch.is_tensor(y_prev) and y_prev.is_contiguous():
+                        tap = dict(y=y_prev, mean=mi_prev[0], invstd=mi_prev[1], gamma=P[prev.slot]["gamma"], beta=P[prev.slot]["beta"],
+                                   act=ops.ACT_LEAKY if prev.leaky else ops.ACT_NONE, slope=0.1)
+                res_ = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=cur is not None, amax_dy=ady, amax_w=aw,
+                                           wt_ready=wtr, wt_b16=wt16, tap=tap)
+                if tap is not None:
+                    res_, part_ = res_
+                    if part_ is not None:
+                        tapped[prev.slot] = part_
                 if cur is None:
-                    g[op.src] = ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, amax_dy=ady, amax_w=aw, wt_ready=wtr, wt_b16=wt16)
-                else:
-                    ops.conv2d_bwd_data(dy, w, hw, op.k, op.stride, out=cur, accumulate=True, amax_dy=ady, amax_w=aw, wt_ready=wtr,
-                                        wt_b16=wt16)
+                    g[op.src] = res_
             if ops.WGRAD_AFTER_DGRAD:      # (schedule experiment: queued behind the data gradient, beside the next layer's BatchNorm passes)
                 d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)
             pg[op.slot] = d

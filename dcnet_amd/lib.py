@@ -27,6 +27,8 @@ SIGNATURES = {
     "dcn_f8_scale": (I, [P, L, I, I, P, P, P]),
     "dcn_conv2d_stats_rows": (I, [I, I, I, I, I, I]),
     "dcn_conv2d_bwd_data": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P, P]),
+    "dcn_conv2d_bwd_data_tap": (I, [P, I, P, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P, P, P, P, P, P, I, F, P, I, P, P]),
+    "dcn_conv2d_bwd_data_tap_rows": (I, [I, I, I, I, I, I, I]),
     "dcn_filter_job_bytes": (I, []),
     "dcn_prepare_filters": (I, [P, I, I, I, P, L, P]),
     "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
@@ -118,8 +120,8 @@ SIGNATURES = {
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
-_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
-ABI_VERSION = 301        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+_VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
+ABI_VERSION = 302        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

@@ -300,9 +300,12 @@ def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, s
 
 
 def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False, amax_dy=None, amax_w=None, wt_ready=None,
-                    wt_b16=None):
+                    wt_b16=None, tap=None):
     """dy (N,Ho,Wo,Cout) (pixel stride may exceed Cout), w_ohwi (Cout,k,k,Cin) -> dx (N,H,W,Cin).
-    wt_ready = (transposed fp32 bank, its split form | None) prepared by FilterBanks: nothing is converted here."""
+    wt_ready = (transposed fp32 bank, its split form | None) prepared by FilterBanks: nothing is converted here.
+    tap = dict(y, mean, invstd, gamma, beta, act, slope) of the BatchNorm + activation whose output this convolution reads (and dx
+    its complete gradient): returns (dx, partials | None) — the [rows][2][Cin] partial sums bn_act_bwd starts with, when the launch
+    could form them (dcn_conv2d_bwd_data_tap), else None."""
     n, ho, wo, cout = dy.shape
     cin = w_ohwi.shape[3]
     h, wd = in_hw
@@ -319,6 +322,18 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     ready = int(wt_ready is not None)
     if wt_ready is not None and wt_b16 is not None and _precision == "bf16":
         wts, ready = wt_b16, 2                                            # transposed bank in bf16 (FilterBanks)
+    if tap is not None:
+        # BatchNorm tap (csrc/nconv.hip): the partial sums of the backward of the layer in front, formed in this launch's epilogue
+        import ctypes
+        cap = lib().conv2d_bwd_data_tap_rows(n, h, wd, cin, cout, ksize, stride)
+        part = torch.empty((max(cap, 1), 2, cin), dtype=torch.float32, device=dy.device)
+        rows = ctypes.c_int(0)
+        lib().conv2d_bwd_data_tap(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
+                                  n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w),
+                                  ready, _p(wts), tap["y"].data_ptr() if cap else 0, tap["mean"].data_ptr(), tap["invstd"].data_ptr(),
+                                  _p(tap.get("gamma")), _p(tap.get("beta")), int(tap["act"]), float(tap["slope"]),
+                                  part.data_ptr() if cap else 0, cap, ctypes.addressof(rows), _s())
+        return out, (part[:rows.value] if rows.value > 0 else None)
     lib().conv2d_bwd_data(dy.data_ptr(), dy.stride(2), w_ohwi.data_ptr(), wt.data_ptr(), out.data_ptr(),
                           n, h, wd, cin, cout, ksize, stride, int(accumulate), _p(f8), _p(amax_dy), _p(amax_w),
                           ready, _p(wts), _s())
@@ -516,17 +531,28 @@ def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=Non
     return out
 
 
-def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None):
+def _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part):
+    """(partials, rows): the given ones (a conv2d_bwd_data tap) or those of a dcn_bn_act_bwd_reduce pass."""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    if part is not None:
+        return part, part.shape[0]
+    r = lib().channel_stats_rows(rows)
+    part = scratch(r * 2 * c, y.device, slot=0)
+    lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), dout.stride(-2), mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+                            act, float(slope), rows, c, part.data_ptr(), _s())
+    return part, r
+
+
+def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, part=None):
     """Returns (dy, dgamma, dbeta) for out = act(gamma*(y-mean)*invstd+beta) with batch statistics; amax_out: word that
-    receives the abs-max of dy (the A operand of the data / weight gradient GEMMs that follow)."""
+    receives the abs-max of dy (the A operand of the data / weight gradient GEMMs that follow); part: partial sums already
+    formed by the launch that produced dout (conv2d_bwd_data(tap=...))."""
     c = y.shape[-1]
     rows = y.numel() // c
     dev = y.device
-    r = lib().channel_stats_rows(rows)
-    part = scratch(r * 2 * c, dev, slot=0)
     lddo = dout.stride(-2)
-    lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
-                            act, float(slope), rows, c, part.data_ptr(), _s())
+    part, r = _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part)
     sums = torch.empty((2, c), dtype=torch.float32, device=dev)
     ws = scratch(lib().bn_ws(c), dev, slot=2)
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
@@ -536,29 +562,27 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None):
     return dy, sums[1], sums[0]
 
 
-def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope):
+def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=None):
     """The stem's weight gradient with its BatchNorm + activation backward applied on the fly (csrc/stem.hip): x (N,H,W,4),
     y (N,H,W,32) the raw convolution output, dout the gradient w.r.t. act(bn(y)).  Returns (dw (32, 64) in the c4 layout of
     conv2d_bwd_weight, dgamma, dbeta) — what bn_act_bwd + conv2d_bwd_weight return, without writing dy."""
     n, h, wd, c = y.shape
     rows = n * h * wd
     dev = y.device
-    r = lib().channel_stats_rows(rows)
-    part = scratch(r * 2 * c, dev, slot=0)
     lddo = dout.stride(-2)
-    lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
-                            act, float(slope), rows, c, part.data_ptr(), _s())
+    part, r = _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part)
     sums = torch.empty((2, c), dtype=torch.float32, device=dev)
     ws = scratch(lib().bn_ws(c), dev, slot=2)
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
     dw = torch.empty((c, 64), dtype=torch.float32, device=dev)
-    slabs = scratch(lib().stem_bwd_weight_bn_ws(n, h, wd), dev, slot=0)          # (the partials in slot 0 have been reduced)
+    slabs = scratch(lib().stem_bwd_weight_bn_ws(n, h, wd), dev, slot=0)          # (slot 0's partials have been reduced by then; slot 3 belongs to the side stream)
     lib().stem_bwd_weight_bn(x.data_ptr(), y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
                              act, float(slope), sums.data_ptr(), rows, n, h, wd, c, dw.data_ptr(), slabs.data_ptr(), _s())
     return dw, sums[1], sums[0]
 
 
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
+BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
 
 
 def act_bwd(out, dout, slope):

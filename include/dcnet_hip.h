@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 301
+#define DCN_ABI_VERSION 302
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -106,6 +106,21 @@ int dcn_conv2d_bwd_data(const float* dy, int lddy, const float* w, float* wt, fl
                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
                         int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
                         int wt_ready, const float* wt_split, void* stream);
+/* dcn_conv2d_bwd_data with a TAP on the BatchNorm + activation in front of the convolution: dx is the gradient w.r.t.
+ * act(bn(tap_y)) (+ a shortcut), so sum(g) and sum(g*xhat) per channel (g = dx*act'(.), the partial sums dcn_bn_act_bwd_reduce would
+ * compute in a pass of its own over tap_y and dx) can be formed while dx is still in registers.  Only the register-bank kernels of
+ * nconv.hip do it (the stride-2 layers of the 416x416 / 208x208 maps): *tap_rows > 0 on return means tap_stats[*tap_rows][2][cin] holds
+ * the partials (feed them to dcn_bn_bwd_sums); 0 means the caller runs dcn_bn_act_bwd_reduce as before.  tap_stats_rows: rows the
+ * buffer holds (dcn_conv2d_bwd_data_tap_rows(...) says how many a launch would need; 0 = it would not tap).  accumulate != 0: the
+ * partials are those of the sum, so the caller must only tap the LAST contribution to dx.  tap_y dense (n, h, wd, cin). */
+int dcn_conv2d_bwd_data_tap(const float* dy, int lddy, const float* w, float* wt, float* dx,
+                            int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                            int accumulate, const float* f8_scales, const uint32_t* amax_dy, const uint32_t* amax_w,
+                            int wt_ready, const float* wt_split,
+                            const float* tap_y, const float* tap_mean, const float* tap_invstd, const float* tap_gamma,
+                            const float* tap_beta, int tap_act, float tap_slope, float* tap_stats, int tap_stats_rows,
+                            int* tap_rows, void* stream);
+int dcn_conv2d_bwd_data_tap_rows(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 /* w_split_ready / wt_ready / wt_split: the banks were prepared for the whole network by dcn_prepare_filters (below) — w_split
  * holds the split OHWI bank, wt the transposed fp32 bank and wt_split its split form; nothing is converted per call.
  * Value 2 (bf16-operand mode, dcn_set_tuning("precision", 2)): w_split / wt_split point at the bank converted to bf16

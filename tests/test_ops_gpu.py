@@ -991,6 +991,24 @@ def test_dgrad2_register_bank_kernel(dev, case):
     _close(new, ref, 2e-5, "dgrad2")
     _close(old, ref, 2e-5, "implicit-GEMM classes")
     _close(acc, ref + base.double().cpu(), 2e-5, "dgrad2 accumulate")
+    # BatchNorm tap: the partial sums of the backward of the layer in front (y_prev -> bn -> LeakyReLU -> this convolution), formed in
+    # the epilogue, against the reduce pass over (y_prev, dx)
+    y_prev = _rand(n, h, w, cin, seed=64).to(dev)
+    mean = (_rand(cin, seed=65) / 4).to(dev); invstd = (torch.rand(cin, generator=torch.Generator().manual_seed(66)) + 0.5).to(dev)
+    gamma = (torch.rand(cin, generator=torch.Generator().manual_seed(67)) + 0.5).to(dev); beta = (_rand(cin, seed=68) / 4).to(dev)
+    tap = dict(y=y_prev, mean=mean, invstd=invstd, gamma=gamma, beta=beta, act=ops.ACT_LEAKY, slope=0.1)
+    dx_t, part = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2, tap=tap)
+    assert torch.equal(dx_t, new)
+    if cin == 32:
+        assert part is not None and part.shape[1:] == (2, cin)
+        want = ops._bn_bwd_partials(y_prev, new, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, None)
+        want = want[0][:want[1] * 2 * cin].view(want[1], 2, cin).double().sum(0)
+        _close(part.double().sum(0), want, 2e-5, "tap partial sums")
+        dy1, dg1, db1 = ops.bn_act_bwd(y_prev, new, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1)
+        dy2, dg2, db2 = ops.bn_act_bwd(y_prev, new, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, part=part)
+        _close(dg2, dg1, 2e-5, "dgamma from the tap"); _close(db2, db1, 2e-5, "dbeta from the tap"); _close(dy2, dy1, 2e-5, "dy from the tap")
+    else:
+        assert part is None                                        # (the 64-channel form has no registers left for it)
     assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
     assert torch.equal(new, new_b)                                 # nor do the prepared banks
     assert torch.equal(new, ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2))
