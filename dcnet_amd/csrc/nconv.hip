@@ -39,6 +39,8 @@ struct D2Params {
 __device__ __forceinline__ f32x4 ldn(__amdgpu_buffer_rsrc_t r, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
+// bytes a buffer descriptor may span (its range check returns zero / drops the store beyond)
+__device__ __forceinline__ unsigned span32(long long bytes) { return bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0u : (unsigned)(bytes < 0 ? 0 : bytes); }
 __device__ __forceinline__ float pow2n(unsigned amax_bits) {
   const int be = (int)((amax_bits >> 23) & 0xFF);
   if (be == 0 || be == 255) return 1.f;
@@ -99,10 +101,13 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   const int m = lane & 31, kg = lane >> 5;
   const int Wp = p.Wo + 1, NR = p.N * p.Ho, W = 2 * p.Wo;
   const float s_a = pow2n(amax_read(p.amax_dy)), s_b = pow2n(amax_read(p.amax_w));
-  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0,
-      (unsigned)((((long long)NR * p.Wo - 1) * p.lddy + CK) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dx, 0,
-      (unsigned)((((long long)NR * 4 * p.Wo - 1) * p.ldo + CN) * 4), 0x00020000);
+  // Buffer descriptors start at the first dY row of THIS workgroup's range (row0): byte offsets stay 32-bit whatever the tensor size
+  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
+  const int row0 = (c_begin * CH) / Wp;
+  const long long a_skip = (long long)row0 * p.Wo * p.lddy * 4, a_all = (((long long)NR * p.Wo - 1) * p.lddy + CK) * 4;
+  const long long o_skip = (long long)row0 * 4 * p.Wo * p.ldo * 4, o_all = (((long long)NR * 4 * p.Wo - 1) * p.ldo + CN) * 4;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.dy + a_skip), 0, span32(a_all - a_skip), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.dx + o_skip), 0, span32(o_all - o_skip), 0x00020000);
 
   // ---- the wave's filter fragments, split once: B[k = co][n = ci = lane % 32], 8 consecutive co per lane ------------------
   f16x8_t bh[NT][KS], bl[NT][KS];
@@ -140,9 +145,8 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     k_off[j] = ((strip * p.Wo + e) * p.lddy + co) * 4;
   }
 
-  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
-  Walk wl, wc;                                       // chunk being LOADED / being computed
-  walk_to(wl, c_begin * CH, Wp, p.Ho); wc = wl;
+  Walk wl, wc;                                       // chunk being LOADED / being computed; rows count from row0
+  walk_to(wl, c_begin * CH, Wp, p.Ho); wl.row -= row0; wc = wl;
 
   auto load_chunk = [&](f32x4* v) {
 #pragma unroll
@@ -191,8 +195,9 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     if (p.tap_gamma) t_ga = p.tap_gamma[nb * 32 + m];
     if (p.tap_beta) t_be = p.tap_beta[nb * 32 + m];
   }
-  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(tapped ? p.tap_y : p.dx), 0,
-      (unsigned)(((long long)NR * 4 * p.Wo) * CN * 4), 0x00020000);
+  const long long y_skip = (long long)row0 * 4 * p.Wo * CN * 4;
+  const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(tapped ? p.tap_y : p.dx) + (tapped ? y_skip : 0)), 0,
+      span32((long long)NR * 4 * p.Wo * CN * 4 - y_skip), 0x00020000);
   f32x4 stage[NSLOT];
   if (c_begin < c_end) {
     load_chunk(stage);
@@ -340,10 +345,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int m = lane & 31, kg = lane >> 5;
   const int Wp = p.Wo + 1, RL = S * Wp, NR = p.N * p.Ho, W = S * p.Wo, H = S * p.Ho;
   const float s_a = pow2n(amax_read(p.amax_x)), s_b = pow2n(amax_read(p.amax_w));
-  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0,
-      (unsigned)((((long long)p.N * H * W - 1) * p.ldi + CK) * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0,
-      (unsigned)((((long long)NR * p.Wo - 1) * p.ldo + CN) * 4), 0x00020000);
+  // Buffer descriptors start at this workgroup's first output row (row0) and, for the input, one input row above S*row0 (the top
+  // strip; `bias` is that row in bytes — zero for row0 = 0, where the row above does not exist and its offsets go negative = out of
+  // range): byte offsets stay 32-bit whatever the tensor size
+  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
+  const int row0 = (c_begin * CH) / Wp;
+  const int bias = row0 > 0 ? W * p.ldi * 4 : 0;
+  const long long a_skip = (long long)S * row0 * W * p.ldi * 4 - bias, a_all = (((long long)p.N * H * W - 1) * p.ldi + CK) * 4;
+  const long long o_skip = (long long)row0 * p.Wo * p.ldo * 4, o_all = (((long long)NR * p.Wo - 1) * p.ldo + CN) * 4;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + a_skip), 0, span32(a_all - a_skip), 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + o_skip), 0, span32(o_all - o_skip), 0x00020000);
 
   // ---- the wave's filter fragments (tap t = 3 j + kx of strip j, entry offset kx; FLIP: the data gradient reads bank tap 8 - t) ----
   f16x8_t bh[9][2], bl[9][2];
@@ -380,9 +391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const int wrap_delta = (S * W - RL) * p.ldi * 4;          // an output row further: S input rows on, one padded row of entries back
 
-  const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
-  Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy, column, oy)
-  walk_to(wl, c_begin * CH, Wp, p.Ho); wc = wl;
+  Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy - row0, column, oy)
+  walk_to(wl, c_begin * CH, Wp, p.Ho); wl.row -= row0; wc = wl;
 
   // scalar state of the chunk being loaded (all derived from the walker): byte offset of its first entry, the entry index from which
   // entries wrap into the next padded row, and whether strip 0 / strip 2 lie outside the image before / after the wrap
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int u = u0 + e - (wrapped ? RL : 0);                      // entry within its padded row: image column u - 1
     const int oy = wrapped ? (wl.r + 1 == p.Ho ? 0 : wl.r + 1) : wl.r;
     const bool row_out = (strip == 0 && oy == 0) || (S == 1 && strip == 2 && oy == p.Ho - 1);
-    const int base = (S * wl.row * W + u0) * p.ldi * 4;             // (scalar)
+    const int base = (S * wl.row * W + u0) * p.ldi * 4 + bias;      // (scalar)
     unsigned off = (unsigned)(base + k_off[j] + (wrapped ? wrap_delta : 0));
     if ((unsigned)(u - 1) >= (unsigned)W || row_out) off = OOBN;    // (rows past the tensor: out of the descriptor's range, read as zero)
     v[j] = ldn(a_rs, off);
@@ -524,7 +534,7 @@ bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int s
   if (!g_nconv || ksize != 3 || stride != 2 || !((cin == 32 && cout == 64) || (cin == 64 && cout == 128 && g_nconv != 2))) return false;
   (void)accumulate;
   if ((h & 1) || (wd & 1) || wd / 2 < 64 || h < 4) return false;                       // (one row wrap per chunk at most)
-  if ((long long)n * h * wd * cin * 4 >= 0x7FFFFFF0LL || (long long)n * (h / 2) * (wd / 2 + 1) >= 0x7FFFFFF0LL) return false;
+  if ((long long)n * (h / 2) * (wd / 2 + 1) >= 0x7FFFFFF0LL / 64 || (long long)n * h >= 0x7FFFFFF0LL / 8) return false;      // (position / row indices in 32 bits)
   return (long long)n * h * wd >= 65536;                                               // (a persistent grid wants work for every CU)
 }
 
@@ -556,7 +566,6 @@ int dgrad2_grid(int n, int h, int wd, int cin) {
 
 int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
                   const uint32_t* amax_dy, const uint32_t* amax_w, const DcnBnTap* tap, hipStream_t stream) {
-  DCN_CHECK_ARG((long long)n * (h / 2) * (wd / 2) * lddy * 4 < 0x7FFFFFF0LL, "conv2d_bwd_data: dY slice exceeds 32-bit byte offsets");
   if (!g_ncus) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
@@ -570,6 +579,8 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
   int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
   p.per_wg = cdiv(p.nchunks, grid);
   grid = cdiv(p.nchunks, p.per_wg);
+  DCN_CHECK_ARG(((long long)p.per_wg * ch / (p.Wo + 1) + 4) * 4 * p.Wo * (lddy > cin ? lddy : cin) * 4 < 0x7FFFFFF0LL,
+                "conv2d_bwd_data: the rows of one workgroup exceed 32-bit byte offsets");
   p.amax_dy = amax_dy; p.amax_w = amax_w;
   if (tap) {
     DCN_CHECK_ARG(cin == 32, "conv2d_bwd_data: the BatchNorm tap exists for the 32-channel form only");
@@ -591,8 +602,7 @@ bool nconv1_applicable(int mode, int n, int h, int wd, int cin, int cout, int ks
   if (mode == 1 && stride != 1) return false;
   if (stride != 1 && stride != 2) return false;
   if ((h % stride) || (wd % stride) || wd / stride < 64 || h / stride < 2) return false;      // (one row wrap per chunk at most)
-  const long long opix = (long long)n * (h / stride) * (wd / stride);
-  if ((long long)n * h * wd * (mode == 0 ? 32 : 64) * 4 >= 0x7FFFFFF0LL || opix * (mode == 0 ? 64 : 32) * 4 >= 0x7FFFFFF0LL) return false;   // 32-bit byte offsets (dense)
+  if ((long long)n * (h / stride) * (wd / stride + 1) >= 0x7FFFFFF0LL / 64 || (long long)n * h >= 0x7FFFFFF0LL / 8) return false;   // (position / row indices in 32 bits)
   return (long long)n * (h / stride) * (wd / stride) >= 65536;                                // (a persistent grid wants work for every CU)
 }
 
@@ -622,8 +632,6 @@ int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, i
     g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int ck = mode == 0 ? 32 : 64, cn = mode == 0 ? 64 : 32;
-  DCN_CHECK_ARG((long long)n * h * wd * ldi * 4 < 0x7FFFFFF0LL && (long long)n * (h / stride) * (wd / stride) * ldo * 4 < 0x7FFFFFF0LL,
-                "conv2d: a sliced operand exceeds the 32-bit byte offsets of the register-bank kernel");
   N1Params p{};
   p.x = x; p.w = w; p.y = y; p.stats = stats; p.N = n; p.Ho = h / stride; p.Wo = wd / stride; p.ldi = ldi; p.ldo = ldo;
   p.Mp = n * p.Ho * (p.Wo + 1);
@@ -631,6 +639,8 @@ int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, i
   int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
   p.per_wg = cdiv(p.nchunks, grid);
   grid = cdiv(p.nchunks, p.per_wg);
+  DCN_CHECK_ARG(((long long)p.per_wg * 64 / (p.Wo + 1) + 4) * stride * wd * (ldi > ldo ? ldi : ldo) * 4 < 0x7FFFFFF0LL,
+                "conv2d: the rows of one workgroup exceed 32-bit byte offsets");
   p.amax_x = amax_x; p.amax_w = amax_w;
   if (stats) {
     DCN_CHECK_ARG(stats_rows >= grid, "conv2d_fwd: %d statistics rows for %d workgroups", stats_rows, grid);

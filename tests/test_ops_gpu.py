@@ -1119,6 +1119,40 @@ def test_stem_bwd_weight_bn_fused(dev, case):
     assert torch.equal(dw_new, ops.stem_bwd_weight_bn(x, y, dout, mi[0], mi[1], gamma.to(dev), beta.to(dev), ops.ACT_LEAKY, 0.1)[0])
 
 
+def test_nconv_kernels_on_tensors_beyond_2_gib(dev):
+    """The register-bank kernels address their operands relative to each workgroup's first row, so tensors of more than 2^31 bytes
+    (configs[3] / configs[4] geometries: 64 x 608 x 608 x 32 floats = 3 GB) stay on them: forward 32 -> 64 stride 2 and its data
+    gradient (with the BatchNorm tap) on 48 images of 608 x 608 against the implicit-GEMM tiles."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w = 48, 608, 608
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(n, h, w, 32, device=dev)
+    assert x.numel() * 4 > 2 ** 31
+    wgt = (torch.randn(64, 32, 3, 3, generator=g) / 6)
+    w_ohwi = wgt.permute(0, 2, 3, 1).contiguous().to(dev)
+    dy = torch.randn(n, h // 2, w // 2, 64, device=dev)
+    try:
+        lib().set_tuning(b"Nconv", 0)
+        y0, st0 = ops.conv2d_fwd(x, w_ohwi, 3, 2, want_stats=True)
+        dx0 = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2)
+        lib().set_tuning(b"Nconv", 1)
+        lib().prof_enable(1)
+        y1, st1 = ops.conv2d_fwd(x, w_ohwi, 3, 2, want_stats=True)
+        dx1 = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), 3, 2)
+        lib().prof_enable(0)
+        ran = _prof_launches(37) + _prof_launches(38)
+    finally:
+        lib().set_tuning(b"Nconv", 1); lib().prof_enable(0)
+    assert ran == 2, "the register-bank kernels declined the large tensors"
+    assert float((y1 - y0).abs().max()) <= 2e-5 * float(y0.abs().max())
+    assert float((dx1 - dx0).abs().max()) <= 2e-5 * float(dx0.abs().max())
+    s0, s1 = st0.double().sum(0), st1.double().sum(0)
+    assert float((s1 - s0).abs().max()) <= 1e-4 * float(s0.abs().max())
+    for t in (y1[-1], y1[0], dx1[-1], dx1[0]):                      # both ends of the tensors were written
+        assert float(t.abs().max()) > 0
+
+
 def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
