@@ -1,20 +1,24 @@
-// Data gradient of the first two 3x3 stride-2 layers (yolov3.cfg: 32 -> 64 on the 416x416 map, 64 -> 128 on the 208x208 map), i.e.
-// transposed convolutions from CK = 64 | 128 channels (dY) to CN = 32 | 64 channels (dX), f16 two-piece split.
+// Register-bank kernels for the 3x3 layers of the 416x416 / 208x208 maps (yolov3.cfg blocks 2-6: 32 -> 64 stride 2, the 32 -> 64 layer
+// of the first residual block, 64 -> 128 stride 2), f16 two-piece split.  Their tensors are the largest of the network (1.4 GB at
+// 416 x 416 x 32 channels, N = 64) and their filter banks the smallest (73-295 KB), so the filter bank lives in REGISTERS and one
+// persistent workgroup per CU (four waves, one per SIMD, up to 512 registers each) streams the activations past it:
 //
-//   dX[2r+a][2c+b][ci] = sum over the taps (ky, kx) of parity class (a, b), over co:  dY[r + (ky==0)][c + (kx==0)][co] * W[co][ky][kx][ci]
-//   class (a, b): ky = 1 for a = 0, ky in {0, 2} for a = 1 (kx likewise): 1 / 2 / 2 / 4 taps
+//   dgrad2_kernel<CK, CN>        data gradient of a stride-2 layer: dY (CK = 64 | 128 channels) -> dX (CN = 32 | 64 channels)
+//   nconv1_kernel<S, CK, CN, F>  forward 32 -> 64 at stride S = 1 | 2 (+ BatchNorm partial sums), data gradient 64 -> 32 at stride 1
 //
+// dgrad2:  dX[2r+a][2c+b][ci] = sum over the taps (ky, kx) of parity class (a, b), over co:  dY[r + (ky==0)][c + (kx==0)][co] * W[co][ky][kx][ci]
+//          class (a, b): ky = 1 for a = 0, ky in {0, 2} for a = 1 (kx likewise): 1 / 2 / 2 / 4 taps
 // igemm.hip runs the four classes as implicit GEMMs on 256 x 32 tiles: K loops of 4-16 steps, dY gathered from L2 once per tap, the
-// 1-tap class on the fp32 pipe — 1.8 ms (32 <- 64) and 1.0 ms (64 <- 128) against 0.4 / 0.2 ms of HBM traffic.  Here the filter
-// bank (73 | 295 KB) lives in REGISTERS: one persistent workgroup per CU (four waves, one per SIMD, up to 512 registers each) walks
+// 1-tap class on the fp32 pipe — 1.8 ms (32 <- 64) and 1.0 ms (64 <- 128) against 0.4 / 0.2 ms of HBM traffic.  Here a workgroup walks
 // a contiguous range of dY positions in chunks of 64 (CN = 32) or 32 (CN = 64); a wave owns 32 positions x 32 output channels and the
 // taps of two classes (role 0: the 4-tap class and the 1-tap class, role 1: the two 2-tap classes — 5 / 4 taps x CK/16 MFMA
 // triples per chunk), whose B fragments it split once (160 | 320 registers).  Per chunk the workgroup stages two row strips of dY
 // (rows r and r+1, chunk + 1 entries x CK channels, split into f16 pieces on the way to LDS, double buffered); every A fragment is
-// one ds_read_b128 at (strip, entry + 0|1).  Positions are PADDED as in
-// wgrad3.hip (rows of Wo + 1 entries, the last one a pad that is staged as zero), so the right neighbour of the last column and
-// the row below the last row read zeros without masks in the loop.  All four classes of a chunk are stored by the workgroup that
-// computed them: full 128-byte pixels.  Roofline: HBM.
+// one ds_read_b128 at (strip, entry + 0|1).  Positions are PADDED as in wgrad3.hip (rows of Wo + 1 entries, the last one a pad that
+// is staged as zero), so the right neighbour of the last column and the row below the last row read zeros without masks in the
+// loop.  All four classes of a chunk are stored by the workgroup that computed them: full 128-byte pixels.  Buffer descriptors start
+// at the workgroup's first row, so byte offsets are 32-bit whatever the tensor size.  Optional BatchNorm tap: the partial sums of the
+// backward of the layer in front, formed on dX in the epilogue.  Roofline: HBM.  (nconv1: see its own comment below.)
 #include "igemm.h"
 #include "prof.h"
 #include <type_traits>
