@@ -405,6 +405,7 @@ def main():
                                                 "wgrad_behind_its_dgrad": (True, True, True, True, 0),
                                                 "wgrad_beside_dgrad_low_priority": (True, True, True, False, 1),
                                                 "wgrad_behind_its_dgrad_low_priority": (True, True, True, True, 1),
+                                                "no_side_streams_again": (False, False, False, False, 0),     # (order check: the first variant runs on a cooler chip)
                                                 **{"tune:" + t: (True, True, True, True, 0) for t in args.schedule_tunes.split(";") if t}}.items():
             was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD)
             ops.WGRAD_SIDE, model.language_stream, model.sampling_stream, ops.WGRAD_AFTER_DGRAD = ws, ls, ss, after
