@@ -277,35 +277,54 @@ __global__ __launch_bounds__(256) void k14_negscatter_kernel(const float* __rest
 }
 
 // dctx[n][l][2c] = (dlag - lag*sum_l(dlag*lag)) / max(lnorm, eps),  dlag[n][l] = sum_{p: cols[n][p] == l} d_k[n][p];  odd channels 0
-__global__ __launch_bounds__(256) void k14_dlag_kernel(const float* __restrict__ lag, const float* __restrict__ lnorm,
-                                                       const int64_t* __restrict__ cols, const float* __restrict__ d_k,
-                                                       int L, int HW, int E, float* __restrict__ dctx) {
-  extern __shared__ int col_s[];            // [HW]
+// Block = (image n, 128 channels).  The positions of every word l are listed first, ascending (20 lanes scan the HW column indices
+// in LDS), so a channel's thread walks each position ONCE — the first form scanned all HW positions for each of the L words (54 k
+// compares per thread, 64 blocks on 256 CUs: 0.79 ms at N = 64, HW = 2704); the sums run in the same order, bit for bit.
+constexpr int DL_C = 128;
+__global__ __launch_bounds__(DL_C) void k14_dlag_kernel(const float* __restrict__ lag, const float* __restrict__ lnorm,
+                                                        const int64_t* __restrict__ cols, const float* __restrict__ d_k,
+                                                        int L, int HW, int E, float* __restrict__ dctx) {
+  extern __shared__ int dl_s[];             // [HW] column of every position, [HW] positions grouped by word, [CM_MAXL + 1] group starts
+  int* col_s = dl_s; int* order = dl_s + HW; int* start = dl_s + 2 * HW;
   const int n = blockIdx.x, tid = threadIdx.x, D = 2 * E;
-  for (int p = tid; p < HW; p += 256) col_s[p] = (int)cols[(size_t)n * HW + p];
+  for (int p = tid; p < HW; p += DL_C) col_s[p] = (int)cols[(size_t)n * HW + p];
   __syncthreads();
-  for (int c = tid; c < E; c += 256) {
-    float dl[CM_MAXL];
-    float dot = 0.f;
-#pragma unroll
-    for (int l = 0; l < CM_MAXL; ++l) {
-      dl[l] = 0.f;
-      if (l < L) {
-        float acc = 0.f;
-        for (int p = 0; p < HW; ++p) if (col_s[p] == l) acc += d_k[((size_t)n * HW + p) * E + c];
-        dl[l] = acc;
-        dot = fmaf(acc, lag[((size_t)n * L + l) * E + c], dot);
-      }
-    }
-    const float inv = 1.f / fmaxf(lnorm[(size_t)n * E + c], 1e-12f);
-#pragma unroll
-    for (int l = 0; l < CM_MAXL; ++l)
-      if (l < L) {
-        float* o = dctx + ((size_t)n * L + l) * D + 2 * c;
-        o[0] = (dl[l] - lag[((size_t)n * L + l) * E + c] * dot) * inv;
-        o[1] = 0.f;
-      }
+  if (tid < L) {                            // counts, then (after the prefix sum) the ascending position list of word tid
+    int cnt = 0;
+    for (int p = 0; p < HW; ++p) cnt += col_s[p] == tid;
+    start[tid + 1] = cnt;
   }
+  __syncthreads();
+  if (tid == 0) { start[0] = 0; for (int l = 0; l < L; ++l) start[l + 1] += start[l]; }
+  __syncthreads();
+  if (tid < L) {
+    int w = start[tid];
+    for (int p = 0; p < HW; ++p) if (col_s[p] == tid) order[w++] = p;
+  }
+  __syncthreads();
+  const int c = blockIdx.y * DL_C + tid;
+  if (c >= E) return;
+  float dl[CM_MAXL];
+  float dot = 0.f;
+  const float* dk = d_k + (size_t)n * HW * E + c;
+#pragma unroll
+  for (int l = 0; l < CM_MAXL; ++l) {
+    dl[l] = 0.f;
+    if (l < L) {
+      float acc = 0.f;
+      for (int i = start[l]; i < start[l + 1]; ++i) acc += dk[(size_t)order[i] * E];
+      dl[l] = acc;
+      dot = fmaf(acc, lag[((size_t)n * L + l) * E + c], dot);
+    }
+  }
+  const float inv = 1.f / fmaxf(lnorm[(size_t)n * E + c], 1e-12f);
+#pragma unroll
+  for (int l = 0; l < CM_MAXL; ++l)
+    if (l < L) {
+      float* o = dctx + ((size_t)n * L + l) * D + 2 * c;
+      o[0] = (dl[l] - lag[((size_t)n * L + l) * E + c] * dot) * inv;
+      o[1] = 0.f;
+    }
 }
 
 }  // namespace
@@ -382,7 +401,8 @@ extern "C" int dcn_k14_negscatter(const float* d_neg, const int* csr_off, const 
 extern "C" int dcn_k14_dlag(const float* lag, const float* lnorm, const int64_t* cols, const float* d_k, int n, int l, int hw, int e,
                             float* dcontext, void* stream) {
   DCN_CHECK_ARG(lag && lnorm && cols && d_k && dcontext && n > 0 && l > 0 && l <= CM_MAXL && hw > 0 && e > 0, "k14_dlag: bad argument");
-  hipLaunchKernelGGL(k14_dlag_kernel, dim3(n), dim3(256), (size_t)hw * sizeof(int), (hipStream_t)stream, lag, lnorm, cols, d_k, l, hw, e, dcontext);
+  hipLaunchKernelGGL(k14_dlag_kernel, dim3(n, cdiv(e, DL_C)), dim3(DL_C), (size_t)(2 * hw + CM_MAXL + 1) * sizeof(int), (hipStream_t)stream,
+                     lag, lnorm, cols, d_k, l, hw, e, dcontext);
   DCN_CHECK_LAUNCH("k14_dlag");
   return DCN_OK;
 }

@@ -1153,6 +1153,30 @@ def test_nconv_kernels_on_tensors_beyond_2_gib(dev):
         assert float(t.abs().max()) > 0
 
 
+@pytest.mark.parametrize("case", [(3, 20, 169, 512), (2, 7, 676, 256), (4, 20, 2704, 512), (1, 32, 100, 96)])
+def test_k14_dlag_grouped_positions(dev, case):
+    """csrc/sample.hip k14_dlag_kernel (gradient of the language side of Crossmodal_corrspondence, model/DCNet_model.py:41-112: the
+    per-word sums of d_k over the positions whose arg-max word it is, then the backward of the column normalisation) against the
+    same formula in torch fp64, with words that own no position and words that own all of them."""
+    from dcnet_amd import ops
+    n, L, hw, e = case
+    g = torch.Generator().manual_seed(17)
+    lag = torch.randn(n, L, e, generator=g); ln = torch.rand(n, e, generator=g) + 0.1
+    cols = torch.randint(0, L, (n, hw), generator=g)
+    cols[0] = 3 % L                                                 # one image: every position on the same word
+    d_k = torch.randn(n, hw, e, generator=g)
+    got = ops.k14_dlag(lag.to(dev), ln.to(dev), cols.to(dev), d_k.to(dev))
+    dlag = torch.zeros(n, L, e, dtype=torch.float64)
+    for i in range(n):
+        dlag[i].index_add_(0, cols[i], d_k[i].double())
+    dot = (dlag * lag.double()).sum(1, keepdim=True)
+    want = (dlag - lag.double() * dot) / ln.double().clamp_min(1e-12).unsqueeze(1)
+    assert got.shape == (n, L, 2 * e)
+    _close(got[..., 0::2], want, 2e-5, "k14_dlag")
+    assert float(got[..., 1::2].abs().max()) == 0
+    assert torch.equal(got, ops.k14_dlag(lag.to(dev), ln.to(dev), cols.to(dev), d_k.to(dev)))
+
+
 def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
