@@ -117,30 +117,44 @@ __global__ __launch_bounds__(SK_T) void k9_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// Gradient of the K9 gathers, by destination: block (pair, frame, group of GP positions), 2 channels per thread.
+// Gradient of the K9 gathers, by destination: block (pair, frame, group of GP positions), 2 channels per thread.  GP lanes first
+// list, per position, the entries of the (direct | negative) lists that point at it — ascending, so the sums keep their order — and
+// the channel threads then add those few rows (most positions have none and are a zero fill; scanning all 30 + 300 entries per
+// position and channel cost 0.64 ms at 32 pairs of 52 x 52).
 constexpr int K9B_GP = 16;
 __global__ __launch_bounds__(256) void k9_bwd_kernel(const int64_t* __restrict__ index, const int64_t* __restrict__ neg_idx,
                                                      const float* __restrict__ d_frame, const float* __restrict__ d_corr,
                                                      const float* __restrict__ d_neg, int HW, int E, int top_k, int neg_n,
                                                      float* __restrict__ dfv) {
-  extern __shared__ int lst[];              // [top_k] positions of this frame's direct list, then [top_k*neg_n] negatives
+  extern __shared__ int lst[];              // [nl] list positions (direct, then negatives) | [GP] match counts | [GP][nl] matching entries
   const int pair = blockIdx.z, f = blockIdx.y, tid = threadIdx.x;
-  const int nneg = top_k * neg_n;
+  const int nneg = top_k * neg_n, nl = top_k + (f == 1 ? nneg : 0), nl_max = top_k + nneg;
+  int* cnt = lst + nl_max; int* match = cnt + K9B_GP;
   for (int j = tid; j < top_k; j += 256) {
     const int64_t i = index[(size_t)pair * top_k + j];
     lst[j] = f == 0 ? (int)(i / HW) : (int)(i % HW);
   }
   if (f == 1) for (int e = tid; e < nneg; e += 256) lst[top_k + e] = (int)neg_idx[(size_t)pair * nneg + e];
   __syncthreads();
+  if (tid < K9B_GP) {
+    const int pos = blockIdx.x * K9B_GP + tid;
+    int m = 0;
+    for (int j = 0; j < nl; ++j) if (lst[j] == pos) match[tid * nl_max + m++] = j;
+    cnt[tid] = m;
+  }
+  __syncthreads();
   const float* dd = (f == 0 ? d_frame : d_corr) + (size_t)pair * top_k * E;
   const float* dn = d_neg + (size_t)pair * nneg * E;
   for (int g = 0; g < K9B_GP; ++g) {
     const int pos = blockIdx.x * K9B_GP + g;
     if (pos >= HW) break;
+    const int m = cnt[g];
     for (int c = tid; c < E; c += 256) {
       float acc = 0.f;
-      for (int j = 0; j < top_k; ++j) if (lst[j] == pos) acc += dd[(size_t)j * E + c];
-      if (f == 1) for (int e = 0; e < nneg; ++e) if (lst[top_k + e] == pos) acc += dn[(size_t)e * E + c];
+      for (int i = 0; i < m; ++i) {
+        const int j = match[g * nl_max + i];
+        acc += j < top_k ? dd[(size_t)j * E + c] : dn[(size_t)(j - top_k) * E + c];
+      }
       dfv[((size_t)(2 * pair + f) * HW + pos) * E + c] = acc;
     }
   }
@@ -343,7 +357,8 @@ extern "C" int dcn_k9_fwd(const float* cmap, const float* fv, const int64_t* raw
 extern "C" int dcn_k9_bwd(const int64_t* index, const int64_t* neg_idx, const float* d_frame, const float* d_corr, const float* d_neg,
                           int pairs, int hw, int e, int top_k, int neg_n, float* dfv, void* stream) {
   DCN_CHECK_ARG(index && neg_idx && d_frame && d_corr && d_neg && dfv && pairs > 0 && hw > 0 && e > 0, "k9_bwd: bad argument");
-  const size_t lds = (size_t)(top_k + top_k * neg_n) * sizeof(int);
+  const size_t lds = (size_t)((top_k + top_k * neg_n) * (K9B_GP + 1) + K9B_GP) * sizeof(int);
+  DCN_CHECK_ARG(lds <= 64 * 1024, "k9_bwd: %zu bytes of LDS (top_k=%d, neg_n=%d)", lds, top_k, neg_n);
   hipLaunchKernelGGL(k9_bwd_kernel, dim3(cdiv(hw, K9B_GP), 2, pairs), dim3(256), lds, (hipStream_t)stream, index, neg_idx, d_frame, d_corr,
                      d_neg, hw, e, top_k, neg_n, dfv);
   DCN_CHECK_LAUNCH("k9_bwd");

@@ -1177,6 +1177,29 @@ def test_k14_dlag_grouped_positions(dev, case):
     assert torch.equal(got, ops.k14_dlag(lag.to(dev), ln.to(dev), cols.to(dev), d_k.to(dev)))
 
 
+@pytest.mark.parametrize("case", [(3, 169, 64, 30, 10), (2, 676, 128, 30, 10), (2, 50, 32, 7, 3)])
+def test_k9_bwd_match_lists(dev, case):
+    """csrc/sample.hip k9_bwd_kernel (gradient of the K9 gathers of Interframe_corrspondence, model/DCNet_model.py:381-430, by
+    destination position) against index_add in fp64: repeated positions, positions hit by both lists, untouched positions."""
+    from dcnet_amd import ops
+    b, hw, e, top_k, neg_n = case
+    g = torch.Generator().manual_seed(23)
+    index = torch.randint(0, hw * hw, (b, top_k), generator=g)
+    index[0, :4] = index[0, 0]                                      # the same (i, j) picked several times
+    neg_idx = torch.randint(0, hw, (b, top_k, neg_n), generator=g)
+    neg_idx[0, 0, :] = int(index[0, 0]) % hw                        # negatives on a position of the direct list
+    d_frame = torch.randn(b, top_k, e, generator=g); d_corr = torch.randn(b, top_k, e, generator=g)
+    d_neg = torch.randn(b, top_k, neg_n, e, generator=g)
+    got = ops.k9_bwd(index.to(dev), neg_idx.to(dev), d_frame.to(dev), d_corr.to(dev), d_neg.to(dev), hw)
+    want = torch.zeros(2 * b, hw, e, dtype=torch.float64)
+    for p in range(b):
+        want[2 * p].index_add_(0, index[p] // hw, d_frame[p].double())
+        want[2 * p + 1].index_add_(0, index[p] % hw, d_corr[p].double())
+        want[2 * p + 1].index_add_(0, neg_idx[p].reshape(-1), d_neg[p].reshape(-1, e).double())
+    _close(got, want, 1e-5, "k9_bwd")
+    assert torch.equal(got, ops.k9_bwd(index.to(dev), neg_idx.to(dev), d_frame.to(dev), d_corr.to(dev), d_neg.to(dev), hw))
+
+
 def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
