@@ -285,7 +285,15 @@ __global__ __launch_bounds__(256) void k14_negscatter_kernel(const float* __rest
   const int lo = csr_off[p], hi = csr_off[p + 1];
   for (int c = threadIdx.x; c < E; c += 256) {
     float acc = 0.f;
-    for (int i = lo; i < hi; ++i) acc += d_neg[(size_t)csr_src[i] * E + c];
+    int i = lo;
+    for (; i + 8 <= hi; i += 8) {            // eight rows in flight, added in source order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = d_neg[(size_t)csr_src[i + k] * E + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; i < hi; ++i) acc += d_neg[(size_t)csr_src[i] * E + c];
     extra[(size_t)p * E + c] = acc;
   }
 }
@@ -326,7 +334,16 @@ __global__ __launch_bounds__(DL_C) void k14_dlag_kernel(const float* __restrict_
     dl[l] = 0.f;
     if (l < L) {
       float acc = 0.f;
-      for (int i = start[l]; i < start[l + 1]; ++i) acc += dk[(size_t)order[i] * E];
+      int i = start[l];
+      const int hi = start[l + 1];
+      for (; i + 8 <= hi; i += 8) {          // eight loads in flight, added in list order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = dk[(size_t)order[i + k] * E];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+      }
+      for (; i < hi; ++i) acc += dk[(size_t)order[i] * E];
       dl[l] = acc;
       dot = fmaf(acc, lag[((size_t)n * L + l) * E + c], dot);
     }

@@ -148,17 +148,22 @@ __global__ __launch_bounds__(256) void score_dq_kernel(const float* __restrict__
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int ch = blockIdx.x * 64 + tx, img = blockIdx.y;
   float s = 0.f;
+  // eight rows of loads in flight per thread, added in row order (one load per iteration ran at the latency of a load: 0.56 ms
+  // for the 354 MB of the 52 x 52 scale)
+  auto sweep = [&](const float* w, int64_t row0) {
+    int r = ty;
+    for (; r + 28 < rpi; r += 32) {
+      float o[8], d[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int64_t row = row0 + r + 4 * k; o[k] = out[row * ldo + ch]; d[k] = w[row]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += d[k] * o[k];
+    }
+    for (; r < rpi; r += 4) { const int64_t row = row0 + r; s += w[row] * out[row * ldo + ch]; }
+  };
   if (ch < c) {
-    if (dscore)
-      for (int r = ty; r < rpi; r += 4) {
-        const int64_t row = (int64_t)img * rpi + r;
-        s += dscore[row] * out[row * ldo + ch];
-      }
-    if (dscore_flip)
-      for (int r = ty; r < rpi; r += 4) {
-        const int64_t row = (int64_t)(gridDim.y - 1 - img) * rpi + r;
-        s += dscore_flip[row] * out[row * ldo + ch];
-      }
+    if (dscore) sweep(dscore, (int64_t)img * rpi);
+    if (dscore_flip) sweep(dscore_flip, (int64_t)(gridDim.y - 1 - img) * rpi);
   }
   red[ty][tx] = s;
   __syncthreads();
