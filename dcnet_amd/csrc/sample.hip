@@ -169,7 +169,17 @@ __global__ __launch_bounds__(256) void colnorm_fwd_kernel(const float* __restric
   const int c = blockIdx.x * 64 + tx;
   const float* src = v + (size_t)n * HW * E;
   float ss = 0.f;
-  if (c < E) for (int p = ty; p < HW; p += 4) { const float x = src[(size_t)p * E + c]; ss = fmaf(x, x, ss); }
+  if (c < E) {
+    int p = ty;
+    for (; p + 28 < HW; p += 32) {           // eight loads in flight, squared and added in position order
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = src[(size_t)(p + 4 * k) * E + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss = fmaf(x[k], x[k], ss);
+    }
+    for (; p < HW; p += 4) { const float x = src[(size_t)p * E + c]; ss = fmaf(x, x, ss); }
+  }
   red[ty][tx] = ss;
   __syncthreads();
   const float nrm = sqrtf(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
@@ -188,18 +198,42 @@ __global__ __launch_bounds__(256) void colnorm_bwd_kernel(const float* __restric
   const int c = blockIdx.x * 64 + tx;
   const bool ex = extra != nullptr && n == n_extra;
   float dot = 0.f;
-  if (c < E)
-    for (int p = ty; p < HW; p += 4) {
+  // eight positions of loads in flight per thread (in position order): one position per iteration ran at the latency of a load
+  if (c < E) {
+    int p = ty;
+    for (; p + 28 < HW; p += 32) {
+      float g[8], v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t i = ((size_t)n * HW + p + 4 * k) * E + c;
+        g[k] = dq[i] + (ex ? extra[(size_t)(p + 4 * k) * E + c] : 0.f); v[k] = vit[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dot = fmaf(g[k], v[k], dot);
+    }
+    for (; p < HW; p += 4) {
       const size_t i = ((size_t)n * HW + p) * E + c;
       const float g = dq[i] + (ex ? extra[(size_t)p * E + c] : 0.f);
       dot = fmaf(g, vit[i], dot);
     }
+  }
   red[ty][tx] = dot;
   __syncthreads();
   dot = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
   if (c >= E) return;
   const float inv = 1.f / fmaxf(cnorm[(size_t)n * E + c], 1e-12f);
-  for (int p = ty; p < HW; p += 4) {
+  int p = ty;
+  for (; p + 28 < HW; p += 32) {
+    float g[8], v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const size_t i = ((size_t)n * HW + p + 4 * k) * E + c;
+      g[k] = dq[i] + (ex ? extra[(size_t)(p + 4 * k) * E + c] : 0.f); v[k] = vit[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dv[((size_t)n * HW + p + 4 * k) * E + c] = (g[k] - v[k] * dot) * inv;
+  }
+  for (; p < HW; p += 4) {
     const size_t i = ((size_t)n * HW + p) * E + c;
     const float g = dq[i] + (ex ? extra[(size_t)p * E + c] : 0.f);
     dv[i] = (g - vit[i] * dot) * inv;
@@ -236,6 +270,28 @@ __global__ __launch_bounds__(1024) void crossmap_kernel(const float* __restrict_
   __syncthreads();
   for (int p = wave; p < HW; p += 16) {
     const float* row = vit + ((size_t)n * HW + p) * E;
+    if (E <= 1024) {                          // the position's row stays in registers for all L words (same sums, same order)
+      f32x4 a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        a[k] = c < E ? *reinterpret_cast<const f32x4*>(row + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int l = 0; l < L; ++l) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = lane * 4 + 256 * k;
+          if (c < E) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lag_s + (size_t)l * E + c);
+            acc += a[k][0] * b[0] + a[k][1] * b[1] + a[k][2] * b[2] + a[k][3] * b[3];
+          }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) lv[l * (HW + 2) + p + 1] = acc;
+      }
+      continue;
+    }
     for (int l = 0; l < L; ++l) {
       float acc = 0.f;
       for (int c = lane * 4; c < E; c += 256) {
