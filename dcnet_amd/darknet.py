@@ -285,6 +285,9 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             p = P[op.slot]
             x = out[op.src]; ax = amx.get(op.src)
             bank = banks.get(op.slot, p["w"]) if banks is not None else None
+            if bank is not None and getattr(banks, "pending", None) is not None:
+                torch.cuda.current_stream().wait_stream(banks.pending)      # the refresh launched by Darknet._filter_banks
+                banks.pending = None
             if bank is not None:       # prepared for the whole network in one go (no per-layer transpose / abs-max / pre-split)
                 w, aw, wsp, w16 = bank["ohwi"], (bank["amax"] if am else None), bank["split"], bank["b16"]
                 w._dcn_wt = (bank["t"], bank["tsplit"]); w._dcn_wt16 = bank["tb16"]
@@ -592,7 +595,17 @@ class Darknet(nn.Module):
         if fb is None or not fb.valid_for(ws):
             fb = ops.FilterBanks(ws, next(iter(ws.values())).device)
             self.__dict__["_fbanks"] = fb
-        fb.refresh()
+        # the refresh (0.6 ms of kernels) runs on a stream of its own, beside the image transpose and the stem, which do not read
+        # the banks; _run_forward joins it in front of the first convolution that does
+        main = torch.cuda.current_stream()
+        prep = self.__dict__.get("_prep_stream")
+        if prep is None or prep.device != main.device:
+            prep = torch.cuda.Stream(device=main.device)
+            self.__dict__["_prep_stream"] = prep
+        prep.wait_stream(main)                        # (the parameters' last writer and the banks' last readers are on `main`)
+        with torch.cuda.stream(prep):
+            fb.refresh()
+        fb.pending = prep
         return fb
 
     def forward_nhwc(self, x: torch.Tensor) -> List[torch.Tensor]:

@@ -493,10 +493,10 @@ class grounding_model(nn.Module):
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
             flang_attn, flang_loc = self._phrases(context, embedded, word_id)    # :525-526, :556-557
+            self._head_filter_banks()                # (0.3 ms of kernels the head needs after the backbone: beside it, not behind it)
         static = self.static_samples if self.training else None
         handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
-        self._head_filter_banks()
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)
