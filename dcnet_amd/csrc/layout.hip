@@ -79,8 +79,31 @@ inline int stream_grid(int64_t work_items) {
 
 }  // namespace
 
+namespace {
+// The image: [C <= 4][HW] planes -> [HW][4] pixels (missing channels zero).  One pixel per thread: plane reads and 16-byte pixel writes
+// are both coalesced (the 32 x 32 tile transpose below moves 32 channels per pixel tile for the 3 that exist: 0.32 ms at 64 x 416 x 416).
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int64_t hw, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t n = i / hw, p = i - n * hw;
+  const float* s = src + n * c * hw + p;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  v[0] = s[0];
+  if (c > 1) v[1] = s[hw];
+  if (c > 2) v[2] = s[2 * hw];
+  if (c > 3) v[3] = s[3 * hw];
+  *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+}
+}  // namespace
+
 extern "C" int dcn_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad, void* stream) {
   DCN_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad argument");
+  if (c_pad == 4 && ((uintptr_t)dst & 15) == 0) {
+    const int64_t total = (int64_t)n * h * w;
+    hipLaunchKernelGGL(image_to_nhwc4_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, c, (int64_t)h * w, total);
+    DCN_CHECK_LAUNCH("image_to_nhwc4");
+    return DCN_OK;
+  }
   // per image: [C][HW] -> [HW][c_pad]
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(h * w, 32), cdiv(c_pad, 32), n), dim3(256), 0, (hipStream_t)stream,
                      src, dst, c, h * w, h * w, c_pad, c_pad, (int64_t)c * h * w, (int64_t)h * w * c_pad);
