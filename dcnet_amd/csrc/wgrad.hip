@@ -605,15 +605,15 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
 
 // wgrad9.hip: the 3x3 layers with 32 input channels and 64 filters, nine taps per workgroup (f16 split)
 bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
-int64_t wgrad9_ws(int n, int h, int wd, int stride);
-int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int stride,
+int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride);
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
                   const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream);
 
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
   if (wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride)) {
-    const int64_t w9 = wgrad9_ws(n, h, wd, stride);
+    const int64_t w9 = wgrad9_ws(n, h, wd, cin, cout, stride);
     if (w9 > ws) ws = w9;
   }
   if (wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride)) {       // (which kernel runs depends on the abs-max words: size for both)
@@ -658,7 +658,7 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
     const long long npix = (long long)n * h * wd;
     const bool f16 = g_wsplit == 4 && amax_x && amax_dy, b16 = g_wsplit == 2;      // (2: the bf16- and fp8-operand modes)
     if (f16 && !g_wabl && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0)
-      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, stride, amax_x, amax_dy, stream);
+      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, stream);
     if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
       return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);

@@ -50,33 +50,50 @@ __device__ __forceinline__ float pow2_9(unsigned amax_bits) {
 }
 
 constexpr int KS = 32;                    // dY positions per K-step (two MFMA K-steps per barrier)
-constexpr int A_PLANE9 = KS * 128;        // [32 positions][64 filters] f16
-// dY plane: 128-B rows, the two 64-B halves swap on rows 2, 3 (mod 4): four consecutive rows of one half sit in four different
-// 64-B bank groups (a half-wave of the transposed read takes 4 rows x 64 B)
-__device__ __forceinline__ int a_off(int row, int c) { return 128 * row + 64 * ((c >> 5) ^ ((row >> 1) & 1)) + 2 * (c & 31); }
 
-// X planes of one filter row: S = 1: [34 entries][32 channels] f16 (64-B rows).  S = 2: even entries (33 rows) then odd entries
-// (32 rows) starting 128 B (mod 256) further, so that a store of entries 4j..4j+3 (two even, two odd rows) spreads over all banks.
-template <int S> struct XLay;
-template <> struct XLay<1> { static constexpr int NU = 34, ROWB = 34 * 64; };
-template <> struct XLay<2> { static constexpr int NU = 65, ODD = 34 * 64, ROWB = 34 * 64 + 32 * 64; };
-template <int S> __device__ __forceinline__ int x_off(int s) {          // entry s of the staged range (U = S*q0 + s)
-  if constexpr (S == 1) return 64 * s;
-  else return (s & 1) ? XLay<2>::ODD + 64 * (s >> 1) : 64 * (s >> 1);
-}
-template <int S> __device__ __forceinline__ int x_tap(int k, int d) {   // LDS row of position k (0..31), tap d
-  if constexpr (S == 1) return 64 * (k + d);
-  else return d == 1 ? XLay<2>::ODD + 64 * k : 64 * (k + (d >> 1));
+// LDS rows hold a position's channels as f16: 64 | 128 | 256 bytes.  A half-wave of the transposed read takes 4 consecutive rows x one
+// 64-byte segment (32 channels); the segment index is XORed with a function of the row so that the four pieces sit in four different
+// 64-byte bank groups: 64-byte rows need nothing, 128-byte rows swap their halves on rows 2, 3 (mod 4), 256-byte rows rotate by row % 4.
+template <int ROWB> __device__ __forceinline__ int seg_swz(int seg, int row) {
+  if constexpr (ROWB == 64) return seg;
+  else if constexpr (ROWB == 128) return seg ^ ((row >> 1) & 1);
+  else return seg ^ (row & 3);
 }
 
-template <int S>
-__global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad9_kernel(const W9Params p) {
-  constexpr int NU = XLay<S>::NU, ROWB = XLay<S>::ROWB, B_PLANE = 3 * ROWB;
-  constexpr int B_BASE = 2 * A_PLANE9, BUF = 2 * A_PLANE9 + 2 * B_PLANE;
-  constexpr int NA = KS * 16, NX = 3 * NU * 8, NSLOT = (NA + NX + 383) / 384;
+// Geometry of one launch form: CO filters x CI channels, stride S
+template <int S, int CO, int CI> struct G9 {
+  static constexpr int NW = CO == 64 ? 6 : 8;            // waves: (64, 32): (filter half, filter row); (128, 64): (filter quarter, channel half), all rows
+  static constexpr int NR = CO == 64 ? 1 : 3;            // filter rows per wave
+  static constexpr int NT = 64 * NW;
+  static constexpr int A_ROWB = 2 * CO, X_ROWB = 2 * CI;
+  static constexpr int A_PLANE = KS * A_ROWB;
+  static constexpr int NU = S == 1 ? KS + 2 : 2 * KS + 1;             // staged X entries per filter row: 34 | 65
+  // S = 2: even entries (33 rows) then the odd ones, starting 128 bytes (mod 256) further so that a store of two even and two odd
+  // rows spreads over all banks
+  static constexpr int ODD = X_ROWB == 64 ? 34 : 33;
+  static constexpr int FROWS = S == 1 ? NU : ODD + KS;
+  static constexpr int FROWB = FROWS * X_ROWB;                         // one filter row's X plane
+  static constexpr int B_PLANE = 3 * FROWB;
+  static constexpr int B_BASE = 2 * A_PLANE, BUF = 2 * A_PLANE + 2 * B_PLANE;
+  static constexpr int NA = KS * (CO / 4), NX = 3 * NU * (CI / 4), NSLOT = (NA + NX + NT - 1) / NT;
+  static_assert(NA % 64 == 0, "a staging slot is one kind per wave");
+  static __device__ __forceinline__ int a_off(int row, int c) { return A_ROWB * row + 64 * seg_swz<A_ROWB>(c >> 5, row) + 2 * (c & 31); }
+  static __device__ __forceinline__ int x_row(int s) { return S == 1 ? s : ((s & 1) ? ODD + (s >> 1) : (s >> 1)); }                 // LDS row of entry s
+  static __device__ __forceinline__ int tap_row(int k, int d) { return S == 1 ? k + d : (d == 1 ? ODD + k : k + (d >> 1)); }        // ... of position k, tap d
+  static __device__ __forceinline__ int x_off(int fr, int row, int c) { return fr * FROWB + X_ROWB * row + 64 * seg_swz<X_ROWB>(c >> 5, row) + 2 * (c & 31); }
+};
+
+template <int S, int CO, int CI>
+__global__ __launch_bounds__(64 * (CO == 64 ? 6 : 8)) __attribute__((amdgpu_waves_per_eu(CO == 64 ? 3 : 2, CO == 64 ? 3 : 2)))
+void wgrad9_kernel(const W9Params p) {
+  typedef G9<S, CO, CI> G;
+  constexpr int NT = G::NT, NR = G::NR, NU = G::NU, A_PLANE = G::A_PLANE, B_PLANE = G::B_PLANE, B_BASE = G::B_BASE, BUF = G::BUF;
+  constexpr int NA = G::NA, NX = G::NX, NSLOT = G::NSLOT;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm9[];     // [2 buffers][dY: 2 planes | X: 2 planes x 3 filter rows]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cb = wave & 1, r = wave >> 1;                                 // 32 filters x 32 channels x filter row r
+  const int cb = CO == 64 ? (wave & 1) : (wave & 3);                      // 32-filter block
+  const int ib = CO == 64 ? 0 : (wave >> 2);                              // 32-channel block
+  const int r0 = CO == 64 ? (wave >> 1) : 0;                              // first filter row of the wave
   const int split = xcd_remap(blockIdx.x, gridDim.x);
   const int Wp = p.Wo + 1, RL = S * Wp;
   const int p_begin = split * p.kchunk;
@@ -84,30 +101,30 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int iters = (p_end - p_begin + KS - 1) / KS;
   const float s_a = pow2_9(amax_read(p.amax_dy)), s_b = pow2_9(amax_read(p.amax_x));
 
-  const __amdgpu_buffer_rsrc_t a_rs = rsrc9(p.dy, (((long long)p.N * p.Ho * p.Wo - 1) * p.lddy + 64) * 4);
-  const __amdgpu_buffer_rsrc_t b_rs = rsrc9(p.x, (((long long)p.N * p.H * p.W - 1) * p.ldx + 32) * 4);
+  const __amdgpu_buffer_rsrc_t a_rs = rsrc9(p.dy, (((long long)p.N * p.Ho * p.Wo - 1) * p.lddy + CO) * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrc9(p.x, (((long long)p.N * p.H * p.W - 1) * p.ldx + CI) * 4);
 
-  // ---- load slots: element e = slot*384 + tid of the K-step's staging list (dY pieces first, then X pieces) ----------------
+  // ---- load slots: element e = slot*NT + tid of the K-step's staging list (dY pieces first, then X pieces) ------------------
   // dY piece: position q0 + idx, filters c..c+3;  X piece: filter row fr, entry idx of the staged range, channels c..c+3.
   // NA is a multiple of 64, so a slot is one kind for a whole wave (is_a: scalar — the two kinds use different buffer
   // descriptors and must not meet in one load); elements past the end of the list repeat the last X piece (same bytes, same place).
-  // meta = fr << 2 | c << 4 | idx << 10.  The step's first position q0 = (row g_row = n*Ho + oy, column g_col) is the same for
+  // meta = fr << 2 | c << 4 | idx << 11.  The step's first position q0 = (row g_row = n*Ho + oy, column g_col) is the same for
   // the whole workgroup (scalar registers); a slot adds its idx and wraps into the next row at most once.
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   int meta[NSLOT], st_off[NSLOT];
   bool is_a[NSLOT];
 #pragma unroll
   for (int j = 0; j < NSLOT; ++j) {
-    const int e = j * 384 + tid;
-    is_a[j] = j * 384 + 64 * wave_u < NA;
+    const int e = j * NT + tid;
+    is_a[j] = j * NT + 64 * wave_u < NA;
     if (is_a[j]) {
-      const int pos = e >> 4, c = (e & 15) * 4;
-      meta[j] = (c << 4) | (pos << 10); st_off[j] = a_off(pos, c);
+      const int pos = e / (CO / 4), c = (e % (CO / 4)) * 4;
+      meta[j] = (c << 4) | (pos << 11); st_off[j] = G::a_off(pos, c);
     } else {
       const int x = min(e - NA, NX - 1);
-      const int fr = x / (NU * 8), rem = x - fr * (NU * 8);
-      const int s = rem >> 3, c = (rem & 7) * 4;
-      meta[j] = (fr << 2) | (c << 4) | (s << 10); st_off[j] = B_BASE + fr * ROWB + x_off<S>(s) + 2 * c;
+      const int fr = x / (NU * (CI / 4)), rem = x - fr * (NU * (CI / 4));
+      const int s_ = rem / (CI / 4), c = (rem % (CI / 4)) * 4;
+      meta[j] = (fr << 2) | (c << 4) | (s_ << 11); st_off[j] = B_BASE + G::x_off(fr, G::x_row(s_), c);
     }
   }
   int q_step = p_begin;                                   // first position of the step being LOADED
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       unsigned off = OOB9;
-      const int c = (meta[j] >> 4) & 63, idx = meta[j] >> 10;
+      const int c = (meta[j] >> 4) & 127, idx = meta[j] >> 11;
       if (is_a[j]) {
         int col = g_col + idx, row = g_row;
         if (col >= Wp) { col -= Wp; ++row; }
@@ -146,17 +163,18 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                          (_Float16)(t[3] - (float)h[3])};
       unsigned char* dst = sm9 + buf * BUF + st_off[j];
       *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h);
-      *reinterpret_cast<uint2*>(dst + (is_a[j] ? A_PLANE9 : B_PLANE)) = __builtin_bit_cast(uint2, l);
+      *reinterpret_cast<uint2*>(dst + (is_a[j] ? A_PLANE : B_PLANE)) = __builtin_bit_cast(uint2, l);
     }
   };
 
-  f32x16 acc[3];
+  f32x16 acc[NR * 3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d)
+  for (int d = 0; d < NR * 3; ++d)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[d][q] = 0.f;
 
-  // transposed-read addresses (wgrad.hip): 16-lane group (hh, gg): K rows 8hh + 4r2 + q, channels 16gg + 4pp of the wave's block
+  // transposed-read addresses (wgrad.hip): 16-lane group (hh, gg): K rows 8hh + 4r2 + q, channels 16gg + 4pp of the wave's block.
+  // X: filter row r0's plane; the wave's other filter rows are FROWB further each.
   const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, qq = (lane & 15) >> 2, pp = lane & 3;
   int a_tr[2][2], b_tr[2][3][2];                           // [MFMA K-step][..][r2]
 #pragma unroll
@@ -164,9 +182,9 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
       const int k = 16 * ks + 8 * hh + 4 * r2 + qq;
-      a_tr[ks][r2] = a_off(k, cb * 32 + 16 * gg + 4 * pp);
+      a_tr[ks][r2] = G::a_off(k, cb * 32 + 16 * gg + 4 * pp);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) b_tr[ks][d][r2] = B_BASE + r * ROWB + x_tap<S>(k, d) + 2 * (16 * gg + 4 * pp);
+      for (int d = 0; d < 3; ++d) b_tr[ks][d][r2] = B_BASE + G::x_off(r0, G::tap_row(k, d), ib * 32 + 16 * gg + 4 * pp);
     }
   auto tr_read = [&](int byte_off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm9 + byte_off));
@@ -177,19 +195,21 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     return __builtin_bit_cast(f16x8_t, v);
   };
   auto k_step = [&](int buf, int ks) {
-    f16x8_t af[2], bf[3][2];
+    f16x8_t af[2];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) af[pl] = frag(buf * BUF + pl * A_PLANE9 + a_tr[ks][0], buf * BUF + pl * A_PLANE9 + a_tr[ks][1]);
+    for (int pl = 0; pl < 2; ++pl) af[pl] = frag(buf * BUF + pl * A_PLANE + a_tr[ks][0], buf * BUF + pl * A_PLANE + a_tr[ks][1]);
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bf[d][pl] = frag(buf * BUF + pl * B_PLANE + b_tr[ks][d][0], buf * BUF + pl * B_PLANE + b_tr[ks][d][1]);
+      for (int d = 0; d < 3; ++d) {                         // fragments per tap: 8 live registers (smallest terms first: (l,h) (h,l) (h,h))
+        f16x8_t bf[2];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {                           // smallest terms first: (l,h) (h,l) (h,h)
-      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[d][0], acc[d], 0, 0, 0);
-      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[d][1], acc[d], 0, 0, 0);
-      acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[d][0], acc[d], 0, 0, 0);
-    }
+        for (int pl = 0; pl < 2; ++pl)
+          bf[pl] = frag(buf * BUF + pl * B_PLANE + rr * G::FROWB + b_tr[ks][d][0], buf * BUF + pl * B_PLANE + rr * G::FROWB + b_tr[ks][d][1]);
+        acc[rr * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1], bf[0], acc[rr * 3 + d], 0, 0, 0);
+        acc[rr * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1], acc[rr * 3 + d], 0, 0, 0);
+        acc[rr * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0], acc[rr * 3 + d], 0, 0, 0);
+      }
   };
 
   // One register set for the staged pieces: step it+1 is split and stored between the two MFMA K-steps of step it, and the loads
@@ -212,17 +232,20 @@ __global__ __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 
   const float dq = 1.f / (s_a * s_b);                        // powers of two: exact
-  float* out = p.out + (size_t)split * 64 * 288;
+  float* out = p.out + (size_t)split * CO * 9 * CI;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int co = cb * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-    const int ci = lane & 31;
+    const int ci = ib * 32 + (lane & 31);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) out[(size_t)co * 288 + (3 * r + d) * 32 + ci] = acc[d][q] * dq;
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) out[(size_t)co * 9 * CI + (3 * (r0 + rr) + d) * CI + ci] = acc[rr * 3 + d][q] * dq;
   }
 }
 
-int g_w9 = 1;             // dcn_set_tuning("9tap", 0): these layers back on the per-tap kernel of wgrad.hip
+int g_w9 = 2;             // dcn_set_tuning("9tap", 0): these layers back on the kernels of wgrad.hip / wgrad3.hip; 1: 32 -> 64 only;
+                          // 2: + 64 -> 128 at stride 1; 3: + 64 -> 128 at stride 2 (54 spilled registers)
 int g_w9_target = 512;    // dcn_set_tuning("9target", n): workgroups (= split-K slabs) per launch
 
 struct Plan9 { int splits, kchunk, Mp; };
@@ -237,27 +260,43 @@ Plan9 plan9(int n, int ho, int wo) {
   return pl;
 }
 
-template <int S> size_t lds9() { return (size_t)2 * (2 * A_PLANE9 + 2 * 3 * XLay<S>::ROWB); }
+template <int S, int CO, int CI> size_t lds9() { return (size_t)2 * G9<S, CO, CI>::BUF; }
+
+template <int S, int CO, int CI>
+int launch9(const W9Params& p, int splits, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
+    attr_done = true;
+  }
+  const int threads = G9<S, CO, CI>::NT;
+  const size_t lds = lds9<S, CO, CI>();
+  hipLaunchKernelGGL((wgrad9_kernel<S, CO, CI>), dim3(splits), dim3(threads), lds, stream, p);
+  return DCN_OK;
+}
 
 }  // namespace
 
 void wgrad9_set_tuning(int key, int value) { if (key == 0) g_w9 = value; else g_w9_target = value > 0 ? value : 512; }
 
-// shape test only (the workspace is sized without knowing whether the abs-max words will be there)
+// shape test only (the workspace is sized without knowing whether the abs-max words will be there): 32 -> 64 (stride 1 | 2) and
+// 64 -> 128 (g_w9 = 2: stride 1 only; 1: neither — the half-empty 128 x 128 tiles of wgrad3.hip / wgrad.hip keep them)
 bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
-  if (!g_w9 || ksize != 3 || (stride != 1 && stride != 2) || cin != 32 || cout != 64) return false;
+  if (!g_w9 || ksize != 3 || (stride != 1 && stride != 2)) return false;
+  const bool small = cin == 32 && cout == 64, big = cin == 64 && cout == 128 && (g_w9 == 3 || (g_w9 == 2 && stride == 1));
+  if (!small && !big) return false;
   if (h % stride || wd % stride || wd / stride < KS || h / stride < 2) return false;       // (one row wrap per K-step at most)
   const long long npix = (long long)n * h * wd, opix = (long long)n * (h / stride) * (wd / stride);
-  if (npix * 32 * 4 >= 0x7FFFFFF0LL || opix * 64 * 4 >= 0x7FFFFFF0LL) return false;        // 32-bit byte offsets from the tensor bases (dense)
+  if (npix * cin * 4 >= 0x7FFFFFF0LL || opix * cout * 4 >= 0x7FFFFFF0LL) return false;     // 32-bit byte offsets from the tensor bases (dense)
   if ((long long)n * (h / stride) * (wd / stride + 1) * stride >= 0x7FFFFFF0LL || npix < 4096) return false;
   return true;
 }
-int64_t wgrad9_ws(int n, int h, int wd, int stride) {
+int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride) {
   const Plan9 pl = plan9(n, h / stride, wd / stride);
-  return pl.splits > 1 ? (int64_t)pl.splits * 64 * 288 : 0;
+  return pl.splits > 1 ? (int64_t)pl.splits * cout * 9 * cin : 0;
 }
 
-int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int stride,
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
                   const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
   const int ho = h / stride, wo = wd / stride;
   const Plan9 pl = plan9(n, ho, wo);
@@ -270,19 +309,13 @@ int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.N = n; p.H = h; p.W = wd; p.Ho = ho; p.Wo = wo; p.ldx = ldx; p.lddy = lddy;
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.amax_dy = amax_dy; p.amax_x = amax_x;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<1>());
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<2>());
-    attr_done = true;
-  }
   // HBM-priced: dY and X once, the slabs written
-  const double bytes = 4.0 * ((double)n * ho * wo * 64 + (double)n * h * wd * 32 + (double)pl.splits * 64 * 288);
-  const int pid = prof_begin(36, 2.0 * (double)n * ho * wo * 64 * 288.0, stream, bytes);
-  if (stride == 1) hipLaunchKernelGGL(wgrad9_kernel<1>, dim3(pl.splits), dim3(384), lds9<1>(), stream, p);
-  else hipLaunchKernelGGL(wgrad9_kernel<2>, dim3(pl.splits), dim3(384), lds9<2>(), stream, p);
+  const double bytes = 4.0 * ((double)n * ho * wo * cout + (double)n * h * wd * cin + (double)pl.splits * cout * 9 * cin);
+  const int pid = prof_begin(36, 2.0 * (double)n * ho * wo * cout * 9.0 * cin, stream, bytes);
+  if (cin == 32) { if (stride == 1) launch9<1, 64, 32>(p, pl.splits, stream); else launch9<2, 64, 32>(p, pl.splits, stream); }
+  else { if (stride == 1) launch9<1, 128, 64>(p, pl.splits, stream); else launch9<2, 128, 64>(p, pl.splits, stream); }
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad9");
-  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)64 * 288 / 4, pl.splits, stream);
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
   return DCN_OK;
 }

@@ -427,7 +427,7 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     geom = conv_geom(x.device, n, h, wd, ksize, stride)
     # the kernels with a split mode: the 128-wide weight-gradient tiles and the nine-tap kernel of the 32 -> 64 3x3 layers
-    if (cin >= 64 and cout >= 64 and (cin >= 128 or cout >= 128)) or (cin == 32 and cout == 64 and ksize == 3):
+    if (cin >= 64 and cout >= 64 and (cin >= 128 or cout >= 128)) or (cin == 32 and cout == 64 and ksize == 3):      # (64 -> 128 is in the first)
         amax_x = _amax_or_pass(x, amax_x); amax_dy = _amax_or_pass(dy, amax_dy)
     lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
                             n, h, wd, cin, cout, ksize, stride, _p(amax_x), _p(amax_dy), _s())

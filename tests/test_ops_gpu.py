@@ -1210,37 +1210,42 @@ def _prof_launches(tag):
 
 
 W9_CASES = [
-    # n, h, w, stride   (3x3, 32 input channels, 64 filters; output rows of >= 32 pixels)
-    (2, 64, 64, 1),
-    (2, 40, 70, 1),      # rows that are no multiple of the 32-position K-step
-    (1, 35, 131, 1),     # odd map
-    (4, 33, 33, 1),      # shortest rows (34 padded entries: a wrap in every K-step), image-to-image wrap
-    (2, 64, 64, 2),      # 32-pixel output rows
-    (1, 72, 136, 2),
-    (3, 66, 96, 2),
+    # n, h, w, stride, cin   (3x3, cin input channels, 2 cin filters; output rows of >= 32 pixels)
+    (2, 64, 64, 1, 32),
+    (2, 40, 70, 1, 32),      # rows that are no multiple of the 32-position K-step
+    (1, 35, 131, 1, 32),     # odd map
+    (4, 33, 33, 1, 32),      # shortest rows (34 padded entries: a wrap in every K-step), image-to-image wrap
+    (2, 64, 64, 2, 32),      # 32-pixel output rows
+    (1, 72, 136, 2, 32),
+    (3, 66, 96, 2, 32),
+    (2, 64, 64, 1, 64),      # 64 -> 128: eight waves, a wave = 32 filters x 32 channels x all nine taps
+    (1, 35, 131, 1, 64),
+    (4, 33, 33, 1, 64),
+    (2, 64, 64, 2, 64),
+    (3, 66, 96, 2, 64),
 ]
 
 
 @pytest.mark.parametrize("case", W9_CASES)
 def test_wgrad9_nine_tap_kernel(dev, case):
-    """csrc/wgrad9.hip (weight gradient of the 32 -> 64 3x3 layers of the 416 / 208 maps, stride 1 and 2, all nine taps per
-    workgroup, K over padded positions) against fp64 and against the per-tap kernel it replaces: image borders (pads must read as
-    zero, top / bottom filter rows masked), the stride-2 even / odd planes, split-K slabs and a dY that is a slice of a wider
-    tensor."""
+    """csrc/wgrad9.hip (weight gradient of the 32 -> 64 and 64 -> 128 3x3 layers of the 416 / 208 / 104 maps, stride 1 and 2, all nine
+    taps per workgroup, K over padded positions) against fp64 and against the kernels it replaces: image borders (pads must read as
+    zero, top / bottom filter rows masked), the stride-2 even / odd planes, split-K slabs and a dY that is a slice of a wider tensor."""
     from dcnet_amd import ops
     from dcnet_amd.lib import lib
-    n, h, w, st = case
-    x = _rand(n, h, w, 32, seed=51).to(dev)
-    wide = (_rand(n, h // st, w // st, 96, seed=52) / 8).to(dev)
-    dy = wide[..., 16:80]                                          # pixel stride 96
+    n, h, w, st, cin = case
+    cout = 2 * cin
+    x = _rand(n, h, w, cin, seed=51).to(dev)
+    wide = (_rand(n, h // st, w // st, cout + 32, seed=52) / 8).to(dev)
+    dy = wide[..., 16:16 + cout]                                   # pixel stride cout + 32
     xd = x.permute(0, 3, 1, 2).double().cpu()
-    wgt = torch.zeros(64, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    wgt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xd, wgt, padding=1, stride=st).backward(dy.permute(0, 3, 1, 2).double().cpu())
     ref = wgt.grad.permute(0, 2, 3, 1)                             # OHWI
     try:
         lib().set_tuning(b"9tap", 0)
         old = ops.conv2d_bwd_weight(x, dy, 3, st)
-        lib().set_tuning(b"9tap", 1)
+        lib().set_tuning(b"9tap", 3)                               # (3: the 64 -> 128 form at both strides)
         lib().prof_enable(1)
         new = ops.conv2d_bwd_weight(x, dy, 3, st)
         lib().prof_enable(0)
@@ -1250,14 +1255,18 @@ def test_wgrad9_nine_tap_kernel(dev, case):
             lib().set_tuning(b"9target", target)
             alt = ops.conv2d_bwd_weight(x, dy, 3, st)
             _close(alt, ref, 3e-5, f"wgrad9 target {target}")
+        lib().set_tuning(b"9target", 512)
+        again = ops.conv2d_bwd_weight(x, dy, 3, st)
     finally:
-        lib().set_tuning(b"9tap", 1); lib().set_tuning(b"9target", 512); lib().prof_enable(0)
+        lib().set_tuning(b"9tap", W9_DEFAULT); lib().set_tuning(b"9target", 512); lib().prof_enable(0)
     assert ran == 1, "the nine-tap kernel did not run"
     _close(new, ref, 3e-5, "wgrad9")
-    _close(old, ref, 3e-5, "per-tap wgrad")
+    _close(old, ref, 3e-5, "the kernel it replaces")
     assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
-    again = ops.conv2d_bwd_weight(x, dy, 3, st)
     assert torch.equal(new, again)                                 # fixed summation order
+
+
+W9_DEFAULT = 2      # csrc/wgrad9.hip g_w9
 
 
 W3_CASES = [
