@@ -19,7 +19,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for (d, c), v in per.items():
         a = acc[nm[d]][c]; a[0] += 1; a[1] += v
 for k, cs in acc.items():
-    if "igemm" in k or "wgrad" in k or "conv3" in k:
+    if "igemm" in k or "wgrad" in k or "conv3" in k or "conv1" in k or "nconv" in k or "dgrad2" in k:
         print(k[:110])
         for c, (n, s) in sorted(cs.items()):
             print(f"    {c:34s} n={n:3d} avg={s/n:16.1f}")
