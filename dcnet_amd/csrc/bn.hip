@@ -334,6 +334,27 @@ extern "C" int dcn_channel_stats(const float* x, int64_t rows, int c, int ld, fl
   return DCN_OK;
 }
 
+// abs-max word of act(scale[c]*y + shift[c]) from the abs-max word of y, without the tensor: max_c(|scale[c]| * max|y| + |shift[c]|) bounds
+// it (LeakyReLU with |slope| <= 1 only shrinks values), and the f16 split needs a bound, not the maximum (a loose bound costs the
+// smallest elements a few of their low bits: the pieces keep 22 bits down to 2^-18 of the bound)
+__global__ __launch_bounds__(64) void amax_bound_kernel(const unsigned* __restrict__ amax_y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int c, unsigned* __restrict__ amax_out) {
+  const float a = __uint_as_float(amax_read(amax_y));
+  float b = 0.f;
+  for (int i = threadIdx.x; i < c; i += 64) b = fmaxf(b, __builtin_fmaf(fabsf(scale[i]), a, fabsf(shift[i])));
+  b = wave_max(b);
+  amax_out[threadIdx.x & (DCN_AMAX_WORDS - 1)] = __float_as_uint(b);
+}
+
+extern "C" int dcn_bn_act_amax_bound(const uint32_t* amax_y, const float* scale, const float* shift, int c, float slope,
+                                     uint32_t* amax_out, void* stream) {
+  DCN_CHECK_ARG(amax_y && scale && shift && amax_out && c > 0, "bn_act_amax_bound: bad argument");
+  DCN_CHECK_ARG(slope >= -1.f && slope <= 1.f, "bn_act_amax_bound: |slope|=%g > 1 would stretch negative values past the bound", slope);
+  hipLaunchKernelGGL(amax_bound_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax_y, scale, shift, c, amax_out);
+  DCN_CHECK_LAUNCH("bn_act_amax_bound");
+  return DCN_OK;
+}
+
 extern "C" int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
                              const float* residual, float* out, int64_t rows, int c, int ldo, uint32_t* amax, void* stream) {
   DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 4 == 0, "scale_act: bad argument (c=%d must be a multiple of 4)", c);

@@ -76,6 +76,26 @@ extern "C" int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, 
   return igemm_grid_m(n * ho * wo, cout, ksize * ksize);
 }
 
+// Forward of a convolution whose input is the RAW output of the conv + BatchNorm layer in front: that layer's per-channel scale / shift
+// and activation are applied where the input is loaded, so its scale_act pass and its activation tensor do not exist.
+extern "C" int dcn_conv2d_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  return igemm_precision() == 4 && nconv1_applicable(0, n, h, wd, cin, cout, ksize, stride) ? 1 : 0;
+}
+
+extern "C" int dcn_conv2d_fwd_pre(const float* x, const float* w, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                                  const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
+                                  int ldy, float* stats, const uint32_t* amax_x, const uint32_t* amax_w, void* stream) {
+  DCN_CHECK_ARG(x && w && y && pre_scale && pre_shift && amax_x && amax_w, "conv2d_fwd_pre: null pointer (the abs-max words are required)");
+  DCN_CHECK_ARG(dcn_conv2d_pre_supported(n, h, wd, cin, cout, ksize, stride),
+                "conv2d_fwd_pre: no loader-side activation for this shape / precision (ask dcn_conv2d_pre_supported first)");
+  DCN_CHECK_ARG(pre_act == DCN_ACT_NONE || pre_act == DCN_ACT_LEAKY, "conv2d_fwd_pre: pre_act=%d", pre_act);
+  if (ldy <= 0) ldy = cout;
+  DCN_CHECK_ARG(ldy >= cout, "conv2d_fwd_pre: ldy=%d < cout=%d", ldy, cout);
+  const DcnPreAct pre{pre_scale, pre_shift, pre_act, pre_slope};
+  return nconv1_launch(0, x, cin, w, y, ldy, stats, stats ? dcn_conv2d_stats_rows(n, h, wd, cout, ksize, stride) : 0,
+                       n, h, wd, stride, amax_x, amax_w, &pre, (hipStream_t)stream);
+}
+
 extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride,
                               const float* scale, const float* shift, int act, float slope,
@@ -116,7 +136,7 @@ extern "C" int dcn_conv2d_fwd(const float* x, const float* w, float* y,
   if (amax_x && amax_w && !amax_y && !f8_scales && !scale && !shift && !residual && act == DCN_ACT_NONE && !accumulate &&
       w_split_ready != 2 && igemm_precision() == 4 && nconv1_applicable(0, n, h, wd, cin, cout, ksize, stride))
     return nconv1_launch(0, x, cin, w, y, p.ldo, stats, stats ? dcn_conv2d_stats_rows(n, h, wd, cout, ksize, stride) : 0,
-                         n, h, wd, stride, amax_x, amax_w, (hipStream_t)stream);
+                         n, h, wd, stride, amax_x, amax_w, nullptr, (hipStream_t)stream);
   if (w_split && w_split_ready == 2) {
     p.wt16 = w_split;             // bf16-operand mode: the bank converted to bf16 (dcn_prepare_filters); read by the strip kernel only
   } else
@@ -195,7 +215,7 @@ int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* d
   }
   if (amax_dy && amax_w && !f8_scales && wt_ready != 2 && !accumulate && igemm_precision() == 4 &&
       nconv1_applicable(1, n, h, wd, cin, cout, ksize, stride))
-    return nconv1_launch(1, dy, lddy, wt, dx, cin, nullptr, 0, n, h, wd, 1, amax_dy, amax_w, stream);
+    return nconv1_launch(1, dy, lddy, wt, dx, cin, nullptr, 0, n, h, wd, 1, amax_dy, amax_w, nullptr, stream);
   IgemmParams p; base_params(p);
   p.in = dy; p.wt = wt; p.f8 = f8_scales; p.out = dx; p.amax_a = amax_dy; p.amax_b = amax_w;
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;

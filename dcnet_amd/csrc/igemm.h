@@ -85,6 +85,8 @@ void nconv_set_tuning(int v);
 int igemm_precision();       // dcn_set_tuning("precision"): 4 = f16 two-piece split (the default)
 // ... and the 3x3 layers between 32 and 64 channels: mode 0 = forward 32 -> 64 (stride 1 | 2, BatchNorm partial sums), mode 1 = data
 // gradient of the stride-1 layer (64 -> 32)
+// loader-side activation: the gathered tensor is the raw output of a conv + BatchNorm layer; x' = act(x * scale[c] + shift[c])
+struct DcnPreAct { const float* scale; const float* shift; int act; float slope; };
 bool nconv1_applicable(int mode, int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, int ldo, float* stats, int stats_rows,
-                  int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, hipStream_t stream);
+                  int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, const DcnPreAct* pre, hipStream_t stream);

@@ -321,6 +321,9 @@ struct N1Params {
   int N, Ho, Wo, ldi, ldo;                                    // Ho x Wo: OUTPUT grid; input (S*Ho) x (S*Wo)
   int Mp, nchunks, per_wg;
   const unsigned* amax_x; const unsigned* amax_w;
+  // PRE: the input is the RAW output of the layer in front; its BatchNorm scale / shift and activation are applied when a piece is
+  // staged (pad pieces stay zero) — that layer's scale_act pass and its activation tensor do not exist.  amax_x: of the activation.
+  const float* pre_scale; const float* pre_shift; int pre_act; float pre_slope;
 };
 
 template <int S, int CK> struct Geo1 {
@@ -345,7 +348,7 @@ template <int S, int CK> struct Geo1 {
 // Eight waves: waves 0-3 compute (MFMAs + epilogue, the filter registers), waves 4-7 stage (global loads, split, LDS stores) — two
 // waves per SIMD, one of each kind, so the staging's vector work and memory latency run under the other wave's MFMAs.  (With four
 // waves doing both, timing ablations showed the three parts adding up: 0.57 ms = 0.38 without MFMAs + 0.19 of MFMAs.)
-template <int S, int CK, int CN, bool FLIP>
+template <int S, int CK, int CN, bool FLIP, bool PRE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nconv1_kernel(const N1Params p) {
   typedef Geo1<S, CK> G;
   constexpr int CH = G::CH, NE = G::NE, PLANE = G::PLANE, BUFB = G::BUFB, NSLOT = G::NSLOT;
@@ -403,6 +406,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     st_off[j] = G::off(strip, G::row_of(e), c);
     k_off[j] = ((((strip - 1) * W + e - 1) * p.ldi) + c) * 4;
   }
+  // PRE: every piece of a thread holds the same four channels (256 and the piece counts per row are multiples of CK/4) — except
+  // the repeats of the list's last piece, which are switched off instead (dead_last)
+  static_assert(256 % (CK / 4) == 0, "one channel group per thread");
+  const bool dead_last = PRE && (FULL * 256 + tid > G::PIECES - 1);
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (PRE) {
+    const int c = (tid % (CK / 4)) * 4;
+    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c); psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+  }
   const int wrap_delta = (S * W - RL) * p.ldi * 4;          // an output row further: S input rows on, one padded row of entries back
 
   Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy - row0, column, oy)
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // scalar state of the chunk being loaded (all derived from the walker): byte offset of its first entry, the entry index from which
   // entries wrap into the next padded row, and whether strip 0 / strip 2 lie outside the image before / after the wrap
-  auto load_slot = [&](int j, f32x4* v) {
+  auto load_slot = [&](int j, f32x4* v, unsigned& vmask) {
     if (j >= FULL && !last_on) return;
     const int strip = meta[j] & 3, e = meta[j] >> 2;
     const int u0 = S * wl.col;
@@ -422,10 +434,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned off = (unsigned)(base + k_off[j] + (wrapped ? wrap_delta : 0));
     if ((unsigned)(u - 1) >= (unsigned)W || row_out || NCONV_ABL == 3) off = OOBN;    // (rows past the tensor: out of the descriptor's range, read as zero)
     v[j] = ldn(a_rs, off);
+    if constexpr (PRE) {                             // (a piece past the tensor's end is a pad as well: its rows do not exist)
+      const bool in = off != OOBN && (S * (wl.row + row0 + (wrapped ? 1 : 0)) + strip - 1) < p.N * H;
+      vmask = in ? (vmask | (1u << j)) : (vmask & ~(1u << j));
+    }
   };
-  auto store_slot = [&](int j, int buf, const f32x4* v) {
+  auto store_slot = [&](int j, int buf, const f32x4* v, unsigned vmask) {
     if (j >= FULL && !last_on) return;
-    const f32x4 t = v[j] * s_a;
+    if (PRE && j >= FULL && dead_last) return;
+    f32x4 x = v[j];
+    if constexpr (PRE) {                             // scale_act_kernel's arithmetic (bn.hip), then zero for the pads
+      x = x * psc + psh;
+      if (p.pre_act == DCN_ACT_LEAKY) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = x[k] > 0.f ? x[k] : x[k] * p.pre_slope;
+      }
+      if (!((vmask >> j) & 1u)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 t = x * s_a;
     const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
     const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
                        (_Float16)(t[3] - (float)h[3])};
@@ -433,14 +459,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h);
     *reinterpret_cast<uint2*>(dst + PLANE) = __builtin_bit_cast(uint2, l);
   };
-  auto load_chunk = [&](f32x4* v) {
+  auto load_chunk = [&](f32x4* v, unsigned& vmask) {
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) load_slot(j, v);
+    for (int j = 0; j < NSLOT; ++j) load_slot(j, v, vmask);
     walk_step(wl, CH, Wp, p.Ho);
   };
-  auto store_chunk = [&](int buf, const f32x4* v) {
+  auto store_chunk = [&](int buf, const f32x4* v, unsigned vmask) {
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) store_slot(j, buf, v);
+    for (int j = 0; j < NSLOT; ++j) store_slot(j, buf, v, vmask);
   };
 
   // A fragment of (strip j, tap column kx, K-step kk): LDS row of entry S*(mb*32 + m) + kx, 8 channels from kofs + kk*16 + 8*kg
@@ -457,21 +483,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // two register sets: the loads of chunk c + 3 are issued when chunk c + 1 is stored, i.e. two chunks of pieces are in flight per
     // CU (with one set the four staging waves kept 28-52 KB in flight and the kernel ran at the latency of its loads)
     f32x4 st0[NSLOT], st1[NSLOT];
+    unsigned vm0 = 0, vm1 = 0;                        // PRE: which pieces of a set are real pixels
     if (c_begin < c_end) {
-      load_chunk(st0);
-      store_chunk(0, st0);
-      load_chunk(st1);                                // chunk c_begin + 1 (past the range: unused)
-      load_chunk(st0);                                // chunk c_begin + 2
+      load_chunk(st0, vm0);
+      store_chunk(0, st0, vm0);
+      load_chunk(st1, vm1);                           // chunk c_begin + 1 (past the range: unused)
+      load_chunk(st0, vm0);                           // chunk c_begin + 2
     }
     for (int c = c_begin; c < c_end; c += 2) {        // chunk c + 1 waits in st1, chunk c + 2 in st0
       __syncthreads();
-      store_chunk(1, st1);
-      load_chunk(st1);                                // chunk c + 3
+      store_chunk(1, st1, vm1);
+      load_chunk(st1, vm1);                           // chunk c + 3
       if constexpr (CN == 32) __syncthreads();        // (the compute waves' exchange)
       if (c + 1 >= c_end) break;
       __syncthreads();
-      store_chunk(0, st0);
-      load_chunk(st0);                                // chunk c + 4
+      store_chunk(0, st0, vm0);
+      load_chunk(st0, vm0);                           // chunk c + 4
       if constexpr (CN == 32) __syncthreads();
     }
     if (p.stats) { __syncthreads(); __syncthreads(); }
@@ -635,17 +662,17 @@ bool nconv1_applicable(int mode, int n, int h, int wd, int cin, int cout, int ks
   return (long long)n * (h / stride) * (wd / stride) >= 65536;                                // (a persistent grid wants work for every CU)
 }
 
-template <int S, int CK, int CN, bool FLIP>
+template <int S, int CK, int CN, bool FLIP, bool PRE = false>
 int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo1<S, CK> G;
   const int lds = 2 * G::BUFB + (CN == 32 ? 2 * 16 * 64 * 4 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const int pid = prof_begin(38, flop, stream, bytes);
-  hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP>), dim3(grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP, PRE>), dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("nconv1");
   return DCN_OK;
@@ -653,8 +680,10 @@ int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stre
 
 // x: the gathered tensor (forward: input (n, h, wd, 32); data gradient: dY (n, h, wd, 64)), w: fp32 bank [CN][9][CK], y: the output
 // (forward: (n, h/s, wd/s, 64) with pixel stride ldo; data gradient: dX (n, h, wd, 32)), stats: [stats_rows][2][64] or null
+// pre (optional, forward only): x is the RAW output of the layer in front; its per-channel scale / shift and activation are applied
+// in the loader (DcnPreAct), amax_x is then the abs-max word of the ACTIVATION (dcn_bn_act_amax_bound)
 int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, int ldo, float* stats, int stats_rows,
-                  int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, hipStream_t stream) {
+                  int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, const DcnPreAct* pre, hipStream_t stream) {
   if (!g_ncus) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("nconv1: device query failed"); return DCN_ERR_LAUNCH; }
@@ -671,6 +700,11 @@ int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, i
   DCN_CHECK_ARG(((long long)p.per_wg * 64 / (p.Wo + 1) + 4) * stride * wd * (ldi > ldo ? ldi : ldo) * 4 < 0x7FFFFFF0LL,
                 "conv2d: the rows of one workgroup exceed 32-bit byte offsets");
   p.amax_x = amax_x; p.amax_w = amax_w;
+  if (pre) {
+    DCN_CHECK_ARG(mode == 0 && pre->scale && pre->shift && (((uintptr_t)pre->scale | (uintptr_t)pre->shift) & 15) == 0 && ldi == 32,
+                  "conv2d_fwd: the loader-side activation exists for the dense 32-channel forward only");
+    p.pre_scale = pre->scale; p.pre_shift = pre->shift; p.pre_act = pre->act; p.pre_slope = pre->slope;
+  }
   if (stats) {
     DCN_CHECK_ARG(stats_rows >= grid, "conv2d_fwd: %d statistics rows for %d workgroups", stats_rows, grid);
     if (stats_rows > grid && hipMemsetAsync(stats + (size_t)grid * 2 * cn, 0, (size_t)(stats_rows - grid) * 2 * cn * sizeof(float), stream) != hipSuccess) {
@@ -680,5 +714,6 @@ int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, i
   const double bytes = 4.0 * ((double)n * h * wd * ck + (double)n * p.Ho * p.Wo * cn + 64.0 * 9 * 32);
   const double flop = 2.0 * (double)n * p.Ho * p.Wo * 64 * 9.0 * 32;
   if (mode == 1) return launch_n1<1, 64, 32, true>(p, grid, flop, bytes, stream);
+  if (pre) return stride == 1 ? launch_n1<1, 32, 64, false, true>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false, true>(p, grid, flop, bytes, stream);
   return stride == 1 ? launch_n1<1, 32, 64, false>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false>(p, grid, flop, bytes, stream);
 }

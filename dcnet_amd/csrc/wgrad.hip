@@ -10,7 +10,7 @@
 // partial slabs go to a workspace and are summed in a fixed order by reduce_slabs_kernel, so
 // the result is bitwise reproducible (no float atomics).
 // Roofline: MFMA (same 157.3 TFLOP/s fp32 peak as the forward).
-#include "common.h"
+#include "igemm.h"
 #include "prof.h"
 #include <type_traits>
 
@@ -607,7 +607,7 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
 bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride);
 int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
-                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream);
+                  const uint32_t* amax_x, const uint32_t* amax_dy, const DcnPreAct* pre, hipStream_t stream);
 
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
@@ -621,6 +621,25 @@ extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int c
     if (w3 > ws) ws = w3;
   }
   return ws;
+}
+
+// Weight gradient of a convolution whose input is the RAW output of the conv + BatchNorm layer in front (dcn_conv2d_fwd_pre): the
+// activation is formed where X is loaded.  Shapes: those dcn_conv2d_pre_supported accepts.
+extern "C" int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                                         int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                                         const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
+                                         const uint32_t* amax_x, const uint32_t* amax_dy, void* stream_) {
+  DCN_CHECK_ARG(x && dy && dw && pre_scale && pre_shift && amax_x && amax_dy, "conv2d_bwd_weight_pre: null pointer (the abs-max words are required)");
+  DCN_CHECK_ARG(g_wsplit == 4 && !g_wabl && cin == 32 && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride),
+                "conv2d_bwd_weight_pre: no loader-side activation for this shape / precision");
+  DCN_CHECK_ARG(pre_act == DCN_ACT_NONE || pre_act == DCN_ACT_LEAKY, "conv2d_bwd_weight_pre: pre_act=%d", pre_act);
+  const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
+  DCN_CHECK_ARG(lx % 4 == 0 && ly % 4 == 0, "conv2d_bwd_weight_pre: pixel strides must be multiples of 4 floats");
+  const DcnPreAct pre{pre_scale, pre_shift, pre_act, pre_slope};
+  return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, &pre, (hipStream_t)stream_);
+}
+extern "C" int dcn_conv2d_bwd_weight_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  return (g_wsplit == 4 && !g_wabl && cin == 32 && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride)) ? 1 : 0;
 }
 
 extern "C" int64_t dcn_conv2d_geom_size(int n, int h, int wd, int ksize, int stride) {
@@ -658,7 +677,7 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
     const long long npix = (long long)n * h * wd;
     const bool f16 = g_wsplit == 4 && amax_x && amax_dy, b16 = g_wsplit == 2;      // (2: the bf16- and fp8-operand modes)
     if (f16 && !g_wabl && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0)
-      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, stream);
+      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, nullptr, stream);
     if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
       return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);

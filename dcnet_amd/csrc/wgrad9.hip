@@ -14,7 +14,7 @@
 // planes, so that every tap reads consecutive rows); both are split into f16 pieces on the way to LDS and the MFMA operands come
 // from ds_read_b64_tr_b16 (wgrad.hip).  Split-K over positions into slabs summed in a fixed order (reduce_slabs_kernel):
 // bitwise reproducible.  Roofline: HBM (dY + X once: 1.06 / 2.13 GB per launch at N = 64) — the MFMA work is 0.12 ms at 838.9.
-#include "common.h"
+#include "igemm.h"
 #include "prof.h"
 
 int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream);
@@ -32,6 +32,9 @@ struct W9Params {
   int N, H, W, Ho, Wo, ldx, lddy;
   int Mp, kchunk, splits;          // padded positions N*Ho*(Wo+1); per split (multiple of 32)
   const unsigned* amax_dy; const unsigned* amax_x;
+  // PRE: x is the RAW output of the layer in front; its BatchNorm scale / shift and activation are applied when a piece of X is staged
+  // (pads stay zero); amax_x is then the abs-max word of the activation
+  const float* pre_scale; const float* pre_shift; int pre_act; float pre_slope;
 };
 
 __device__ __forceinline__ f32x4 ld9(__amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -83,7 +86,7 @@ template <int S, int CO, int CI> struct G9 {
   static __device__ __forceinline__ int x_off(int fr, int row, int c) { return fr * FROWB + X_ROWB * row + 64 * seg_swz<X_ROWB>(c >> 5, row) + 2 * (c & 31); }
 };
 
-template <int S, int CO, int CI>
+template <int S, int CO, int CI, bool PRE = false>
 __global__ __launch_bounds__(64 * (CO == 64 ? 6 : 8)) __attribute__((amdgpu_waves_per_eu(CO == 64 ? 3 : 2, CO == 64 ? 3 : 2)))
 void wgrad9_kernel(const W9Params p) {
   typedef G9<S, CO, CI> G;
@@ -127,6 +130,16 @@ void wgrad9_kernel(const W9Params p) {
       meta[j] = (fr << 2) | (c << 4) | (s_ << 11); st_off[j] = B_BASE + G::x_off(fr, G::x_row(s_), c);
     }
   }
+  // PRE: every X piece of a thread holds the same four channels (NT and NA are multiples of CI/4); the repeats of the list's last
+  // piece are switched off instead (dead_last)
+  static_assert(NT % (CI / 4) == 0 && NA % (CI / 4) == 0, "one channel group per thread");
+  const bool dead_last = PRE && ((NSLOT - 1) * NT + tid - NA > NX - 1);
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (PRE) {
+    const int c = (tid % (CI / 4)) * 4;
+    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c); psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+  }
+  unsigned vmask = 0;                                     // PRE: which X pieces of the loaded step are real pixels
   int q_step = p_begin;                                   // first position of the step being LOADED
   int g_row = p_begin / Wp, g_col = p_begin - g_row * Wp;
   int g_nb = (g_row / p.Ho) * p.H, g_oy = g_row % p.Ho;
@@ -149,6 +162,7 @@ void wgrad9_kernel(const W9Params p) {
         if ((unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H && nb < rows_x)
           off = (unsigned)((((nb + iy) * p.W + ix) * p.ldx + c) * 4);
         v[j] = ld9(b_rs, off);
+        if constexpr (PRE) vmask = off != OOB9 ? (vmask | (1u << j)) : (vmask & ~(1u << j));
       }
     }
     q_step += KS; g_col += KS;
@@ -157,7 +171,17 @@ void wgrad9_kernel(const W9Params p) {
   auto store_step = [&](int buf, const f32x4* v) {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-      const f32x4 t = v[j] * (is_a[j] ? s_a : s_b);
+      if (PRE && j == NSLOT - 1 && !is_a[j] && dead_last) continue;
+      f32x4 x = v[j];
+      if (PRE && !is_a[j]) {                              // scale_act_kernel's arithmetic (bn.hip), then zero for the pads
+        x = x * psc + psh;
+        if (p.pre_act == DCN_ACT_LEAKY) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = x[k] > 0.f ? x[k] : x[k] * p.pre_slope;
+        }
+        if (!((vmask >> j) & 1u)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const f32x4 t = x * (is_a[j] ? s_a : s_b);
       const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
       const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
                          (_Float16)(t[3] - (float)h[3])};
@@ -262,16 +286,16 @@ Plan9 plan9(int n, int ho, int wo) {
 
 template <int S, int CO, int CI> size_t lds9() { return (size_t)2 * G9<S, CO, CI>::BUF; }
 
-template <int S, int CO, int CI>
+template <int S, int CO, int CI, bool PRE = false>
 int launch9(const W9Params& p, int splits, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
     attr_done = true;
   }
   const int threads = G9<S, CO, CI>::NT;
   const size_t lds = lds9<S, CO, CI>();
-  hipLaunchKernelGGL((wgrad9_kernel<S, CO, CI>), dim3(splits), dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL((wgrad9_kernel<S, CO, CI, PRE>), dim3(splits), dim3(threads), lds, stream, p);
   return DCN_OK;
 }
 
@@ -297,7 +321,7 @@ int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride) {
 }
 
 int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
-                  const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
+                  const uint32_t* amax_x, const uint32_t* amax_dy, const DcnPreAct* pre, hipStream_t stream) {
   const int ho = h / stride, wo = wd / stride;
   const Plan9 pl = plan9(n, ho, wo);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
@@ -309,10 +333,16 @@ int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.N = n; p.H = h; p.W = wd; p.Ho = ho; p.Wo = wo; p.ldx = ldx; p.lddy = lddy;
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.amax_dy = amax_dy; p.amax_x = amax_x;
+  if (pre) {
+    DCN_CHECK_ARG(cin == 32 && pre->scale && pre->shift && (((uintptr_t)pre->scale | (uintptr_t)pre->shift) & 15) == 0,
+                  "conv2d_bwd_weight: the loader-side activation exists for the 32-channel form only");
+    p.pre_scale = pre->scale; p.pre_shift = pre->shift; p.pre_act = pre->act; p.pre_slope = pre->slope;
+  }
   // HBM-priced: dY and X once, the slabs written
   const double bytes = 4.0 * ((double)n * ho * wo * cout + (double)n * h * wd * cin + (double)pl.splits * cout * 9 * cin);
   const int pid = prof_begin(36, 2.0 * (double)n * ho * wo * cout * 9.0 * cin, stream, bytes);
-  if (cin == 32) { if (stride == 1) launch9<1, 64, 32>(p, pl.splits, stream); else launch9<2, 64, 32>(p, pl.splits, stream); }
+  if (cin == 32 && pre) { if (stride == 1) launch9<1, 64, 32, true>(p, pl.splits, stream); else launch9<2, 64, 32, true>(p, pl.splits, stream); }
+  else if (cin == 32) { if (stride == 1) launch9<1, 64, 32>(p, pl.splits, stream); else launch9<2, 64, 32>(p, pl.splits, stream); }
   else { if (stride == 1) launch9<1, 128, 64>(p, pl.splits, stream); else launch9<2, 128, 64>(p, pl.splits, stream); }
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad9");

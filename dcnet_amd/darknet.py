@@ -280,6 +280,23 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
     # that consume it (forward here, weight gradient in the backward) to pick their power-of-two operand scales
     am = ops.use_amax()
     amx: Dict[int, Optional[torch.Tensor]] = {-1: None}
+    # outputs with exactly ONE reader, a train-mode conv + BatchNorm whose kernels can apply the activation while loading
+    # (ops.pre_supported): they are handed on as ops.PreAct — no scale_act pass, no activation tensor
+    readers: Dict[int, list] = {}
+    for op in plan:
+        ins = (op.src, op.res) if isinstance(op, _ConvOp) else (op.up_src, op.lat_src) if isinstance(op, _UpCatOp) else (op.src,)
+        for s_ in ins:
+            if s_ is not None:
+                readers.setdefault(s_, []).append(op)
+
+    def sole_pre_reader(op, y):
+        rd = readers.get(op.dst, [])
+        if not (am and training and save is not None and len(rd) == 1 and op.dst not in taps and op.res is None and y.is_contiguous()):
+            return False
+        nx = rd[0]
+        return (isinstance(nx, _ConvOp) and nx.bn and nx.src == op.dst and nx.res != op.dst
+                and ops.pre_supported(y.shape[0], y.shape[1], y.shape[2], nx.cin, nx.cout, nx.k, nx.stride))
+
     for op in plan:
         if isinstance(op, _ConvOp):
             p = P[op.slot]
@@ -298,10 +315,19 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
             if op.bn and training:
-                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp, w_b16=w16)
+                # (the stem kernel hands out the abs-max of its raw output for free: the bound below starts from it)
+                ay = ops.amax_slot(x.device) if (am and ops.PRE_ACT and op.cin <= 4 and op.res is None and save is not None) else None
+                y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, amax_out=ay,
+                                          w_split_ready=wsp, w_b16=w16)
                 cnt = y.numel() // op.cout
                 mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
-                o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
+                if ay is not None and sole_pre_reader(op, y):
+                    ao = ops.bn_act_amax_bound(ay, mi[2], mi[3], 0.1)
+                    o = ops.PreAct(y, mi[2], mi[3], act, 0.1)
+                    if ops.PRE_ACT == "check":        # (tests: the activation written out, read with the same abs-max word)
+                        o = o.materialise()
+                else:
+                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
                 if save is not None:
                     save[op.slot] = (x, y, mi, w, ax, aw)
             else:

@@ -261,13 +261,63 @@ def f8_scales(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class PreAct:
+    """The output of a conv + train-mode BatchNorm + activation layer that was never materialised: ``y`` is the raw convolution
+    output, the consumer forms act(scale*y + shift) where it loads its input (dcn_conv2d_fwd_pre / dcn_conv2d_bwd_weight_pre)."""
+    __slots__ = ("y", "scale", "shift", "act", "slope")
+
+    def __init__(self, y, scale, shift, act, slope):
+        self.y, self.scale, self.shift, self.act, self.slope = y, scale, shift, act, slope
+
+    shape = property(lambda self: self.y.shape)
+    device = property(lambda self: self.y.device)
+
+    def materialise(self, amax_out=None):
+        return scale_act(self.y, self.scale, self.shift, self.act, self.slope, amax_out=amax_out)
+
+
+PRE_ACT = True             # A/B switch: False = every BatchNorm + activation output is written by scale_act; "check" = written, but read
+                           # with the abs-max bound the fused path uses (bit-identical to it: tests)
+
+
+def pre_supported(n, h, wd, cin, cout, ksize, stride) -> bool:
+    """Can BOTH readers of a layer's input (its forward and its weight gradient) form the activation of the layer in front themselves?"""
+    return bool(PRE_ACT and _precision == "fp32" and lib().conv2d_pre_supported(n, h, wd, cin, cout, ksize, stride)
+                and lib().conv2d_bwd_weight_pre_supported(n, h, wd, cin, cout, ksize, stride))
+
+
+def bn_act_amax_bound(amax_y, scale, shift, slope):
+    """abs-max word (a bound) of act(scale*y + shift) from the abs-max word of y."""
+    out = amax_slot(amax_y.device)
+    lib().bn_act_amax_bound(amax_y.data_ptr(), scale.data_ptr(), shift.data_ptr(), scale.numel(), float(slope), out.data_ptr(), _s())
+    return out
+
+
 def conv2d_fwd(x, w_ohwi, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0,
                residual=None, out=None, want_stats=False, accumulate=False, amax_x=None, amax_w=None, amax_out=None,
                w_split_ready=None, w_b16=None):
     """x (N,H,W,Cin) NHWC, w_ohwi (Cout,k,k,Cin) [or (Cout,64) for the stem].  Returns (y, stats)
     where stats is the [rows][2][Cout] partial-sum buffer (None unless want_stats).
     amax_x / amax_w: abs-max words of the operands (computed here by a pass over the data when missing and the
-    precision mode needs them); amax_out: word that receives the abs-max of what is stored."""
+    precision mode needs them); amax_out: word that receives the abs-max of what is stored.
+    x may be a PreAct (pre_supported shapes, raw output only: no epilogue arguments); amax_x is then the word of the activation."""
+    if isinstance(x, PreAct):
+        if not (scale is None and shift is None and residual is None and act == ACT_NONE and not accumulate and amax_out is None
+                and amax_x is not None and amax_w is not None):
+            raise DcnError("conv2d_fwd: a PreAct input takes no epilogue and needs both abs-max words")
+        _chk(x.y, "conv2d_fwd x")
+        n, h, wd, cin = x.shape
+        cout = w_ohwi.shape[0]
+        ho, wo = conv_out_hw(h, wd, ksize, stride)
+        if out is None:
+            out = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        stats = None
+        if want_stats:
+            stats = torch.empty((lib().conv2d_stats_rows(n, h, wd, cout, ksize, stride), 2, cout), dtype=torch.float32, device=x.device)
+        lib().conv2d_fwd_pre(x.y.data_ptr(), w_ohwi.data_ptr(), out.data_ptr(), n, h, wd, cin, cout, ksize, stride,
+                             x.scale.data_ptr(), x.shift.data_ptr(), x.act, float(x.slope), out.stride(2), _p(stats),
+                             amax_x.data_ptr(), amax_w.data_ptr(), _s())
+        return out, stats
     _chk(x, "conv2d_fwd x")
     n, h, wd, cin = x.shape
     cout = w_ohwi.shape[0]
@@ -419,12 +469,21 @@ def conv_geom(device, n: int, h: int, wd: int, ksize: int, stride: int) -> torch
 
 def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=None, amax_dy=None):
     """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
-    ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0)."""
+    ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0).
+    x may be a PreAct (see conv2d_fwd); amax_x is then the word of the activation."""
     n, h, wd, cin = x.shape
     cout = dy.shape[3] if cout is None else cout
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
+    if isinstance(x, PreAct):
+        if amax_x is None:
+            raise DcnError("conv2d_bwd_weight: a PreAct input needs the abs-max word of the activation")
+        amax_dy = _amax_or_pass(dy, amax_dy)
+        lib().conv2d_bwd_weight_pre(x.y.data_ptr(), x.y.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws),
+                                    n, h, wd, cin, cout, ksize, stride, x.scale.data_ptr(), x.shift.data_ptr(), x.act, float(x.slope),
+                                    amax_x.data_ptr(), amax_dy.data_ptr(), _s())
+        return dw
     geom = conv_geom(x.device, n, h, wd, ksize, stride)
     # the kernels with a split mode: the 128-wide weight-gradient tiles and the nine-tap kernel of the 32 -> 64 3x3 layers
     if (cin >= 64 and cout >= 64 and (cin >= 128 or cout >= 128)) or (cin == 32 and cout == 64 and ksize == 3):      # (64 -> 128 is in the first)
@@ -480,7 +539,7 @@ def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
         if wshape[0] != dw.shape[0]:
             dw = dw[:wshape[0]].contiguous()
         out = weight_grad_to_oihw(dw, wshape)
-    for t in (x, dy):
+    for t in (x.y if isinstance(x, PreAct) else x, dy):
         t.record_stream(side)                    # keep the allocator from recycling them under the side kernels
     out.record_stream(main)
     return out

@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 302
+#define DCN_ABI_VERSION 303
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -121,6 +121,24 @@ int dcn_conv2d_bwd_data_tap(const float* dy, int lddy, const float* w, float* wt
                             const float* tap_beta, int tap_act, float tap_slope, float* tap_stats, int tap_stats_rows,
                             int* tap_rows, void* stream);
 int dcn_conv2d_bwd_data_tap_rows(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+/* Convolution whose input x is the RAW output of the conv + train-mode BatchNorm layer in front: x' = act(pre_scale[c]*x + pre_shift[c])
+ * (scale / shift of dcn_bn_finalize) is formed where the input is loaded — padding stays zero — so that layer's dcn_scale_act pass and
+ * its activation tensor do not exist (the activation is recomputed from x by the weight gradient the same way).  Same result as
+ * dcn_scale_act followed by dcn_conv2d_fwd(..., no epilogue) / dcn_conv2d_bwd_weight, bit for bit in the operand (the arithmetic of
+ * dcn_scale_act), to summation order in the GEMM.  x dense (n,h,wd,cin); y raw outputs, pixel stride ldy; stats as dcn_conv2d_fwd.
+ * amax_x: abs-max word of the ACTIVATION x' (dcn_bn_act_amax_bound gives a bound from the word of x); amax_w, amax_dy required.
+ * Only the register-bank kernels do it: dcn_conv2d_pre_supported / dcn_conv2d_bwd_weight_pre_supported say whether a shape can
+ * (3x3, 32 -> 64 channels, stride 1 | 2, large maps; default precision).  The two nn.Sequential blocks conv_0 / conv_1 of
+ * model/yolov3.cfg as built at model/darknet.py:179-191. */
+int dcn_conv2d_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int dcn_conv2d_fwd_pre(const float* x, const float* w, float* y, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                       const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
+                       int ldy, float* stats, const uint32_t* amax_x, const uint32_t* amax_w, void* stream);
+int dcn_conv2d_bwd_weight_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                              int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                              const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
+                              const uint32_t* amax_x, const uint32_t* amax_dy, void* stream);
 /* w_split_ready / wt_ready / wt_split: the banks were prepared for the whole network by dcn_prepare_filters (below) — w_split
  * holds the split OHWI bank, wt the transposed fp32 bank and wt_split its split form; nothing is converted per call.
  * Value 2 (bf16-operand mode, dcn_set_tuning("precision", 2)): w_split / wt_split point at the bank converted to bf16
@@ -194,6 +212,10 @@ int dcn_channel_stats_rows(int64_t rows);
  * The normalise+LeakyReLU/ReLU(+shortcut) half of a train-mode block: model/darknet.py:189-191,403-405. */
 int dcn_scale_act(const float* y, const float* scale, const float* shift, int act, float slope,
                   const float* residual, float* out, int64_t rows, int c, int ldo, uint32_t* amax, void* stream);
+/* amax_out (all 64 words) = max_c(|scale[c]| * max|y| + |shift[c]|): a bound on the abs-max of act(scale*y + shift) from the abs-max
+ * word of y, for consumers that form the activation themselves (dcn_conv2d_fwd_pre).  |slope| <= 1. */
+int dcn_bn_act_amax_bound(const uint32_t* amax_y, const float* scale, const float* shift, int c, float slope,
+                          uint32_t* amax_out, void* stream);
 /* Backward of out = act(bn(y)) (a residual's gradient is the identity and handled by the caller):
  *   reduce: partials of g = dout*act'(.) and g*xhat per channel -> stats [dcn_channel_stats_rows(rows)][2][c]
  *   sums:   totals [2][c]  (sums[0] = dbeta, sums[1] = dgamma)

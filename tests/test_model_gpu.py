@@ -61,6 +61,50 @@ def test_backbone_taps_match_oracle(dev):
         assert maxdiff(a, b) < 1e-3 * max(1.0, float(b.abs().max()))
 
 
+def test_backbone_with_and_without_loader_side_activation(dev):
+    """Train-mode backbone, forward and backward, with the stem's activation formed by its reader (ops.PreAct: no scale_act pass, no
+    activation tensor) and with it written out.  Read with the same abs-max word ("check") the two are the same bits everywhere — taps,
+    running statistics, every parameter gradient; with the word of the written tensor (False: another power-of-two operand scale in
+    one layer) they agree to rounding.  The fused path really is the one that ran (the stem's scale_act launch is gone)."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    from dcnet_amd.utils.synth import synth_inputs
+    from test_ops_gpu import _prof_launches
+    size, n = 256, 4
+    sd = synth_sd(size)
+    image, _, _ = synth_inputs(n, size, seed=9)
+    res = {}
+    try:
+        for mode in (True, "check", False):
+            ops.PRE_ACT = mode
+            m = build_product(size, sd, dev).train()
+            lib().prof_enable(1)
+            taps = m.visumodel(image.to(dev))
+            lib().prof_enable(0)
+            n_sa = _prof_launches(10)
+            sum((t * torch.randn(t.shape, generator=torch.Generator().manual_seed(t.shape[1])).to(dev)).sum() for t in taps).backward()
+            grads = {k: p.grad.clone() for k, p in m.visumodel.named_parameters() if p.grad is not None}
+            res[mode] = (taps, grads, {k: v.clone() for k, v in m.visumodel.state_dict().items() if "running" in k}, n_sa)
+    finally:
+        ops.PRE_ACT = True; lib().prof_enable(0)
+    assert res[False][3] - res[True][3] == 1 and res["check"][3] == res[False][3], "the stem's scale_act pass was not dropped"
+    assert all(torch.equal(a, b) for a, b in zip(res[True][0], res["check"][0]))
+    assert res[True][1].keys() == res["check"][1].keys()
+    assert all(torch.equal(res[True][1][k], g) for k, g in res["check"][1].items())
+    assert all(torch.equal(res[True][2][k], v) for k, v in res["check"][2].items())
+    for a, b in zip(res[True][0], res[False][0]):
+        assert maxdiff(a.detach(), b.detach()) < 2e-5 * max(1.0, float(b.detach().abs().max()))
+    for k, v in res[False][2].items():
+        assert maxdiff(res[True][2][k], v) < 1e-5 * max(1.0, float(v.abs().max())), k
+    assert res[True][1].keys() == res[False][1].keys() and len(res[True][1]) > 150
+    # (75 layers of batch-statistics BatchNorm and LeakyReLU amplify the last-bit differences of one layer's operand scale — see
+    # test_train_forward_backward_matches_oracle; the kernels themselves are compared tightly in test_ops_gpu.py)
+    rel = {k: float(maxdiff(res[True][1][k], g) / max(1e-6, float(g.abs().max()))) for k, g in res[False][1].items()}
+    cos = {k: float(torch.nn.functional.cosine_similarity(res[True][1][k].flatten().double(), g.flatten().double(), dim=0))
+           for k, g in res[False][1].items() if float(g.abs().max()) > 0}
+    assert float(np.median(list(rel.values()))) < 5e-2 and min(cos.values()) > 0.999, (np.median(list(rel.values())), max(rel.values()), min(cos.values()))
+
+
 @pytest.mark.parametrize("size,b,t", [(256, 1, 5), (256, 2, 2), (416, 1, 8)])
 def test_nframe_forward_matches_oracle_and_golden(dev, size, b, t):
     from dcnet_amd.utils.synth import synth_inputs

@@ -1028,6 +1028,76 @@ N1_CASES = [
 ]
 
 
+PRE_CASES = [
+    # stride, n, h, w   (32 -> 64 channels, 3x3; >= 65536 output pixels, output rows of >= 64)
+    (1, 4, 128, 128),
+    (1, 1, 258, 255),
+    (2, 4, 256, 256),
+    (2, 3, 264, 352),
+    (2, 2, 520, 260),
+]
+
+
+@pytest.mark.parametrize("case", PRE_CASES)
+def test_loader_side_activation(dev, case):
+    """dcn_conv2d_fwd_pre / dcn_conv2d_bwd_weight_pre (the BatchNorm scale / shift + LeakyReLU of the layer in front applied where the
+    input is staged, csrc/nconv.hip and csrc/wgrad9.hip) against dcn_scale_act followed by the plain calls, and against fp64.  The shifts
+    are large so that a pad read as act(shift) instead of zero would show at every border."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    st, n, h, w = case
+    assert ops.pre_supported(n, h, w, 32, 64, 3, st)
+    assert not ops.pre_supported(n, h, w, 64, 128, 3, st) and not ops.pre_supported(2, 16, 16, 32, 64, 3, st)
+    y_raw = (_rand(n, h, w, 32, seed=61) * 3).to(dev)
+    scale = (_rand(32, seed=62) * 1.5).to(dev); shift = (_rand(32, seed=63) * 2 + 1).to(dev)
+    wgt = (_rand(64, 32, 3, 3, seed=64) / 6)
+    w_ohwi = wgt.permute(0, 2, 3, 1).contiguous().to(dev)
+    aw = ops.absmax(w_ohwi)
+    ay = ops.absmax(y_raw)
+    act = ops.scale_act(y_raw, scale, shift, ops.ACT_LEAKY, 0.1)
+    bound = ops.bn_act_amax_bound(ay, scale, shift, 0.1)
+    b_, a_ = bound.view(torch.float32), ops.absmax(act).view(torch.float32)
+    assert float(b_.min()) == float(b_.max()) >= float(a_.max()) > 0
+    want = float((scale.abs() * float(y_raw.abs().max()) + shift.abs()).max())
+    assert abs(float(b_.max()) - want) <= 1e-6 * want
+    pre = ops.PreAct(y_raw, scale, shift, ops.ACT_LEAKY, 0.1)
+    dy = (_rand(n, h // st, w // st, 96, seed=65) / 8).to(dev)[..., 16:80]
+    # fp64 truth from the fp32 activation (the operand both paths see, bit for bit)
+    ad = act.permute(0, 3, 1, 2).double().cpu()
+    wd_ = wgt.double().requires_grad_(True)
+    ref = F.conv2d(ad, wd_, padding=1, stride=st)
+    ref.backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = ref.detach().permute(0, 2, 3, 1); ref_dw = wd_.grad.permute(0, 2, 3, 1)
+    try:
+        lib().prof_enable(1)
+        y1, s1 = ops.conv2d_fwd(pre, w_ohwi, 3, st, want_stats=True, amax_x=bound, amax_w=aw)
+        dw1 = ops.conv2d_bwd_weight(pre, dy, 3, st, amax_x=bound)
+        lib().prof_enable(0)
+        ran = (_prof_launches(38), _prof_launches(36))
+    finally:
+        lib().prof_enable(0)
+    assert ran == (1, 1), f"the register-bank kernels did not run: {ran}"
+    y0, s0 = ops.conv2d_fwd(act, w_ohwi, 3, st, want_stats=True, amax_w=aw)
+    dw0 = ops.conv2d_bwd_weight(act, dy, 3, st)
+    _close(y1, ref, 2e-5, "conv2d_fwd_pre"); _close(y0, ref, 2e-5, "scale_act + conv2d_fwd")
+    _close(dw1, ref_dw, 3e-5, "conv2d_bwd_weight_pre"); _close(dw0, ref_dw, 3e-5, "scale_act + conv2d_bwd_weight")
+    rawl = ref.reshape(-1, 64)
+    _close(s1[:, 0].double().sum(0), rawl.sum(0), 1e-4, "pre stats sum")
+    _close(s1[:, 1].double().sum(0), (rawl * rawl).sum(0), 1e-4, "pre stats sumsq")
+    # with the SAME abs-max word the operand pieces are the same bits: identical results
+    y2, s2 = ops.conv2d_fwd(act, w_ohwi, 3, st, want_stats=True, amax_x=bound, amax_w=aw)
+    dw2 = ops.conv2d_bwd_weight(act, dy, 3, st, amax_x=bound)
+    assert torch.equal(y1, y2) and torch.equal(s1, s2) and torch.equal(dw1, dw2)
+    # no activation: the loader only scales and shifts
+    lin = ops.PreAct(y_raw, scale, shift, ops.ACT_NONE, 0.0)
+    act_l = ops.scale_act(y_raw, scale, shift, ops.ACT_NONE, 0.0)
+    bl = ops.bn_act_amax_bound(ay, scale, shift, 0.0)
+    assert torch.equal(ops.conv2d_fwd(lin, w_ohwi, 3, st, amax_x=bl, amax_w=aw)[0], ops.conv2d_fwd(act_l, w_ohwi, 3, st, amax_x=bl, amax_w=aw)[0])
+    assert torch.equal(ops.conv2d_bwd_weight(lin, dy, 3, st, amax_x=bl), ops.conv2d_bwd_weight(act_l, dy, 3, st, amax_x=bl))
+    with pytest.raises(Exception):
+        ops.conv2d_fwd(pre, w_ohwi, 3, st, scale=scale, amax_x=bound, amax_w=aw)
+
+
 @pytest.mark.parametrize("case", N1_CASES)
 def test_nconv1_register_bank_kernels(dev, case):
     """csrc/nconv.hip nconv1_kernel (32 -> 64 3x3 forward at stride 1 and 2 with BatchNorm partial sums, and the stride-1 data
