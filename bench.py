@@ -63,9 +63,10 @@ NAMES = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,
          36: "wgrad9_kernel (32 -> 64 3x3 layers, nine taps per workgroup, f16 split)",
          37: "dgrad2_kernel (stride-2 data gradients 64 -> 32 / 128 -> 64 channels, filter bank in registers, f16 split)",
          38: "nconv1_kernel (3x3 layers between 32 and 64 channels, filter bank in registers, f16 split)",
-         39: "stem_wgrad_bn_kernel (stem weight gradient + BatchNorm backward, fp32 MFMA)"}
-FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38}
-PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38)
+         39: "stem_wgrad_bn_kernel (stem weight gradient + BatchNorm backward, fp32 MFMA)",
+         40: "gemm3_kernel (co-attention products on pre-split operands, f16 split)"}
+FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40}
+PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38, 40)
                else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
@@ -73,9 +74,9 @@ RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_k
             26: ["igemm_kernel<256,64,4,1,0,false,16,true,0,2,", "igemm_kernel<256,32,4,1,0,false,16,true,0,2,"],
             27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"],
             29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2>"], 35: ["conv1_kernel<"],
-            36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"]}
+            36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
 FAMILY = {28: "conv3_kernel<*,2,4> (3x3 stride-1 strip kernel, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 stride-1 strip kernel, f16 split)"}
-NT = 40            # DCN_PROF_TAGS
+NT = 48            # DCN_PROF_TAGS
 
 
 def parse():

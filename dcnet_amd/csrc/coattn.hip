@@ -27,6 +27,11 @@ constexpr int EXP_ROWS = 32;
 // E = exp(t*A - t) in place (pad columns -> 0), row sums, per-row-block column partial sums.
 // grid (ceil(hw/32), b); each thread owns FOUR consecutive columns (16-B accesses: with one float per lane this pass ran at
 // 0.34 of the HBM rate) 4*tid, 4*tid + 1024, ... and walks the 32 rows, all 32 loads of a column group in flight together.
+// SPLIT: E is written in the f16 two-piece split form the products on gemm3.hip read ([8 h | 8 l] per 8 columns, scale 2^13 for values
+// <= 1): a thread's four columns are half of such a run — 8 bytes of the h piece, 8 of the l piece; the sums are those of the fp32 values.
+typedef _Float16 f16x4c_t __attribute__((ext_vector_type(4)));
+constexpr float E_SPLIT_SCALE = 8192.f;           // = pow2_scale(1.0): brings 1.0 below 2^14
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void exp_sums_kernel(float* __restrict__ E, int hw, int ldE, float t,
                                                        float* __restrict__ rsum, float* __restrict__ colpart) {
   __shared__ float red[4][EXP_ROWS];
@@ -49,7 +54,17 @@ __global__ __launch_bounds__(256) void exp_sums_kernel(float* __restrict__ E, in
         f32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = (j + k < hw) ? expf(t * v[r][k] - t) : 0.f;
-        *reinterpret_cast<f32x4*>(e + (size_t)r * ldE + j) = o;
+        if constexpr (SPLIT) {
+          const f32x4 ts = o * E_SPLIT_SCALE;
+          const f16x4c_t h = {(_Float16)ts[0], (_Float16)ts[1], (_Float16)ts[2], (_Float16)ts[3]};
+          const f16x4c_t l = {(_Float16)(ts[0] - (float)h[0]), (_Float16)(ts[1] - (float)h[1]), (_Float16)(ts[2] - (float)h[2]),
+                              (_Float16)(ts[3] - (float)h[3])};
+          unsigned char* run = reinterpret_cast<unsigned char*>(e + (size_t)r * ldE + (j & ~7)) + (j & 4) * 2;
+          *reinterpret_cast<f16x4c_t*>(run) = h;
+          *reinterpret_cast<f16x4c_t*>(run + 16) = l;
+        } else {
+          *reinterpret_cast<f32x4*>(e + (size_t)r * ldE + j) = o;
+        }
         cs += o; racc[r] += (o[0] + o[1]) + (o[2] + o[3]);
       }
     }
@@ -116,6 +131,7 @@ __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restri
 }
 
 // dA = t * E * ((dP1 - d1[i]) * rinv[i] + (dP2 - d2[j]) * cinv[j]), written over dP1; pad columns -> 0
+template <bool ESPLIT>
 __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, float* __restrict__ dP1, const float* __restrict__ dP2,
                                                  const float* __restrict__ rinv, const float* __restrict__ cinv,
                                                  const float* __restrict__ d1, const float* __restrict__ d2,
@@ -127,7 +143,15 @@ __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, fl
     const int64_t row = idx / l4;                 // = b*hw + i
     const int j = (int)(idx - row * l4) * 4;
     const int64_t bb = row / hw;
-    const f32x4 e = *reinterpret_cast<const f32x4*>(E + row * ldE + j);
+    f32x4 e;
+    if constexpr (ESPLIT) {                       // h + l of the split form: E to 22 bits
+      const unsigned char* run = reinterpret_cast<const unsigned char*>(E + row * ldE + (j & ~7)) + (j & 4) * 2;
+      const f16x4c_t h = *reinterpret_cast<const f16x4c_t*>(run), l = *reinterpret_cast<const f16x4c_t*>(run + 16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) e[k] = ((float)h[k] + (float)l[k]) * (1.f / E_SPLIT_SCALE);
+    } else {
+      e = *reinterpret_cast<const f32x4*>(E + row * ldE + j);
+    }
     const f32x4 p1 = *reinterpret_cast<const f32x4*>(dP1 + row * ldE + j);
     const f32x4 p2 = *reinterpret_cast<const f32x4*>(dP2 + row * ldE + j);
     const float ri = rinv[row], di = d1[row];
@@ -158,9 +182,12 @@ void gemm_params(IgemmParams& p, const float* A, int lda, long long a_bs, const 
 
 }  // namespace
 
+// the products of a (b, hw, c) problem run on gemm3.hip (pre-split operands)?  A function of the shape, the precision mode and the
+// "Gemm3" knob only: dcn_coattn_bwd must see what dcn_coattn_fwd saw (E is saved in the form the forward wrote).
+static bool on_gemm3(int b, int hw, int c) { return c % 32 == 0 && gemm3_applicable(hw, c, hw, b) && gemm3_applicable(hw, hw, c, b); }
+
 extern "C" int64_t dcn_coattn_fwd_ws(int b, int hw, int c) {
-  (void)c;
-  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw) + AM_SLOTS * DCN_AMAX_WORDS;
+  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw) + AM_SLOTS * DCN_AMAX_WORDS + (on_gemm3(b, hw, c) ? (int64_t)2 * b * hw * c : 0);
 }
 extern "C" int64_t dcn_coattn_e_size(int b, int hw) { return (int64_t)b * hw * ld_pad(hw); }
 
@@ -181,6 +208,31 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   hipLaunchKernelGGL(amax_init_kernel, dim3(1), dim3(256), 0, stream, am);
   DCN_CHECK_LAUNCH("coattn amax_init");
   const unsigned* one = am + AM_ONE * DCN_AMAX_WORDS;
+  const int nrb = cdiv(hw, EXP_ROWS);
+  const long long bsE = (long long)hw * ldE;
+  if (on_gemm3(b, hw, c)) {
+    // every product on gemm3.hip: f1, f2 split once (unit norm: the constant word), E written in split form by its own pass
+    float* f1s = ws + (int64_t)nrb * b * ldE + AM_SLOTS * DCN_AMAX_WORDS;
+    float* f2s = f1s + (int64_t)b * hw * c;
+    const long long bss = (long long)hw * c;
+    int rc = gemm3_presplit(f1, ldf, bsf, f1s, c, bss, b, hw, c, one, stream);
+    if (rc) return rc;
+    if ((rc = gemm3_presplit(f2, ldf, bsf, f2s, c, bss, b, hw, c, one, stream))) return rc;
+    // 1. A = f1 . f2^T -> E                                              (NT)
+    if ((rc = gemm3_launch(f1s, c, bss, 0, f2s, c, bss, 0, E, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, one, one, stream))) return rc;
+    // 2. E = exp(t*A - t) in split form, rinv, cinv
+    const int pid = prof_begin(12, (double)b * hw * ldE * 8.0, stream);
+    hipLaunchKernelGGL(exp_sums_kernel<true>, dim3(nrb, b), dim3(256), 0, stream, E, hw, ldE, temperature, rinv, ws);
+    prof_end(pid, stream);
+    DCN_CHECK_LAUNCH("exp_sums");
+    hipLaunchKernelGGL(colsum_inv_kernel, dim3(cdiv(hw, 256), b), dim3(256), 0, stream, ws, nrb, b, hw, ldE, cinv);
+    DCN_CHECK_LAUNCH("colsum_inv");
+    // 3. f1_attn = diag(rinv) E f2                                       (NN, K = keys j)
+    if ((rc = gemm3_launch(E, ldE, bsE, 0, f2s, c, bss, 1, f1_attn, ldo, bso, rinv, hw, hw, c, hw, b, 0, one, one, stream))) return rc;
+    // 4. f2_attn = diag(cinv) E^T f1                                     (TN, K = queries i)
+    if (f2_attn) rc = gemm3_launch(E, ldE, bsE, 1, f1s, c, bss, 1, f2_attn, ldo, bso, cinv, hw, hw, c, hw, b, 0, one, one, stream);
+    return rc;
+  }
   IgemmParams p;
   // 1. A = f1 . f2^T  -> E                                             (NT)
   gemm_params(p, f1, ldf, bsf, f2, ldf, bsf, E, ldE, (long long)hw * ldE, hw, hw, c, b);
@@ -188,9 +240,8 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   int rc = igemm_launch(p, stream);
   if (rc) return rc;
   // 2. E = exp(t*A - t), rinv = 1/rowsum, cinv = 1/colsum
-  const int nrb = cdiv(hw, EXP_ROWS);
   const int pid = prof_begin(12, (double)b * hw * ldE * 8.0, stream);
-  hipLaunchKernelGGL(exp_sums_kernel, dim3(nrb, b), dim3(256), 0, stream, E, hw, ldE, temperature, rinv, ws);
+  hipLaunchKernelGGL(exp_sums_kernel<false>, dim3(nrb, b), dim3(256), 0, stream, E, hw, ldE, temperature, rinv, ws);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("exp_sums");
   hipLaunchKernelGGL(colsum_inv_kernel, dim3(cdiv(hw, 256), b), dim3(256), 0, stream, ws, nrb, b, hw, ldE, cinv);
@@ -208,7 +259,8 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
 }
 
 extern "C" int64_t dcn_coattn_bwd_ws(int b, int hw, int c) {
-  return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw + AM_SLOTS * DCN_AMAX_WORDS;
+  return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw + AM_SLOTS * DCN_AMAX_WORDS +
+         (on_gemm3(b, hw, c) ? (int64_t)4 * b * hw * c + 4 : 0);
 }
 
 extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
@@ -248,6 +300,40 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
   hipLaunchKernelGGL(rowdot_scale_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, d_f2_attn, lddo, bsdo, f2_attn, ldo, bso, hw, cinv, rows, c, del2, dO2s,
                      slot(AM_DO2), slot(AM_DO2S));
   DCN_CHECK_LAUNCH("rowdot_scale");
+  const int64_t total4 = rows * (ldE / 4);
+  int64_t g = (total4 + 255) / 256; if (g > 8192) g = 8192;
+  if (g > 1024) g = 1024;      // (one abs-max atomic per workgroup)
+  const long long bsE = (long long)hw * ldE;
+  if (on_gemm3(b, hw, c)) {
+    // every product on gemm3.hip (E arrives in split form from dcn_coattn_fwd): the six narrow operands are split once each, dA in place
+    float* dO1p = reinterpret_cast<float*>(((uintptr_t)(am + AM_SLOTS * DCN_AMAX_WORDS) + 15) & ~(uintptr_t)15);      // (b * hw may be odd)
+    float* dO2p = dO1p + rows * c;
+    float* f1s = dO2p + rows * c;
+    float* f2s = f1s + rows * c;
+    const long long bss = (long long)hw * c;
+    int rc;
+    if ((rc = gemm3_presplit(d_f1_attn, lddo, bsdo, dO1p, c, bss, b, hw, c, slot(AM_DO1), stream))) return rc;
+    if ((rc = gemm3_presplit(d_f2_attn, lddo, bsdo, dO2p, c, bss, b, hw, c, slot(AM_DO2), stream))) return rc;
+    if ((rc = gemm3_presplit(f1, ldf, bsf, f1s, c, bss, b, hw, c, slot(AM_ONE), stream))) return rc;
+    if ((rc = gemm3_presplit(f2, ldf, bsf, f2s, c, bss, b, hw, c, slot(AM_ONE), stream))) return rc;
+    if ((rc = gemm3_presplit(dO1s, c, bss, dO1s, c, bss, b, hw, c, slot(AM_DO1S), stream))) return rc;
+    if ((rc = gemm3_presplit(dO2s, c, bss, dO2s, c, bss, b, hw, c, slot(AM_DO2S), stream))) return rc;
+    // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                (NT x2)
+    if ((rc = gemm3_launch(dO1p, c, bss, 0, f2s, c, bss, 0, dP1, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_DO1), slot(AM_ONE), stream))) return rc;
+    if ((rc = gemm3_launch(f1s, c, bss, 0, dO2p, c, bss, 0, dP2, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_ONE), slot(AM_DO2), stream))) return rc;
+    // 3. dA (over dP1; pads -> 0), then split in place with its own abs-max
+    const int pid_da = prof_begin(31, (double)total4 * 16.0 * 4.0, stream);
+    hipLaunchKernelGGL(dA_kernel<true>, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
+    prof_end(pid_da, stream);
+    DCN_CHECK_LAUNCH("dA");
+    if ((rc = gemm3_presplit(dP1, ldE, bsE, dP1, ldE, bsE, b, hw, ldE, slot(AM_DA), stream))) return rc;
+    // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                 (NN x2)
+    if ((rc = gemm3_launch(dP1, ldE, bsE, 0, f2s, c, bss, 1, d_f1, lddf, bsdf, nullptr, 0, hw, c, hw, b, accumulate, slot(AM_DA), slot(AM_ONE), stream))) return rc;
+    if ((rc = gemm3_launch(E, ldE, bsE, 0, dO2s, c, bss, 1, d_f1, lddf, bsdf, nullptr, 0, hw, c, hw, b, 1, slot(AM_ONE), slot(AM_DO2S), stream))) return rc;
+    // 5. d_f2 (+)= dA^T f1 + E^T (dO1 / rowsum)                             (TN x2)
+    if ((rc = gemm3_launch(dP1, ldE, bsE, 1, f1s, c, bss, 1, d_f2, lddf, bsdf, nullptr, 0, hw, c, hw, b, accumulate, slot(AM_DA), slot(AM_ONE), stream))) return rc;
+    return gemm3_launch(E, ldE, bsE, 1, dO1s, c, bss, 1, d_f2, lddf, bsdf, nullptr, 0, hw, c, hw, b, 1, slot(AM_ONE), slot(AM_DO1S), stream);
+  }
   IgemmParams p;
   int rc;
   // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                  (NT x2)
@@ -258,11 +344,8 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
   p.amax_a = slot(AM_ONE); p.amax_b = slot(AM_DO2);
   if ((rc = igemm_launch(p, stream))) return rc;
   // 3. dA (over dP1)
-  const int64_t total4 = rows * (ldE / 4);
-  int64_t g = (total4 + 255) / 256; if (g > 8192) g = 8192;
-  if (g > 1024) g = 1024;      // (one abs-max atomic per workgroup)
   const int pid_da = prof_begin(31, (double)total4 * 16.0 * 4.0, stream);             // HBM-priced: E, dP1, dP2 read, dA written
-  hipLaunchKernelGGL(dA_kernel, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
+  hipLaunchKernelGGL(dA_kernel<false>, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
   prof_end(pid_da, stream);
   DCN_CHECK_LAUNCH("dA");
   // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                   (NN x2)

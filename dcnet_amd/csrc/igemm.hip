@@ -729,6 +729,7 @@ inline int tile_bm(int M, int Co, int ntaps, int Ci) {
 int igemm_grid_m(int M, int Co, int ntaps) { return cdiv(M, tile_bm(M, Co, ntaps, 32)); }   // Ci >= 32 on every multi-tap path
 
 void wgrad_set_split(int v);
+void wgrad_set_lds_pad(int kb);
 void wgrad_set_abl(int v);
 void wgrad_set_target(int v);
 void wgrad_set_wide64(int v);
@@ -744,10 +745,12 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : 0), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"
+  if (k == 'G') { gemm3_set_tuning(value); return DCN_OK; }       // "Gemm3": the co-attention products on pre-split operands (gemm3.hip)
   if (k == 'N') { nconv_set_tuning(value); return DCN_OK; }       // "Nconv": register-bank kernels of the 32 <-> 64 channel layers (nconv.hip)
   if (k == 'd') { bn_set_tuning(value); return DCN_OK; }          // "dbnrev": sweep direction of the BatchNorm streaming passes (bn.hip)
   if (k == 'e') { score_set_tuning(0, value); return DCN_OK; }    // "e2rpw": rows per wave of l2norm_score_fwd
   if (k == 'f') { score_set_tuning(1, value); return DCN_OK; }    // "f2nt": non-temporal loads there
+  if (k == 'l') { wgrad_set_lds_pad(value); return DCN_OK; }      // "lwgpad": KB of LDS a weight-gradient launch reserves at least (occupancy experiment)
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)

@@ -518,6 +518,11 @@ int g_wabl = 0;            // timing-only ablations of the split kernel (wrong r
 int g_wsplit = 4;          // 128x128 weight-gradient / TN tiles: 0 native fp32 MFMA, 1 bf16 three-piece split, 2 bf16 operands,
                            // 4 f16 two-piece split where the operands carry their abs-max (else as 1)   (dcn_set_tuning("precision"|"wsplit"))
 
+int g_wg_lds_pad = 0;      // dcn_set_tuning("lwgpad", KB): dynamic LDS the weight-gradient launches ask for at least (81+ = one workgroup per CU)
+}
+int wgrad_lds_pad() { return g_wg_lds_pad; }
+void wgrad_set_lds_pad(int kb) { g_wg_lds_pad = kb * 1024; }
+namespace {
 template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
@@ -525,11 +530,12 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
   size_t lds = SP ? (size_t)2 * 2 * NP * 4096 : (size_t)2 * KP * (TM + TN) * sizeof(float);
   const size_t red = (size_t)(WK - 1) * TM * TN * sizeof(float);
   if (red > lds) lds = red;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();      // (occupancy experiment: "lwgpad")
+  static size_t attr_done = 0;
+  if (attr_done < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL, NP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+    attr_done = lds;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
   const int pid = prof_begin(SP ? (NP == 1 ? 20 : NP == 2 ? 25 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);

@@ -299,6 +299,8 @@ int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout) {
   return pl.splits > 1 ? (int64_t)pl.splits * cout * 9 * cin : 0;
 }
 
+int wgrad_lds_pad();
+
 int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
                   const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream) {
   const Plan3 pl = plan3(n, h, wd, cin, cout);
@@ -309,12 +311,13 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
   p.amax_dy = amax_dy; p.amax_x = amax_x;
-  const size_t lds = (size_t)2 * np * (A_PLANE + B_PLANE);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * (A_PLANE + B_PLANE));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_PLANE + B_PLANE));
-    attr_done = true;
+  size_t lds = (size_t)2 * np * (A_PLANE + B_PLANE);
+  if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();       // (occupancy experiment: "lwgpad")
+  static size_t attr_done = 0;
+  if (attr_done < lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 2 * 2 * (A_PLANE + B_PLANE) ? lds : 2 * 2 * (A_PLANE + B_PLANE)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 2 * (A_PLANE + B_PLANE) ? lds : 2 * (A_PLANE + B_PLANE)));
+    attr_done = lds;
   }
   const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
   const int pid = prof_begin(np == 2 ? 32 : 20, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);

@@ -289,13 +289,15 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             if s_ is not None:
                 readers.setdefault(s_, []).append(op)
 
-    def sole_pre_reader(op, y):
+    def sole_pre_reader(op, x):
+        """the only reader of op's output, when that is a train-mode conv + BatchNorm whose kernels take the raw tensor"""
         rd = readers.get(op.dst, [])
-        if not (am and training and save is not None and len(rd) == 1 and op.dst not in taps and op.res is None and y.is_contiguous()):
+        if not (am and ops.PRE_ACT and training and save is not None and len(rd) == 1 and op.dst not in taps and op.res is None):
             return False
         nx = rd[0]
+        ho, wo = ops.conv_out_hw(x.shape[1], x.shape[2], op.k, op.stride)
         return (isinstance(nx, _ConvOp) and nx.bn and nx.src == op.dst and nx.res != op.dst
-                and ops.pre_supported(y.shape[0], y.shape[1], y.shape[2], nx.cin, nx.cout, nx.k, nx.stride))
+                and ops.pre_supported(x.shape[0], ho, wo, nx.cin, nx.cout, nx.k, nx.stride))
 
     for op in plan:
         if isinstance(op, _ConvOp):
@@ -315,13 +317,13 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
             if op.bn and training:
-                # (the stem kernel hands out the abs-max of its raw output for free: the bound below starts from it)
-                ay = ops.amax_slot(x.device) if (am and ops.PRE_ACT and op.cin <= 4 and op.res is None and save is not None) else None
+                # (the conv hands out the abs-max of its raw output with its store: the bound below starts from it)
+                ay = ops.amax_slot(x.device) if (not isinstance(x, ops.PreAct) and sole_pre_reader(op, x)) else None
                 y, stats = ops.conv2d_fwd(x, w, op.k, op.stride, want_stats=True, amax_x=ax, amax_w=aw, amax_out=ay,
                                           w_split_ready=wsp, w_b16=w16)
                 cnt = y.numel() // op.cout
                 mi = ops.bn_finalize(stats, cnt, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
-                if ay is not None and sole_pre_reader(op, y):
+                if ay is not None and y.is_contiguous():
                     ao = ops.bn_act_amax_bound(ay, mi[2], mi[3], 0.1)
                     o = ops.PreAct(y, mi[2], mi[3], act, 0.1)
                     if ops.PRE_ACT == "check":        # (tests: the activation written out, read with the same abs-max word)

@@ -34,6 +34,9 @@ SIGNATURES = {
     "dcn_conv2d_bwd_weight_pre_supported": (I, [I, I, I, I, I, I, I]),
     "dcn_conv2d_bwd_weight_pre": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, P, P, I, F, P, P, P]),
     "dcn_bn_act_amax_bound": (I, [P, P, P, I, F, P, P]),
+    "dcn_gemm3_supported": (I, [I, I, I, I]),
+    "dcn_gemm3_presplit": (I, [P, I, L, P, I, L, I, I, I, P, P]),
+    "dcn_gemm3": (I, [P, I, L, I, P, I, L, I, P, I, L, P, L, I, I, I, I, I, P, P, P]),
     "dcn_filter_job_bytes": (I, []),
     "dcn_prepare_filters": (I, [P, I, I, I, P, L, P]),
     "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
@@ -126,8 +129,8 @@ SIGNATURES = {
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
-                "dcn_conv2d_bwd_weight_pre_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
-ABI_VERSION = 303        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+                "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
+ABI_VERSION = 304        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

@@ -681,6 +681,25 @@ def coattn_bwd(f1, f2, d_out1, d_out2, out1, out2, E, rc, d_f1, d_f2, accumulate
                      b, hw, c, float(temperature), _s())
 
 
+def gemm3_presplit(x, amax, out=None):
+    """x (b, rows, c) fp32 view (last dim contiguous) -> its f16 two-piece split form (same shape / bytes; csrc/gemm3.hip), scaled by the
+    power of two of the abs-max word ``amax``.  out=x splits in place."""
+    b, rows, c = x.shape
+    if out is None:
+        out = torch.empty((b, rows, c), dtype=torch.float32, device=x.device)
+    lib().gemm3_presplit(x.data_ptr(), x.stride(1), x.stride(0), out.data_ptr(), out.stride(1), out.stride(0), b, rows, c, amax.data_ptr(), _s())
+    return out
+
+
+def gemm3(a, b, out, m, n, k, amax_a, amax_b, a_t=False, b_t=False, row_scale=None, accumulate=False):
+    """out[i] (+)= diag(row_scale[i]) op(a[i]) op(b[i])^T on operands in split form (gemm3_presplit).  a: (batch, m, >=k) or, a_t,
+    (batch, k, >=m); b: (batch, n, >=k) or, b_t, (batch, k, >=n); out (batch, m, >=n) fp32; all last-dim contiguous views."""
+    lib().gemm3(a.data_ptr(), a.stride(1), a.stride(0), int(a_t), b.data_ptr(), b.stride(1), b.stride(0), int(b_t),
+                out.data_ptr(), out.stride(1), out.stride(0), _p(row_scale), 0 if row_scale is None else row_scale.stride(0),
+                m, n, k, a.shape[0], int(accumulate), amax_a.data_ptr(), amax_b.data_ptr(), _s())
+    return out
+
+
 # ---- scoring ------------------------------------------------------------------------------------------
 def l2norm_score_fwd(x, q=None, rows_per_image=0, out=None, want_flip=False, out_scale=1.0, accumulate=False):
     """x (...,c) rows (pixel stride = x.stride(-2)).  Returns (out, norm, score|None, score_flip|None); score_flip scores

@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 303
+#define DCN_ABI_VERSION 304
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -186,6 +186,25 @@ int dcn_stem_bwd_weight_bn(const float* x, const float* y, const float* dout, in
                            int act, float slope, const float* sums, int64_t count,
                            int n, int h, int wd, int cout, float* dw, float* ws, void* stream);
 int64_t dcn_stem_bwd_weight_bn_ws(int n, int h, int wd);
+
+/* ---- batched GEMM on pre-split operands (gemm3.hip) ----------------------------------- */
+/* The torch.bmm products of the inter-frame co-attention (model/DCNet_model.py:449-459: affinity, the two attended features; and
+ * their autograd) have two ACTIVATION operands: dcn_coattn_fwd / dcn_coattn_bwd run them through these.
+ * dcn_gemm3_presplit: x [batch][rows][c] fp32 (row stride ld, batch stride bs, floats) -> its split form at dst (same shape and
+ * byte size, strides ldd / bsd; dst == src allowed when the strides agree): every run of 8 consecutive elements of a row becomes
+ * [8 f16 high | 8 f16 low] of s*x, s = the power of two that brings the abs-max word `amax` below 2^14 (see dcn_absmax).  c % 8 == 0.
+ * dcn_gemm3: C[b] (+)= diag(row_scale[b]) . op(A[b]) . op(B[b])^T, fp32 result (three f16 MFMAs per product, as the conv engine):
+ *   a_t == 0: A is [M][K] (row stride lda);  a_t != 0: A is [K][M] — likewise b_t for B ([N][K] | [K][N]).  (a_t, b_t) = (0,0) is
+ *   torch.bmm(A, B.transpose(1, 2)), (0,1) torch.bmm(A, B), (1,1) torch.bmm(A.transpose(1, 2), B); (1,0) does not exist.
+ *   A / B in split form with the abs-max words they were split with; operands with K along the row must hold zeros in columns
+ *   [K, ceil16(K)) (lda / ldb >= ceil16(K)); rows / columns beyond a tensor read as zeros.  row_scale: optional [batch][M], batch
+ *   stride rs_bs.  dcn_gemm3_supported says whether a shape runs here (large M; default precision). */
+int dcn_gemm3_supported(int m, int n, int k, int batch);
+int dcn_gemm3_presplit(const float* src, int ld, int64_t bs, float* dst, int ldd, int64_t bsd, int batch, int rows, int c,
+                       const uint32_t* amax, void* stream);
+int dcn_gemm3(const float* a, int lda, int64_t a_bs, int a_t, const float* b, int ldb, int64_t b_bs, int b_t,
+              float* c, int ldc, int64_t c_bs, const float* row_scale, int64_t rs_bs,
+              int m, int n, int k, int batch, int accumulate, const uint32_t* amax_a, const uint32_t* amax_b, void* stream);
 
 /* ---- BatchNorm (train mode) + activation + shortcut ---------------------------------- */
 /* Scratch (floats, 8-byte aligned) needed by dcn_bn_finalize / dcn_bn_bwd_sums for c channels. */

@@ -207,10 +207,13 @@ def test_bn_fold_and_act_bwd(dev):
     _close(got, torch.where(o > 0, d, d * 0.1), 1e-6)
 
 
-@pytest.mark.parametrize("b,g,c", [(2, 8, 64), (1, 13, 512), (3, 5, 96), (8, 13, 128), (2, 26, 128), (1, 52, 128)])   # (the last three: >= 1024 rows, the f16-split GEMMs; 52x52: the TN tile too)
+@pytest.mark.parametrize("b,g,c", [(2, 8, 64), (1, 13, 512), (3, 5, 96), (8, 13, 128), (2, 26, 128), (1, 52, 128),   # (the last three: >= 1024 rows, the f16-split GEMMs; 52x52: the TN tile too)
+                                   (2, 26, 256), (1, 23, 256), (2, 52, 512)])      # all nine products on pre-split operands (csrc/gemm3.hip); 23 x 23: odd row counts
 def test_coattn_fwd_bwd(dev, b, g, c):
     from dcnet_amd import ops
+    from dcnet_amd.lib import lib
     hw = g * g
+    lib().prof_enable(1)
     f1 = F.normalize(_rand(b, hw, c, seed=30), dim=2); f2 = F.normalize(_rand(b, hw, c, seed=31), dim=2)
     a = f1.double().requires_grad_(True); bb = f2.double().requires_grad_(True)
     A = torch.bmm(a, bb.transpose(1, 2))
@@ -232,6 +235,8 @@ def test_coattn_fwd_bwd(dev, b, g, c):
     o_only = torch.empty(b, hw, c, device=dev)
     ops.coattn_fwd(f1d, f2d, o_only, None, 10.0)
     _close(o_only, o1.float(), 2e-5, "f1_attn only")
+    lib().prof_enable(0)
+    assert _prof_launches(40) == (11 if (hw >= 512 and c >= 256) else 0), "which engine ran the products"
 
 
 def test_l2norm_score_fwd_bwd(dev):
@@ -811,7 +816,7 @@ def test_conv1_lds_dma_kernel(dev, case):
         lib().prof_enable(1)
         run()
         lib().prof_enable(0)
-        c = (ctypes.c_int64 * 40)(); m = (ctypes.c_double * 40)(); wk = (ctypes.c_double * 40)()
+        c = (ctypes.c_int64 * 48)(); m = (ctypes.c_double * 48)(); wk = (ctypes.c_double * 48)()
         lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
         return c[35]
 
@@ -1036,6 +1041,73 @@ PRE_CASES = [
     (2, 3, 264, 352),
     (2, 2, 520, 260),
 ]
+
+
+G3_CASES = [
+    # batch, M, N, K, form   (forms: "nt" A [M][K] B [N][K]; "nn" B [K][N]; "tn" A [K][M], B [K][N])
+    (2, 512, 512, 64, "nt"),
+    (3, 700, 530, 96, "nt"),       # ragged M / N tiles
+    (2, 2704, 2704, 512, "nt"),    # the affinity of the 52 x 52 maps
+    (2, 676, 256, 676, "nn"),      # K = 676: a 4-wide last slice; E rows padded to 704
+    (3, 600, 512, 1000, "nn"),
+    (2, 2704, 512, 2704, "nn"),
+    (2, 676, 256, 676, "tn"),
+    (3, 600, 512, 1000, "tn"),
+    (2, 2704, 512, 2704, "tn"),
+]
+
+
+@pytest.mark.parametrize("case", G3_CASES)
+def test_gemm3_presplit_operands(dev, case):
+    """csrc/gemm3.hip (batched GEMM on pre-split operands: both tiles by LDS-DMA, K along the row or across rows from the same bytes)
+    against fp64 in its three forms, with ragged tiles, padded rows (pads must be zero, rows / k beyond the tensors must read as
+    zeros), strided batches, the row scale and accumulation."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    bsz, M, N, K, form = case
+    assert lib().gemm3_supported(M, N, K, bsz)
+    pad32 = lambda v: (v + 31) // 32 * 32
+    a_t, b_t = form == "tn", form != "nt"
+    a_shape = (K, M) if a_t else (M, K)
+    b_shape = (K, N) if b_t else (N, K)
+    # operands as views of wider, batch-interleaved buffers (row stride > columns; pads zero as the contract asks)
+    def make(shape, seed, scale):
+        rows, cols = shape
+        buf = torch.zeros(bsz, 2, rows, pad32(cols) + 32, device=dev)
+        v = buf[:, 1, :, :pad32(cols)]
+        v[:, :, :cols] = (_rand(bsz, rows, cols, seed=seed) * scale).to(dev)
+        return v, cols
+    a, a_cols = make(a_shape, 81, 3.0)
+    b, b_cols = make(b_shape, 82, 0.05)
+    ad, bd = a[:, :, :a_cols].double().cpu(), b[:, :, :b_cols].double().cpu()
+    A2 = ad.transpose(1, 2) if a_t else ad          # (b, M, K)
+    B2 = bd if b_t else bd.transpose(1, 2)          # (b, K, N)
+    ref = torch.bmm(A2, B2)
+    am_a, am_b = ops.absmax(a.contiguous()), ops.absmax(b.contiguous())
+    a_s = ops.gemm3_presplit(a, am_a)
+    b_s = a_s.new_zeros(b.shape); ops.gemm3_presplit(b, am_b, out=b_s)
+    # in place gives the same bytes
+    a_ip = a.clone(); ops.gemm3_presplit(a_ip, am_a, out=a_ip)
+    assert torch.equal(a_ip.view(torch.int32), a_s.view(torch.int32))
+    out = torch.full((bsz, M, N + 32), 7.0, device=dev)
+    c = out[:, :, 16:16 + N]
+    try:
+        lib().prof_enable(1)
+        ops.gemm3(a_s, b_s, c, M, N, K, am_a, am_b, a_t=a_t, b_t=b_t)
+        lib().prof_enable(0)
+        ran = _prof_launches(40)
+    finally:
+        lib().prof_enable(0)
+    assert ran == 1
+    _close(c, ref, 2e-5, f"gemm3 {form}")
+    assert float((out[:, :, :16] - 7).abs().max()) == 0 and float((out[:, :, 16 + N:] - 7).abs().max()) == 0
+    rs = (torch.rand(bsz, M, generator=torch.Generator().manual_seed(83)) + 0.5).to(dev)
+    base = c.clone()
+    ops.gemm3(a_s, b_s, c, M, N, K, am_a, am_b, a_t=a_t, b_t=b_t, row_scale=rs, accumulate=True)
+    _close(c, ref * (1 + rs.double().cpu().unsqueeze(2)), 3e-5, f"gemm3 {form} row scale + accumulate")
+    again = torch.full_like(out, 7.0)[:, :, 16:16 + N]
+    ops.gemm3(a_s, b_s, again, M, N, K, am_a, am_b, a_t=a_t, b_t=b_t)
+    assert torch.equal(again, base)
 
 
 @pytest.mark.parametrize("case", PRE_CASES)
@@ -1274,7 +1346,7 @@ def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
     from dcnet_amd.lib import lib
-    c = (ctypes.c_int64 * 40)(); m = (ctypes.c_double * 40)(); wk = (ctypes.c_double * 40)()
+    c = (ctypes.c_int64 * 48)(); m = (ctypes.c_double * 48)(); wk = (ctypes.c_double * 48)()
     lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
     return c[tag]
 
