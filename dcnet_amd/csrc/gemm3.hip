@@ -52,6 +52,7 @@ struct G3Params {
   const float* row_scale; long long rs_bs;        // optional [batch][M]
   int accumulate;
   const unsigned* amax_a; const unsigned* amax_b;
+  int var;                                        // schedule variant (dcn_set_tuning("Gemm3", 1 + 256 * v))
   int abl;                                        // timing-only ablations (wrong results): 1 no DMA, 2 no fragment reads, 4 no MFMAs
 };
 
@@ -110,20 +111,28 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
   const int my_dst = 2 * wave * 1024;
 
   int k_done = 0;
-  auto issue = [&]() {                      // this wave's pieces of its next K-slice (past the end: no-ops that still count in vmcnt)
+  // this wave's pieces of its next K-slice: the two of the A tile, then the two of the B tile (past the end: no-ops that still count in vmcnt)
+  auto issue_a = [&]() {
     const bool live = k_done < kslices && !(G3_ABL && (p.abl & 1));
     unsigned char* st = smem3g + (k_done & (G3_STAGES - 1)) * G3_STAGE + my_dst;
-    int sa_ = live ? k_done * sstep_a : 0, sb_ = live ? k_done * sstep_b : 0;
-    if (G3_ABL && (p.abl & 8)) { sa_ = 0; sb_ = 0; }        // every slice re-reads the first one (cache-hot)
+    int sa_ = live ? k_done * sstep_a : 0;
+    if (G3_ABL && (p.abl & 8)) sa_ = 0;                     // every slice re-reads the first one (cache-hot)
 #pragma unroll
     for (int e = 0; e < 2; ++e)
       // (explicit int casts: with unsigned arguments hipcc 7.2 silently drops the instantiation of the whole kernel template)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(st + e * 1024), 16, (int)(live ? voff[e] : G3_OOB), sa_, 0, 0);
+  };
+  auto issue_b = [&]() {
+    const bool live = k_done < kslices && !(G3_ABL && (p.abl & 1));
+    unsigned char* st = smem3g + (k_done & (G3_STAGES - 1)) * G3_STAGE + my_dst;
+    int sb_ = live ? k_done * sstep_b : 0;
+    if (G3_ABL && (p.abl & 8)) sb_ = 0;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(st + G3_TILE + e * 1024), 16, (int)(live ? voff[2 + e] : G3_OOB), sb_, 0, 0);
     ++k_done;
   };
+  auto issue = [&]() { issue_a(); issue_b(); };
 
   // ---- fragment addresses (bytes inside a stage) ---------------------------------------------------------------------------------
   // R: lane (r = lane & 31, g = lane >> 5): h = chunk 2 g, l = chunk 2 g + 1 of row r.
@@ -215,8 +224,13 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
     // slice it + 3, into the stage of slice it - 1.  BEHIND the fragment reads: the memory path is the narrow one here (a CU gets
     // ~40 GB/s from L2 into LDS, measured with the loop stripped to its DMA), so a DMA instruction can sit in the issue stage until
     // the queue has room — in front of the reads it kept this group's fragments, hence its MFMA phase, waiting (0.92 -> 0.70 ms)
-    issue();
-    if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G3_STAGES - 2) * 4) : "memory");      // slice it + 1 of this wave
+    if (p.var == 1) {                        // (variant: the B pieces behind the MFMAs)
+      issue_a();
+      if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G3_STAGES - 2) * 4 - 2) : "memory");
+    } else {
+      issue();
+      if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G3_STAGES - 2) * 4) : "memory");      // slice it + 1 of this wave
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                     // b2
     asm volatile("" ::: "memory");
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
+    if (p.var == 1) issue_b();
     if (wm == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G3_STAGES - 2) * 4) : "memory");      // slice it + 1 of this wave
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -339,7 +354,7 @@ int gemm3_launch(const float* A, int lda, long long a_bs, int at, const float* B
   p.a_cols = at ? (M + 7) / 8 * 8 : k16; p.b_cols = bt ? (N + 7) / 8 * 8 : k16;
   DCN_CHECK_ARG(p.a_cols <= lda && p.b_cols <= ldb, "gemm3: rows shorter than the tile reads (lda=%d ldb=%d)", lda, ldb);
   p.tiles_m = cdiv(M, G3_BM); p.tiles_n = cdiv(N, G3_BN);
-  p.row_scale = row_scale; p.rs_bs = rs_bs; p.accumulate = accumulate; p.amax_a = amax_a; p.amax_b = amax_b; p.abl = g_gemm3 >> 4;
+  p.row_scale = row_scale; p.rs_bs = rs_bs; p.accumulate = accumulate; p.amax_a = amax_a; p.amax_b = amax_b; p.abl = (g_gemm3 >> 4) & 15; p.var = g_gemm3 >> 8;
   const int grid = p.tiles_m * p.tiles_n * batch;
   const int pid = prof_begin(40, 2.0 * batch * (double)M * N * K, stream);
   int rc;

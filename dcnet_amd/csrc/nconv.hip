@@ -413,8 +413,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if constexpr (PRE) {
     const int c = (tid % (CK / 4)) * 4;
-    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c); psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c) * s_a; psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c) * s_a;
   }
+  const bool leaky_max = p.pre_slope >= 0.f && p.pre_slope <= 1.f;
   const int wrap_delta = (S * W - RL) * p.ldi * 4;          // an output row further: S input rows on, one padded row of entries back
 
   Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy - row0, column, oy)
@@ -442,16 +443,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto store_slot = [&](int j, int buf, const f32x4* v, unsigned vmask) {
     if (j >= FULL && !last_on) return;
     if (PRE && j >= FULL && dead_last) return;
-    f32x4 x = v[j];
-    if constexpr (PRE) {                             // scale_act_kernel's arithmetic (bn.hip), then zero for the pads
-      x = x * psc + psh;
+    f32x4 t;
+    if constexpr (PRE) {
+      // scale_act_kernel's arithmetic (bn.hip) on operands that carry the power-of-two operand scale already (psc, psh = s_a * scale,
+      // s_a * shift: exact, and LeakyReLU commutes with a positive factor), then zero for the pads.  max(z, slope z) IS z > 0 ? z : slope z
+      // for 0 <= slope <= 1
+      t = v[j] * psc + psh;
       if (p.pre_act == DCN_ACT_LEAKY) {
+        if (leaky_max) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = x[k] > 0.f ? x[k] : x[k] * p.pre_slope;
+          for (int k = 0; k < 4; ++k) t[k] = fmaxf(t[k], t[k] * p.pre_slope);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t[k] = t[k] > 0.f ? t[k] : t[k] * p.pre_slope;
+        }
       }
-      if (!((vmask >> j) & 1u)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!((vmask >> j) & 1u)) t = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      t = v[j] * s_a;
     }
-    const f32x4 t = x * s_a;
     const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
     const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
                        (_Float16)(t[3] - (float)h[3])};

@@ -137,8 +137,9 @@ void wgrad9_kernel(const W9Params p) {
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if constexpr (PRE) {
     const int c = (tid % (CI / 4)) * 4;
-    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c); psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c);
+    psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c) * s_b; psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c) * s_b;
   }
+  const bool leaky_max = p.pre_slope >= 0.f && p.pre_slope <= 1.f;
   unsigned vmask = 0;                                     // PRE: which X pieces of the loaded step are real pixels
   int q_step = p_begin;                                   // first position of the step being LOADED
   int g_row = p_begin / Wp, g_col = p_begin - g_row * Wp;
@@ -172,16 +173,24 @@ void wgrad9_kernel(const W9Params p) {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       if (PRE && j == NSLOT - 1 && !is_a[j] && dead_last) continue;
-      f32x4 x = v[j];
-      if (PRE && !is_a[j]) {                              // scale_act_kernel's arithmetic (bn.hip), then zero for the pads
-        x = x * psc + psh;
+      f32x4 t;
+      if (PRE && !is_a[j]) {
+        // scale_act_kernel's arithmetic (bn.hip) on operands that carry the power-of-two operand scale already (psc, psh = s_b * scale,
+        // s_b * shift: exact, and LeakyReLU commutes with a positive factor), then zero for the pads
+        t = v[j] * psc + psh;
         if (p.pre_act == DCN_ACT_LEAKY) {
+          if (leaky_max) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] = x[k] > 0.f ? x[k] : x[k] * p.pre_slope;
+            for (int k = 0; k < 4; ++k) t[k] = fmaxf(t[k], t[k] * p.pre_slope);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = t[k] > 0.f ? t[k] : t[k] * p.pre_slope;
+          }
         }
-        if (!((vmask >> j) & 1u)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!((vmask >> j) & 1u)) t = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        t = v[j] * (is_a[j] ? s_a : s_b);
       }
-      const f32x4 t = x * (is_a[j] ? s_a : s_b);
       const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
       const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
                          (_Float16)(t[3] - (float)h[3])};

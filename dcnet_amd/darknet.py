@@ -299,7 +299,14 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
         return (isinstance(nx, _ConvOp) and nx.bn and nx.src == op.dst and nx.res != op.dst
                 and ops.pre_supported(x.shape[0], ho, wo, nx.cin, nx.cout, nx.k, nx.stride))
 
-    for op in plan:
+    # the last layer of the persistent one-workgroup-per-CU kernels (csrc/nconv.hip: the 32 <-> 64 channel 3x3 layers): an event behind
+    # it lets other streams start their LDS-heavy work (the persistent BiLSTM) where it no longer takes CUs from those launches
+    early = [i for i, op in enumerate(plan) if isinstance(op, _ConvOp) and op.k == 3 and op.cin == 32 and op.cout == 64]
+    early_at = early[-1] if early else -1
+    early_event = None
+    for i_op, op in enumerate(plan):
+        if i_op == early_at + 1 and early_at >= 0:
+            early_event = torch.cuda.Event(); early_event.record()
         if isinstance(op, _ConvOp):
             p = P[op.slot]
             x = out[op.src]; ax = amx.get(op.src)
@@ -361,7 +368,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             amx[op.dst] = ops.absmax(lat, ops.absmax(up)) if am else None
         else:
             out[op.dst] = out[op.src]; amx[op.dst] = amx.get(op.src)
-    return [out[t] for t in taps], [amx.get(t) for t in taps]
+    return [out[t] for t in taps], [amx.get(t) for t in taps], early_event
 
 
 def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bucket_bytes: int = 0):
@@ -511,7 +518,7 @@ class _DarknetFn(torch.autograd.Function):
         x = ops.nchw_to_nhwc(image.contiguous(), 4)
         need_grad = any(ctx.needs_input_grad[3:])
         save = {} if need_grad else None
-        outs, tap_amax = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P))
+        outs, tap_amax, net._early_event = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P))
         net._tap_amax = tap_amax              # abs-max words of the three taps (read by the head's first convolutions)
         if save is not None:
             # outputs must go through save_for_backward (an attribute reference would make a

@@ -489,14 +489,32 @@ class grounding_model(nn.Module):
         if ops.use_amax():
             ops.amax_begin_step(image.device)        # (before any stream forks: the step's abs-max words are zeroed on `main`)
         side = self._side_stream(image.device) if self.language_stream else main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            word_id, flang, context, embedded = self._language(word_id)
-            flang_attn, flang_loc = self._phrases(context, embedded, word_id)    # :525-526, :556-557
-            self._head_filter_banks()                # (0.3 ms of kernels the head needs after the backbone: beside it, not behind it)
         static = self.static_samples if self.training else None
+        # In a captured step (only the dependencies count, not the order of the calls) the language branch is queued BEHIND the backbone's
+        # first layers: its persistent BiLSTM holds 64 KB of LDS on half the CUs for 1.2 ms, and beside the one-workgroup-per-CU
+        # kernels of those layers that costs them a second round (nconv1_kernel 0.62 -> 1.2 ms).  Eager: in front, so that the host's
+        # 20 ms of backbone launches do not delay it.
+        late = (ops.LANGUAGE_LATE and side is not main and self.training and torch.cuda.is_current_stream_capturing())
+
+        def language():
+            with torch.cuda.stream(side):
+                w_, fl_, ctx_, emb_ = self._language(word_id)
+                fa_, floc_ = self._phrases(ctx_, emb_, w_)    # :525-526, :556-557
+                self._head_filter_banks()            # (0.3 ms of kernels the head needs after the backbone: beside it, not behind it)
+            return w_, fl_, ctx_, emb_, fa_, floc_
+
+        if not late:
+            side.wait_stream(main)
+            word_id, flang, context, embedded, flang_attn, flang_loc = language()
         handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
         raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
+        if late:
+            ev = self.visumodel.__dict__.get("_early_event")
+            if ev is not None:
+                side.wait_event(ev)
+            else:
+                side.wait_stream(main)
+            word_id, flang, context, embedded, flang_attn, flang_loc = language()
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)

@@ -640,6 +640,7 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
     return dw, sums[1], sums[0]
 
 
+LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
 BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
 

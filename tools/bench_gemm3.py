@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--g", type=int, default=52); ap.add_argument("--b", type=int, default=32)
     ap.add_argument("--c", type=int, default=512)
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--abl", type=str, default="0", help="timing-only ablations to run (bits: 1 no DMA, 2 no fragment reads, 4 no MFMAs)")
+    ap.add_argument("--abl", type=str, default="0", help="timing-only ablations to run (bits: 1 no DMA, 2 no fragment reads, 4 no MFMAs; needs G3_ABL 1) + 16 * schedule variant")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     hw, b, c = args.g * args.g, args.b, args.c
@@ -45,7 +45,7 @@ def main():
             ("TN  E^T . f1", lambda: ops.gemm3(Es, f1s, out_f, hw, c, hw, one, one, a_t=True, b_t=True), 2.0 * b * hw * hw * c, 0.0)]
     from dcnet_amd.lib import lib
     for abl in [int(v) for v in args.abl.split(",")]:
-      lib().set_tuning(b"Gemm3", 1 + 16 * abl)
+      lib().set_tuning(b"Gemm3", 1 + 16 * (abl & 15) + 256 * (abl >> 4))
       print("ablation", abl)
       for name, fn, flop, byt in rows:
         if abl and not flop:
