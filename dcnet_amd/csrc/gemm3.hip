@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
     // slice it + 3, into the stage of slice it - 1.  BEHIND the fragment reads: the memory path is the narrow one here (a CU gets
     // ~40 GB/s from L2 into LDS, measured with the loop stripped to its DMA), so a DMA instruction can sit in the issue stage until
     // the queue has room — in front of the reads it kept this group's fragments, hence its MFMA phase, waiting (0.92 -> 0.70 ms)
-    if (p.var == 1) {                        // (variant: the B pieces behind the MFMAs)
+    if (p.var >= 1) {                        // (variants: the B pieces behind (1) / between (2) the MFMAs)
       issue_a();
       if (wm == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((G3_STAGES - 2) * 4 - 2) : "memory");
     } else {
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+      if (p.var == 2) issue_b();
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

@@ -254,7 +254,10 @@ int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int6
  *   f1_attn[i,:] = sum_j softmax_j(t*A[i,j]) * f2[j,:]
  *   f2_attn[j,:] = sum_i softmax_i(t*A[i,j]) * f1[i,:]      (f2_attn may be NULL: inference model)
  * E (dcn_coattn_e_size floats) receives exp(t*A - t), rinv/cinv ([b][hw]) the inverse row / column
- * sums; all three are kept for the backward.  ws: dcn_coattn_fwd_ws floats of scratch.
+ * sums; all three are kept for the backward.  E is OPAQUE to the caller: at the large scales (hw >= 512, c >= 256, default precision)
+ * it holds the f16 two-piece split form the products on gemm3.hip read (dcn_gemm3_presplit's layout), otherwise fp32; dcn_coattn_bwd
+ * decides the same way, so precision mode and the "Gemm3" knob must not change between a forward and its backward.
+ * ws: dcn_coattn_fwd_ws floats of scratch.
  * Outputs have pixel stride ldo (they land in a channel slice of the concat [f, f_attn] buffer).
  * bsf / bso (and bsdo / bsdf in the backward) are the strides, in floats, between consecutive batch
  * items of the feature / output (gradient) tensors — frames of a pair are interleaved in the image
