@@ -182,7 +182,10 @@ extern "C" int dcn_conv2d_bwd_data_tap(const float* dy, int lddy, const float* w
 }
 
 extern "C" int dcn_conv2d_bwd_data_tap_rows(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
-  return (cin == 32 && dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, 0)) ? dgrad2_grid(n, h, wd, cin) : 0;
+  if (cin == 32 && dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, 0)) return dgrad2_grid(n, h, wd, cin);
+  // stride-1 layers on conv1.hip / conv3.hip (an upper bound here: whether a launch taps is reported by the launch itself)
+  if (stride == 1 && igemm_precision() == 4 && cin % 32 == 0 && cin >= 64) return igemm_grid_m(n * h * wd, cin, ksize * ksize);
+  return 0;
 }
 
 namespace {
@@ -250,6 +253,20 @@ int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* d
         const int t = r * ksize + s;
         p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
       }
+    if (tap) {
+      // a stride-1 data gradient IS a forward convolution on the transposed bank: the BatchNorm partial-sum epilogues of conv1.hip /
+      // conv3.hip take the tap (one partial row per M-tile, as dcn_conv2d_stats_rows counts them for the mirrored forward)
+      const int rows = igemm_grid_m(p.M, cin, T);
+      p.stats = tap->stats;
+      if (tap->stats_rows >= rows && igemm_tap_capable(p)) {
+        p.bt_y = tap->y; p.bt_mean = tap->mean; p.bt_invstd = tap->invstd; p.bt_gamma = tap->gamma; p.bt_beta = tap->beta;
+        p.bt_act = tap->act; p.bt_slope = tap->slope;
+        const int rc = igemm_launch(p, stream);
+        if (rc == DCN_OK && tap_rows) *tap_rows = rows;
+        return rc;
+      }
+      p.stats = nullptr;
+    }
     return igemm_launch(p, stream);
   }
   // 1x1 stride 2: only the even-even pixels receive a gradient; the other three parity classes have no tap and are

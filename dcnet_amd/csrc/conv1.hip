@@ -240,10 +240,36 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       float s = 0.f, ss = 0.f;
+      if (p.bt_y) {                                        // BatchNorm tap (igemm.h): channel_partials_kernel<1>'s terms (bn.hip)
+        const int co = bn * BN + ni * 32 + (lane & 31);
+        const float mu = p.bt_mean[co], is = p.bt_invstd[co], ga = p.bt_gamma ? p.bt_gamma[co] : 1.f, be = p.bt_beta ? p.bt_beta[co] : 0.f;
+        // all loads of the block first (rows past the end clamped, their terms dropped below): one wait instead of one per element
+        const float* yb = p.bt_y + co;
+        float yv[MI][16];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s += v; ss += v * v; }
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+            yv[mi][r] = yb[(size_t)(m < M ? m : M - 1) * p.Co];
+          }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+            const float xh = (yv[mi][r] - mu) * is;
+            float g = acc[mi][ni][r];
+            if (p.bt_act == DCN_ACT_LEAKY) g = (ga * xh + be <= 0.f) ? g * p.bt_slope : g;
+            g = m < M ? g : 0.f;
+            s += g; ss += g * xh;
+          }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s += v; ss = __builtin_fmaf(v, v, ss); }      // (fma, spelled out: the sums are bitwise those of the build without the tap)
+      }
       s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
       if (lane < 32) {
         red[(0 * 4 + wave) * BN + ni * 32 + lane] = s;

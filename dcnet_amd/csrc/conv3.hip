@@ -321,10 +321,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       float s = 0.f, ss = 0.f;
+      const int co = bn * BN + wn * 64 + ni * 32 + (lane & 31);
+      if (p.bt_y && co < p.Co) {                           // BatchNorm tap (igemm.h): channel_partials_kernel<1>'s terms (bn.hip)
+        const float mu = p.bt_mean[co], is = p.bt_invstd[co], ga = p.bt_gamma ? p.bt_gamma[co] : 1.f, be = p.bt_beta ? p.bt_beta[co] : 0.f;
+        // all loads of the block first (rows past the end clamped, their terms dropped below): one wait instead of one per element
+        const float* yb = p.bt_y + co;
+        float yv[2][16];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s += v; ss += v * v; }
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            yv[mi][r] = yb[(size_t)(m < M ? m : M - 1) * p.Co];
+          }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float xh = (yv[mi][r] - mu) * is;
+            float g = acc[mi][ni][r];
+            if (p.bt_act == DCN_ACT_LEAKY) g = (ga * xh + be <= 0.f) ? g * p.bt_slope : g;
+            g = m < M ? g : 0.f;
+            s += g; ss += g * xh;
+          }
+      } else if (!p.bt_y) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s += v; ss = __builtin_fmaf(v, v, ss); }      // (fma, spelled out: the sums are bitwise those of the build without the tap)
+      }
       s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
       if (lane < 32) {
         const int col = wn * 64 + ni * 32 + lane;

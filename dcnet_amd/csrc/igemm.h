@@ -47,7 +47,14 @@ struct IgemmParams {
   // ox0 / ntaps below and its taps at tap_*[4c ...]; M, ntaps above then hold the largest class (tile and grid sizing)
   int ncls;
   int cls_M[4], cls_Hs[4], cls_Ws[4], cls_oy0[4], cls_ox0[4], cls_ntaps[4];
+  // BatchNorm tap (stride-1 data gradients on conv1.hip / conv3.hip): the result is the complete gradient w.r.t. act(bn(bt_y)) (+ a
+  // shortcut); `stats` then receives the partial sums of g = result * act'(.) and g * xhat per channel — what dcn_bn_act_bwd_reduce
+  // would compute in a pass of its own — instead of sum / sum of squares.  bt_y dense [M][Co].
+  const float* bt_y; const float* bt_mean; const float* bt_invstd; const float* bt_gamma; const float* bt_beta;
+  int bt_act; float bt_slope;
 };
+// can this launch take a BatchNorm tap (i.e. does it run on conv1.hip / conv3.hip, whose statistics epilogues know the tap)?
+bool igemm_tap_capable(const IgemmParams& p);
 
 // rows of the stats partial buffer (= number of M-blocks) the launch will use
 int igemm_grid_m(int M, int Co, int ntaps);

@@ -784,6 +784,12 @@ bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci) {
   return tile_bm((int)rows, Co, ntaps, Ci) == 128;                     // the 128x128 tile
 }
 
+bool igemm_tap_capable(const IgemmParams& p) {
+  if (!p.stats || p.ncls || p.batch > 1 || !p.dense_out) return false;
+  const int gran = tile_bm(p.M, p.Co, p.ntaps, 32);
+  return conv3_applicable(p, g_precision, gran) || conv1_applicable(p, g_precision, gran);
+}
+
 int igemm_launch(const IgemmParams& p, hipStream_t stream) {
   DCN_CHECK_ARG(p.in && p.wt && p.out, "igemm: null pointer");
   DCN_CHECK_ARG(p.M > 0 && p.Co > 0 && p.Ci > 0, "igemm: empty problem (M=%d Co=%d Ci=%d)", p.M, p.Co, p.Ci);
@@ -809,6 +815,7 @@ int igemm_launch(const IgemmParams& p, hipStream_t stream) {
     // 1x1 layers and their data gradients (plain GEMM rows, pre-split bank): both tiles by LDS-DMA, conv1.hip
     if (conv1_applicable(p, g_precision, gran)) return conv1_launch(p, gran, stream);
   }
+  DCN_CHECK_ARG(!p.bt_y, "igemm: a BatchNorm tap on a launch outside conv1.hip / conv3.hip (ask igemm_tap_capable first)");
   if (p.bmode == 1) {
     DCN_CHECK_ARG(p.ntaps == 1 && !p.c4 && p.Co % 4 == 0, "igemm: NN mode needs one tap and Co %% 4 == 0 (Co=%d)", p.Co);
     if (p.Co <= 64) return launch_variant<128, 64, 2, 2, 1>(p, stream);

@@ -539,7 +539,7 @@ def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
         if wshape[0] != dw.shape[0]:
             dw = dw[:wshape[0]].contiguous()
         out = weight_grad_to_oihw(dw, wshape)
-    for t in (x.y if isinstance(x, PreAct) else x, dy):
+    for t in ((x.y, x.scale, x.shift) if isinstance(x, PreAct) else (x,)) + (dy,):
         t.record_stream(side)                    # keep the allocator from recycling them under the side kernels
     out.record_stream(main)
     return out
@@ -643,6 +643,9 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
 LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
 BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
+BN_TAP_TRUNK = False       # ... also from the stride-1 layers (the partial-sum epilogues of csrc/conv1.hip / conv3.hip): 53 of the 87 reduce
+                           # passes of a step go (-2.7 ms of kernel time) and the data gradients' epilogues take as much longer: +-0.05 ms on
+                           # the step in two A/B runs, so it stays off
 
 
 def act_bwd(out, dout, slope):

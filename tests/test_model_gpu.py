@@ -106,6 +106,37 @@ def test_backbone_with_and_without_loader_side_activation(dev):
     assert float(np.median(list(rel.values()))) < 5e-2 and min(cos.values()) > 0.999, (np.median(list(rel.values())), max(rel.values()), min(cos.values()))
 
 
+def test_backbone_with_batchnorm_taps_on_the_trunk(dev):
+    """ops.BN_TAP_TRUNK: the BatchNorm backward's partial sums formed in the epilogues of the stride-1 data gradients (csrc/conv1.hip,
+    conv3.hip) instead of by reduce passes — same taps, and parameter gradients that agree up to the summation order of those sums."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    from dcnet_amd.utils.synth import synth_inputs
+    from test_ops_gpu import _prof_launches
+    size, n = 256, 4
+    sd = synth_sd(size)
+    image, _, _ = synth_inputs(n, size, seed=11)
+    res = {}
+    try:
+        for mode in (False, True):
+            ops.BN_TAP_TRUNK = mode
+            m = build_product(size, sd, dev).train()
+            taps = m.visumodel(image.to(dev))
+            lib().prof_enable(1)
+            sum((t * torch.randn(t.shape, generator=torch.Generator().manual_seed(t.shape[1])).to(dev)).sum() for t in taps).backward()
+            lib().prof_enable(0)
+            res[mode] = ([t.detach() for t in taps], {k: p.grad.clone() for k, p in m.visumodel.named_parameters() if p.grad is not None},
+                         _prof_launches(22))
+    finally:
+        ops.BN_TAP_TRUNK = False; lib().prof_enable(0)
+    assert res[False][2] - res[True][2] >= 30, (res[False][2], res[True][2])      # reduce passes (channel_partials_kernel<1>) that went
+    assert all(torch.equal(a, b) for a, b in zip(res[True][0], res[False][0]))
+    rel = {k: float(maxdiff(res[True][1][k], g) / max(1e-6, float(g.abs().max()))) for k, g in res[False][1].items()}
+    cos = {k: float(torch.nn.functional.cosine_similarity(res[True][1][k].flatten().double(), g.flatten().double(), dim=0))
+           for k, g in res[False][1].items() if float(g.abs().max()) > 0}
+    assert float(np.median(list(rel.values()))) < 5e-2 and min(cos.values()) > 0.999, (np.median(list(rel.values())), max(rel.values()), min(cos.values()))
+
+
 @pytest.mark.parametrize("size,b,t", [(256, 1, 5), (256, 2, 2), (416, 1, 8)])
 def test_nframe_forward_matches_oracle_and_golden(dev, size, b, t):
     from dcnet_amd.utils.synth import synth_inputs

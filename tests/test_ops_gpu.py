@@ -1110,6 +1110,49 @@ def test_gemm3_presplit_operands(dev, case):
     assert torch.equal(again, base)
 
 
+TAP1_CASES = [
+    # n, h, w, cin, cout, k   (stride 1; the data gradient goes cout -> cin channels and taps the BatchNorm of the cin-channel layer in front)
+    (4, 26, 26, 256, 128, 1),      # conv1.hip, accumulating into a shortcut gradient
+    (2, 52, 52, 256, 128, 1),
+    (8, 13, 13, 1024, 512, 1),
+    (4, 26, 26, 128, 256, 3),      # conv3.hip
+    (2, 52, 52, 128, 256, 3),
+    (8, 13, 21, 256, 512, 3),      # ragged last M-tile
+]
+
+
+@pytest.mark.parametrize("case", TAP1_CASES)
+def test_bn_tap_on_stride1_data_gradients(dev, case):
+    """The BatchNorm tap in the partial-sum epilogues of csrc/conv1.hip / conv3.hip: the data gradient of a stride-1 layer forms
+    sum(g) and sum(g * xhat) of the BatchNorm + LeakyReLU in front (g = dx * act') while dx is in registers — against
+    dcn_bn_act_bwd_reduce over the written dx, with and without accumulation into an existing gradient."""
+    from dcnet_amd import ops
+    n, h, w, cin, cout, k = case
+    wgt = (_rand(cout, cin, k, k, seed=101) / (3 * k)).to(dev)
+    w_ohwi = wgt.permute(0, 2, 3, 1).contiguous()
+    dy = _rand(n, h, w, cout, seed=102).to(dev)
+    y_prev = (_rand(n, h, w, cin, seed=103) * 2).to(dev)
+    gamma = (_rand(cin, seed=104)).to(dev); beta = (_rand(cin, seed=105) / 2).to(dev)      # (negative gammas too)
+    mean = y_prev.reshape(-1, cin).mean(0); invstd = 1.0 / torch.sqrt(y_prev.reshape(-1, cin).var(0, unbiased=False) + 1e-5)
+    tap = dict(y=y_prev, mean=mean, invstd=invstd, gamma=gamma, beta=beta, act=ops.ACT_LEAKY, slope=0.1)
+    for accumulate in (False, True):
+        base = _rand(n, h, w, cin, seed=106).to(dev)
+        plain = base.clone() if accumulate else None
+        plain = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), k, 1, out=plain, accumulate=accumulate)
+        tapped = base.clone() if accumulate else None
+        tapped, part = ops.conv2d_bwd_data(dy, w_ohwi, (h, w), k, 1, out=tapped, accumulate=accumulate, tap=tap)
+        assert part is not None, "the launch did not tap"
+        assert torch.equal(plain, tapped)
+        ref, r_ = ops._bn_bwd_partials(y_prev, plain, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, None)
+        ref = ref[:r_ * 2 * cin].view(r_, 2, cin).clone()
+        _close(part.double().sum(0), ref.double().sum(0), 2e-5, f"tap partial sums (accumulate={accumulate})")
+        # the BatchNorm backward fed with the tapped partials equals the one that reduces by itself
+        d0 = ops.bn_act_bwd(y_prev, plain, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1)
+        d1 = ops.bn_act_bwd(y_prev, plain, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, part=part)
+        for a_, b_ in zip(d0, d1):
+            _close(a_, b_, 2e-5, "bn_act_bwd with tapped partials")
+
+
 @pytest.mark.parametrize("case", PRE_CASES)
 def test_loader_side_activation(dev, case):
     """dcn_conv2d_fwd_pre / dcn_conv2d_bwd_weight_pre (the BatchNorm scale / shift + LeakyReLU of the layer in front applied where the
