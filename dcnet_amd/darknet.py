@@ -480,7 +480,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 # (the register-bank kernel of the stride-2 layer behind the stem; every stride-1 layer on conv1.hip / conv3.hip)
                 if (ops.BN_TAP and training and prev is not None and prev.bn and first_use.get(op.src) == index_of[id(op)]
                         and prev.slot in save
-                        and ((x.shape[3] == 32 and op.stride == 2 and op.k == 3) or (ops.BN_TAP_TRUNK and op.stride == 1 and x.shape[3] >= 64))):
+                        and ((x.shape[3] == 32 and op.stride == 2 and op.k == 3) or (ops.BN_TAP_TRUNK and op.stride == 1 and x.shape[3] >= 64
+                                 and (ops.BN_TAP_TRUNK is True or ops.BN_TAP_TRUNK == 1 or (ops.BN_TAP_TRUNK == 2) == (op.k == 3))))):
                     _, y_prev, mi_prev = save[prev.slot][:3]
                     if torch.is_tensor(y_prev) and y_prev.is_contiguous():
                         tap = dict(y=y_prev, mean=mi_prev[0], invstd=mi_prev[1], gamma=P[prev.slot]["gamma"], beta=P[prev.slot]["beta"],

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from .lib import DcnError, lib
@@ -643,9 +645,10 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
 LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
 BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
-BN_TAP_TRUNK = False       # ... also from the stride-1 layers (the partial-sum epilogues of csrc/conv1.hip / conv3.hip): 53 of the 87 reduce
-                           # passes of a step go (-2.7 ms of kernel time) and the data gradients' epilogues take as much longer: +-0.05 ms on
-                           # the step in two A/B runs, so it stays off
+BN_TAP_TRUNK = os.environ.get("DCN_BN_TAP_TRUNK", "1") != "0"
+# ... also from the stride-1 layers (the partial-sum epilogues of csrc/conv1.hip / conv3.hip): 53 of the 87 reduce passes of a step go
+# (-2.7 ms of kernel time) and the data gradients' epilogues take most of it back: -0.3 .. +0.05 ms on the step in four A/B runs
+# (2: the 3x3 layers only, 3: the 1x1 layers only)
 
 
 def act_bwd(out, dout, slope):

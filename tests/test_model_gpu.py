@@ -117,6 +117,7 @@ def test_backbone_with_batchnorm_taps_on_the_trunk(dev):
     sd = synth_sd(size)
     image, _, _ = synth_inputs(n, size, seed=11)
     res = {}
+    default = ops.BN_TAP_TRUNK
     try:
         for mode in (False, True):
             ops.BN_TAP_TRUNK = mode
@@ -128,7 +129,7 @@ def test_backbone_with_batchnorm_taps_on_the_trunk(dev):
             res[mode] = ([t.detach() for t in taps], {k: p.grad.clone() for k, p in m.visumodel.named_parameters() if p.grad is not None},
                          _prof_launches(22))
     finally:
-        ops.BN_TAP_TRUNK = False; lib().prof_enable(0)
+        ops.BN_TAP_TRUNK = default; lib().prof_enable(0)
     assert res[False][2] - res[True][2] >= 30, (res[False][2], res[True][2])      # reduce passes (channel_partials_kernel<1>) that went
     assert all(torch.equal(a, b) for a, b in zip(res[True][0], res[False][0]))
     rel = {k: float(maxdiff(res[True][1][k], g) / max(1e-6, float(g.abs().max()))) for k, g in res[False][1].items()}
