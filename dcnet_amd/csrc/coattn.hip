@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void colsum_inv_kernel(const float* __restrict
 // Abs-max words of the co-attention GEMM operands (DCN_AMAX_WORDS each, in the caller's workspace): slot 0 holds the
 // constant 1 — unit-norm features, E = exp(t*A - t) <= 1 — the others start at 0 and are raised by the kernels that write
 // or read the gradient operands.  With both words present a GEMM runs on the f16 two-piece split (igemm.hip).
-enum { AM_ONE = 0, AM_DO1, AM_DO2, AM_DO1S, AM_DO2S, AM_DA, AM_SLOTS };
+enum { AM_ONE = 0, AM_DO1, AM_DO2, AM_DO1S, AM_DO2S, AM_DA, AM_DP1, AM_DP2, AM_SLOTS };
 __global__ __launch_bounds__(256) void amax_init_kernel(unsigned* __restrict__ w) {
   for (int i = threadIdx.x; i < AM_SLOTS * DCN_AMAX_WORDS; i += 256) w[i] = i < DCN_AMAX_WORDS ? 0x3F800000u : 0u;
 }
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void rowdot_scale_kernel(const float* __restri
 }
 
 // dA = t * E * ((dP1 - d1[i]) * rinv[i] + (dP2 - d2[j]) * cinv[j]), written over dP1; pad columns -> 0
-template <bool ESPLIT>
+// OSPLIT: dA is written in the split form as well, scaled by the word in amax_da, which then holds a BOUND (da_bound_kernel) instead
+// of receiving the maximum.
+template <bool ESPLIT, bool OSPLIT = false>
 __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, float* __restrict__ dP1, const float* __restrict__ dP2,
                                                  const float* __restrict__ rinv, const float* __restrict__ cinv,
                                                  const float* __restrict__ d1, const float* __restrict__ d2,
@@ -139,6 +141,13 @@ __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, fl
   __shared__ float red[4];
   float vmax = 0.f;
   const int l4 = ldE >> 2;
+  float s_out = 1.f;
+  if constexpr (OSPLIT) {                         // (= igemm.hip pow2_scale of the bound)
+    const int be = (int)((amax_read(amax_da) >> 23) & 0xFF);
+    int ex = (be == 0 || be == 255) ? 0 : 14 - (be - 126);
+    ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    s_out = __uint_as_float((unsigned)(ex + 127) << 23);
+  }
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / l4;                 // = b*hw + i
     const int j = (int)(idx - row * l4) * 4;
@@ -162,10 +171,30 @@ __global__ __launch_bounds__(256) void dA_kernel(const float* __restrict__ E, fl
       if (j + k < hw) v = t * e[k] * ((p1[k] - di) * ri + (p2[k] - d2[bb * hw + j + k]) * cinv[bb * hw + j + k]);
       o[k] = v;
     }
-    *reinterpret_cast<f32x4*>(dP1 + row * ldE + j) = o;
-    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    if constexpr (OSPLIT) {                       // (a lane pair shares a run of 8 columns: both have read their 16 bytes by now)
+      const f32x4 ts = o * s_out;
+      const f16x4c_t h = {(_Float16)ts[0], (_Float16)ts[1], (_Float16)ts[2], (_Float16)ts[3]};
+      const f16x4c_t l = {(_Float16)(ts[0] - (float)h[0]), (_Float16)(ts[1] - (float)h[1]), (_Float16)(ts[2] - (float)h[2]),
+                          (_Float16)(ts[3] - (float)h[3])};
+      unsigned char* run = reinterpret_cast<unsigned char*>(dP1 + row * ldE + (j & ~7)) + (j & 4) * 2;
+      *reinterpret_cast<f16x4c_t*>(run) = h;
+      *reinterpret_cast<f16x4c_t*>(run + 16) = l;
+    } else {
+      *reinterpret_cast<f32x4*>(dP1 + row * ldE + j) = o;
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
   }
-  amax_update_block(amax_da, vmax, red);
+  if constexpr (!OSPLIT) amax_update_block(amax_da, vmax, red);
+}
+
+// |dA_ij| = t E_ij |(dP1_ij - d1_i) r_i + (dP2_ij - d2_j) c_j| <= 2 t (max|dP1| + max|dP2|): E_ij r_i <= 1 and E_ij c_j <= 1 (an entry is
+// one term of its row / column sum) and d1_i, d2_j are softmax-weighted means of dP1's row / dP2's column.  The f16 split needs a bound,
+// not the maximum (a loose one costs the smallest entries their lowest bits: absolute error <= 2^-39 of the bound), so dA_kernel can
+// write the split form directly instead of fp32 + a split pass over 0.94 GB.
+__global__ __launch_bounds__(64) void da_bound_kernel(const unsigned* __restrict__ a1, const unsigned* __restrict__ a2, float t,
+                                                      unsigned* __restrict__ out) {
+  const float b = 2.f * t * (__uint_as_float(amax_read(a1)) + __uint_as_float(amax_read(a2)));
+  out[threadIdx.x & (DCN_AMAX_WORDS - 1)] = __float_as_uint(b);
 }
 
 inline int ld_pad(int hw) { return (hw + 31) / 32 * 32; }
@@ -319,14 +348,15 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
     if ((rc = gemm3_presplit(dO1s, c, bss, dO1s, c, bss, b, hw, c, slot(AM_DO1S), stream))) return rc;
     if ((rc = gemm3_presplit(dO2s, c, bss, dO2s, c, bss, b, hw, c, slot(AM_DO2S), stream))) return rc;
     // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                (NT x2)
-    if ((rc = gemm3_launch(dO1p, c, bss, 0, f2s, c, bss, 0, dP1, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_DO1), slot(AM_ONE), stream))) return rc;
-    if ((rc = gemm3_launch(f1s, c, bss, 0, dO2p, c, bss, 0, dP2, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_ONE), slot(AM_DO2), stream))) return rc;
-    // 3. dA (over dP1; pads -> 0), then split in place with its own abs-max
+    if ((rc = gemm3_launch(dO1p, c, bss, 0, f2s, c, bss, 0, dP1, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_DO1), slot(AM_ONE), stream, slot(AM_DP1)))) return rc;
+    if ((rc = gemm3_launch(f1s, c, bss, 0, dO2p, c, bss, 0, dP2, ldE, bsE, nullptr, 0, hw, hw, c, b, 0, slot(AM_ONE), slot(AM_DO2), stream, slot(AM_DP2)))) return rc;
+    // 3. dA (over dP1; pads -> 0) in split form straight away, scaled by a bound from the two maxima the products above left
+    hipLaunchKernelGGL(da_bound_kernel, dim3(1), dim3(64), 0, stream, slot(AM_DP1), slot(AM_DP2), temperature, slot(AM_DA));
+    DCN_CHECK_LAUNCH("dA bound");
     const int pid_da = prof_begin(31, (double)total4 * 16.0 * 4.0, stream);
-    hipLaunchKernelGGL(dA_kernel<true>, dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
+    hipLaunchKernelGGL((dA_kernel<true, true>), dim3((int)g), dim3(256), 0, stream, E, dP1, dP2, rinv, cinv, del1, del2, hw, ldE, temperature, total4, slot(AM_DA));
     prof_end(pid_da, stream);
     DCN_CHECK_LAUNCH("dA");
-    if ((rc = gemm3_presplit(dP1, ldE, bsE, dP1, ldE, bsE, b, hw, ldE, slot(AM_DA), stream))) return rc;
     // 4. d_f1 (+)= dA f2 + E (dO2 / colsum)                                 (NN x2)
     if ((rc = gemm3_launch(dP1, ldE, bsE, 0, f2s, c, bss, 1, d_f1, lddf, bsdf, nullptr, 0, hw, c, hw, b, accumulate, slot(AM_DA), slot(AM_ONE), stream))) return rc;
     if ((rc = gemm3_launch(E, ldE, bsE, 0, dO2s, c, bss, 1, d_f1, lddf, bsdf, nullptr, 0, hw, c, hw, b, 1, slot(AM_ONE), slot(AM_DO2S), stream))) return rc;

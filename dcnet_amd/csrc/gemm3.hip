@@ -52,6 +52,7 @@ struct G3Params {
   const float* row_scale; long long rs_bs;        // optional [batch][M]
   int accumulate;
   const unsigned* amax_a; const unsigned* amax_b;
+  unsigned* amax_out;                             // optional: abs-max word of what is stored
   int var;                                        // schedule variant (dcn_set_tuning("Gemm3", 1 + 256 * v))
   int abl;                                        // timing-only ablations (wrong results): 1 no DMA, 2 no fragment reads, 4 no MFMAs
 };
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
   const float dq = 1.f / (g3_pow2_scale(amax_read(p.amax_a)) * g3_pow2_scale(amax_read(p.amax_b)));      // powers of two: exact
   float* __restrict__ cb = p.C + batch * p.c_bs;
   const float* rs = p.row_scale ? p.row_scale + batch * p.rs_bs : nullptr;
+  float vmax = 0.f;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -283,8 +285,13 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
         float* dst = cb + (long long)m * p.ldc + n;
         if (p.accumulate) v += *dst;
         *dst = v;
+        vmax = fmaxf(vmax, fabsf(v));
       }
     }
+  if (p.amax_out) {
+    vmax = wave_max(vmax);
+    if (lane == 0) amax_update(p.amax_out, vmax, blockIdx.x * 8 + wave);
+  }
 }
 
 // x (fp32 [batch][rows][c], row stride ld) -> its split form, dense or in place: 8 elements per thread
@@ -344,7 +351,8 @@ int gemm3_presplit(const float* src, int ld, long long bs, float* dst, int ldd, 
 // rows).  a_cols / b_cols: floats of a row that exist (R operands: zeros in [K, ceil16 K) required; T operands: the M / N columns).
 int gemm3_launch(const float* A, int lda, long long a_bs, int at, const float* B, int ldb, long long b_bs, int bt,
                  float* C, int ldc, long long c_bs, const float* row_scale, long long rs_bs,
-                 int M, int N, int K, int batch, int accumulate, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream) {
+                 int M, int N, int K, int batch, int accumulate, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream,
+                 unsigned* amax_out) {
   DCN_CHECK_ARG(A && B && C && amax_a && amax_b, "gemm3: null pointer");
   DCN_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && a_bs % 4 == 0 && b_bs % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0, "gemm3: 16-byte rows");
   G3Params p{};
@@ -355,7 +363,7 @@ int gemm3_launch(const float* A, int lda, long long a_bs, int at, const float* B
   p.a_cols = at ? (M + 7) / 8 * 8 : k16; p.b_cols = bt ? (N + 7) / 8 * 8 : k16;
   DCN_CHECK_ARG(p.a_cols <= lda && p.b_cols <= ldb, "gemm3: rows shorter than the tile reads (lda=%d ldb=%d)", lda, ldb);
   p.tiles_m = cdiv(M, G3_BM); p.tiles_n = cdiv(N, G3_BN);
-  p.row_scale = row_scale; p.rs_bs = rs_bs; p.accumulate = accumulate; p.amax_a = amax_a; p.amax_b = amax_b; p.abl = (g_gemm3 >> 4) & 15; p.var = g_gemm3 >> 8;
+  p.row_scale = row_scale; p.rs_bs = rs_bs; p.accumulate = accumulate; p.amax_a = amax_a; p.amax_b = amax_b; p.amax_out = amax_out; p.abl = (g_gemm3 >> 4) & 15; p.var = g_gemm3 >> 8;
   const int grid = p.tiles_m * p.tiles_n * batch;
   const int pid = prof_begin(40, 2.0 * batch * (double)M * N * K, stream);
   int rc;
@@ -380,5 +388,5 @@ extern "C" int dcn_gemm3(const float* a, int lda, int64_t a_bs, int a_t, const f
                          int m, int n, int k, int batch, int accumulate, const uint32_t* amax_a, const uint32_t* amax_b, void* stream) {
   DCN_CHECK_ARG(m > 0 && n > 0 && k > 0 && batch > 0, "gemm3: empty problem");
   return gemm3_launch(a, lda, a_bs, a_t, b, ldb, b_bs, b_t, c, ldc, c_bs, row_scale, rs_bs, m, n, k, batch, accumulate, amax_a, amax_b,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, nullptr);
 }

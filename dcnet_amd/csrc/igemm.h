@@ -96,7 +96,8 @@ int gemm3_presplit(const float* src, int ld, long long bs, float* dst, int ldd, 
                    const unsigned* amax, hipStream_t stream);
 int gemm3_launch(const float* A, int lda, long long a_bs, int at, const float* B, int ldb, long long b_bs, int bt,
                  float* C, int ldc, long long c_bs, const float* row_scale, long long rs_bs,
-                 int M, int N, int K, int batch, int accumulate, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream);
+                 int M, int N, int K, int batch, int accumulate, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream,
+                 unsigned* amax_out = nullptr);
 int igemm_precision();       // dcn_set_tuning("precision"): 4 = f16 two-piece split (the default)
 // ... and the 3x3 layers between 32 and 64 channels: mode 0 = forward 32 -> 64 (stride 1 | 2, BatchNorm partial sums), mode 1 = data
 // gradient of the stride-1 layer (64 -> 32)
