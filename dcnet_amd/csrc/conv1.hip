@@ -360,9 +360,16 @@ int g_conv1_fill = 0;     // dcn_set_tuning("1fill", n): grids of fewer 128 x 12
                           // 1024->512 0.058 -> 0.064 ms, 512->512 data gradient 0.039 -> 0.048: half the MFMAs per barrier costs more than
                           // the second round of workgroups brings; off.
 
+int g_conv1_wide = 1024;  // dcn_set_tuning("1wide", min workgroups; 0 = off): 128 x 256 tiles (a wave owns 32 rows x 256 filters: half the split work and
+                          // 0.75 instead of 0.83 fragment reads per MFMA) where the filter count allows and that many workgroups remain.
+                          // tools/bench_convs.py --set 1wide=0|1, forward / data gradient: 1024->512 @52 0.806 -> 0.707 / 0.757 -> 0.691 ms,
+                          // 512->512 @52 0.419 -> 0.372 / 0.433 -> 0.397, 256->512 @52 0.267 -> 0.235 / 0.225 -> 0.205; the short grids lose
+                          // (512->256 @26, 338 workgroups: 0.062 -> 0.065; 1024->512 @13, 170: 0.070 -> 0.086): from 1024 workgroups on
+
 int conv1_shape(const IgemmParams& p, int gran) {
   int ni = p.Co % 128 == 0 ? 4 : (p.Co % 64 == 0 ? 2 : (p.Co % 32 == 0 ? 1 : 0));
   if (!ni) return 0;
+  if (g_conv1_wide && p.Co % 256 == 0 && (!p.stats || gran == 128) && (long long)cdiv(p.M, 128) * (p.Co / 256) >= g_conv1_wide) return 18;
   // (experiment knob, off by default — see g_conv1_fill)
   if (ni == 4 && (!p.stats || gran == 128) && (long long)cdiv(p.M, 128) * (p.Co / 128) < g_conv1_fill) ni = 2;
   int mi;
@@ -374,7 +381,7 @@ int conv1_shape(const IgemmParams& p, int gran) {
 
 }  // namespace
 
-void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else g_conv1_fill = value; }
+void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value; else g_conv1_fill = value; }
 
 // shape part of the decision.  The kernel only takes launches that igemm.hip would run on its f16-split tiles WITH the pre-split
 // bank (b_scale set by conv.hip under igemm_will_presplit): the arithmetic — which products, in which order — is then the same and
@@ -403,6 +410,7 @@ bool conv1_applicable(const IgemmParams& p, int precision, int gran) {
 
 int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
   switch (conv1_shape(p, gran)) {
+    case 18: return launch1_ring<8, 1>(p, stream);
     case 14: return launch1_ring<4, 1>(p, stream);
     case 12: return launch1_ring<2, 1>(p, stream);
     case 22: return launch1_ring<2, 2>(p, stream);

@@ -742,7 +742,7 @@ void wgrad9_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
-  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : 0), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
+  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"
   if (k == 'G') { gemm3_set_tuning(value); return DCN_OK; }       // "Gemm3": the co-attention products on pre-split operands (gemm3.hip)
