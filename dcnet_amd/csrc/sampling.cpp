@@ -17,32 +17,47 @@
 //   randbelow(n): b = n.bit_length(); r = getrandbits(b) until r < n;  getrandbits(b<=32) = genrand32 >> (32-b).
 #include <stdint.h>
 #include <math.h>
+#include <algorithm>
 #include <vector>
 #include "common.h"
 
 namespace {
 
+// One regeneration of the 624-word state ("twist"), written as three dependence-free loops so that the
+// compiler vectorises them: word kk reads kk+1 and kk+397 of the OLD block in the first loop and
+// kk-227 of the NEW block in the others (227 apart: chunks of any vector width are independent).
+inline void mt_twist(uint32_t* mt) {
+  for (int kk = 0; kk < 227; ++kk) {
+    const uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+    mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
+  }
+  for (int kk = 227; kk < 454; ++kk) {
+    const uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+    mt[kk] = mt[kk - 227] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
+  }
+  for (int kk = 454; kk < 623; ++kk) {
+    const uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+    mt[kk] = mt[kk - 227] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
+  }
+  const uint32_t y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+  mt[623] = mt[396] ^ (y >> 1) ^ ((0U - (y & 1U)) & 0x9908b0dfU);
+}
+
+inline uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= (y >> 18);
+  return y;
+}
+
+inline int bit_length(uint32_t n) { int b = 0; for (; n; n >>= 1) ++b; return b; }
+
 struct MT {
   uint32_t* mt;   // 624 words
   uint32_t* pos;  // index word
   uint32_t next() {
-    static const uint32_t mag01[2] = {0x0U, 0x9908b0dfU};
-    if (*pos >= 624) {
-      int kk;
-      uint32_t y;
-      for (kk = 0; kk < 624 - 397; kk++) { y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1U]; }
-      for (; kk < 623; kk++) { y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1U]; }
-      y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
-      mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1U];
-      *pos = 0;
-    }
-    uint32_t y = mt[(*pos)++];
-    y ^= (y >> 11); y ^= (y << 7) & 0x9d2c5680U; y ^= (y << 15) & 0xefc60000U; y ^= (y >> 18);
-    return y;
+    if (*pos >= 624) { mt_twist(mt); *pos = 0; }
+    return mt_temper(mt[(*pos)++]);
   }
-  uint32_t randbelow(uint32_t n) {
-    int bits = 0;
-    for (uint32_t v = n; v; v >>= 1) ++bits;
+  uint32_t randbelow(uint32_t n, int bits) {
     uint32_t r = next() >> (32 - bits);
     while (r >= n) r = next() >> (32 - bits);
     return r;
@@ -55,26 +70,57 @@ int set_size(int k) {
   return s;
 }
 
-// indices (positions in the population list) of random.sample(population of length n, k)
-void sample_positions(MT& g, int n, int k, std::vector<int>& pool, std::vector<uint8_t>& seen, int* out) {
-  if (n <= set_size(k)) {
+// indices (positions in the population list) of random.sample(population of length n, k).  `stamp` (>= n entries,
+// zero before the first call) and `tick` replace CPython's `selected` set: an entry is taken when it holds this call's tick.
+void sample_positions(MT& g, int n, int k, bool pool_path, std::vector<int>& pool, std::vector<uint32_t>& stamp, uint32_t& tick,
+                      int* out) {
+  if (pool_path) {
     pool.resize(n);
     for (int i = 0; i < n; ++i) pool[i] = i;
     for (int i = 0; i < k; ++i) {
-      const uint32_t j = g.randbelow((uint32_t)(n - i));
+      const uint32_t j = g.randbelow((uint32_t)(n - i), bit_length((uint32_t)(n - i)));
       out[i] = pool[j];
       pool[j] = pool[n - i - 1];
     }
   } else {
-    seen.assign(n, 0);
+    const int bits = bit_length((uint32_t)n);
+    if (++tick == 0) { std::fill(stamp.begin(), stamp.end(), 0u); tick = 1; }
     for (int i = 0; i < k; ++i) {
-      uint32_t j = g.randbelow((uint32_t)n);
-      while (seen[j]) j = g.randbelow((uint32_t)n);
-      seen[j] = 1;
+      uint32_t j = g.randbelow((uint32_t)n, bits);
+      while (stamp[j] == tick) j = g.randbelow((uint32_t)n, bits);
+      stamp[j] = tick;
       out[i] = (int)j;
     }
   }
 }
+
+// The rejection branch of random.sample on a stream of ACCEPTED draws.  Every randbelow(n) of that branch takes
+// the top `bits` bits of one generator output and discards it when it is >= n; which outputs survive r < limit
+// does not depend on what was drawn before, so a whole 624-word block is tempered, shifted and compacted at once
+// (branch-free), and the sample loop — duplicates, the one-smaller population of the (ii == index) draw — walks
+// the survivors.  idx[] remembers where each survivor sat in the block: the stream position after the last draw
+// is the position behind the last survivor USED, exactly where CPython's generator stands.
+struct Accepted {
+  uint32_t* mt; uint32_t* pos;
+  int shift; uint32_t limit;       // survivors: (y >> shift) < limit
+  uint16_t val[624], idx[624];
+  int cn = 0, ci = 0;
+  void fill(int from) {
+    int c = 0;
+    for (int i = from; i < 624; ++i) {
+      const uint32_t r = mt_temper(mt[i]) >> shift;
+      val[c] = (uint16_t)r; idx[c] = (uint16_t)(i + 1);
+      c += r < limit;
+    }
+    cn = c; ci = 0;
+  }
+  void begin() { if (*pos < 624) fill((int)*pos); }
+  inline uint32_t next() {
+    while (ci == cn) { mt_twist(mt); *pos = 0; fill(0); }
+    return val[ci++];
+  }
+  void end() { if (ci > 0) *pos = idx[ci - 1]; }
+};
 
 }  // namespace
 
@@ -84,13 +130,14 @@ extern "C" int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, in
   DCN_CHECK_ARG(state && out && pairs > 0 && top_k > 0 && hw > 1 && neg_n > 0 && neg_n <= hw - 1 && neg_n <= 64,
                 "mt_sample_interframe: bad argument");
   MT g{state, state + 624};
-  std::vector<int> pool; std::vector<uint8_t> seen; int tmp[64];
+  std::vector<int> pool; std::vector<uint32_t> stamp((size_t)hw, 0u); uint32_t tick = 0; int tmp[64];
+  const bool pool_path = hw - 1 <= set_size(neg_n);
   for (int p = 0; p < pairs; ++p)
     for (int j = 0; j < top_k; ++j) {
       // kpos == NULL: emit the raw list positions; the caller maps them (pos >= kp ? pos+1 : pos) on the
       // device, so the draw — which does not depend on kp — can run while the GPU is still computing kp
       const int64_t kp = kpos ? kpos[(size_t)p * top_k + j] : (int64_t)hw;
-      sample_positions(g, hw - 1, neg_n, pool, seen, tmp);       // list(range(hw)) with kp removed
+      sample_positions(g, hw - 1, neg_n, pool_path, pool, stamp, tick, tmp);   // list(range(hw)) with kp removed
       for (int e = 0; e < neg_n; ++e) out[((size_t)p * top_k + j) * neg_n + e] = tmp[e] < kp ? tmp[e] : tmp[e] + 1;
     }
   return DCN_OK;
@@ -100,12 +147,57 @@ extern "C" int dcn_mt_sample_interframe(uint32_t* state, const int64_t* kpos, in
 extern "C" int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int neg_n, int64_t* out) {
   DCN_CHECK_ARG(state && out && n > 0 && rows > 1 && neg_n > 0 && neg_n <= rows - 1 && neg_n <= 64,
                 "mt_sample_crossmodal: bad argument");
+  const int setsz = set_size(neg_n);
+  const int bits = bit_length((uint32_t)rows);
+  if (rows - 1 > setsz && bits == bit_length((uint32_t)(rows - 1)) && neg_n <= 8) {
+    // both populations (rows, rows - 1 entries) take the rejection branch with the same bit count: the block form.
+    // A draw is compared with the <= 7 earlier ones of its sample instead of a set; only the n-th sample of a
+    // (ii, jj) is written, the others just advance the stream.
+    Accepted a; a.mt = state; a.pos = state + 624; a.shift = 32 - bits; a.limit = (uint32_t)rows;
+    a.begin();
+    for (int ii = 0; ii < n; ++ii)
+      for (int jj = 0; jj < rows; ++jj) {
+        uint32_t sel[8];
+        for (int index = 0; index < n; ++index) {
+          const uint32_t lim = (uint32_t)(index == ii ? rows - 1 : rows);
+          if (neg_n == 5 && a.ci + 5 <= a.cn) {
+            // the common case (94 % at 169 rows): the next five survivors are distinct and inside the population
+            const uint16_t* v = a.val + a.ci;
+            const uint32_t v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4];
+            const bool bad = (v0 == v1) | (v0 == v2) | (v0 == v3) | (v0 == v4) | (v1 == v2) | (v1 == v3) | (v1 == v4) |
+                             (v2 == v3) | (v2 == v4) | (v3 == v4) |
+                             (v0 >= lim) | (v1 >= lim) | (v2 >= lim) | (v3 >= lim) | (v4 >= lim);
+            if (!bad) {
+              a.ci += 5;
+              if (index == n - 1) { sel[0] = v0; sel[1] = v1; sel[2] = v2; sel[3] = v3; sel[4] = v4; }
+              continue;
+            }
+          }
+          for (int i = 0; i < neg_n; ++i) {
+            uint32_t r; bool again;
+            do {
+              r = a.next();
+              again = r >= lim;
+              for (int e = 0; e < i; ++e) again |= (sel[e] == r);
+            } while (again);
+            sel[i] = r;
+          }
+        }
+        const bool removed = (ii == n - 1);
+        for (int e = 0; e < neg_n; ++e)
+          out[((size_t)ii * rows + jj) * neg_n + e] = (removed && sel[e] >= (uint32_t)jj) ? (int64_t)sel[e] + 1 : (int64_t)sel[e];
+      }
+    a.end();
+    return DCN_OK;
+  }
   MT g{state, state + 624};
-  std::vector<int> pool; std::vector<uint8_t> seen; int tmp[64];
+  std::vector<int> pool; std::vector<uint32_t> stamp((size_t)rows, 0u); uint32_t tick = 0; int tmp[64];
   for (int ii = 0; ii < n; ++ii)
     for (int jj = 0; jj < rows; ++jj) {
-      for (int index = 0; index < n; ++index)
-        sample_positions(g, index == ii ? rows - 1 : rows, neg_n, pool, seen, tmp);
+      for (int index = 0; index < n; ++index) {
+        const int pop = index == ii ? rows - 1 : rows;
+        sample_positions(g, pop, neg_n, pop <= setsz, pool, stamp, tick, tmp);
+      }
       const bool removed = (ii == n - 1);
       for (int e = 0; e < neg_n; ++e)
         out[((size_t)ii * rows + jj) * neg_n + e] = (removed && tmp[e] >= jj) ? tmp[e] + 1 : tmp[e];

@@ -99,20 +99,22 @@ def test_native_sampler_is_bit_exact_with_python_random():
         state = np.array(st[1], dtype=np.uint32); out = np.zeros_like(ref)
         L.mt_sample_interframe(state.ctypes.data, kpos.ctypes.data, pairs, top_k, hw, neg_n, out.ctypes.data)
         assert (out == ref).all() and tuple(int(x) for x in state) == after[1]
-    for n, rows in ((2, 64), (3, 169)):
+    # (2, 64): the two populations differ in bit length (generic path); 169/170/676: the block path and its five-survivor
+    # shortcut; 22/23: the pool branch on one / both populations; k = 8, 9: the set-size rule for k > 5
+    for n, rows, k in ((2, 64, 5), (3, 169, 5), (3, 170, 5), (2, 676, 5), (2, 22, 5), (2, 23, 5), (2, 100, 8), (2, 400, 9)):
         random.seed(5); st = random.getstate()
-        ref = np.zeros((n, rows, 5), dtype=np.int64)
+        ref = np.zeros((n, rows, k), dtype=np.int64)
         for ii in range(n):
             for jj in range(rows):
                 for index in range(n):
                     lst = list(range(rows))
                     if index == ii:
                         lst.remove(jj)
-                    s = random.sample(lst, 5)
+                    s = random.sample(lst, k)
                 ref[ii, jj] = s
         after = random.getstate()
         state = np.array(st[1], dtype=np.uint32); out = np.zeros_like(ref)
-        L.mt_sample_crossmodal(state.ctypes.data, n, rows, 5, out.ctypes.data)
+        L.mt_sample_crossmodal(state.ctypes.data, n, rows, k, out.ctypes.data)
         assert (out == ref).all() and tuple(int(x) for x in state) == after[1]
 
 
