@@ -75,8 +75,66 @@ RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_k
             27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"],
             29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2>"], 35: ["conv1_kernel<"],
             36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
-FAMILY = {28: "conv3_kernel<*,2,4> (3x3 stride-1 strip kernel, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 stride-1 strip kernel, f16 split)"}
+FAMILY = {28: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)"}
 NT = 48            # DCN_PROF_TAGS
+
+
+def read_sclk_mhz(device_index: int = 0):
+    """Shader clock (MHz) the card holds right now, from rocm-smi; None when the tool or the line is missing."""
+    import re
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks"], capture_output=True, text=True, timeout=20)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", r.stdout, flags=re.I)
+    return int(m.group(1)) if m else None
+
+
+LINE_LIMIT = 2000          # the driver keeps the tail of stdout: the line stays under 2 KB
+
+
+def compact_line(res: dict) -> str:
+    """The ONE stdout line.  north_star's numbers sit as flat scalars INSIDE `roofline` (the driver's parser keeps that object
+    whole and cuts long strings): dominant kernel alone / in the step, conv engine against 838.9, cross-modal scoring against
+    8 TB/s, the same step on exact-arithmetic alternatives, the held shader clock.  Strings are short by construction; if the
+    line still came out long, bookkeeping keys go first and the contract keys never."""
+    out = dict(res)
+    rf = dict(out.get("roofline") or {})
+    ins = rf.pop("in_step", None)
+    if ins:
+        rf["in_step_frac"] = ins["frac"]; rf["in_step_ms"] = ins["avg_launch_ms"]
+    ce = out.pop("conv_engine", None)
+    if ce:
+        rf["conv_engine_frac"] = ce["frac_of_838.9"]; rf["conv_engine_tflops"] = ce["tflops_over_kernel_time"]
+        rf["conv_tflop_per_step"] = ce["tflop_per_step"]
+    hs = out.pop("hbm_scoring", None)
+    if hs:
+        rf["hbm_scoring_frac"] = hs["frac"]; rf["hbm_scoring_gbs"] = hs["achieved"]
+    fd = out.pop("flop_dominant", None)
+    if fd and fd["kernel"] != rf.get("kernel"):
+        rf["flop_dominant"] = fd["kernel"][:40]; rf["flop_dominant_frac"] = fd["frac"]
+    alt = out.pop("alt", None)
+    if alt:
+        for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms"):
+            rf[k] = alt.get(k)
+        rf["alone_ms"] = alt.get("exclusive_ms")
+    if "sclk_mhz" in out:
+        rf["sclk_mhz"] = out.pop("sclk_mhz")
+    if rf:
+        rf["note"] = "kernel alone (HIP events); in_step: rocprofv3 of replays"
+        out["roofline"] = rf
+    line = json.dumps(out, separators=(",", ":"))
+    for path in (("roofline", "rocprof_match"), ("roofline", "alg_bytes_per_launch"), ("roofline", "hbm_frac_algorithmic"),
+                 ("roofline", "flop_dominant"), ("roofline", "flop_dominant_frac"), ("bn_passes_ms_per_step",), ("host_queue_ms_per_step",),
+                 ("loss",), ("roofline", "conv_tflop_per_step"), ("roofline", "launches_per_step"), ("roofline", "note")):
+        if len(line) < LINE_LIMIT:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k, {})
+        d.pop(path[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 def parse():
@@ -200,8 +258,7 @@ def cpu_baseline(size: int, frames: int, steps: int):
     return {"value": 1.0 / t, "unit": "clips/s", "cores": best, "kind": "port",
             "thread_sweep_eval_pair_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "parity": parity_check(),
-            "sample": f"oracle/ (CPU port pinned to the reference) fwd+5 losses+bwd, 1 clip T={frames} {size}x{size}, "
-                      f"{steps} timed steps, median, best of 8/16/32/64 threads; host has {os.cpu_count()} cpus"}
+            "sample": f"oracle port fwd+5 losses+bwd, 1 clip T={frames} {size}x{size}, median of {steps} steps, {os.cpu_count()} cpus on host"}
 
 
 def main():
@@ -278,12 +335,14 @@ def main():
         reducer_name = args.reducer
         if args.reducer == "overlap":
             red = attach_overlapped_reducer(model)
+            red.always_collective = args.force_ddp
         elif args.reducer == "ddp":
             net = wrap_ddp(model, local_rank)
         else:
             if world > 1:
                 broadcast_parameters(model, 0)
             flat = FlatGradAllReduce(model.parameters()).bind()       # gradients live in one flat buffer: no per-parameter copies
+            flat.always_collective = args.force_ddp                   # (one-rank RCCL group: the collective is issued all the same)
     from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
     opt = make_optimizer(model, 1e-4)
 
@@ -326,7 +385,7 @@ def main():
         try:
             gstep = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, reducer=flat, warmup=max(1, min(args.warmup, 2)))
             step = gstep
-            graph_note = "hipGraph replay (forward + losses + backward" + (" + RMSprop)" if flat is None else "); flat all-reduce + RMSprop eager")
+            graph_note = "hipGraph replay (fwd+losses+bwd" + ("+RMSprop)" if flat is None else "); all-reduce+RMSprop eager")
         except Exception as e:           # capture refused: say so loudly, run the eager step (still the HIP path, never a fallback off it)
             if args.graph == "on":
                 raise
@@ -354,6 +413,12 @@ def main():
         dt = float(t.item())
     last_loss = float(last.detach())
     max_alloc = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    sclk = None
+    for _ in range(3):                # the clock the card holds UNDER this load: three more (untimed) steps queued on every rank,
+        step()                        # rank 0 reads rocm-smi while they run
+    if rank == 0:
+        sclk = read_sclk_mhz(local_rank)
+    barrier()
 
     # ---- untimed passes (every rank runs them, so collectives stay in step) -------------------------------------------
     # from here on the eager step: the profiler wraps each launch in a HIP event pair, which a captured graph cannot hold
@@ -480,11 +545,13 @@ def main():
         res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt,
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips} clips/GPU, L=20, fp32 (f16x2-split MFMA, fp32 accumulate), "
-                                      f"pair semantics ({n_img} img/GPU/step), fwd+5 losses+bwd+RMSprop",
-                          "parallelism": f"dp{world}", "ranks_seen": dist.get_world_size() if use_dist else 1,
-                          "reducer": reducer_name, "step": graph_note},
-               "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4)}
+               "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips}/GPU L=20 fp32, {n_img} img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
+                          "arith": "f16x2-split MFMA, fp32 accumulate", "parallelism": f"dp{world}",
+                          "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note},
+               "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4),
+               "loss_hex": float(last_loss).hex()}
+        if use_dist:
+            res["config"]["collectives"] = (flat.collectives if flat is not None else red.buckets_last_step if red is not None else None)
         if step is not eager_step:
             # what the host does per replayed step: launching (graph + optimiser-side calls) vs waiting for the native sampler thread
             # (the reference's O(N^2 HW) random.sample loop, serial by construction; it runs under the previous replay)
@@ -517,17 +584,14 @@ def main():
             if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
                 with open(pmc_file) as f:
                     pmc = json.load(f)
-                if pmc.get("kernel") == e["kernel"]:
+                if pmc.get("kernel", "").split(" (")[0] == e["kernel"].split(" (")[0]:
                     traffic = pmc.get("hbm_bytes_per_launch")
             roofline = {"bound": "mfma", "kernel": e["kernel"], "rocprof_match": RP_MATCH.get(dom), "achieved": e["achieved"], "peak": e["peak"], "unit": "TFLOP/s",
                         "frac": e["frac"], "traffic": traffic,
                         "traffic_ratio": round(traffic / e["alg_bytes_per_launch"], 3) if traffic else None,
                         "avg_launch_ms": e["avg_launch_ms"], "ms_per_step": e["ms_per_step"], "launches_per_step": e["launches_per_step"],
                         "alg_bytes_per_launch": e["alg_bytes_per_launch"], "hbm_frac_algorithmic": e["hbm_frac_algorithmic"],
-                        "binding_frac": e["binding_frac"],
-                        "note": "time-dominant conv-engine kernel; HIP event pair per launch, untimed eager pass, kernels alone on the GPU "
-                                "(side streams off); in_step = inside the replayed step, from the committed rocprofv3 summary; "
-                                "binding_frac = sum over launches of max(FLOP/838.9T, bytes/8TB/s) / time"}
+                        "binding_frac": e["binding_frac"]}
             ins_file = os.path.join(ROOT, "profiles", "in_step_latest.json")
             if os.path.exists(ins_file):     # launch durations inside the replayed step (rocprofv3 of this command, committed profile)
                 with open(ins_file) as f:
@@ -537,8 +601,7 @@ def main():
                 if k_:
                     fl_per_launch = fam_sum(prof, dom, "work") / fam_sum(prof, dom, "c")
                     roofline["in_step"] = {"avg_launch_ms": round(k_["avg_launch_ms"], 4),
-                                           "frac": round(fl_per_launch / (k_["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_OF[dom], 4),
-                                           "source": ins.get("source")}
+                                           "frac": round(fl_per_launch / (k_["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_OF[dom], 4)}
             res["roofline"] = roofline
             fe = entry(prof, fdom)
             res["flop_dominant"] = {k: fe[k] for k in ("kernel", "frac", "ms_per_step", "binding_frac")}
@@ -558,8 +621,7 @@ def main():
         if alts:
             res["alt"] = {"exclusive_ms": round(prof["ms_per_step"], 1) if prof else None, "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
                           "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1),
-                          "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1),
-                          "note": "eager steps, side streams off, untimed; bf16/fp8 = reduced-precision operand modes, never `value`"}
+                          "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1)}
             for k_, r_ in alts.items():
                 full[k_] = {"ms_per_step": r_["ms_per_step"], "kernels": table(r_)}
         if world == 1 and not args.no_cpu_baseline:
@@ -569,7 +631,7 @@ def main():
                                    "sample": cb["sample"], "gpu_vs_oracle_max_abs_err": round(cb["parity"]["max_abs_err_outbox"], 6),
                                    "acc_at_0.5_vs_oracle_boxes": cb["parity"]["acc_at_iou_0.5_vs_oracle_boxes"]}
         res["full"] = "profiles/bench_full_latest.json"
-        line = json.dumps(res, separators=(",", ":"))
+        res["sclk_mhz"] = sclk
         full["bench_line"] = res
         for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
             try:
@@ -578,11 +640,7 @@ def main():
                         json.dump(full, f, indent=1)
             except OSError:
                 pass
-        for drop in ("conv_engine", "flop_dominant", "hbm_scoring", "alt"):     # the driver keeps the tail of stdout: stay under 2 KB
-            if len(line) < 2000:
-                break
-            res.pop(drop, None)
-            line = json.dumps(res, separators=(",", ":"))
+        line = compact_line(res)
         sys.stdout.flush()
         os.write(json_fd, (line + "\n").encode())
     if use_dist:

@@ -30,6 +30,34 @@ void dcn_set_error(const char* fmt, ...);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Function attributes (the dynamic-LDS limit) and the CU count belong to a DEVICE, not to the process: launch-site caches are
+// indexed by the calling thread's current device, so a process that drives a second GPU sets its limits there too.
+#define DCN_MAX_DEVICES 32
+static inline int dcn_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d % DCN_MAX_DEVICES;
+}
+struct DcnPerDeviceFlag {      // `static DcnPerDeviceFlag f; if (f.first()) { ...once per device... }`
+  bool done[DCN_MAX_DEVICES] = {};
+  bool first() { const int d = dcn_device_slot(); const bool was = done[d]; done[d] = true; return !was; }
+};
+struct DcnPerDeviceSize {      // `static DcnPerDeviceSize s; if (s.raise(lds)) { ...limit grows on this device... }`
+  size_t v[DCN_MAX_DEVICES] = {};
+  bool raise(size_t want) { size_t& c = v[dcn_device_slot()]; if (c >= want) return false; c = want; return true; }
+};
+// CUs of the current device (0 on a failed query), cached per device
+static inline int dcn_device_cus() {
+  static int cus[DCN_MAX_DEVICES] = {};
+  const int d = dcn_device_slot();
+  if (!cus[d]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    cus[d] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus[d];
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of
 // the logical tile order so that neighbouring tiles (which share operand panels) hit the
 // same 4 MiB L2.  Bijective for any grid size.  Speed only, never correctness.

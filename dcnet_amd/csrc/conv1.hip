@@ -323,11 +323,10 @@ int g_conv1_stages = 32;  // dcn_set_tuning("1stages", 10 * SA + SB): ring depth
 template <int SA, int SB, int NI, int MI>
 int launch1(const IgemmParams& p, hipStream_t stream) {
   constexpr int BM = 128 * MI, BN = 32 * NI;
-  static bool attr_done = false;
+  static DcnPerDeviceFlag attr_once;
   const size_t lds = (size_t)SA * BM * 64 + (size_t)SB * 2 * BN * 32;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_kernel<SA, SB, NI, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   const int gm = cdiv(p.M, BM), gn = p.Co / BN;
   const double k_alg = (double)p.ntaps * p.Ci;

@@ -319,10 +319,9 @@ int g_gemm3 = 1;          // dcn_set_tuning("Gemm3", 0): the co-attention produc
 
 template <bool AT, bool BT>
 int launch3g(const G3Params& p, int grid, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-    attr_done = true;
   }
   hipLaunchKernelGGL((gemm3_kernel<AT, BT>), dim3(grid), dim3(512), G3_LDS, stream, p);
   return DCN_OK;

@@ -617,11 +617,10 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   constexpr int LD16 = (BK == 16 || F8) ? 16 : BK + 8;
   const size_t lds = SP ? (size_t)2 * NP * (BM * LD16 + (BMODE == 0 ? BN * LD16 : 2048) + (BPRE ? 32 : 0)) * sizeof(unsigned short)
                         : (size_t)2 * (BM * LDS_LD + (BMODE == 0 ? BN * LDS_LD : BK * BN)) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   const int nb = p.batch > 0 ? p.batch : 1;
   // latency-bound little GEMMs (LSTM steps: 64 rows) are booked separately from the conv-stack tiles

@@ -235,12 +235,11 @@ extern "C" int dcn_bilstm_fwd(const float* xg, const float* whh_fwd, const float
   DCN_CHECK_ARG(n > 0 && n <= 64 * LS_MAXC && l > 0, "bilstm_fwd: %d rows (1..%d), %d steps", n, 64 * LS_MAXC, l);
   if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_fwd: memset failed"); return DCN_ERR_LAUNCH; }   // the counters; the error word sync[8] is sticky
   const size_t lds = (size_t)32 * LS_H * sizeof(float) + 16;
-  static bool attr_done = false;
+  static DcnPerDeviceFlag attr_once;
   static int resident = 0;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     resident = resident_blocks(bilstm_fwd_kernel, lds);
-    attr_done = true;
   }
   DCN_CHECK_ARG(resident < 0 || resident >= 2 * (LS_H / LS_UNITS), "bilstm_fwd: the device keeps %d workgroups of this kernel resident, the "
                 "persistent recurrence needs all %d at once (use the per-step dcn_lstm_cell_* path)", resident, 2 * (LS_H / LS_UNITS));
@@ -258,12 +257,11 @@ extern "C" int dcn_bilstm_bwd(const float* dout, const float* whh_fwd, const flo
   DCN_CHECK_ARG(n > 0 && n <= 64 * LS_MAXC && l > 0, "bilstm_bwd: %d rows (1..%d), %d steps", n, 64 * LS_MAXC, l);
   if (hipMemsetAsync(sync, 0, 32, stream) != hipSuccess) { dcn_set_error("bilstm_bwd: memset failed"); return DCN_ERR_LAUNCH; }
   const size_t lds = (size_t)LS_UNITS * 4 * LS_H * sizeof(float) + 16;
-  static bool attr_done = false;
+  static DcnPerDeviceFlag attr_once;
   static int resident = 0;
-  if (!attr_done) {
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilstm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     resident = resident_blocks(bilstm_bwd_kernel, lds);
-    attr_done = true;
   }
   DCN_CHECK_ARG(resident < 0 || resident >= 2 * (LS_H / LS_UNITS), "bilstm_bwd: the device keeps %d workgroups of this kernel resident, the "
                 "persistent recurrence needs all %d at once", resident, 2 * (LS_H / LS_UNITS));

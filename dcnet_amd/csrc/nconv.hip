@@ -589,7 +589,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 int g_nconv = 1;          // dcn_set_tuning("Nconv", 0): these layers back on the implicit-GEMM tiles
-int g_ncus = 0;
 
 }  // namespace
 
@@ -607,10 +606,9 @@ bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int s
 template <int CK, int CN, bool TAP>
 int launch_d2(D2Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo<CK, CN> G;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN, TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
-    attr_done = true;
   }
   const int pid = prof_begin(37, flop, stream, bytes);
   hipLaunchKernelGGL((dgrad2_kernel<CK, CN, TAP>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
@@ -620,11 +618,8 @@ int launch_d2(D2Params& p, int grid, double flop, double bytes, hipStream_t stre
 }
 
 int dgrad2_grid(int n, int h, int wd, int cin) {
-  if (!g_ncus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int g_ncus = dcn_device_cus();
+  if (!g_ncus) return -1;
   const int nchunks = cdiv((long long)n * (h / 2) * (wd / 2 + 1), cin == 32 ? 64 : 32);
   const int grid = g_ncus < nchunks ? g_ncus : nchunks;
   return cdiv(nchunks, cdiv(nchunks, grid));
@@ -632,11 +627,8 @@ int dgrad2_grid(int n, int h, int wd, int cin) {
 
 int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,
                   const uint32_t* amax_dy, const uint32_t* amax_w, const DcnBnTap* tap, hipStream_t stream) {
-  if (!g_ncus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
-    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int g_ncus = dcn_device_cus();
+  if (!g_ncus) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
   const int ch = cin == 32 ? 64 : 32, ck = 2 * cin;
   D2Params p{};
   p.dy = dy; p.wt = wt; p.dx = dx; p.N = n; p.Ho = h / 2; p.Wo = wd / 2; p.lddy = lddy; p.ldo = cin; p.accumulate = accumulate;
@@ -676,10 +668,9 @@ template <int S, int CK, int CN, bool FLIP, bool PRE = false>
 int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo1<S, CK> G;
   const int lds = 2 * G::BUFB + (CN == 32 ? 2 * 16 * 64 * 4 : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   const int pid = prof_begin(38, flop, stream, bytes);
   hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP, PRE>), dim3(grid), dim3(512), lds, stream, p);
@@ -694,11 +685,8 @@ int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stre
 // in the loader (DcnPreAct), amax_x is then the abs-max word of the ACTIVATION (dcn_bn_act_amax_bound)
 int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, int ldo, float* stats, int stats_rows,
                   int n, int h, int wd, int stride, const uint32_t* amax_x, const uint32_t* amax_w, const DcnPreAct* pre, hipStream_t stream) {
-  if (!g_ncus) {
-    int dev = 0; hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { dcn_set_error("nconv1: device query failed"); return DCN_ERR_LAUNCH; }
-    g_ncus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int g_ncus = dcn_device_cus();
+  if (!g_ncus) { dcn_set_error("nconv1: device query failed"); return DCN_ERR_LAUNCH; }
   const int ck = mode == 0 ? 32 : 64, cn = mode == 0 ? 64 : 32;
   N1Params p{};
   p.x = x; p.w = w; p.y = y; p.stats = stats; p.N = n; p.Ho = h / stride; p.Wo = wd / stride; p.ldi = ldi; p.ldo = ldo;

@@ -531,11 +531,10 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
   const size_t red = (size_t)(WK - 1) * TM * TN * sizeof(float);
   if (red > lds) lds = red;
   if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();      // (occupancy experiment: "lwgpad")
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
+  static DcnPerDeviceSize attr_lds;
+  if (attr_lds.raise(lds)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL, NP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = lds;
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
   const int pid = prof_begin(SP ? (NP == 1 ? 20 : NP == 2 ? 25 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);

@@ -313,11 +313,10 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.amax_dy = amax_dy; p.amax_x = amax_x;
   size_t lds = (size_t)2 * np * (A_PLANE + B_PLANE);
   if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();       // (occupancy experiment: "lwgpad")
-  static size_t attr_done = 0;
-  if (attr_done < lds) {
+  static DcnPerDeviceSize attr_lds;
+  if (attr_lds.raise(lds)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 2 * 2 * (A_PLANE + B_PLANE) ? lds : 2 * 2 * (A_PLANE + B_PLANE)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 2 * (A_PLANE + B_PLANE) ? lds : 2 * (A_PLANE + B_PLANE)));
-    attr_done = lds;
   }
   const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
   const int pid = prof_begin(np == 2 ? 32 : 20, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);

@@ -297,10 +297,9 @@ template <int S, int CO, int CI> size_t lds9() { return (size_t)2 * G9<S, CO, CI
 
 template <int S, int CO, int CI, bool PRE = false>
 int launch9(const W9Params& p, int splits, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
-    attr_done = true;
   }
   const int threads = G9<S, CO, CI>::NT;
   const size_t lds = lds9<S, CO, CI>();

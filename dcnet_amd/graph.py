@@ -66,6 +66,11 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
+        if reducer is not None and hasattr(reducer, "check_all_received"):
+            # a bound flat buffer gives EVERY parameter a gradient: one that autograd never writes would be decayed by the optimiser
+            # where the reference skips it (parallel.freeze_gradless must have run)
+            ids = {id(p): n for n, p in self.core.named_parameters()}
+            reducer.check_all_received([ids.get(id(p), "?") for p in reducer.params])
         self._zero_grads()
         self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
         torch.cuda.synchronize(dev)

@@ -44,10 +44,11 @@ def get_precision() -> str:
 
 # ---- abs-max words of GEMM operands (the f16 two-piece split derives its power-of-two scales from them) --------------
 # A word holds the float bits of max|tensor| and is written with order-independent atomic maxima by the kernels that
-# produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool (one quarter of
-# it per training step, amax_begin_step) and are used once per step, so a saved activation keeps its word for the backward.
+# produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool (one per
+# forward, amax_begin_step) and are used once per step, so a saved activation keeps its word for the backward.
 AMAX_WORDS = 64          # DCN_AMAX_WORDS: the waves of a producer spread their atomic maxima over this many words
 _amax_pools = {}
+_amax_recent = {}
 _amax_consts = {}
 
 
@@ -57,51 +58,44 @@ def use_amax() -> bool:
     return _precision in ("fp32", "fp8")
 
 
-AMAX_SLOTS = 8192        # slots of the shared pool, handed out in four quarters (one per training step in flight)
-_AMAX_Q = AMAX_SLOTS // 4
+AMAX_SLOTS = 2048        # slots of one pool = what a forward (and its backward) may hand out before a second pool is taken
 
 
-def _amax_new_pool(device):
-    """[pool tensor, cursor (slots), end of the current quarter (slots)], zero-filled on the current stream; the device is
-    synchronised ONCE here (pool creation) so that no stream can see the memset land after its first atomic maximum."""
+def _amax_new_pool(device, sync: bool):
+    """[pool tensor, cursor (slots), end (slots)], zero-filled on the current stream.  ``sync``: the caller is not on a stream
+    every later user forks from (op-level calls outside a step) — the device is synchronised once so that no stream can see the
+    memset land after its first atomic maximum."""
     t = torch.zeros(AMAX_SLOTS * AMAX_WORDS, dtype=torch.int32, device=device)
-    if not torch.cuda.is_current_stream_capturing():
+    if sync and not torch.cuda.is_current_stream_capturing():
         torch.cuda.synchronize(device)
-    return [t, 0, _AMAX_Q]
+    return [t, 0, AMAX_SLOTS]
 
 
 def amax_begin_step(device) -> None:
-    """Call at the start of a forward, on the stream every other stream of the step forks from: moves the slot cursor to the
-    next quarter of the pool and zeroes that quarter there, so the words a step hands out are zero before any of its kernels
-    (on whichever stream) updates them, and the words of the previous three steps stay untouched (a saved activation keeps
-    its word for the backward).  Under hipGraph capture the step gets a pool of its own whose memset is part of the graph:
-    every replay starts from zeroed words."""
+    """Call at the start of a forward, on the stream every other stream of the step forks from: the step gets a pool of its
+    OWN (512 KB from torch's caching allocator, zeroed on that stream), so the words it hands out are zero before any of its
+    kernels (on whichever stream) updates them.  A saved activation holds a view of its word and thereby the pool: however many
+    forwards — training micro-batches, validation passes — run before a backward, its words are never recycled under it (the
+    round-3 form rotated four quarters of one pool and zeroed the oldest).  Under hipGraph capture the allocation and the memset
+    are part of the graph: every replay starts from zeroed words."""
     key = torch.device(device).index
-    if torch.cuda.is_current_stream_capturing():
-        _amax_pools[key] = [torch.zeros(_AMAX_Q * AMAX_WORDS, dtype=torch.int32, device=device), 0, _AMAX_Q, True]
-        return
-    pool = _amax_pools.get(key)
-    if pool is None or len(pool) > 3:          # (no pool yet, or the private pool of a finished capture)
-        _amax_pools[key] = _amax_new_pool(device)
-        return
-    q = (pool[2] // _AMAX_Q) % 4               # next quarter
-    pool[0][q * _AMAX_Q * AMAX_WORDS:(q + 1) * _AMAX_Q * AMAX_WORDS].zero_()
-    pool[1], pool[2] = q * _AMAX_Q, (q + 1) * _AMAX_Q
+    pool = _amax_new_pool(device, sync=False)
+    _amax_pools[key] = pool
+    if not torch.cuda.is_current_stream_capturing():
+        # side streams read a step's words too: the block goes back to the allocator no earlier than four forwards later, long
+        # after every stream of its step has joined the main one
+        recent = _amax_recent.setdefault(key, [])
+        recent.append(pool[0])
+        del recent[:-4]
 
 
 def amax_slot(device) -> torch.Tensor:
     key = torch.device(device).index
     pool = _amax_pools.get(key)
-    if pool is None or (len(pool) > 3 and not torch.cuda.is_current_stream_capturing()):
-        pool = _amax_new_pool(device)
-        _amax_pools[key] = pool
-    if pool[1] >= pool[2]:
-        # the quarter is used up (op-level tests that never call amax_begin_step, or a step with > 2048 GEMM operands): take a
-        # fresh pool — the old one stays alive through the slots that reference it
-        if len(pool) > 3:
-            pool = [torch.zeros(_AMAX_Q * AMAX_WORDS, dtype=torch.int32, device=device), 0, _AMAX_Q, True]
-        else:
-            pool = _amax_new_pool(device)
+    if pool is None or pool[1] >= pool[2]:
+        # no step has begun (op-level tests) or the pool is used up (> 2048 GEMM operands in one step): take another one — the
+        # old one stays alive through the slots that reference it
+        pool = _amax_new_pool(device, sync=True)
         _amax_pools[key] = pool
     t = pool[0][pool[1] * AMAX_WORDS:(pool[1] + 1) * AMAX_WORDS]
     pool[1] += 1
@@ -824,7 +818,18 @@ def fusion_bwd(dy, coord2d, flang, dweight, e):
     return d_img
 
 
+def _ids(ids: torch.Tensor, name: str) -> torch.Tensor:
+    """Token ids as the kernels read them: contiguous int64 on the device.  The reference's `(ids != 0).sum(1)` and nn.Embedding
+    take int32 ids as well (DCNet_model.py:150,168), so integer dtypes are widened; anything else raises."""
+    if not ids.is_cuda:
+        raise ValueError(f"{name}: token ids must be a CUDA tensor (no CPU path), got {ids.device}")
+    if ids.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
+        raise ValueError(f"{name}: token ids must be an integer tensor, got {ids.dtype}")
+    return ids.to(torch.int64).contiguous()
+
+
 def row_lengths(ids):
+    ids = _ids(ids, "row_lengths")
     n, L = ids.shape
     out = torch.empty(n, dtype=torch.int64, device=ids.device)
     lib().row_lengths(ids.data_ptr(), n, L, out.data_ptr(), _s())
@@ -832,6 +837,9 @@ def row_lengths(ids):
 
 
 def embedding_fwd(ids, table):
+    ids = _ids(ids, "embedding_fwd"); _chk(table, "embedding_fwd table")
+    if ids.device != table.device:
+        raise ValueError("embedding_fwd: ids and table on different devices")
     v, e = table.shape
     out = torch.empty(tuple(ids.shape) + (e,), dtype=torch.float32, device=table.device)
     lib().embedding_fwd(ids.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), e, v, _s())
@@ -839,6 +847,9 @@ def embedding_fwd(ids, table):
 
 
 def embedding_bwd(ids, dout, vocab):
+    ids = _ids(ids, "embedding_bwd"); _chk(dout, "embedding_bwd dout")
+    if ids.device != dout.device or dout.numel() != ids.numel() * dout.shape[-1]:
+        raise ValueError("embedding_bwd: dout must be (ids.shape, e) on the ids' device")
     e = dout.shape[-1]
     dt = torch.empty((vocab, e), dtype=torch.float32, device=dout.device)
     lib().embedding_bwd(ids.data_ptr(), dout.data_ptr(), dt.data_ptr(), ids.numel(), e, vocab, _s())

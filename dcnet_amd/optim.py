@@ -28,18 +28,34 @@ class RMSprop(torch.optim.Optimizer):
         self._lr_dev = {}
         self._stepped = []           # the "step" counters touched by the last step() (bump_steps: replays of a captured step)
 
+    LR_RING = 4
+
     def sync_lr(self, device=None) -> None:
-        """Copy every group's current ``lr`` into its device scalar (async, from page-locked memory)."""
+        """Upload every group's current ``lr`` into its device scalar when it changed (async, from page-locked memory).
+
+        The host may run several replays ahead of the GPU, so one staging word would be overwritten before its copy has
+        run: each group stages through a ring of ``LR_RING`` pinned words, a slot is rewritten only after the event recorded
+        behind its last copy has completed.  The "changed" test compares Python floats (the value last uploaded), not the
+        float32 staging word against a double."""
         for gi, group in enumerate(self.param_groups):
             ent = self._lr_dev.get(gi)
             if ent is None:
                 dev = device if device is not None else next(p.device for p in group["params"] if p.is_cuda)
-                ent = (torch.empty(1, dtype=torch.float32).pin_memory(), torch.empty(1, dtype=torch.float32, device=dev))
+                ent = {"pinned": torch.empty(self.LR_RING, dtype=torch.float32).pin_memory(), "dev": torch.empty(1, dtype=torch.float32, device=dev),
+                       "events": [None] * self.LR_RING, "next": 0, "last": None}
                 self._lr_dev[gi] = ent
-            if float(ent[0][0]) != float(group["lr"]) or not getattr(self, "_lr_uploaded", False):
-                ent[0][0] = float(group["lr"])
-                ent[1].copy_(ent[0], non_blocking=True)
-        self._lr_uploaded = True
+            lr = float(group["lr"])
+            if ent["last"] is not None and ent["last"] == lr:
+                continue
+            i = ent["next"]
+            if ent["events"][i] is not None:
+                ent["events"][i].synchronize()          # the copy that last read this slot has run
+            ent["pinned"][i] = lr
+            ent["dev"].copy_(ent["pinned"][i:i + 1], non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(ent["dev"].device))
+            ent["events"][i] = ev
+            ent["next"] = (i + 1) % self.LR_RING
+            ent["last"] = lr
 
     def bump_steps(self) -> None:
         """Advance the per-parameter ``step`` counters once more (a replay of a captured step ran the device update)."""
@@ -79,7 +95,7 @@ class RMSprop(torch.optim.Optimizer):
                 continue
             n = len(ps)
             A = ctypes.c_void_p * n
-            lr_dev = self._lr_dev[gi][1].data_ptr() if self.device_lr else 0
+            lr_dev = self._lr_dev[gi]["dev"].data_ptr() if self.device_lr else 0
             L.rmsprop_step(A(*ps), A(*gs), A(*vs), (ctypes.c_int64 * n)(*ns), n, float(group["lr"]), lr_dev, float(group["alpha"]),
                            float(group["eps"]), float(group["weight_decay"]), torch.cuda.current_stream().cuda_stream)
         return loss

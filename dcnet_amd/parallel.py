@@ -61,13 +61,20 @@ class FlatGradAllReduce:
     (start each step with ``zero()`` instead of ``zero_grad(set_to_none=True)``), the all-reduce runs on the buffer in place and
     the optimiser reads the views — no per-parameter copies (unbound, a step costs ~600 small copy launches).  This is the form
     the graph-replayed data-parallel step uses (dcnet_amd.graph.GraphedTrainStep: the zeroing and the accumulation are part of
-    the captured graph, the collective follows the replay)."""
+    the captured graph, the collective follows the replay).
+
+    A bound parameter ALWAYS has a gradient (zeros when the step produced none), so the optimiser updates it every step —
+    weight decay, the running square average, the step counter — where the reference skips a parameter whose ``.grad`` is
+    None.  Bind only parameters that receive a gradient every step: run ``freeze_gradless(model)`` first (the dead YOLO
+    heads and ``feature_map``); ``check_all_received()`` after a warm-up step verifies it."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self._flat = None
         self.bound = False
+        self.always_collective = False   # tests: issue the all-reduce on a one-rank group as well (RCCL behind a graph replay)
+        self.collectives = 0             # all-reduces issued so far
 
     def bind(self) -> "FlatGradAllReduce":
         n = sum(p.numel() for p in self.params)
@@ -80,6 +87,18 @@ class FlatGradAllReduce:
         self.bound = True
         return self
 
+    def check_all_received(self, names=None) -> None:
+        """After a backward: every bound parameter must have received a gradient (an all-zero view means autograd never
+        wrote it — such a parameter would still be decayed by the optimiser, unlike in the reference).  One synchronisation."""
+        if not self.bound:
+            return
+        norms = torch.stack(torch._foreach_norm([p.grad for p in self.params], float("inf"))).cpu()
+        dead = [i for i, v in enumerate(norms.tolist()) if v == 0.0]
+        if dead:
+            label = [(names[i] if names else f"#{i} {tuple(self.params[i].shape)}") for i in dead[:8]]
+            raise RuntimeError(f"FlatGradAllReduce: {len(dead)} bound parameter(s) received no gradient ({', '.join(label)}); "
+                               "freeze them first (parallel.freeze_gradless) — a bound parameter is updated every step")
+
     def zero(self) -> None:
         """Bound form: zero every gradient with one memset (the views stay attached)."""
         if not self.bound:
@@ -89,9 +108,11 @@ class FlatGradAllReduce:
     def __call__(self) -> None:
         world = dist.get_world_size(self.group)
         if self.bound:
-            if world > 1:
+            if world > 1 or self.always_collective:
                 dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-                self._flat.div_(world)
+                self.collectives += 1
+                if world > 1:
+                    self._flat.div_(world)
             return
         if world == 1:
             return

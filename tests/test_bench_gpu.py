@@ -34,8 +34,10 @@ def test_single_gpu_line_is_compact_and_complete():
     assert res["n_gpus"] == 1 and res["steps"] == 2 and res["dtype"] == "f32" and res["vs_baseline"] is None
     assert "workload" in res["config"] and "hipGraph" in res["config"]["step"]
     rf = res["roofline"]
-    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step", "binding_frac"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step", "binding_frac",
+              "conv_engine_frac", "hbm_scoring_frac", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz"):
         assert k in rf, k
+    assert rf["sclk_mhz"] is None or 300 <= rf["sclk_mhz"] <= 3000
     assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = res["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["gpu_vs_oracle_max_abs_err"] < 1e-3
@@ -51,3 +53,19 @@ def test_gpus_2_self_launch_rehearsal():
     assert res["config"]["reducer"] == "flat" and res["scaling"] == "weak"
     assert abs(res["value"] - 2 * 1 * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-9   # whole-job clips / s
     assert "spawning 2 ranks" in err
+
+
+def test_one_rank_rccl_group_behind_the_graph_replay():
+    """RCCL insurance on one GPU: a one-rank **nccl** process group with the collective forced — the flat all-reduce issued right
+    behind a graph replay (the data-parallel default), then the overlapped reducer's buckets on its communication stream.  Both
+    must leave the loss of step 3 bitwise where the run without any process group puts it (a sum over one rank is the identity)."""
+    common = ["--steps", "3", "--warmup", "1", "--clips", "1", "--frames", "2", "--size", "256", "--no-cpu-baseline", "--alt-steps", "0",
+              "--profile-steps", "0"]
+    base, _ = _run(common)
+    flat, err = _run(common + ["--force-ddp", "--reducer", "flat", "--graph", "on"])
+    assert flat["config"]["ranks_seen"] == 1 and flat["config"]["reducer"] == "flat" and "hipGraph" in flat["config"]["step"]
+    assert flat["config"]["collectives"] >= 3 + 1 + 3, flat["config"]        # timed + warm-up + the three clock-read steps
+    assert flat["loss_hex"] == base["loss_hex"], (flat["loss"], base["loss"])
+    over, _ = _run(common + ["--force-ddp", "--reducer", "overlap"])
+    assert over["config"]["ranks_seen"] == 1 and over["config"]["reducer"] == "overlap" and over["config"]["collectives"] >= 2
+    assert over["loss_hex"] == base["loss_hex"], (over["loss"], base["loss"])

@@ -266,3 +266,47 @@ def test_oracle_decode_matches_the_reference_fixture():
         iou = O.bbox_iou_xyxy(boxes, torch.from_numpy(g[f"gt_bbox_{tag}"]))
         assert torch.allclose(iou, torch.from_numpy(g[f"iou_{tag}"]), atol=1e-6)
         assert abs(float((iou > 0.5).float().mean()) - float(g[f"accu_{tag}"])) < 1e-6
+
+
+def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
+    """bench.compact_line on a canned result of the benchmark geometry (the strings and digit counts of a real driver run):
+    the line stays under 2 KB AND carries, inside `roofline`, what north_star asks for — the dominant kernel alone and in the
+    step, the conv engine against 838.9, the cross-modal scoring against 8 TB/s, the exact-arithmetic alternatives, the clock."""
+    import json
+    import bench
+    res = {"metric": "clips/sec (T=8, 416x416, bs8) fwd+bwd", "value": 80.7918522545519, "unit": "clips/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+           "ms_per_step": 99.01988600031473, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "T=8 416x416 bs8/GPU L=20 fp32, 64 img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
+                      "arith": "f16x2-split MFMA, fp32 accumulate", "parallelism": "dp1", "ranks_seen": 1, "reducer": "none",
+                      "step": "hipGraph replay (fwd+losses+bwd+RMSprop)"},
+           "host_queue_ms_per_step": 89.53, "mem_gb": 30.1, "loss": 123.4567, "host_ms_per_step": {"launch": 5.01, "sampler_wait": 84.42},
+           "roofline": {"bound": "mfma", "kernel": bench.FAMILY[28], "rocprof_match": bench.RP_MATCH[28], "achieved": 334.0, "peak": 838.9,
+                        "unit": "TFLOP/s", "frac": 0.3982, "traffic": 389711014.40000004, "traffic_ratio": 1.933, "avg_launch_ms": 0.382,
+                        "ms_per_step": 22.92, "launches_per_step": 60.0, "alg_bytes_per_launch": 201624781, "hbm_frac_algorithmic": 0.066,
+                        "binding_frac": 0.3982, "in_step": {"avg_launch_ms": 0.4176, "frac": 0.3642}},
+           "flop_dominant": {"kernel": bench.FAMILY[28], "frac": 0.3982, "ms_per_step": 22.92, "binding_frac": 0.3982},
+           "hbm_scoring": {"kernel": bench.NAMES[8], "achieved": 5188.3, "peak": 8000.0, "unit": "GB/s", "frac": 0.6485},
+           "conv_engine": {"tflop_per_step": 18.87, "tflops_over_kernel_time": 258.9, "frac_of_838.9": 0.3086, "frac_of_fp32_mfma_157.3": 1.646,
+                           "tflops_over_step_wall": 190.6},
+           "bn_passes_ms_per_step": 13.71,
+           "alt": {"exclusive_ms": 112.0, "bf16x3_ms": 152.6, "native_fp32_ms": 221.8, "bf16_ms": 102.7, "fp8_ms": 109.1},
+           "cpu_baseline": {"value": 0.2383, "unit": "clips/s", "cores": 8, "kind": "port",
+                            "sample": "oracle port fwd+5 losses+bwd, 1 clip T=8 416x416, median of 3 steps, 128 cpus on host",
+                            "gpu_vs_oracle_max_abs_err": 0.00019, "acc_at_0.5_vs_oracle_boxes": 1.0},
+           "full": "profiles/bench_full_latest.json", "sclk_mhz": 2104}
+    line = bench.compact_line(res)
+    assert len(line) < 2000, len(line)
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "host_ms_per_step"):
+        assert k in out, k
+    rf = out["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "in_step_frac", "in_step_ms", "conv_engine_frac",
+              "hbm_scoring_frac", "hbm_scoring_gbs", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz", "rocprof_match"):
+        assert k in rf, k
+    assert rf["in_step_frac"] == 0.3642 and rf["hbm_scoring_frac"] == 0.6485 and rf["conv_engine_frac"] == 0.3086 and rf["sclk_mhz"] == 2104
+    assert all(len(v) <= 120 for v in (out["config"]["workload"], rf["kernel"], rf["note"], out["cpu_baseline"]["sample"]))   # the driver cuts strings
+    # an absurdly long line sheds bookkeeping keys, never the contract or the north_star numbers
+    res["config"]["workload"] = "x" * 700
+    out = json.loads(bench.compact_line(res))
+    assert "rocprof_match" not in out["roofline"] and out["roofline"]["hbm_scoring_frac"] == 0.6485 and "cpu_baseline" in out
