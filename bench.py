@@ -400,6 +400,7 @@ def main():
     barrier()
     if use_graph and step is not eager_step:
         step.host_launch_s = step.host_sampler_s = 0.0
+    model.sampler_busy_s = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
@@ -443,7 +444,14 @@ def main():
             else:
                 tm = 0.0; th = rw[i] / (PEAK_HBM_GBS * 1e9) * 1e3
             bound[t_] += max(tm, th); hbm_bound[t_] += th
-        return dict(c=list(c), ms=list(m), work=list(w), bytes=list(by), bound=bound, hbm=hbm_bound)
+        # per (kernel, launch shape): launches that share tag, FLOP and bytes are one layer form — where inside a family the time goes
+        shapes = {}
+        for i in range(max(n, 0)):
+            t_ = tg[i]
+            if 0 <= t_ < NT and t_ in FLOP_TAGS:
+                e_ = shapes.setdefault((t_, round(rw[i]), round(rb[i])), [0, 0.0])
+                e_[0] += 1; e_[1] += rm[i]
+        return dict(c=list(c), ms=list(m), work=list(w), bytes=list(by), bound=bound, hbm=hbm_bound, shapes=shapes)
 
     def run_pass(nsteps, precision=4, side_streams=True):
         was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream)
@@ -555,8 +563,11 @@ def main():
         if step is not eager_step:
             # what the host does per replayed step: launching (graph + optimiser-side calls) vs waiting for the native sampler thread
             # (the reference's O(N^2 HW) random.sample loop, serial by construction; it runs under the previous replay)
+            # sampler_thread = what the draws cost their worker thread; gpu_wait = the host held back by the GPU (a staging set is
+            # rewritten only after its upload of two steps ago has run: the host stays <= 2 steps ahead) + joining the worker
             res["host_ms_per_step"] = {"launch": round(step.host_launch_s / args.steps * 1e3, 2),
-                                       "sampler_wait": round(step.host_sampler_s / args.steps * 1e3, 2)}
+                                       "sampler_thread": round(model.sampler_busy_s / args.steps * 1e3, 2),
+                                       "gpu_wait": round(step.host_sampler_s / args.steps * 1e3, 2)}
         full = {"bench_line": None, "timed": {"ms_per_step": res["ms_per_step"], "step": graph_note}}
         if sched:
             full["schedules_ms_per_step"] = sched
@@ -617,7 +628,14 @@ def main():
                                   "tflops_over_step_wall": round(mfma_work / prof["steps"] / 1e12 / (dt / args.steps), 1)}
             bn = sum(prof["ms"][t] for t in (10, 11, 22)) / prof["steps"]
             res["bn_passes_ms_per_step"] = round(bn, 2)
-            full["profiled_pass_kernels_alone"] = {"ms_per_step": prof["ms_per_step"], "kernels": table(prof)}
+            per_shape = []
+            for (t_, wk_, by_), (cnt_, ms_) in prof["shapes"].items():
+                tm_ = wk_ / (PEAK_OF[t_] * 1e12) * 1e3; th_ = by_ / (PEAK_HBM_GBS * 1e9) * 1e3
+                per_shape.append({"kernel": NAMES[t_][:28], "gflop": round(wk_ / 1e9, 2), "mb": round(by_ / 1e6, 1), "launches_per_step": cnt_ / prof["steps"],
+                                  "avg_ms": round(ms_ / cnt_, 4), "ms_per_step": round(ms_ / prof["steps"], 3),
+                                  "mfma_frac": round(tm_ / (ms_ / cnt_), 3), "hbm_frac": round(th_ / (ms_ / cnt_), 3)})
+            per_shape.sort(key=lambda e_: -e_["ms_per_step"])
+            full["profiled_pass_kernels_alone"] = {"ms_per_step": prof["ms_per_step"], "kernels": table(prof), "per_shape": per_shape}
         if alts:
             res["alt"] = {"exclusive_ms": round(prof["ms_per_step"], 1) if prof else None, "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
                           "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1),

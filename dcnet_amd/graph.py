@@ -53,6 +53,8 @@ class GraphedTrainStep:
         self.replays = 0
         self.host_launch_s = 0.0         # host time spent launching (graph replay, reducer, optimiser step, learning-rate upload)
         self.host_sampler_s = 0.0        # host time spent waiting for / uploading the draws of the sampling heads (worker thread)
+        if reducer is not None and hasattr(reducer, "check_bound_set"):
+            reducer.check_bound_set(self.core)       # a bound flat buffer must not hold parameters autograd never writes
         if hasattr(optimizer, "device_lr"):
             optimizer.device_lr = True
             optimizer.sync_lr(dev)
@@ -66,11 +68,6 @@ class GraphedTrainStep:
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
-        if reducer is not None and hasattr(reducer, "check_all_received"):
-            # a bound flat buffer gives EVERY parameter a gradient: one that autograd never writes would be decayed by the optimiser
-            # where the reference skips it (parallel.freeze_gradless must have run)
-            ids = {id(p): n for n, p in self.core.named_parameters()}
-            reducer.check_all_received([ids.get(id(p), "?") for p in reducer.params])
         self._zero_grads()
         self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
         torch.cuda.synchronize(dev)

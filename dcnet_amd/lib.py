@@ -127,10 +127,12 @@ SIGNATURES = {
     "dcn_prof_records": (I, [P, P, P, P, I]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
+    "dcn_post_topk": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "dcn_post_fusion": (I, [P, P, P, P, I, I, I, I, P, P, P]),
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
                 "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
-ABI_VERSION = 304        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+ABI_VERSION = 305        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

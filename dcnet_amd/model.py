@@ -20,6 +20,7 @@ from __future__ import annotations
 import os
 import random
 import threading
+import time
 from collections import OrderedDict
 from typing import List, Optional
 
@@ -213,6 +214,7 @@ class grounding_model(nn.Module):
                                        nn.Conv2d(emb_size // 2, 3 * 5, kernel_size=1))) for i in range(3)]))
         self._coord_cache = {}
         self._pinned = {}
+        self.sampler_busy_s = 0.0  # seconds the sampling worker threads spent drawing (accumulated)
         self._spec = None          # draws made ahead for the next training forward (_presample_take)
         # device tensors (sample_buffers) that already hold this forward's draws (draw_samples): the forward then neither
         # draws nor uploads — a captured training step reads its draws from these static buffers
@@ -374,6 +376,7 @@ class grounding_model(nn.Module):
         box = {"err": None, "shape": (n, top_k, hw, neg_n, neg_c), "pin": pin, "which": which, "g0": g0}
 
         def work():
+            t_ = time.perf_counter()
             try:
                 L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
                 L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
@@ -382,6 +385,7 @@ class grounding_model(nn.Module):
                 L.mt_sample_crossmodal_csr(k14.data_ptr(), n, hw, neg_c, csr_off.data_ptr(), csr_src.data_ptr())
             except BaseException as e:       # re-raised on the caller's thread by _presample_join
                 box["err"] = e
+            box["busy_s"] = time.perf_counter() - t_
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
@@ -422,6 +426,7 @@ class grounding_model(nn.Module):
         th.join()
         if box["err"] is not None:
             raise box["err"]
+        self.sampler_busy_s += box.get("busy_s", 0.0)      # what the native draws cost the worker thread (not the wait for the GPU)
         if random.getstate() != st:
             # someone drew from the global stream while the worker was running (another thread: forward itself draws
             # nothing else).  The worker started from a stale state: redo the draws from the current one, synchronously.

@@ -1139,6 +1139,51 @@ def decode_boxes(outbox, anchors, size, want_cells=False):
     return (boxes, cells) if want_cells else boxes
 
 
+def post_topk(outbox, corr_feat, anchors, size, topk, ratio, dw, dh, frame_hw):
+    """csrc/post.hip: outbox[s] (B,15,g,g) contiguous fp32, corr_feat[s] (B,E,g,g) fp32 with any strides, ratio/dw/dh (B,) fp32,
+    frame_hw (B,2) int64.  Returns boxes (B,k,4), scores (B,k), feats (B,k,E), cells (B,k,4) int64."""
+    B = outbox[0].shape[0]
+    dev = outbox[0].device
+    E = corr_feat[0].shape[1]
+    for t in outbox:
+        _chk(t, "post_topk outbox")
+    for t in corr_feat:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.shape[0] == B and t.shape[1] == E):
+            raise ValueError("post_topk: corr_feat[s] must be an fp32 CUDA tensor (B,E,g,g)")
+    for t, nm in ((ratio, "ratio"), (dw, "dw"), (dh, "dh")):
+        _chk(t, "post_topk " + nm)
+        if t.numel() != B:
+            raise ValueError(f"post_topk: {nm} must have one entry per clip")
+    if not (frame_hw.is_cuda and frame_hw.dtype == torch.int64 and frame_hw.is_contiguous() and tuple(frame_hw.shape) == (B, 2)):
+        raise ValueError("post_topk: frame_hw must be a contiguous int64 CUDA tensor (B,2)")
+    grids = [int(o.shape[-1]) for o in outbox]
+    strides = (_ct.c_int64 * 12)(*[int(v) for t in corr_feat for v in t.stride()])
+    boxes = torch.empty((B, topk, 4), dtype=torch.float32, device=dev); scores = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    feats = torch.empty((B, topk, E), dtype=torch.float32, device=dev); cells = torch.empty((B, topk, 4), dtype=torch.int64, device=dev)
+    lib().post_topk(_ptrs(outbox), _ptrs(corr_feat), strides, _ints(grids), anchors.data_ptr(), size, B, E, topk, ratio.data_ptr(),
+                    dw.data_ptr(), dh.data_ptr(), frame_hw.data_ptr(), boxes.data_ptr(), scores.data_ptr(), feats.data_ptr(),
+                    cells.data_ptr(), _s())
+    return boxes, scores, feats, cells
+
+
+def post_fusion(center, ref, ref_score, valid=None):
+    """csrc/post.hip: center (B,k,E), ref (B,R,k,E), ref_score (B,R,k) fp32 contiguous; valid (B,R) bool/uint8 or None.
+    Returns (best (B,) int64, fused (B,k))."""
+    _chk(center, "post_fusion center"); _chk(ref, "post_fusion ref"); _chk(ref_score, "post_fusion ref_score")
+    B, k, E = center.shape
+    R = ref.shape[1]
+    if tuple(ref.shape) != (B, R, k, E) or tuple(ref_score.shape) != (B, R, k):
+        raise ValueError("post_fusion: shapes must be center (B,k,E), ref (B,R,k,E), ref_score (B,R,k)")
+    v = None
+    if valid is not None:
+        if not valid.is_cuda or tuple(valid.shape) != (B, R):
+            raise ValueError("post_fusion: valid must be a CUDA tensor (B,R)")
+        v = valid.to(torch.uint8).contiguous()
+    fused = torch.empty((B, k), dtype=torch.float32, device=center.device); best = torch.empty(B, dtype=torch.int64, device=center.device)
+    lib().post_fusion(center.data_ptr(), ref.data_ptr(), ref_score.data_ptr(), _p(v), B, k, R, E, fused.data_ptr(), best.data_ptr(), _s())
+    return best, fused
+
+
 def box_iou(b1, b2):
     _chk(b1, "box_iou"); _chk(b2, "box_iou")
     iou = torch.empty(b1.shape[0], dtype=torch.float32, device=b1.device)

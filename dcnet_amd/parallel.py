@@ -66,7 +66,7 @@ class FlatGradAllReduce:
     A bound parameter ALWAYS has a gradient (zeros when the step produced none), so the optimiser updates it every step —
     weight decay, the running square average, the step counter — where the reference skips a parameter whose ``.grad`` is
     None.  Bind only parameters that receive a gradient every step: run ``freeze_gradless(model)`` first (the dead YOLO
-    heads and ``feature_map``); ``check_all_received()`` after a warm-up step verifies it."""
+    heads and ``feature_map``); ``check_bound_set(model)`` verifies it (GraphedTrainStep calls it)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -87,17 +87,19 @@ class FlatGradAllReduce:
         self.bound = True
         return self
 
-    def check_all_received(self, names=None) -> None:
-        """After a backward: every bound parameter must have received a gradient (an all-zero view means autograd never
-        wrote it — such a parameter would still be decayed by the optimiser, unlike in the reference).  One synchronisation."""
+    def check_bound_set(self, model) -> None:
+        """No parameter that can never receive a gradient (``gradless_parameter_names``: the dead YOLO heads, ``feature_map``) may
+        be bound: autograd never writes it, yet its zero view would be decayed by the optimiser every step — the reference skips
+        it (``.grad is None``).  (A value test cannot tell: ``loc_text_embedding.0.bias`` sits in front of a BatchNorm and gets
+        a gradient of exact zeros from autograd, in the reference too.)"""
         if not self.bound:
             return
-        norms = torch.stack(torch._foreach_norm([p.grad for p in self.params], float("inf"))).cpu()
-        dead = [i for i, v in enumerate(norms.tolist()) if v == 0.0]
-        if dead:
-            label = [(names[i] if names else f"#{i} {tuple(self.params[i].shape)}") for i in dead[:8]]
-            raise RuntimeError(f"FlatGradAllReduce: {len(dead)} bound parameter(s) received no gradient ({', '.join(label)}); "
-                               "freeze them first (parallel.freeze_gradless) — a bound parameter is updated every step")
+        mine = {id(p) for p in self.params}
+        table = dict(model.named_parameters())
+        bad = [n for n in gradless_parameter_names(model) if id(table[n]) in mine]
+        if bad:
+            raise RuntimeError(f"FlatGradAllReduce: {len(bad)} bound parameter(s) never receive a gradient ({', '.join(bad[:6])}, ...); "
+                               "run parallel.freeze_gradless(model) before bind() — a bound parameter is updated every step")
 
     def zero(self) -> None:
         """Bound form: zero every gradient with one memset (the views stay attached)."""

@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 304
+#define DCN_ABI_VERSION 305
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -437,6 +437,24 @@ int dcn_contrastive_bwd(const float* q, const float* pos, const float* neg, int6
 int dcn_decode_boxes(const float* const* outbox, const float* anchors, int size, int n, float* boxes, int* cellinfo, void* stream);
 /* utils/utils.py:76-104 (x1y1x2y2) row by row. */
 int dcn_box_iou(const float* box1, const float* box2, int n, float* iou, void* stream);
+
+/* ---- top-k candidate cache + temporal post-processing of the inference path (ABI 305) ----------------------------- */
+/* test_DCNet.py:587-643,662-705 (save_cache / get_topk_pred_bbox): per clip b of n, the top_k (<= 64) largest modulated
+ * confidences over 3 scales x 3 anchors x g x g of outbox[s] [n][15][g][g] (contiguous; grids[s] = size / (32 >> s)), sorted
+ * by value (equal values: lowest flat index first, the reference's "first exact match" :684); boxes [n][top_k][4] = the cell's
+ * box (sigmoid / exp decode with anchors [3][3][2] as for dcn_decode_boxes, :670-681) un-letterboxed with ratio / dw / dh [n]
+ * and clamped to [0, frame_hw[b] = (height, width)] (:615-633); scores [n][top_k]; feats [n][top_k][e] = the correspondence
+ * feature of the winning cell, read from feat[s] through feat_strides[s][4] = (batch, channel, row, column) strides in floats
+ * (the model hands out NHWC memory as a logical NCHW view); cells [n][top_k][4] = (scale, anchor, gj, gi).  Radix select,
+ * no sort, no host synchronisation. */
+int dcn_post_topk(const float* const* outbox, const float* const* feat, const int64_t* feat_strides, const int* grids,
+                  const float* anchors, int size, int n, int e, int top_k, const float* ratio, const float* dw, const float* dh,
+                  const int64_t* frame_hw, float* boxes, float* scores, float* feats, int64_t* cells, void* stream);
+/* post_processing.py:246-278 for n windows at once: center [n][k][e], ref [n][r][k][e] (every frame of the window, centre
+ * included), ref_score [n][r][k], valid [n][r] bytes or NULL (0 = neighbour missing: its weight is zeroed AFTER the softmax,
+ * :266-269).  fused [n][k] = sum_r softmax_r(max_i <c, ref_r,i>) * ref_score[r][argmax_i], best [n] = first arg-max of fused. */
+int dcn_post_fusion(const float* center, const float* ref, const float* ref_score, const unsigned char* valid, int n, int k, int r,
+                    int e, float* fused, int64_t* best, void* stream);
 
 /* ---- location module core (rank-8 form of model/DCNet_model.py:581-594) ------------------------- */
 /* loc[n,i] = < normalize_c( relu( E[i,:8] . Mp[n,:8,:c] + bp[:c] ) ), q[n,:c] >   for i < p, c == 512.

@@ -279,7 +279,7 @@ def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
            "config": {"workload": "T=8 416x416 bs8/GPU L=20 fp32, 64 img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
                       "arith": "f16x2-split MFMA, fp32 accumulate", "parallelism": "dp1", "ranks_seen": 1, "reducer": "none",
                       "step": "hipGraph replay (fwd+losses+bwd+RMSprop)"},
-           "host_queue_ms_per_step": 89.53, "mem_gb": 30.1, "loss": 123.4567, "host_ms_per_step": {"launch": 5.01, "sampler_wait": 84.42},
+           "host_queue_ms_per_step": 89.53, "mem_gb": 30.1, "loss": 123.4567, "host_ms_per_step": {"launch": 5.01, "sampler_thread": 18.2, "gpu_wait": 84.42},
            "roofline": {"bound": "mfma", "kernel": bench.FAMILY[28], "rocprof_match": bench.RP_MATCH[28], "achieved": 334.0, "peak": 838.9,
                         "unit": "TFLOP/s", "frac": 0.3982, "traffic": 389711014.40000004, "traffic_ratio": 1.933, "avg_launch_ms": 0.382,
                         "ms_per_step": 22.92, "launches_per_step": 60.0, "alg_bytes_per_launch": 201624781, "hbm_frac_algorithmic": 0.066,
