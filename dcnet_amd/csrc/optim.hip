@@ -10,7 +10,10 @@ struct RmsChunk {
   float* p[RMS_CHUNK]; const float* g[RMS_CHUNK]; float* v[RMS_CHUNK]; long long n[RMS_CHUNK];
 };
 
+// (no FMA contraction: the 16-byte path and the scalar path of a misaligned tensor — a view into a flat gradient buffer — must
+//  round alike, or a data-parallel run with bound gradients drifts away from the single-GPU run by an ulp per step)
 __device__ __forceinline__ void rms_update(float& p, const float g0, float& v, float lr, float alpha, float eps, float wd) {
+#pragma clang fp contract(off)
   const float g = wd != 0.f ? g0 + wd * p : g0;          // grad = grad.add(param, alpha=weight_decay)
   v = v * alpha + (1.f - alpha) * g * g;                 // square_avg.mul_(alpha).addcmul_(grad, grad, value=1-alpha)
   p = p - lr * (g / (sqrtf(v) + eps));                   // param.addcdiv_(grad, square_avg.sqrt().add_(eps), value=-lr)

@@ -76,14 +76,17 @@ class FlatGradAllReduce:
         self.always_collective = False   # tests: issue the all-reduce on a one-rank group as well (RCCL behind a graph replay)
         self.collectives = 0             # all-reduces issued so far
 
+    ALIGN = 64           # floats: every view starts on a 256-byte boundary (16-byte vector paths of the kernels that read it)
+
     def bind(self) -> "FlatGradAllReduce":
-        n = sum(p.numel() for p in self.params)
+        pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        n = sum(pad(p.numel()) for p in self.params)
         p0 = self.params[0]
         self._flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         off = 0
         for p in self.params:
             p.grad = self._flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+            off += pad(p.numel())
         self.bound = True
         return self
 
