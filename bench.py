@@ -64,10 +64,13 @@ NAMES = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,
          37: "dgrad2_kernel (stride-2 data gradients 64 -> 32 / 128 -> 64 channels, filter bank in registers, f16 split)",
          38: "nconv1_kernel (3x3 layers between 32 and 64 channels, filter bank in registers, f16 split)",
          39: "stem_wgrad_bn_kernel (stem weight gradient + BatchNorm backward, fp32 MFMA)",
-         40: "gemm3_kernel (co-attention products on pre-split operands, f16 split)"}
-FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40}
+         40: "gemm3_kernel (co-attention products on pre-split operands, f16 split)",
+         41: "conv1b_kernel (bf16 storage: forward / data gradient, both tiles by LDS-DMA)",
+         42: "wgrad_kernel<128,128,16,true,0,1,true> (bf16 storage)", 43: "scale_act16_kernel (bf16 storage)",
+         44: "partials16_kernel (bf16 storage)", 45: "bn_bwd_apply16_kernel (bf16 storage)"}
+FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40, 41, 42}
 PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38, 40)
-               else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
+               else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33, 41, 42) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
 RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2>"],
@@ -115,7 +118,7 @@ def compact_line(res: dict) -> str:
         rf["flop_dominant"] = fd["kernel"][:40]; rf["flop_dominant_frac"] = fd["frac"]
     alt = out.pop("alt", None)
     if alt:
-        for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms"):
+        for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "bf16s_ms", "fp8_ms"):
             rf[k] = alt.get(k)
         rf["alone_ms"] = alt.get("exclusive_ms")
     if "sclk_mhz" in out:
@@ -453,11 +456,11 @@ def main():
                 e_[0] += 1; e_[1] += rm[i]
         return dict(c=list(c), ms=list(m), work=list(w), bytes=list(by), bound=bound, hbm=hbm_bound, shapes=shapes)
 
-    def run_pass(nsteps, precision=4, side_streams=True):
+    def run_pass(nsteps, precision="fp32", side_streams=True):
         was = (ops.WGRAD_SIDE, model.language_stream, model.sampling_stream)
         if not side_streams:
             ops.WGRAD_SIDE = False; model.language_stream = False; model.sampling_stream = False
-        ops.set_precision({v: k for k, v in ops.PRECISIONS.items()}[precision])
+        ops.set_precision(precision)
         eager_step(); barrier()
         L.prof_enable(1)
         t1 = time.perf_counter()
@@ -518,13 +521,14 @@ def main():
     # tools/graph_event_probe.hip).  `rocprofv3 -- python3 bench.py --graph off --no-side-streams` shows the same averages.  The
     # in-step durations of the replayed step (weight gradients beside the data-gradient chain) come from the committed rocprofv3
     # summary of the default command (profiles/in_step_latest.json) and are quoted beside them.
-    prof = run_pass(args.profile_steps, 4, False) if args.profile_steps > 0 else None
+    prof = run_pass(args.profile_steps, "fp32", False) if args.profile_steps > 0 else None
     alts = {}
     if args.alt_steps > 0:
-        alts["fp32_bf16x3"] = run_pass(args.alt_steps, 1, False)
-        alts["native_fp32"] = run_pass(args.alt_steps, 0, False)
-        alts["bf16_operands"] = run_pass(args.alt_steps, 2, False)
-        alts["fp8_operands"] = run_pass(args.alt_steps, 3, False)
+        alts["fp32_bf16x3"] = run_pass(args.alt_steps, "fp32_bf16x3", False)
+        alts["native_fp32"] = run_pass(args.alt_steps, "fp32_mfma", False)
+        alts["bf16_operands"] = run_pass(args.alt_steps, "bf16", False)
+        alts["bf16_storage"] = run_pass(args.alt_steps, "bf16s", False)
+        alts["fp8_operands"] = run_pass(args.alt_steps, "fp8", False)
     if use_dist:
         dist.barrier()                           # every rank got here: only now may rank 0 print the line
 
@@ -638,7 +642,7 @@ def main():
             full["profiled_pass_kernels_alone"] = {"ms_per_step": prof["ms_per_step"], "kernels": table(prof), "per_shape": per_shape}
         if alts:
             res["alt"] = {"exclusive_ms": round(prof["ms_per_step"], 1) if prof else None, "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
-                          "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1),
+                          "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1), "bf16s_ms": round(alts["bf16_storage"]["ms_per_step"], 1),
                           "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1)}
             for k_, r_ in alts.items():
                 full[k_] = {"ms_per_step": r_["ms_per_step"], "kernels": table(r_)}

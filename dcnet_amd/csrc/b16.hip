@@ -1,0 +1,318 @@
+// bf16 storage (BASELINE.json configs[2]): the streaming passes around the bf16 convolutions — BatchNorm apply / backward, the
+// route concat, casts at the boundary to fp32 consumers — on tensors that ARE bf16 in HBM.
+//
+// Same arithmetic as bn.hip / layout.hip, term by term, in fp32 registers; what changes is the traffic: 2 bytes per element
+// read and written.  A thread handles 8 consecutive channels of a pixel (one 16-byte access on bf16, two on fp32), per-channel
+// parameters (scale / shift, mean / invstd / gamma / beta, the backward sums) stay fp32.  Reference sites: nn.BatchNorm2d +
+// LeakyReLU + shortcut of model/darknet.py:179-191,403-405 and their autograd; MyUpsample2 + route concat (:158-160,400-402).
+// Roofline: HBM — scale_act 4 B/element (6 with a shortcut), backward apply 6 B/element, reduce 4 B/element.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+struct F8 { float v[8]; };
+
+template <typename T> __device__ __forceinline__ F8 ld8(const T* p);
+template <> __device__ __forceinline__ F8 ld8<float>(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return F8{{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}};
+}
+template <> __device__ __forceinline__ F8 ld8<__bf16>(const __bf16* p) {
+  const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p);
+  F8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (float)a[k];
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const F8& x);
+template <> __device__ __forceinline__ void st8<float>(float* p, const F8& x) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{x.v[0], x.v[1], x.v[2], x.v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{x.v[4], x.v[5], x.v[6], x.v[7]};
+}
+template <> __device__ __forceinline__ void st8<__bf16>(__bf16* p, const F8& x) {
+  bf16x8_t a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = (__bf16)x.v[k];               // round to nearest even
+  *reinterpret_cast<bf16x8_t*>(p) = a;
+}
+
+inline int grid_for(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// ---- dst[r][0..c) (+)= src[r][0..c)   (cast / strided copy / accumulate; rows of `c` elements, c % 8 == 0) ---------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, int64_t rows, int c,
+                                                        int accumulate) {
+  const int c8 = c >> 3;
+  const int64_t total = rows * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c8; const int ch = (int)(i - r * c8) * 8;
+    F8 v = ld8<TS>(src + r * lds_ + ch);
+    if (accumulate) {
+      const F8 o = ld8<TD>(dst + r * ldd + ch);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] += o.v[k];
+    }
+    st8<TD>(dst + r * ldd + ch, v);
+  }
+}
+
+// ---- out = act(scale * y + shift) + residual   (y: raw conv output, fp32 for the stem, bf16 elsewhere; out, residual: bf16) ------
+template <typename TY>
+__global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act, float slope,
+                                                          const __bf16* __restrict__ residual, int ldr, __bf16* __restrict__ out,
+                                                          int64_t rows, int c, int ldo) {
+  const int c8 = c >> 3;
+  const int64_t total = rows * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c8; const int ch = (int)(i - r * c8) * 8;
+    F8 v = ld8<TY>(y + r * c + ch);
+    F8 sc, sh;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc.v[k] = 1.f; sh.v[k] = 0.f; }
+    if (scale) sc = ld8<float>(scale + ch);
+    if (shift) sh = ld8<float>(shift + ch);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = v.v[k] * sc.v[k] + sh.v[k];
+      if (act == DCN_ACT_LEAKY) t = t > 0.f ? t : t * slope;
+      v.v[k] = t;
+    }
+    if (residual) {
+      const F8 rr = ld8<__bf16>(residual + r * ldr + ch);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] += rr.v[k];
+    }
+    st8<__bf16>(out + r * ldo + ch, v);
+  }
+}
+
+// ---- dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * act'(bn(y))   (bn.hip bn_act_bwd_apply_kernel) --------
+template <typename TY>
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restrict__ y, const __bf16* __restrict__ dout, int lddo,
+                                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                             int act, float slope, const float* sums, float inv_count, int64_t rows, int c,
+                                                             __bf16* __restrict__ dy) {
+  const int c8 = c >> 3;
+  const int64_t total = rows * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / c8; const int ch = (int)(i - r * c8) * 8;
+    const F8 v = ld8<TY>(y + r * c + ch);
+    const F8 d = ld8<__bf16>(dout + r * lddo + ch);
+    const F8 mu = ld8<float>(mean + ch), is = ld8<float>(invstd + ch);
+    F8 g, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { g.v[k] = 1.f; b.v[k] = 0.f; }
+    if (gamma) g = ld8<float>(gamma + ch);
+    if (beta) b = ld8<float>(beta + ch);
+    const F8 sg = ld8<float>(sums + ch), sgx = ld8<float>(sums + c + ch);
+    F8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (v.v[k] - mu.v[k]) * is.v[k];
+      float dd = d.v[k];
+      if (act == DCN_ACT_LEAKY && (g.v[k] * xh + b.v[k]) <= 0.f) dd *= slope;
+      o.v[k] = g.v[k] * is.v[k] * (dd - sg.v[k] * inv_count - xh * sgx.v[k] * inv_count);
+    }
+    st8<__bf16>(dy + r * c + ch, o);
+  }
+}
+
+// ---- per-channel partial sums of g and g * xhat over 128-row blocks (bn.hip channel_partials_kernel<1>) ----------------------------
+// block (row block, 128 channels): thread = (8 channels, row phase of 16); stats [row blocks][2][c]
+template <typename TY>
+__global__ __launch_bounds__(256) void partials16_kernel(const TY* __restrict__ y, const __bf16* __restrict__ dout, int lddo, const float* mean,
+                                                         const float* invstd, const float* gamma, const float* beta, int act, float slope,
+                                                         int64_t rows, int c, float* __restrict__ stats) {
+  __shared__ float red[2][16][128];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ch = blockIdx.y * 128 + tx * 8;
+  const int64_t r0 = (int64_t)blockIdx.x * 128;
+  F8 s, ss;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s.v[k] = 0.f; ss.v[k] = 0.f; }
+  if (ch < c) {
+    const F8 mu = ld8<float>(mean + ch), is = ld8<float>(invstd + ch);
+    F8 g, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { g.v[k] = 1.f; b.v[k] = 0.f; }
+    if (gamma) g = ld8<float>(gamma + ch);
+    if (beta) b = ld8<float>(beta + ch);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = r0 + ty + 16 * j;
+      if (r >= rows) continue;
+      const F8 v = ld8<TY>(y + r * c + ch);
+      const F8 d = ld8<__bf16>(dout + r * lddo + ch);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v.v[k] - mu.v[k]) * is.v[k];
+        float dd = d.v[k];
+        if (act == DCN_ACT_LEAKY && g.v[k] * xh + b.v[k] <= 0.f) dd *= slope;
+        s.v[k] += dd; ss.v[k] += dd * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { red[0][ty][tx * 8 + k] = s.v[k]; red[1][ty][tx * 8 + k] = ss.v[k]; }
+  __syncthreads();
+  {
+    const int which = threadIdx.x >> 7, t = threadIdx.x & 127, cc = blockIdx.y * 128 + t;
+    if (cc < c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += red[which][k][t];
+      stats[((size_t)blockIdx.x * 2 + which) * c + cc] = acc;
+    }
+  }
+}
+
+// ---- nearest x2 into a channel slice; its backward (sum of the 2 x 2 children) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2_16_kernel(const __bf16* __restrict__ src, int lds_, __bf16* __restrict__ dst, int ldd, int n,
+                                                           int h, int w, int c) {
+  const int c8 = c >> 3;
+  const int64_t total = (int64_t)n * 2 * h * 2 * w * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c8) * 8;
+    int64_t pix = i / c8;
+    const int x = (int)(pix % (2 * w)); pix /= 2 * w;
+    const int yy = (int)(pix % (2 * h)); const int64_t b = pix / (2 * h);
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + ((b * h + (yy >> 1)) * w + (x >> 1)) * lds_ + ch);
+    *reinterpret_cast<bf16x8_t*>(dst + ((b * 2 * h + yy) * 2 * w + x) * ldd + ch) = v;
+  }
+}
+__global__ __launch_bounds__(256) void upsample2_bwd16_kernel(const __bf16* __restrict__ ddst, int ldd, __bf16* __restrict__ dsrc, int lds_,
+                                                              int n, int h, int w, int c, int accumulate) {
+  const int c8 = c >> 3;
+  const int64_t total = (int64_t)n * h * w * c8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c8) * 8;
+    int64_t pix = i / c8;
+    const int x = (int)(pix % w); pix /= w;
+    const int yy = (int)(pix % h); const int64_t b = pix / h;
+    F8 s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s.v[k] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const F8 v = ld8<__bf16>(ddst + ((b * 2 * h + 2 * yy + dy) * 2 * w + 2 * x + dx) * ldd + ch);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s.v[k] += v.v[k];
+      }
+    __bf16* o = dsrc + ((b * h + yy) * w + x) * lds_ + ch;
+    if (accumulate) {
+      const F8 v = ld8<__bf16>(o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s.v[k] += v.v[k];
+    }
+    st8<__bf16>(o, s);
+  }
+}
+
+}  // namespace
+
+// src / dst element types: 0 = fp32, 1 = bf16.  dst[r][:c] (+)= src[r][:c] for `rows` rows with element strides lds / ldd.
+extern "C" int dcn_cast_rows(const void* src, int src_b16, int lds_, void* dst, int dst_b16, int ldd, int64_t rows, int c, int accumulate,
+                             void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (lds_ <= 0) lds_ = c;
+  if (ldd <= 0) ldd = c;
+  DCN_CHECK_ARG(src && dst && rows > 0 && c > 0 && c % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0 && lds_ >= c && ldd >= c,
+                "cast_rows: bad argument (c=%d lds=%d ldd=%d must be multiples of 8)", c, lds_, ldd);
+  DCN_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cast_rows: pointers must be 16-byte aligned");
+  const dim3 g(grid_for(rows * (c / 8)));
+  if (src_b16 && dst_b16)
+    hipLaunchKernelGGL((cast_rows_kernel<__bf16, __bf16>), g, dim3(256), 0, stream, (const __bf16*)src, lds_, (__bf16*)dst, ldd, rows, c, accumulate);
+  else if (src_b16)
+    hipLaunchKernelGGL((cast_rows_kernel<__bf16, float>), g, dim3(256), 0, stream, (const __bf16*)src, lds_, (float*)dst, ldd, rows, c, accumulate);
+  else if (dst_b16)
+    hipLaunchKernelGGL((cast_rows_kernel<float, __bf16>), g, dim3(256), 0, stream, (const float*)src, lds_, (__bf16*)dst, ldd, rows, c, accumulate);
+  else
+    hipLaunchKernelGGL((cast_rows_kernel<float, float>), g, dim3(256), 0, stream, (const float*)src, lds_, (float*)dst, ldd, rows, c, accumulate);
+  DCN_CHECK_LAUNCH("cast_rows");
+  return DCN_OK;
+}
+
+extern "C" int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, const float* shift, int act, float slope, const void* residual,
+                                 int ldr, void* out, int64_t rows, int c, int ldo, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ldo <= 0) ldo = c;
+  if (ldr <= 0) ldr = c;
+  DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0, "scale_act_b16: bad argument (c=%d)", c);
+  const int pid = prof_begin(43, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 2.0 + (residual ? 2.0 : 0.0)), stream);
+  const dim3 g(grid_for(rows * (c / 8)));
+  if (y_f32)
+    hipLaunchKernelGGL((scale_act16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, scale, shift, act, slope, (const __bf16*)residual, ldr,
+                       (__bf16*)out, rows, c, ldo);
+  else
+    hipLaunchKernelGGL((scale_act16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, scale, shift, act, slope, (const __bf16*)residual, ldr,
+                       (__bf16*)out, rows, c, ldo);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("scale_act_b16");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_act_bwd_reduce_rows_b16(int64_t rows) { return cdiv(rows, 128); }
+
+extern "C" int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+                                         const float* gamma, const float* beta, int act, float slope, int64_t rows, int c, float* stats,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (lddo <= 0) lddo = c;
+  DCN_CHECK_ARG(y && dout && mean && invstd && stats && rows > 0 && c > 0 && c % 8 == 0 && lddo % 8 == 0, "bn_act_bwd_reduce_b16: bad argument");
+  const int pid = prof_begin(44, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 2.0), stream);
+  const dim3 g(cdiv(rows, 128), cdiv(c, 128));
+  if (y_f32)
+    hipLaunchKernelGGL((partials16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
+                       act, slope, rows, c, stats);
+  else
+    hipLaunchKernelGGL((partials16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
+                       act, slope, rows, c, stats);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("bn_act_bwd_reduce_b16");
+  return DCN_OK;
+}
+
+extern "C" int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, int act, float slope, const float* sums, int64_t count,
+                                        int64_t rows, int c, void* dy, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (lddo <= 0) lddo = c;
+  DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 8 == 0 && lddo % 8 == 0 && count > 0,
+                "bn_act_bwd_apply_b16: bad argument");
+  const int pid = prof_begin(45, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 4.0), stream);
+  const dim3 g(grid_for(rows * (c / 8)));
+  if (y_f32)
+    hipLaunchKernelGGL((bn_bwd_apply16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
+                       act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, (const __bf16*)dout, lddo, mean, invstd, gamma,
+                       beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("bn_act_bwd_apply_b16");
+  return DCN_OK;
+}
+
+extern "C" int dcn_upsample2_nhwc_b16(const void* src, int lds_, void* dst, int ldd, int n, int h, int w, int c, void* stream) {
+  DCN_CHECK_ARG(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "upsample2_b16: bad argument");
+  hipLaunchKernelGGL(upsample2_16_kernel, dim3(grid_for((int64_t)n * 4 * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)src, lds_, (__bf16*)dst, ldd, n, h, w, c);
+  DCN_CHECK_LAUNCH("upsample2_b16");
+  return DCN_OK;
+}
+
+extern "C" int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc, int lds_, int n, int h, int w, int c, int accumulate,
+                                          void* stream) {
+  DCN_CHECK_ARG(ddst && dsrc && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "upsample2_bwd_b16: bad argument");
+  hipLaunchKernelGGL(upsample2_bwd16_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)ddst, ldd, (__bf16*)dsrc, lds_, n, h, w, c, accumulate);
+  DCN_CHECK_LAUNCH("upsample2_bwd_b16");
+  return DCN_OK;
+}

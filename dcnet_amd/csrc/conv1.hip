@@ -316,6 +316,257 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
   }
 }
 
+// ---- bf16 storage (BASELINE.json configs[2]) ------------------------------------------------------------------------------------
+// The same ring kernel on tensors that ARE bf16 in HBM: activations / raw conv outputs / gradients [pixels][C] bf16, the filter
+// bank [Co][taps*Ci] bf16 (dcn_prepare_filters' b16 / tb16 forms).  A K-step is 32 channels = the same 64 bytes per row, so the
+// LDS-DMA geometry of the activation tile is unchanged and the filter tile takes it over (64-byte rows, chunk XOR swizzle: one
+// plane instead of the h | l pair).  A lane's 16-byte fragment is 8 bf16 = one MFMA operand: no split, no vector ALU in the
+// loop, one v_mfma_f32_32x32x16_bf16 per product instead of three (ceiling 2516.6 TFLOP/s), half the bytes per element.
+// fp32 accumulate; the raw result is rounded to bf16 BEFORE the BatchNorm partial sums, so the statistics are those of the stored
+// tensor.  Serves every forward / data-gradient launch with Ci % 32 == 0 (1x1, 3x3 of either stride, parity classes).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool O32> struct OutT { typedef __bf16 type; };
+template <> struct OutT<true> { typedef float type; };
+
+template <int SA, int SB, int NI, int MI, bool O32>
+__global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
+  typedef typename OutT<O32>::type out_t;
+  constexpr int BM = 128 * MI, BN = 32 * NI;
+  constexpr int ASTAGE = BM * 64, BSTAGE = BN * 64;
+  constexpr int AP = 4 * MI;                      // A pieces (16 rows x 64 B) per loader wave and K-step
+  constexpr int NLD = AP > NI ? AP : NI;          // B: 2 NI pieces per K-step over two waves
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem1[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gn = p.Co / BN;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = lin / gn, bn = lin - bm * gn;
+  const int M = p.M, m0 = bm * BM;
+  const int cpt = p.Ci >> 5;                      // 32-channel steps per tap
+  const int kiters = p.ntaps * cpt;
+  const int hsws = p.Hs * p.Ws;
+  const bool plain = p.ntaps == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 &&
+                     p.Ws == p.Wi && p.Hs == p.Hi;
+  const __bf16* in16 = reinterpret_cast<const __bf16*>(p.in);
+  const __bf16* wt16 = reinterpret_cast<const __bf16*>(p.wt);
+
+  const int n0 = m0 / hsws;
+  const long long img = (long long)p.Hi * p.Wi * p.ldi;               // elements per image of the gathered tensor
+  const __bf16* a_base = in16 + (long long)n0 * img;
+  const long long a_bytes = ((long long)(p.N - n0) * img - p.ldi + p.Ci) * 2;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0 : (int)a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)wt16, 0, (int)((long long)p.Co * p.ldw * 2), 0x00020000);
+
+  // per-lane source offsets of this wave's 1-KiB pieces: LDS position (row, c') = (16 j + lane / 4, lane % 4) of a tile with 64-byte
+  // rows holds the row's 16-byte chunk c = c' ^ ((row >> 2) & 3) — activations (waves 0-1) and filters (waves 2-3) alike
+  const bool loads_a = wave < 2;
+  unsigned voff[NLD], msk[NLD];
+#pragma unroll
+  for (int e = 0; e < NLD; ++e) { voff[e] = C1_OOB; msk[e] = 0; }
+  if (loads_a) {
+#pragma unroll
+    for (int e = 0; e < AP; ++e) {
+      const int j = AP * (wave & 1) + e;
+      const int row = 16 * j + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+      const int m = m0 + row;
+      if (m < M) {
+        if (plain) { voff[e] = (unsigned)((m - n0 * hsws) * p.ldi * 2 + c * 16); msk[e] = 1u; }
+        else {
+          const int n = m / hsws, rem = m - n * hsws;
+          const int i = rem / p.Ws, jx = rem - i * p.Ws;
+          const int iy0 = i * p.isy, ix0 = jx * p.isx;
+          voff[e] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * 2 + c * 16);
+          unsigned mk = 0;
+          for (int t = 0; t < p.ntaps; ++t)
+            if ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.Hi && (unsigned)(ix0 + p.tap_dx[t]) < (unsigned)p.Wi) mk |= 1u << t;
+          msk[e] = mk;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+      const int j = NI * (wave & 1) + e;
+      const int row = 16 * j + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
+      voff[e] = (unsigned)((bn * BN + row) * p.ldw * 2 + c * 16);
+      msk[e] = 0xFFFFu;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t my_rs = loads_a ? a_rs : b_rs;
+  const int my_dst = loads_a ? AP * (wave & 1) * 1024 : SA * ASTAGE + NI * (wave & 1) * 1024;
+  const int my_n = loads_a ? AP : NI;
+
+  int k_tap = 0, k_c = 0, k_done = 0;
+  auto issue = [&]() {
+    const bool live = k_done < kiters;
+    const unsigned bit = 1u << k_tap;
+    int delta = 0; unsigned soff = 0;
+    if (live) {
+      if (loads_a) { delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * 2; soff = (unsigned)k_c * 64u; }
+      else soff = (unsigned)(p.tap_w[k_tap] + k_c * 32) * 2u;
+    }
+    unsigned char* st = smem1 + (loads_a ? (k_done % SA) * ASTAGE : (k_done % SB) * BSTAGE) + my_dst;
+#pragma unroll
+    for (int e = 0; e < NLD; ++e)
+      if (e < my_n)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(my_rs, (lds_void*)(st + e * 1024), 16,
+                                                 (int)((live && (msk[e] & bit)) ? voff[e] + (unsigned)delta : C1_OOB), (int)soff, 0, 0);
+    ++k_done; ++k_c;
+    if (k_c == cpt) { k_c = 0; ++k_tap; }
+  };
+
+  // fragments: MFMA k-block kb (16 channels) of a K-step, lane half kh: chunk 2 kb + kh of the row
+  const int kh = lane >> 5;
+  int a_rd[MI][2], b_rd[NI][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int ar = (wave * MI + mi) * 32 + (lane & 31);
+      a_rd[mi][kb] = ar * 64 + (((2 * kb + kh) ^ ((ar >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row = ni * 32 + (lane & 31);
+      b_rd[ni][kb] = SA * ASTAGE + row * 64 + (((2 * kb + kh) ^ ((row >> 2) & 3)) << 4);
+    }
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  for (int s = 0; s < (loads_a ? SA : SB) - 1; ++s) issue();
+
+  for (int it = 0; it < kiters; ++it) {
+    if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SA - 2) * AP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((SB - 2) * NI) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue();
+    const unsigned char* st = smem1 + (it % SA) * ASTAGE;
+    const unsigned char* sb_ = smem1 + (it % SB) * BSTAGE;
+    bf16x8_t af[MI][2], bf[NI][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni][kb] = *reinterpret_cast<const bf16x8_t*>(sb_ + b_rd[ni][kb]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[mi][kb] = *reinterpret_cast<const bf16x8_t*>(st + a_rd[mi][kb]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][kb], bf[ni][kb], acc[mi][ni], 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------------------
+  out_t* __restrict__ gout = reinterpret_cast<out_t*>(p.out);
+  auto out_pix = [&](int m) -> size_t {
+    if (p.dense_out) return (size_t)m;
+    const int n = m / hsws, rem = m - n * hsws;
+    const int i = rem / p.Ws, jx = rem - i * p.Ws;
+    return ((size_t)n * p.Ho + p.oy0 + i * p.osy) * p.Wo + p.ox0 + jx * p.osx;
+  };
+  if (p.accumulate) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+        if (m >= M) continue;
+        const size_t pix = out_pix(m);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] += (float)gout[pix * p.ldo + bn * BN + ni * 32 + (lane & 31)];
+      }
+  }
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem1);      // [2][4 waves][BN]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      float s = 0.f, ss = 0.f;
+      if (p.bt_y) {                                      // BatchNorm tap (igemm.h): the terms of bn_act_bwd's reduce pass
+        const int co = bn * BN + ni * 32 + (lane & 31);
+        const float mu = p.bt_mean[co], is = p.bt_invstd[co], ga = p.bt_gamma ? p.bt_gamma[co] : 1.f, be = p.bt_beta ? p.bt_beta[co] : 0.f;
+        const __bf16* yb = reinterpret_cast<const __bf16*>(p.bt_y) + co;
+        float yv[MI][16];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+            yv[mi][r] = (float)yb[(size_t)(m < M ? m : M - 1) * p.Co];
+          }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+            const float xh = (yv[mi][r] - mu) * is;
+            float g = O32 ? acc[mi][ni][r] : (float)(__bf16)acc[mi][ni][r];      // (the gradient as it is stored)
+            if (p.bt_act == DCN_ACT_LEAKY) g = (ga * xh + be <= 0.f) ? g * p.bt_slope : g;
+            g = m < M ? g : 0.f;
+            s += g; ss += g * xh;
+          }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {             // the statistics of the tensor as it is stored (rounded to bf16)
+            const float v = O32 ? acc[mi][ni][r] : (float)(__bf16)acc[mi][ni][r];
+            s += v; ss = __builtin_fmaf(v, v, ss);
+          }
+      }
+      s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+      if (lane < 32) {
+        red[(0 * 4 + wave) * BN + ni * 32 + lane] = s;
+        red[(1 * 4 + wave) * BN + ni * 32 + lane] = ss;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * BN; idx += 256) {
+      const int which = idx / BN, col = idx - which * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(which * 4 + w) * BN + col];
+      p.stats[((size_t)bm * 2 + which) * p.Co + bn * BN + col] = t;
+    }
+  }
+  float sc[NI], sh[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int co = bn * BN + ni * 32 + (lane & 31);
+    sc[ni] = p.scale ? p.scale[co] : 1.f;
+    sh[ni] = p.shift ? p.shift[co] : 0.f;
+  }
+  const __bf16* res16 = reinterpret_cast<const __bf16*>(p.residual);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (wave * MI + mi) * 32 + 4 * kh + (r & 3) + 8 * (r >> 2);
+      if (m >= M) continue;
+      const size_t pix = out_pix(m);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int co = bn * BN + ni * 32 + (lane & 31);
+        float v = acc[mi][ni][r] * sc[ni] + sh[ni];
+        if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        if (res16) v += (float)res16[pix * p.ldr + co];
+        gout[pix * p.ldo + co] = (out_t)v;
+      }
+    }
+}
+
 int g_conv1 = 1;          // dcn_set_tuning("1x1dma", 0): back on the implicit-GEMM tiles of igemm.hip; 2: 1x1 launches only
 int g_conv1_stages = 32;  // dcn_set_tuning("1stages", 10 * SA + SB): ring depths.  Default 3 activation + 2 filter K-steps = 40 KB at the 128 x 128 tile:
                           // FOUR workgroups per CU (measured per layer, tools/bench_convs.py --set 1stages=..: 32 < 33 < 42 < 44 ~ 63 << 84: occupancy beats ring depth)
@@ -378,6 +629,34 @@ int conv1_shape(const IgemmParams& p, int gran) {
   return mi * 10 + ni;
 }
 
+// bf16 storage: (MI, NI) of a launch; 0 = no tile (Co not a multiple of 32).  One BatchNorm partial row per 128 MI output rows.
+int conv1b_shape(int M, int Co) {
+  if (Co % 32 != 0) return 0;
+  if (Co % 256 == 0 && (long long)cdiv(M, 128) * (Co / 256) >= 1024) return 18;
+  if (Co % 128 == 0) return 14;
+  if (Co % 64 == 0) return 12;
+  return 21;
+}
+
+template <int NI, int MI, bool O32>
+int launch1b(const IgemmParams& p, hipStream_t stream) {
+  constexpr int SA = 3, SB = 2;
+  constexpr int BM = 128 * MI, BN = 32 * NI;
+  static DcnPerDeviceFlag attr_once;
+  const size_t lds = (size_t)SA * BM * 64 + (size_t)SB * BN * 64;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1b_kernel<SA, SB, NI, MI, O32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const int gm = cdiv(p.M, BM), gn = p.Co / BN;
+  const double k_alg = (double)p.ntaps * p.Ci;
+  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) + (O32 ? 4.0 : 2.0) * (double)p.M * p.Co;
+  const int pid = prof_begin(41, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  hipLaunchKernelGGL((conv1b_kernel<SA, SB, NI, MI, O32>), dim3(gm * gn), dim3(256), lds, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("conv1b");
+  return DCN_OK;
+}
+
 }  // namespace
 
 void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value; else g_conv1_fill = value; }
@@ -415,5 +694,29 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
     case 22: return launch1_ring<2, 2>(p, stream);
     case 21: return launch1_ring<1, 2>(p, stream);
     default: dcn_set_error("conv1: no tile for this launch"); return DCN_ERR_ARG;
+  }
+}
+
+// ---- bf16 storage ------------------------------------------------------------------------------------------------------
+int conv1b_grid_m(int M, int Co) {
+  const int sh = conv1b_shape(M, Co);
+  return sh ? cdiv(M, 128 * (sh / 10)) : 0;
+}
+
+// p.in / p.residual / p.bt_y / p.wt point at bf16 data, p.out at bf16 (out_f32 = 0) or fp32 data; no abs-max words, no f8.
+int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
+  if (p.Ci % 32 != 0 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale || p.ncls || p.ntaps < 1 || p.ntaps > 16 ||
+      (long long)p.M != (long long)p.N * p.Hs * p.Ws) {
+    dcn_set_error("conv1b: launch form not supported on bf16 storage (Ci=%d taps=%d)", p.Ci, p.ntaps); return DCN_ERR_ARG;
+  }
+  if (p.Hs * p.Ws < 1 || (256 / (p.Hs * p.Ws) + 2) * (long long)p.Hi * p.Wi * p.ldi * 2 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 2 >= 0x7FFFFFF0LL) {
+    dcn_set_error("conv1b: tensor beyond the 2 GiB buffer window"); return DCN_ERR_ARG;
+  }
+  switch (conv1b_shape(p.M, p.Co)) {
+    case 18: return out_f32 ? launch1b<8, 1, true>(p, stream) : launch1b<8, 1, false>(p, stream);
+    case 14: return out_f32 ? launch1b<4, 1, true>(p, stream) : launch1b<4, 1, false>(p, stream);
+    case 12: return out_f32 ? launch1b<2, 1, true>(p, stream) : launch1b<2, 1, false>(p, stream);
+    case 21: return out_f32 ? launch1b<1, 2, true>(p, stream) : launch1b<1, 2, false>(p, stream);
+    default: dcn_set_error("conv1b: Co=%d is not a multiple of 32", p.Co); return DCN_ERR_ARG;
   }
 }

@@ -73,6 +73,10 @@ void conv3_set_tuning(int key, int value);
 bool conv1_applicable(const IgemmParams& p, int precision, int gran);
 int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv1_set_tuning(int key, int value);
+// ... and its bf16-storage form (activations, gradients and filter banks bf16 in HBM): every forward / data-gradient launch with
+// Ci % 32 == 0.  conv1b_grid_m = BatchNorm partial rows (M-tiles) of a launch.
+int conv1b_grid_m(int M, int Co);
+int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
 
 
 // stem.hip: the 4-channel 3x3 stride-1 stem directly on the vector ALU (forward).  scratch: >= 27*32 floats.

@@ -98,12 +98,17 @@ __device__ __forceinline__ int sp_off(int row, int c) { return 256 * row + 16 * 
 
 // NP: 16-bit pieces per operand (3 = fp32-accurate bf16 split, 1 = plain bf16 operands, 2 = fp32-accurate f16 split with
 // per-tensor power-of-two scales and three MFMAs per product; igemm.hip)
-template <int TM, int TN, int KP, bool SP = false, int ABL = 0, int NP = 3>
+// IN16 (bf16 storage, NP = 1 only): x and dy ARE bf16 tensors — a 16-byte piece is 8 channels and goes to its LDS plane as it is
+// (no conversion, half the loads); strides stay in elements.
+template <int TM, int TN, int KP, bool SP = false, int ABL = 0, int NP = 3, bool IN16 = false>
 __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kernel(const WgradParams p) {
   static_assert(!SP || (TM == 128 && TN == 128 && KP == 16), "split mode: 128x128x16 tiles");
+  static_assert(!IN16 || (SP && NP == 1), "bf16 inputs: the one-plane 128x128 tile");
+  constexpr int EPP = IN16 ? 8 : 4;                                 // elements per 16-byte piece
+  constexpr int ESZ = IN16 ? 2 : 4;                                 // bytes per element
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int MI = TM / (32 * WM), NI = TN / (32 * WN);
-  constexpr int A_N = KP * TM / 4, B_N = KP * TN / 4;               // 16-B pieces per tile
+  constexpr int A_N = KP * TM / EPP, B_N = KP * TN / EPP;           // 16-B pieces per tile
   constexpr int A_LD = (A_N + 255) / 256, B_LD = (B_N + 255) / 256; // per thread per K-step
   constexpr int KS = KP / 2 / WK;                                   // k2-steps per wave per K-step
   static_assert(KS >= 1, "K-step too small for the wave split");
@@ -131,27 +136,29 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
   const int howo = p.Ho * p.Wo;
 
   // descriptors: dY window starts at this split's first row; X window at the first image it touches
-  const float* a_base = p.dy + (long long)blockIdx.y * p.dy_bs + (long long)m_begin * p.lddy;
-  const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(a_base, (long long)(p.M - m_begin) * p.lddy * 4);
+  const float* a_base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.dy) +
+                                                       ((long long)blockIdx.y * p.dy_bs + (long long)m_begin * p.lddy) * ESZ);
+  const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(a_base, (long long)(p.M - m_begin) * p.lddy * ESZ);
   const int n_first = m_begin / howo;
   const long long ximg = (long long)p.H * p.W * p.ldx;
-  const float* b_base = p.x + (long long)blockIdx.y * p.x_bs + (long long)n_first * ximg;
-  const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(b_base, (long long)(p.N - n_first) * ximg * 4);
+  const float* b_base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.x) +
+                                                       ((long long)blockIdx.y * p.x_bs + (long long)n_first * ximg) * ESZ);
+  const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(b_base, (long long)(p.N - n_first) * ximg * ESZ);
 
   unsigned a_voff[A_LD]; int a_pix[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
     const int idx = tid + 256 * j;
-    const int pix = idx / (TM / 4), c = (idx - pix * (TM / 4)) * 4;
+    const int pix = idx / (TM / EPP), c = (idx - pix * (TM / EPP)) * EPP;
     a_pix[j] = pix;
-    a_voff[j] = (idx < A_N && co0 + c < p.Co_ld) ? (unsigned)((pix * p.lddy + co0 + c) * 4) : OOB;
+    a_voff[j] = (idx < A_N && co0 + c < p.Co_ld) ? (unsigned)((pix * p.lddy + co0 + c) * ESZ) : OOB;
   }
   // gathered operand: the (n, ho, wo) decomposition of an output pixel never happens in this kernel — the
   // geometry table (dcn_conv2d_geom, built once per conv geometry) holds per output pixel m the index of its
   // centre input pixel and four edge flags; a tap is a wave-uniform pixel delta plus a flag mask.  The entry
   // for the next K-step is fetched while the current one is consumed (one 4-B load per slot, L1/L2 resident).
   int b_pix[B_LD], b_tdelta[B_LD]; unsigned b_ent[B_LD], b_tmask[B_LD], b_coff[B_LD]; bool b_ok[B_LD];
-  const int ldx4 = p.ldx * 4;
+  const int ldx4 = p.ldx * ESZ;
   const int pixbase = n_first * p.H * p.W;
   // (a buffer load whose offset goes out of range when there is no table: no branch around the load — a load inside a
   //  wave-uniform branch makes every later s_waitcnt conservative, here a vmcnt(0) in front of each K-step's tile loads)
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     const int idx = tid + 256 * j;
-    const int pix = idx / (TN / 4), c = (idx - pix * (TN / 4)) * 4;
+    const int pix = idx / (TN / EPP), c = (idx - pix * (TN / EPP)) * EPP;
     b_pix[j] = pix;
     int rr = r, ss = s, ci = ci0 + c;
     bool ok = idx < B_N && ci < p.Ci;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
     b_tdelta[j] = (rr - p.pad) * p.W + (ss - p.pad) - pixbase;
     b_tmask[j] = (rr < p.pad ? GEOM_TOP : 0u) | (rr > p.pad ? GEOM_BOTTOM : 0u) | (ss < p.pad ? GEOM_LEFT : 0u) |
                  (ss > p.pad ? GEOM_RIGHT : 0u) | GEOM_INVALID;
-    b_coff[j] = (unsigned)ci * 4u;
+    b_coff[j] = (unsigned)ci * (unsigned)ESZ;
     b_ent[j] = entry(m_begin + pix);
   }
   int m_cur = m_begin;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
       const unsigned voff = (unsigned)(((int)(e >> 5) + b_tdelta[j]) * ldx4) + b_coff[j];
       b_reg[j] = buf_load16(b_rs, ok ? voff : OOB, 0);
     }
-    a_soff += (unsigned)(KP * p.lddy * 4); rows_left -= KP;
+    a_soff += (unsigned)(KP * p.lddy * ESZ); rows_left -= KP;
   };
   auto load_tiles = [&]() { load_tiles_into(a_reg, b_reg); };
   unsigned char* sp_base = reinterpret_cast<unsigned char*>(smem);   // SP: [2 buf][A,B][NP planes][16][256 B]
@@ -250,6 +257,11 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
     const bool isb = pc >= A_LD;
     const int j = isb ? pc - A_LD : pc;
     const int idx = tid + 256 * j;
+    if constexpr (IN16) {               // 8 bf16 channels of a pixel: one 16-byte chunk of the plane, as loaded
+      const int pix = idx / 16, c = (idx - pix * 16) * 8;
+      *reinterpret_cast<f32x4*>(sp_base + buf * SP_BUF + (isb ? SP_OPND : 0) + sp_off(pix, c)) = isb ? br[j] : ar[j];
+      return;
+    }
     const int pix = idx / 32, c = (idx - pix * 32) * 4;
     split_store(sp_base + buf * SP_BUF + (isb ? SP_OPND : 0), sp_off(pix, c), isb ? br[j] : ar[j], isb ? s_b : s_a);
   };
@@ -523,7 +535,7 @@ int g_wg_lds_pad = 0;      // dcn_set_tuning("lwgpad", KB): dynamic LDS the weig
 int wgrad_lds_pad() { return g_wg_lds_pad; }
 void wgrad_set_lds_pad(int kb) { g_wg_lds_pad = kb * 1024; }
 namespace {
-template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3>
+template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3, bool IN16 = false>
 int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) {
   constexpr int WM = TM >= 64 ? 2 : 1, WN = TN >= 64 ? 2 : 1, WK = 4 / (WM * WN);
   constexpr int KP = SP ? 16 : (WGRAD_KP < 2 * WK ? 2 * WK : WGRAD_KP);
@@ -533,12 +545,12 @@ int launch_wgrad(const WgradParams& p, int grid, int batch, hipStream_t stream) 
   if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();      // (occupancy experiment: "lwgpad")
   static DcnPerDeviceSize attr_lds;
   if (attr_lds.raise(lds)) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL, NP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TM, TN, KP, SP, ABL, NP, IN16>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const double n_alg = p.c4 ? 27.0 : (double)p.T * p.Ci;
-  const int pid = prof_begin(SP ? (NP == 1 ? 20 : NP == 2 ? 25 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
-  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL, NP>), dim3(grid, batch), dim3(256), lds, stream, p);
+  const int pid = prof_begin(IN16 ? 42 : SP ? (NP == 1 ? 20 : NP == 2 ? 25 : 17) : p.M < 1024 ? 14 : 5, 2.0 * batch * (double)p.M * p.Co * n_alg, stream);
+  hipLaunchKernelGGL((wgrad_kernel<TM, TN, KP, SP, ABL, NP, IN16>), dim3(grid, batch), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad");
   return DCN_OK;
@@ -704,5 +716,64 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   if (pl.splits > 1) {
     return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   }
+  return DCN_OK;
+}
+
+// ---- bf16 storage: x and dy are bf16 NHWC tensors, dw is fp32 [Cout][k][k][Cin] --------------------------------------------------
+// Always the 128 x 128 one-plane tile of wgrad_kernel with bf16 loads (narrower layers leave part of it empty: those launches are
+// bound by their 9-fold gather, not by the matrix pipe).  Split-K over the pixels into fp32 slabs, summed in a fixed order.
+namespace {
+Plan make_plan_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  Plan pl;
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  pl.M = n * ho * wo; pl.tm = pl.tn = 128;
+  pl.tiles_co = cdiv(cout, 128); pl.tiles_ci = cdiv(cin, 128);
+  pl.T = ksize * ksize; pl.ld_out = pl.T * cin;
+  const int base = pl.tiles_co * pl.tiles_ci * pl.T;
+  const int max_splits = pl.M / 256 > 0 ? pl.M / 256 : 1;
+  const int target = (ksize == 1 || stride == 2) ? g_wg_target_small : g_wg_target;
+  int splits = target / base;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  for (;;) {
+    pl.kchunk = cdiv(cdiv(pl.M, splits), 32) * 32;
+    pl.splits = cdiv(pl.M, pl.kchunk);
+    if (base * pl.splits <= target || splits == 1 || base > target) break;
+    --splits;
+  }
+  return pl;
+}
+}  // namespace
+
+extern "C" int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
+  return pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+}
+
+extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
+                                         int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_bwd_weight_b16: ksize=%d stride=%d", ksize, stride);
+  DCN_CHECK_ARG(cin % 8 == 0 && cout % 8 == 0, "conv2d_bwd_weight_b16: cin=%d / cout=%d must be multiples of 8", cin, cout);
+  DCN_CHECK_ARG(x && dy && dw && geom, "conv2d_bwd_weight_b16: null pointer (geom = table of dcn_conv2d_geom for this geometry)");
+  const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
+  DCN_CHECK_ARG(lx % 8 == 0 && ly % 8 == 0, "conv2d_bwd_weight_b16: pixel strides must be multiples of 8 elements");
+  const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
+  DCN_CHECK_ARG(pl.M >= 16, "conv2d_bwd_weight_b16: fewer than 16 output pixels");
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
+  WgradParams p{};
+  p.x = (const float*)x; p.dy = (const float*)dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = lx;
+  p.ksize = ksize; p.stride = stride; p.pad = (ksize - 1) / 2; p.T = pl.T;
+  p.Ho = (h + 2 * p.pad - ksize) / stride + 1; p.Wo = (wd + 2 * p.pad - ksize) / stride + 1;
+  p.Co = cout; p.lddy = ly;
+  p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = 0; p.ld_out = pl.ld_out;
+  p.Co_ld = cout; p.geom = geom;
+  const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
+  int rc = launch_wgrad<128, 128, true, 0, 1, true>(p, grid, 1, stream);
+  if (rc != DCN_OK) return rc;
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   return DCN_OK;
 }

@@ -279,6 +279,9 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
     # abs-max word of every activation (ops.amax_*): written by the kernel that produces the tensor, read by the GEMMs
     # that consume it (forward here, weight gradient in the backward) to pick their power-of-two operand scales
     am = ops.use_amax()
+    # bf16 storage (ops.set_precision("bf16s")): every activation / raw conv output behind the stem is a bf16 tensor; the three taps are
+    # cast to fp32 for the head (and their gradients back to bf16 in _run_backward)
+    s16 = ops.storage_b16()
     amx: Dict[int, Optional[torch.Tensor]] = {-1: None}
     # outputs with exactly ONE reader, a train-mode conv + BatchNorm whose kernels can apply the activation while loading
     # (ops.pre_supported): they are handed on as ops.PreAct — no scale_act pass, no activation tensor
@@ -323,6 +326,26 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
+            if s16 and x.dtype == torch.bfloat16:
+                if bank is None:
+                    raise RuntimeError("bf16 storage needs the prepared filter banks (ops.FILTER_BANKS) for every layer behind the stem")
+                if op.bn and training:
+                    y, stats = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, want_stats=True)
+                    mi = ops.bn_finalize(stats, y.numel() // op.cout, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
+                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res)
+                    if save is not None:
+                        save[op.slot] = (x, y, mi, w, None, None)
+                else:
+                    if save is not None:
+                        raise NotImplementedError("bf16 storage: frozen-BatchNorm fine-tuning is not built (train-mode BatchNorm or inference)")
+                    if op.bn:
+                        ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5)
+                        scale, shift = ss[0], ss[1]
+                    else:
+                        scale, shift = None, p["b"]
+                    o, _ = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, scale, shift, act, 0.1, residual=res)
+                out[op.dst] = o; amx[op.dst] = None
+                continue
             if op.bn and training:
                 # (the conv hands out the abs-max of its raw output with its store: the bound below starts from it)
                 ay = ops.amax_slot(x.device) if (not isinstance(x, ops.PreAct) and sole_pre_reader(op, x)) else None
@@ -336,7 +359,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     if ops.PRE_ACT == "check":        # (tests: the activation written out, read with the same abs-max word)
                         o = o.materialise()
                 else:
-                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao)
+                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, amax_out=ao, out_b16=s16)    # (s16: the stem's fp32 raw output -> bf16)
                 if save is not None:
                     save[op.slot] = (x, y, mi, w, ax, aw)
             else:
@@ -356,11 +379,15 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                         a, _ = ops.conv2d_fwd(x, w, op.k, op.stride, scale, shift, act, 0.1, amax_x=ax, amax_w=aw, w_split_ready=wsp, w_b16=w16)
                         o = ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res, amax_out=ao)
                     save[op.slot] = (x, a, scale, w, ax, aw)
+            if s16:
+                if save is not None and not (op.bn and training):
+                    raise NotImplementedError("bf16 storage: frozen-BatchNorm fine-tuning is not built")
+                o = ops.to_b16(o)          # (the stem in inference: its fused epilogue wrote fp32)
             out[op.dst] = o; amx[op.dst] = ao
         elif isinstance(op, _UpCatOp):
             up, lat = out[op.up_src], out[op.lat_src]
             n, h, w_, _ = lat.shape
-            buf = torch.empty((n, h, w_, op.c_up + op.c_lat), dtype=torch.float32, device=lat.device)
+            buf = torch.empty((n, h, w_, op.c_up + op.c_lat), dtype=lat.dtype, device=lat.device)
             ops.upsample2_into(up, buf[..., :op.c_up])
             ops.copy_slice(lat, buf[..., op.c_up:])
             out[op.dst] = buf
@@ -368,7 +395,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             amx[op.dst] = ops.absmax(lat, ops.absmax(up)) if am else None
         else:
             out[op.dst] = out[op.src]; amx[op.dst] = amx.get(op.src)
-    return [out[t] for t in taps], [amx.get(t) for t in taps], early_event
+    return [ops.to_f32(out[t]) if s16 else out[t] for t in taps], [amx.get(t) for t in taps], early_event
 
 
 def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bucket_bytes: int = 0):
@@ -378,12 +405,13 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
     pending: list = []
     pending_bytes = 0
     g: Dict[int, Optional[torch.Tensor]] = {}
+    s16 = ops.storage_b16()
 
     def add(slot, t):
         cur = g.get(slot)
         if cur is None:
             if not t.is_contiguous():
-                buf = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+                buf = torch.empty(t.shape, dtype=t.dtype, device=t.device)
                 ops.copy_slice(t, buf)
                 t = buf
             g[slot] = t
@@ -392,7 +420,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
 
     for t, gt in zip(taps, grads_taps):
         if gt is not None:
-            add(t, gt.clone(memory_format=torch.contiguous_format))   # never accumulate into autograd's tensor
+            g0 = gt.clone(memory_format=torch.contiguous_format)      # never accumulate into autograd's tensor
+            add(t, ops.to_b16(g0) if s16 else g0)
     pg: Dict[int, dict] = {}
     # BatchNorm taps: the data gradient that completes the gradient of a conv + BN + activation output (= the FIRST consumer of that
     # output in plan order, processed last) can form the partial sums that layer's BatchNorm backward starts with (ops.conv2d_bwd_data)
@@ -415,7 +444,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
             n, h2, w2, _ = dout.shape
             cur = g.get(op.up_src)
             if cur is None:
-                cur = torch.empty((n, h2 // 2, w2 // 2, op.c_up), dtype=torch.float32, device=dout.device)
+                cur = torch.empty((n, h2 // 2, w2 // 2, op.c_up), dtype=dout.dtype, device=dout.device)
                 ops.upsample2_bwd(dout[..., :op.c_up], cur, False)
                 g[op.up_src] = cur
             else:
@@ -424,6 +453,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
         else:
             p = P[op.slot]
             x, y, aux, w, ax, aw = save.pop(op.slot)
+            if s16 and torch.is_tensor(x) and x.dtype == torch.float32 and dout.dtype == torch.bfloat16:
+                dout = ops.to_f32(dout)           # bf16 storage: the 3-channel stem's kernels (BatchNorm backward, weight gradient) stay fp32
             shape = tuple(p["w"].shape)
             d = {}
             ady = ops.amax_slot(dout.device) if ops.use_amax() else None
@@ -470,7 +501,25 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 add(op.res, dout)
             if not ops.WGRAD_AFTER_DGRAD:
                 d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)     # overlaps with the data gradient below
-            if op.need_dx:
+            if op.need_dx and s16 and dy.dtype == torch.bfloat16:
+                cur = g.get(op.src)
+                tap = None
+                prev = producer.get(op.src)
+                if (ops.BN_TAP and ops.BN_TAP_TRUNK and training and op.stride == 1 and prev is not None and prev.bn
+                        and first_use.get(op.src) == index_of[id(op)] and prev.slot in save):
+                    _, y_prev, mi_prev = save[prev.slot][:3]
+                    if torch.is_tensor(y_prev) and y_prev.dtype == torch.bfloat16 and y_prev.is_contiguous():
+                        tap = dict(y=y_prev, mean=mi_prev[0], invstd=mi_prev[1], gamma=P[prev.slot]["gamma"], beta=P[prev.slot]["beta"],
+                                   act=ops.ACT_LEAKY if prev.leaky else ops.ACT_NONE, slope=0.1)
+                res_ = ops.conv2d_bwd_data_b16(dy, getattr(w, "_dcn_wt16"), (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
+                                               out=cur, accumulate=cur is not None, tap=tap)
+                if tap is not None:
+                    res_, part_ = res_
+                    if part_ is not None:
+                        tapped[prev.slot] = part_
+                if cur is None:
+                    g[op.src] = res_
+            elif op.need_dx:
                 cur = g.get(op.src)
                 hw = (x.shape[1], x.shape[2])
                 wtr = getattr(w, "_dcn_wt", None)      # the transposed banks of this step (ops.FilterBanks)

@@ -127,11 +127,24 @@ SIGNATURES = {
     "dcn_prof_records": (I, [P, P, P, P, I]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
+    "dcn_conv2d_stats_rows_b16": (I, [I, I, I, I, I, I]),
+    "dcn_conv2d_fwd_b16": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P]),
+    "dcn_conv2d_bwd_data_b16": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, F, P, I, P, P]),
+    "dcn_conv2d_bwd_weight_ws_b16": (L, [I, I, I, I, I, I, I]),
+    "dcn_conv2d_bwd_weight_b16": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "dcn_scale_act_b16": (I, [P, I, P, P, I, F, P, I, P, L, I, I, P]),
+    "dcn_bn_act_bwd_reduce_rows_b16": (I, [L]),
+    "dcn_bn_act_bwd_reduce_b16": (I, [P, I, P, I, P, P, P, P, I, F, L, I, P, P]),
+    "dcn_bn_act_bwd_apply_b16": (I, [P, I, P, I, P, P, P, P, I, F, P, L, L, I, P, P]),
+    "dcn_cast_rows": (I, [P, I, I, P, I, I, L, I, I, P]),
+    "dcn_upsample2_nhwc_b16": (I, [P, I, P, I, I, I, I, I, P]),
+    "dcn_upsample2_nhwc_bwd_b16": (I, [P, I, P, I, I, I, I, I, I, P]),
     "dcn_post_topk": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     "dcn_post_fusion": (I, [P, P, P, P, I, I, I, I, P, P, P]),
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
-                "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records"}
+                "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records",
+                "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16"}
 ABI_VERSION = 305        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 

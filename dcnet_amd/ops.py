@@ -26,7 +26,12 @@ ACT_NONE, ACT_LEAKY = 0, 1
 #               builder-defined (the reference has no bf16 semantics); tensors in HBM stay fp32
 #   "fp8"       forward and data-gradient tiles with OCP fp8 e4m3 operands (per-tensor power-of-two scales from an abs-max
 #               pass, fp32 accumulate), weight gradient with bf16 operands: BASELINE.json configs[4]; reduced precision
-PRECISIONS = {"fp32_mfma": 0, "fp32_bf16x3": 1, "bf16": 2, "fp8": 3, "fp32": 4}
+#   "bf16s"     bf16 STORAGE (configs[2] proper): the convolution stacks keep activations, raw conv outputs and their
+#               gradients as bf16 tensors in HBM (fp32 accumulators, BatchNorm statistics, weight gradients and master
+#               weights); their kernels are the *_b16 entry points (csrc/conv1.hip conv1b, wgrad.hip IN16, b16.hip) — one
+#               MFMA per product, half the bytes per element.  What stays on fp32 tensors (the 3-channel stem, co-attention,
+#               scoring, heads' tails, language branch) runs as in "bf16" (bf16 operands)
+PRECISIONS = {"fp32_mfma": 0, "fp32_bf16x3": 1, "bf16": 2, "fp8": 3, "fp32": 4, "bf16s": 2}
 _precision = "fp32"
 
 
@@ -36,6 +41,48 @@ def set_precision(mode: str) -> None:
         raise ValueError(f"precision {mode!r}: expected one of {sorted(PRECISIONS)}")
     lib().set_tuning(b"precision", PRECISIONS[mode])
     _precision = mode
+
+
+def storage_b16() -> bool:
+    """True in the bf16-storage mode: conv stacks allocate and exchange bf16 tensors."""
+    return _precision == "bf16s"
+
+
+def _b16(t) -> bool:
+    return t is not None and t.dtype == torch.bfloat16
+
+
+def _chk16(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous bf16 CUDA tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def _rows16(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype in (torch.bfloat16, torch.float32) and _rows_ok(t) and t.stride(-2) % 8 == 0 and t.shape[-1] % 8 == 0
+            and t.data_ptr() % 16 == 0):
+        raise ValueError(f"{name}: expected a bf16 / fp32 CUDA [rows][c] view, c and row stride multiples of 8, 16-byte aligned; got "
+                         f"{t.dtype} shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def cast_rows(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """dst[..., :c] (+)= src[..., :c] between fp32 / bf16 [rows][c] views (csrc/b16.hip): casts at the fp32 boundary of the
+    bf16-storage mode, channel-slice copies of the route concat."""
+    c = src.shape[-1]
+    rows = src.numel() // c
+    _rows16(src, "cast_rows src"); _rows16(dst, "cast_rows dst")
+    if dst.shape[-1] != c or dst.numel() // c != rows:
+        raise ValueError("cast_rows: shapes differ")
+    lib().cast_rows(src.data_ptr(), int(_b16(src)), src.stride(-2), dst.data_ptr(), int(_b16(dst)), dst.stride(-2), rows, c,
+                    int(accumulate), _s())
+    return dst
+
+
+def to_b16(x: torch.Tensor) -> torch.Tensor:
+    return x if _b16(x) else cast_rows(x, torch.empty(x.shape, dtype=torch.bfloat16, device=x.device))
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    return cast_rows(x, torch.empty(x.shape, dtype=torch.float32, device=x.device)) if _b16(x) else x
 
 
 def get_precision() -> str:
@@ -55,7 +102,7 @@ _amax_consts = {}
 def use_amax() -> bool:
     """The precision modes whose GEMM tiles scale their operands by a power of two derived from the tensors' abs-max words:
     the f16 two-piece split ("fp32") and the fp8 path (whose separate abs-max passes, dcn_f8_scale, they replace)."""
-    return _precision in ("fp32", "fp8")
+    return _precision in ("fp32", "fp8")      # ("bf16s": no operand scaling at all)
 
 
 AMAX_SLOTS = 2048        # slots of one pool = what a forward (and its backward) may hand out before a second pool is taken
@@ -386,6 +433,77 @@ def conv2d_bwd_data(dy, w_ohwi, in_hw, ksize, stride, out=None, accumulate=False
     return out
 
 
+def conv2d_fwd_b16(x, w16, cout, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0, residual=None, out=None,
+                   want_stats=False, accumulate=False, out_f32=False):
+    """bf16 storage: x (N,H,W,Cin) bf16 NHWC, w16 the bf16 bank [Cout][k*k*Cin] (FilterBanks "b16").  Returns (y, stats): y bf16
+    (fp32 with out_f32), stats [rows][2][Cout] fp32 partial sums of the raw result as stored (None unless want_stats)."""
+    _chk16(x, "conv2d_fwd_b16 x")
+    n, h, wd, cin = x.shape
+    if not (w16.is_cuda and w16.dtype == torch.bfloat16 and w16.is_contiguous() and w16.numel() == cout * ksize * ksize * cin):
+        raise ValueError("conv2d_fwd_b16: w16 must be the contiguous bf16 bank [Cout][k*k*Cin]")
+    ho, wo = conv_out_hw(h, wd, ksize, stride)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if out.dtype != (torch.float32 if out_f32 else torch.bfloat16) or out.stride(3) != 1:
+        raise ValueError("conv2d_fwd_b16: out dtype / layout")
+    if residual is not None:
+        _rows16(residual, "conv2d_fwd_b16 residual")
+        if not _b16(residual):
+            raise ValueError("conv2d_fwd_b16: residual must be bf16")
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib().conv2d_stats_rows_b16(n, h, wd, cout, ksize, stride), 2, cout), dtype=torch.float32, device=x.device)
+    lib().conv2d_fwd_b16(x.data_ptr(), w16.data_ptr(), out.data_ptr(), int(out_f32), n, h, wd, cin, cout, ksize, stride, _p(scale), _p(shift),
+                         act, float(slope), _p(residual), 0 if residual is None else residual.stride(2), out.stride(2), _p(stats),
+                         int(accumulate), _s())
+    return out, stats
+
+
+def conv2d_bwd_data_b16(dy, wt16, in_hw, cin, ksize, stride, out=None, accumulate=False, tap=None, out_f32=False):
+    """bf16 storage: dy (N,Ho,Wo,Cout) bf16 (pixel stride may exceed Cout), wt16 the transposed bf16 bank [Cin][k*k*Cout]
+    (FilterBanks "tb16") -> dx (N,H,W,Cin) bf16 (fp32 with out_f32).  tap: as conv2d_bwd_data (y bf16); returns (dx, partials | None)."""
+    import ctypes
+    n, ho, wo, cout = dy.shape
+    h, wd = in_hw
+    _rows16(dy, "conv2d_bwd_data_b16 dy")
+    if not _b16(dy) or not (wt16.dtype == torch.bfloat16 and wt16.is_contiguous() and wt16.numel() == cin * ksize * ksize * cout):
+        raise ValueError("conv2d_bwd_data_b16: dy must be bf16, wt16 the contiguous bf16 bank [Cin][k*k*Cout]")
+    if out is None:
+        out = torch.empty((n, h, wd, cin), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy.device)
+    if out.dtype != (torch.float32 if out_f32 else torch.bfloat16) or not out.is_contiguous():
+        raise ValueError("conv2d_bwd_data_b16: out dtype / layout")
+    part = None
+    rows = ctypes.c_int(0)
+    cap = 0
+    if tap is not None and stride == 1 and _b16(tap["y"]) and tap["y"].is_contiguous():
+        cap = lib().conv2d_stats_rows_b16(n, h, wd, cin, 1, 1)            # M-tiles of the launch (rows = n*h*wd, filters = cin)
+        part = torch.empty((max(cap, 1), 2, cin), dtype=torch.float32, device=dy.device)
+    lib().conv2d_bwd_data_b16(dy.data_ptr(), dy.stride(2), wt16.data_ptr(), out.data_ptr(), int(out_f32), n, h, wd, cin, cout, ksize, stride,
+                              int(accumulate), tap["y"].data_ptr() if cap else 0, tap["mean"].data_ptr() if cap else 0,
+                              tap["invstd"].data_ptr() if cap else 0, _p(tap.get("gamma")) if cap else 0, _p(tap.get("beta")) if cap else 0,
+                              int(tap["act"]) if cap else 0, float(tap["slope"]) if cap else 0.0, part.data_ptr() if cap else 0, cap,
+                              ctypes.addressof(rows), _s())
+    if tap is not None:
+        return out, (part[:rows.value] if rows.value > 0 else None)
+    return out
+
+
+def conv2d_bwd_weight_b16(x, dy, ksize, stride, slot: int = 0):
+    """bf16 storage: x (N,H,W,Cin), dy (N,Ho,Wo,Cout) bf16 -> dw OHWI (Cout,k,k,Cin) fp32."""
+    n, h, wd, cin = x.shape
+    cout = dy.shape[3]
+    _rows16(x, "conv2d_bwd_weight_b16 x"); _rows16(dy, "conv2d_bwd_weight_b16 dy")
+    if not (_b16(x) and _b16(dy)):
+        raise ValueError("conv2d_bwd_weight_b16: bf16 tensors only")
+    dw = torch.empty((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    nws = lib().conv2d_bwd_weight_ws_b16(n, h, wd, cin, cout, ksize, stride)
+    ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
+    geom = conv_geom(x.device, n, h, wd, ksize, stride)
+    lib().conv2d_bwd_weight_b16(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
+                                n, h, wd, cin, cout, ksize, stride, _s())
+    return dw
+
+
 FILTER_BANKS = True      # A/B switch: False = per-layer transposes / abs-max / pre-split again
 
 
@@ -467,6 +585,8 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
     ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0).
     x may be a PreAct (see conv2d_fwd); amax_x is then the word of the activation."""
+    if _b16(dy) and not isinstance(x, PreAct):
+        return conv2d_bwd_weight_b16(x, dy, ksize, stride, slot=slot)
     n, h, wd, cin = x.shape
     cout = dy.shape[3] if cout is None else cout
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
@@ -575,9 +695,21 @@ def channel_stats(x2d):
     return stats
 
 
-def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None):
+def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None, out_b16=False):
     c = y.shape[-1]
     rows = y.numel() // c
+    if _b16(y) or out_b16 or _b16(out):
+        # bf16 storage (csrc/b16.hip): y bf16 (fp32 for the stem's raw output), residual / out bf16
+        if out is None:
+            out = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+        if not y.is_contiguous() or not _b16(out) or (residual is not None and not _b16(residual)):
+            raise ValueError("scale_act (bf16 storage): contiguous y, bf16 out / residual")
+        _rows16(out, "scale_act out")
+        if residual is not None:
+            _rows16(residual, "scale_act residual")
+        lib().scale_act_b16(y.data_ptr(), int(not _b16(y)), _p(scale), _p(shift), act, float(slope), _p(residual),
+                            0 if residual is None else residual.stride(-2), out.data_ptr(), rows, c, out.stride(-2), _s())
+        return out
     if out is None:
         out = torch.empty_like(y)
     _chk(y, "scale_act y"); _rows(out, "scale_act out")
@@ -592,6 +724,12 @@ def _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part):
     rows = y.numel() // c
     if part is not None:
         return part, part.shape[0]
+    if _b16(dout):
+        r = lib().bn_act_bwd_reduce_rows_b16(rows)
+        part = scratch(r * 2 * c, y.device, slot=0)
+        lib().bn_act_bwd_reduce_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), dout.stride(-2), mean.data_ptr(), invstd.data_ptr(),
+                                    _p(gamma), _p(beta), act, float(slope), rows, c, part.data_ptr(), _s())
+        return part, r
     r = lib().channel_stats_rows(rows)
     part = scratch(r * 2 * c, y.device, slot=0)
     lib().bn_act_bwd_reduce(y.data_ptr(), dout.data_ptr(), dout.stride(-2), mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
@@ -611,6 +749,11 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, pa
     sums = torch.empty((2, c), dtype=torch.float32, device=dev)
     ws = scratch(lib().bn_ws(c), dev, slot=2)
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
+    if _b16(dout):          # bf16 storage: dy bf16 (y bf16, or the stem's fp32 raw output)
+        dy = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+        lib().bn_act_bwd_apply_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma),
+                                   _p(beta), act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _s())
+        return dy, sums[1], sums[0]
     dy = torch.empty_like(y)
     lib().bn_act_bwd_apply(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
                            act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _p(amax_out), _s())
@@ -1195,16 +1338,26 @@ def box_iou(b1, b2):
 def upsample2_into(src, dst_view):
     """src (N,h,w,c) -> dst_view (N,2h,2w,c) (a channel slice of a wider NHWC buffer)."""
     n, h, w, c = src.shape
+    if _b16(src):
+        lib().upsample2_nhwc_b16(src.data_ptr(), src.stride(2), dst_view.data_ptr(), dst_view.stride(2), n, h, w, c, _s())
+        return
     lib().upsample2_nhwc(src.data_ptr(), src.stride(2), dst_view.data_ptr(), dst_view.stride(2), n, h, w, c, _s())
 
 
 def upsample2_bwd(ddst_view, dsrc, accumulate):
     n, h, w, c = dsrc.shape
+    if _b16(dsrc):
+        lib().upsample2_nhwc_bwd_b16(ddst_view.data_ptr(), ddst_view.stride(2), dsrc.data_ptr(), dsrc.stride(2), n, h, w, c,
+                                     int(accumulate), _s())
+        return
     lib().upsample2_nhwc_bwd(ddst_view.data_ptr(), ddst_view.stride(2), dsrc.data_ptr(), dsrc.stride(2), n, h, w, c,
                              int(accumulate), _s())
 
 
 def copy_slice(src_view, dst_view, accumulate=False):
+    if _b16(src_view) or _b16(dst_view):
+        cast_rows(src_view, dst_view, accumulate)
+        return
     c = src_view.shape[-1]
     rows = src_view.numel() // c
     _rows(src_view, "copy_slice src"); _rows(dst_view, "copy_slice dst")

@@ -438,6 +438,53 @@ int dcn_decode_boxes(const float* const* outbox, const float* anchors, int size,
 /* utils/utils.py:76-104 (x1y1x2y2) row by row. */
 int dcn_box_iou(const float* box1, const float* box2, int n, float* iou, void* stream);
 
+/* ---- bf16 storage (BASELINE.json configs[2], ABI 305) -------------------------------------------------------------------
+ * The conv stack on tensors that ARE bf16 in HBM: activations, raw conv outputs and their gradients are bf16 NHWC tensors,
+ * filter banks the bf16 forms dcn_prepare_filters writes ([Cout][k*k*Cin] for the forward, [Cin][k*k*Cout] for the data
+ * gradient); accumulators, BatchNorm statistics, weight gradients and master weights stay fp32.  Replaces, like their fp32
+ * namesakes, nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU / the shortcut add / MyUpsample2 + route concat of
+ * model/darknet.py:158-191,400-405 and their autograd (train_DCNet.py:645).  cin, cout multiples of 32 (the 3-channel stem
+ * keeps fp32 kernels; dcn_scale_act_b16 with y_f32 = 1 turns its raw output into the first bf16 activation).  `*_f32` flags:
+ * that tensor is fp32 instead (the boundary to fp32 consumers).  The reference has no bf16 semantics: parity
+ * is defined against the exact model — the same arithmetic on the bf16 values — in tests/test_b16_gpu.py. */
+int dcn_conv2d_stats_rows_b16(int n, int h, int wd, int cout, int ksize, int stride);
+/* y = epilogue(conv(x, w16)): scale / shift / act / residual (bf16, pixel stride ldr) / accumulate as dcn_conv2d_fwd; stats
+ * [dcn_conv2d_stats_rows_b16][2][cout] = sum / sum of squares of the raw result AS STORED (rounded to bf16 first). */
+int dcn_conv2d_fwd_b16(const void* x, const void* w16, void* y, int y_f32, int n, int h, int wd, int cin, int cout, int ksize, int stride,
+                       const float* scale, const float* shift, int act, float slope, const void* residual, int ldr, int ldy,
+                       float* stats, int accumulate, void* stream);
+/* dx (+)= conv^T(dy, wt16) (stride 1: flipped taps; stride 2: four parity classes).  tap_* (stride 1, optional): the BatchNorm +
+ * activation whose output this convolution read, y in bf16 — tap_stats receives the partial sums dcn_bn_act_bwd_reduce_b16 would
+ * form from the finished dx, *tap_rows the rows written (0: no tap taken). */
+int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt16, void* dx, int dx_f32, int n, int h, int wd, int cin, int cout,
+                            int ksize, int stride, int accumulate, const void* tap_y, const float* tap_mean, const float* tap_invstd,
+                            const float* tap_gamma, const float* tap_beta, int tap_act, float tap_slope, float* tap_stats,
+                            int tap_stats_rows, int* tap_rows, void* stream);
+/* dw [cout][k][k][cin] fp32 = sum over pixels of dy (x) x, both bf16; ws: dcn_conv2d_bwd_weight_ws_b16 floats (split-K slabs,
+ * summed in a fixed order); geom: the table of dcn_conv2d_geom for this geometry. */
+int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
+                              int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
+/* out (bf16, pixel stride ldo) = act(scale * y + shift) + residual (bf16): BatchNorm apply + LeakyReLU + shortcut. */
+int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, const float* shift, int act, float slope, const void* residual,
+                      int ldr, void* out, int64_t rows, int c, int ldo, void* stream);
+/* BatchNorm + activation backward on bf16 y / dout / dy: the reduce pass (stats [dcn_bn_act_bwd_reduce_rows_b16(rows)][2][c], to be
+ * summed by dcn_bn_bwd_sums) and the apply pass, arithmetic of dcn_bn_act_bwd_reduce / _apply term by term. */
+int dcn_bn_act_bwd_reduce_rows_b16(int64_t rows);
+int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, int act, float slope, int64_t rows, int c, float* stats,
+                              void* stream);
+int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, int act, float slope, const float* sums, int64_t count,
+                             int64_t rows, int c, void* dy, void* stream);
+/* dst[r][:c] (+)= src[r][:c], element types by flag (0 fp32, 1 bf16), element strides lds / ldd: casts at the fp32 boundary,
+ * channel-slice copies of the route concat and their accumulating backward. */
+int dcn_cast_rows(const void* src, int src_b16, int lds, void* dst, int dst_b16, int ldd, int64_t rows, int c, int accumulate,
+                  void* stream);
+int dcn_upsample2_nhwc_b16(const void* src, int lds, void* dst, int ldd, int n, int h, int w, int c, void* stream);
+int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc, int lds, int n, int h, int w, int c, int accumulate,
+                               void* stream);
+
 /* ---- top-k candidate cache + temporal post-processing of the inference path (ABI 305) ----------------------------- */
 /* test_DCNet.py:587-643,662-705 (save_cache / get_topk_pred_bbox): per clip b of n, the top_k (<= 64) largest modulated
  * confidences over 3 scales x 3 anchors x g x g of outbox[s] [n][15][g][g] (contiguous; grids[s] = size / (32 >> s)), sorted

@@ -1,0 +1,220 @@
+"""bf16 storage (BASELINE.json configs[2]; ``ops.set_precision("bf16s")``): activations, raw conv outputs and their gradients ARE bf16
+tensors in HBM.  The reference has no bf16 semantics, so parity is defined against each kernel's EXACT MODEL — the same
+arithmetic in fp64 on the bf16 values the kernel reads, rounded to bf16 where the kernel stores bf16 — which the kernels must meet to
+accumulation-order accuracy; the end-to-end tests then bound the mode against the fp32 run of the same network."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _ulp_close(got, ref64, name, ulps=1.01, floor=1e-6):
+    """got (bf16 tensor) against an fp64 reference: within `ulps` bf16 roundings of it (2^-8 relative each) plus a floor."""
+    g = got.double().cpu(); r = ref64.double().cpu()
+    assert g.shape == r.shape, (name, g.shape, r.shape)
+    tol = ulps * 2.0 ** -8 * r.abs() + floor * max(1.0, float(r.abs().max()))
+    bad = (g - r).abs() > tol
+    assert not bool(bad.any()), f"{name}: {int(bad.sum())} of {bad.numel()} beyond {ulps} bf16 ulp; worst {float(((g - r).abs() - tol).max()):.3e}"
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride
+    (2, 13, 13, 64, 128, 3, 1),
+    (2, 13, 13, 128, 64, 1, 1),
+    (1, 26, 26, 32, 64, 3, 2),
+    (2, 16, 20, 64, 32, 1, 1),        # 32 filters: the 256 x 32 tile
+    (1, 9, 11, 96, 160, 3, 1),        # ragged M, 160 = 5 x 32 filters
+    (3, 8, 8, 256, 256, 1, 1),
+    (1, 27, 29, 64, 128, 3, 2),       # odd sizes under stride 2 (ragged parity classes)
+    (2, 52, 52, 128, 256, 3, 1),      # more than one round of tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case):
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, cin, cout, k, st = case
+    T = k * k
+    x = _bf(_rand(n, h, w, cin, seed=1)).to(dev)
+    wt = _bf(_rand(cout, k, k, cin, seed=2) / (cin * T) ** 0.5).to(dev)              # OHWI bank, bf16
+    xd = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wd = wt.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    yd = F.conv2d(xd, wd, stride=st, padding=(k - 1) // 2)
+    ho, wo = yd.shape[2], yd.shape[3]
+    dy = _bf(_rand(n, ho, wo, cout, seed=3) / 8).to(dev)
+    yd.backward(dy.double().cpu().permute(0, 3, 1, 2))
+    ref_y = yd.detach().permute(0, 2, 3, 1)
+    # ---- forward: raw result bf16 + BatchNorm partial sums of the stored values ----
+    y, stats = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st, want_stats=True)
+    assert y.dtype == torch.bfloat16 and y.shape == (n, ho, wo, cout)
+    _ulp_close(y, ref_y, "fwd")
+    s = stats.double().sum(0).cpu()
+    yf = y.double().cpu().reshape(-1, cout)
+    assert torch.allclose(s[0], yf.sum(0), rtol=1e-5, atol=1e-4 * float(yf.abs().sum(0).max()))
+    assert torch.allclose(s[1], (yf * yf).sum(0), rtol=1e-5, atol=1e-6 * float((yf * yf).sum(0).max()))
+    y32, _ = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st, out_f32=True)
+    assert y32.dtype == torch.float32 and float((y32.double().cpu() - ref_y).abs().max()) <= 3e-5 * max(1.0, float(ref_y.abs().max()))
+    again, _ = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st)
+    assert torch.equal(again, y)                                                      # bitwise repeatable
+    # ---- epilogue: scale / shift / LeakyReLU / shortcut (bf16) ----
+    sc = (_rand(cout, seed=4).abs() + 0.5).to(dev); sh = _rand(cout, seed=5).to(dev)
+    res = _bf(_rand(n, ho, wo, cout, seed=6)).to(dev)
+    o, _ = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st, sc, sh, ops.ACT_LEAKY, 0.1, residual=res)
+    t = ref_y * sc.double().cpu() + sh.double().cpu()
+    _ulp_close(o, torch.where(t > 0, t, 0.1 * t) + res.double().cpu(), "fwd epilogue")
+    # ---- data gradient (transposed bank [Cin][T][Cout]) ----
+    wt_t = wt.reshape(cout, T, cin).permute(2, 1, 0).contiguous().reshape(-1)
+    dx = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st)
+    ref_dx = xd.grad.permute(0, 2, 3, 1)
+    _ulp_close(dx, ref_dx, "dgrad")
+    base = _bf(_rand(n, h, w, cin, seed=7)).to(dev)
+    acc = base.clone()
+    ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st, out=acc, accumulate=True)
+    _ulp_close(acc, ref_dx + base.double().cpu(), "dgrad accumulate")
+    dx32 = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st, out_f32=True)
+    assert float((dx32.double().cpu() - ref_dx).abs().max()) <= 3e-5 * max(1.0, float(ref_dx.abs().max()))
+    # ---- weight gradient: fp32 out, fp32 accumulation of exact bf16 products ----
+    dw = ops.conv2d_bwd_weight_b16(x, dy, k, st)
+    ref_dw = wd.grad.permute(0, 2, 3, 1)
+    assert dw.dtype == torch.float32 and dw.shape == (cout, k, k, cin)
+    assert float((dw.double().cpu() - ref_dw).abs().max()) <= 5e-5 * max(1.0, float(ref_dw.abs().max()))
+    assert torch.equal(ops.conv2d_bwd_weight_b16(x, dy, k, st), dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 26, 26, 128, 256, 3), (3, 13, 13, 256, 128, 1), (1, 20, 12, 64, 64, 3)])
+def test_b16_dgrad_batchnorm_tap_equals_the_reduce_pass(shape):
+    """A stride-1 data gradient that completes the gradient of a conv + BatchNorm output forms that BatchNorm's backward partial sums in
+    its epilogue: they must equal dcn_bn_act_bwd_reduce_b16 on the gradient as stored."""
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w, cout, cin, k = shape           # the convolution maps cin -> cout; its data gradient has cin "filters"
+    T = k * k
+    dy = _bf(_rand(n, h, w, cout, seed=1) / 4).to(dev)
+    wt_t = _bf(_rand(cin, T, cout, seed=2) / (cout * T) ** 0.5).to(dev).reshape(-1)
+    yprev = _bf(_rand(n, h, w, cin, seed=3)).to(dev)
+    mean = _rand(cin, seed=4, scale=0.1).to(dev); invstd = (_rand(cin, seed=5).abs() + 0.5).to(dev)
+    gamma = _rand(cin, seed=6).to(dev); beta = _rand(cin, seed=7, scale=0.3).to(dev)
+    tap = dict(y=yprev, mean=mean, invstd=invstd, gamma=gamma, beta=beta, act=ops.ACT_LEAKY, slope=0.1)
+    dx, part = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, 1, tap=tap)
+    assert part is not None
+    plain = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, 1)
+    assert torch.equal(dx, plain)
+    ref_part, r = ops._bn_bwd_partials(yprev, dx, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, None)
+    a = part.double().sum(0).cpu(); b = ref_part[:r * 2 * cin].reshape(r, 2, cin).double().sum(0).cpu()
+    assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * float(b.abs().max()))
+
+
+def test_b16_batchnorm_passes_match_their_formulas():
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    for (rows_shape, c, y_f32) in (((2, 13, 13), 128, False), ((1, 37, 5), 32, True), ((3, 8, 8), 264, False)):
+        n_rows = rows_shape[0] * rows_shape[1] * rows_shape[2]
+        y = _rand(*rows_shape, c, seed=1)
+        y = (y if y_f32 else _bf(y)).to(dev)
+        scale = (_rand(c, seed=2).abs() + 0.3).to(dev); shift = _rand(c, seed=3).to(dev)
+        res = _bf(_rand(*rows_shape, c, seed=4)).to(dev)
+        out = ops.scale_act(y, scale, shift, ops.ACT_LEAKY, 0.1, residual=res, out_b16=True)
+        t = y.double().cpu() * scale.double().cpu() + shift.double().cpu()
+        _ulp_close(out, torch.where(t > 0, t, 0.1 * t) + res.double().cpu(), "scale_act")
+        # into a channel slice of a wider buffer
+        wide = torch.zeros(*rows_shape, c + 64, dtype=torch.bfloat16, device=dev)
+        ops.scale_act(y, scale, shift, ops.ACT_NONE, 0.0, out=wide[..., 64:])
+        _ulp_close(wide[..., 64:], t, "scale_act slice")
+        assert float(wide[..., :64].abs().max()) == 0.0
+        # backward
+        mean = _rand(c, seed=5, scale=0.2).to(dev); invstd = (_rand(c, seed=6).abs() + 0.5).to(dev)
+        gamma = _rand(c, seed=7).to(dev); beta = _rand(c, seed=8, scale=0.3).to(dev)
+        dout = _bf(_rand(*rows_shape, c, seed=9)).to(dev)
+        dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1)
+        assert dy.dtype == torch.bfloat16
+        yd, dd = y.double().cpu().reshape(-1, c), dout.double().cpu().reshape(-1, c)
+        xh = (yd - mean.double().cpu()) * invstd.double().cpu()
+        g = torch.where(gamma.double().cpu() * xh + beta.double().cpu() <= 0, 0.1 * dd, dd)
+        sg, sgx = g.sum(0), (g * xh).sum(0)
+        ref = gamma.double().cpu() * invstd.double().cpu() * (g - sg / n_rows - xh * sgx / n_rows)
+        _ulp_close(dy.reshape(-1, c), ref, "bn backward", ulps=1.5, floor=2e-6)
+        assert torch.allclose(dbeta.double().cpu(), sg, rtol=1e-4, atol=1e-4 * float(sg.abs().max()))
+        assert torch.allclose(dgamma.double().cpu(), sgx, rtol=1e-4, atol=1e-4 * float(sgx.abs().max()))
+
+
+def test_b16_layout_kernels():
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    up = _bf(_rand(2, 5, 7, 64, seed=1)).to(dev); lat = _bf(_rand(2, 10, 14, 96, seed=2)).to(dev)
+    buf = torch.zeros(2, 10, 14, 160, dtype=torch.bfloat16, device=dev)
+    ops.upsample2_into(up, buf[..., :64]); ops.copy_slice(lat, buf[..., 64:])
+    ref = torch.cat([up.repeat_interleave(2, 1).repeat_interleave(2, 2), lat], dim=3)
+    assert torch.equal(buf, ref)
+    d = _bf(_rand(2, 10, 14, 160, seed=3)).to(dev)
+    dsrc = torch.empty(2, 5, 7, 64, dtype=torch.bfloat16, device=dev)
+    ops.upsample2_bwd(d[..., :64], dsrc, False)
+    s4 = d[..., :64].double().reshape(2, 5, 2, 7, 2, 64).sum((2, 4))
+    _ulp_close(dsrc, s4, "upsample2 bwd")
+    ops.upsample2_bwd(d[..., :64], dsrc, True)
+    _ulp_close(dsrc, s4 * 2, "upsample2 bwd accumulate", ulps=2.0)
+    acc = lat.clone()
+    ops.copy_slice(d[..., 64:], acc, accumulate=True)
+    _ulp_close(acc, lat.double() + d[..., 64:].double(), "copy_slice accumulate")
+    x = _rand(3, 4, 4, 72, seed=4).to(dev)
+    assert torch.equal(ops.to_b16(x), x.to(torch.bfloat16)) and torch.equal(ops.to_f32(ops.to_b16(x)), x.to(torch.bfloat16).float())
+
+
+def test_b16_backbone_training_step_against_the_fp32_run():
+    """The whole backbone in bf16 storage, forward + backward in train mode: taps and parameter gradients stay within what bf16 rounding
+    over ~75 layers does to this random-init network (the bf16-operand mode's own distance from fp32 is the yardstick), nothing is
+    non-finite, fp32 is what comes out at the boundary, and the step is bitwise repeatable."""
+    from dcnet_amd import ops
+    from dcnet_amd.darknet import Darknet
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = Darknet(config_path="", img_size=128).to(dev).train()
+    img = _rand(4, 3, 128, 128, seed=1).to(dev)
+    gouts = None
+    res = {}
+    for mode in ("fp32", "bf16", "bf16s", "bf16s"):
+        ops.set_precision(mode)
+        try:
+            for p in net.parameters():
+                p.grad = None
+            taps = net.forward_nhwc(img)
+            if gouts is None:
+                gouts = [_rand(*t.shape, seed=10 + i).to(dev) / t[0].numel() ** 0.5 for i, t in enumerate(taps)]
+            torch.autograd.backward(taps, gouts)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_precision("fp32")
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        key = mode if mode not in res else mode + "_again"
+        res[key] = ([t.detach().clone() for t in taps], grads)
+    assert all(t.dtype == torch.float32 and bool(torch.isfinite(t).all()) for t in res["bf16s"][0])
+    assert all(bool(torch.isfinite(g).all()) for g in res["bf16s"][1].values())
+    assert set(res["bf16s"][1]) == set(res["fp32"][1])
+    for a, b in zip(res["bf16s"][0], res["bf16s_again"][0]):
+        assert torch.equal(a, b)
+    for k_ in res["bf16s"][1]:
+        assert torch.equal(res["bf16s"][1][k_], res["bf16s_again"][1][k_]), k_
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-20))
+    for i in range(3):
+        d_ops, d_sto = rel(res["bf16"][0][i], res["fp32"][0][i]), rel(res["bf16s"][0][i], res["fp32"][0][i])
+        assert d_sto < max(4 * d_ops, 0.05), (i, d_ops, d_sto)
+    worst = 0.0
+    for k_, gref in res["fp32"][1].items():
+        if gref.numel() < 64 or float(gref.norm()) == 0.0:
+            continue
+        d_ops, d_sto = rel(res["bf16"][1][k_], gref), rel(res["bf16s"][1][k_], gref)
+        worst = max(worst, d_sto)
+        assert d_sto < max(5 * d_ops, 0.25), (k_, d_ops, d_sto)
+    assert worst > 1e-4          # it IS reduced precision
