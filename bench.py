@@ -149,6 +149,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="T")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s", "fp8"], default="fp32",
+                    help="arithmetic of the TIMED region (default fp32 = BASELINE configs[1]; bf16s = bf16 storage, configs[2] on one GPU; "
+                         "reduced-precision runs say so in dtype / config.arith)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="timed region as one replayed hipGraph per step (auto: on; off = the eager Python step)")
     ap.add_argument("--profile-steps", type=int, default=2,
@@ -320,6 +323,7 @@ def main():
     for kv in [t for t in args.tune.split(",") if t]:
         k_, v_ = kv.split("=")
         L.set_tuning(k_.encode(), int(v_))
+    ops.set_precision(args.precision)
     torch.manual_seed(1234)            # identical initial weights on every rank (rank 0's are broadcast as well)
     model = grounding_model(corpus=list(range(1000)), light=False, emb_size=512, coordmap=True,
                             bert_model="bert-base-uncased", dataset="vid", img_size=args.size,
@@ -470,7 +474,7 @@ def main():
         el = time.perf_counter() - t1
         L.prof_enable(0)
         ops.WGRAD_SIDE, model.language_stream, model.sampling_stream = was
-        ops.set_precision("fp32")
+        ops.set_precision(args.precision)
         r = collect(); r["ms_per_step"] = el / nsteps * 1e3; r["steps"] = nsteps
         return r
 
@@ -521,7 +525,7 @@ def main():
     # tools/graph_event_probe.hip).  `rocprofv3 -- python3 bench.py --graph off --no-side-streams` shows the same averages.  The
     # in-step durations of the replayed step (weight gradients beside the data-gradient chain) come from the committed rocprofv3
     # summary of the default command (profiles/in_step_latest.json) and are quoted beside them.
-    prof = run_pass(args.profile_steps, "fp32", False) if args.profile_steps > 0 else None
+    prof = run_pass(args.profile_steps, args.precision, False) if args.profile_steps > 0 else None
     alts = {}
     if args.alt_steps > 0:
         alts["fp32_bf16x3"] = run_pass(args.alt_steps, "fp32_bf16x3", False)
@@ -556,9 +560,12 @@ def main():
 
         res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt,
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips}/GPU L=20 fp32, {n_img} img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
-                          "arith": "f16x2-split MFMA, fp32 accumulate", "parallelism": f"dp{world}",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+               "dtype": {"fp32": "f32", "bf16": "bf16", "bf16s": "bf16", "fp8": "fp8"}[args.precision],
+               "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips}/GPU L=20 {args.precision}, {n_img} img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
+                          "arith": {"fp32": "f16x2-split MFMA, fp32 accumulate", "bf16": "bf16 operands, fp32 tensors, fp32 accumulate",
+                                    "bf16s": "bf16 storage (conv stacks), fp32 accumulate + master weights",
+                                    "fp8": "fp8 e4m3 operands, fp32 accumulate"}[args.precision], "parallelism": f"dp{world}",
                           "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4),
                "loss_hex": float(last_loss).hex()}

@@ -62,10 +62,10 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const TS* __restrict__ s
 }
 
 // ---- out = act(scale * y + shift) + residual   (y: raw conv output, fp32 for the stem, bf16 elsewhere; out, residual: bf16) ------
-template <typename TY>
+template <typename TY, typename TO>
 __global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act, float slope,
-                                                          const __bf16* __restrict__ residual, int ldr, __bf16* __restrict__ out,
+                                                          const __bf16* __restrict__ residual, int ldr, TO* __restrict__ out,
                                                           int64_t rows, int c, int ldo) {
   const int c8 = c >> 3;
   const int64_t total = rows * c8;
@@ -88,13 +88,13 @@ __global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__
 #pragma unroll
       for (int k = 0; k < 8; ++k) v.v[k] += rr.v[k];
     }
-    st8<__bf16>(out + r * ldo + ch, v);
+    st8<TO>(out + r * ldo + ch, v);
   }
 }
 
 // ---- dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * act'(bn(y))   (bn.hip bn_act_bwd_apply_kernel) --------
-template <typename TY>
-__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restrict__ y, const __bf16* __restrict__ dout, int lddo,
+template <typename TY, typename TD>
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restrict__ y, const TD* __restrict__ dout, int lddo,
                                                              const float* mean, const float* invstd, const float* gamma, const float* beta,
                                                              int act, float slope, const float* sums, float inv_count, int64_t rows, int c,
                                                              __bf16* __restrict__ dy) {
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restric
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / c8; const int ch = (int)(i - r * c8) * 8;
     const F8 v = ld8<TY>(y + r * c + ch);
-    const F8 d = ld8<__bf16>(dout + r * lddo + ch);
+    const F8 d = ld8<TD>(dout + r * lddo + ch);
     const F8 mu = ld8<float>(mean + ch), is = ld8<float>(invstd + ch);
     F8 g, b;
 #pragma unroll
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restric
 
 // ---- per-channel partial sums of g and g * xhat over 128-row blocks (bn.hip channel_partials_kernel<1>) ----------------------------
 // block (row block, 128 channels): thread = (8 channels, row phase of 16); stats [row blocks][2][c]
-template <typename TY>
-__global__ __launch_bounds__(256) void partials16_kernel(const TY* __restrict__ y, const __bf16* __restrict__ dout, int lddo, const float* mean,
+template <typename TY, typename TD>
+__global__ __launch_bounds__(256) void partials16_kernel(const TY* __restrict__ y, const TD* __restrict__ dout, int lddo, const float* mean,
                                                          const float* invstd, const float* gamma, const float* beta, int act, float slope,
                                                          int64_t rows, int c, float* __restrict__ stats) {
   __shared__ float red[2][16][128];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void partials16_kernel(const TY* __restrict__ 
       const int64_t r = r0 + ty + 16 * j;
       if (r >= rows) continue;
       const F8 v = ld8<TY>(y + r * c + ch);
-      const F8 d = ld8<__bf16>(dout + r * lddo + ch);
+      const F8 d = ld8<TD>(dout + r * lddo + ch);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = (v.v[k] - mu.v[k]) * is.v[k];
@@ -241,19 +241,18 @@ extern "C" int dcn_cast_rows(const void* src, int src_b16, int lds_, void* dst, 
 }
 
 extern "C" int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, const float* shift, int act, float slope, const void* residual,
-                                 int ldr, void* out, int64_t rows, int c, int ldo, void* stream_) {
+                                 int ldr, void* out, int out_f32, int64_t rows, int c, int ldo, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (ldo <= 0) ldo = c;
   if (ldr <= 0) ldr = c;
   DCN_CHECK_ARG(y && out && rows > 0 && c > 0 && c % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0, "scale_act_b16: bad argument (c=%d)", c);
-  const int pid = prof_begin(43, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 2.0 + (residual ? 2.0 : 0.0)), stream);
+  const int pid = prof_begin(43, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0) + (residual ? 2.0 : 0.0)), stream);
   const dim3 g(grid_for(rows * (c / 8)));
-  if (y_f32)
-    hipLaunchKernelGGL((scale_act16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, scale, shift, act, slope, (const __bf16*)residual, ldr,
-                       (__bf16*)out, rows, c, ldo);
-  else
-    hipLaunchKernelGGL((scale_act16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, scale, shift, act, slope, (const __bf16*)residual, ldr,
-                       (__bf16*)out, rows, c, ldo);
+  const __bf16* res = (const __bf16*)residual;
+#define DCN_SA(TY, TO) hipLaunchKernelGGL((scale_act16_kernel<TY, TO>), g, dim3(256), 0, stream, (const TY*)y, scale, shift, act, slope, res, ldr, (TO*)out, rows, c, ldo)
+  if (y_f32) { if (out_f32) DCN_SA(float, float); else DCN_SA(float, __bf16); }
+  else { if (out_f32) DCN_SA(__bf16, float); else DCN_SA(__bf16, __bf16); }
+#undef DCN_SA
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("scale_act_b16");
   return DCN_OK;
@@ -261,40 +260,36 @@ extern "C" int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, c
 
 extern "C" int dcn_bn_act_bwd_reduce_rows_b16(int64_t rows) { return cdiv(rows, 128); }
 
-extern "C" int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+extern "C" int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int dout_f32, int lddo, const float* mean, const float* invstd,
                                          const float* gamma, const float* beta, int act, float slope, int64_t rows, int c, float* stats,
                                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (lddo <= 0) lddo = c;
   DCN_CHECK_ARG(y && dout && mean && invstd && stats && rows > 0 && c > 0 && c % 8 == 0 && lddo % 8 == 0, "bn_act_bwd_reduce_b16: bad argument");
-  const int pid = prof_begin(44, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 2.0), stream);
+  const int pid = prof_begin(44, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + (dout_f32 ? 4.0 : 2.0)), stream);
   const dim3 g(cdiv(rows, 128), cdiv(c, 128));
-  if (y_f32)
-    hipLaunchKernelGGL((partials16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
-                       act, slope, rows, c, stats);
-  else
-    hipLaunchKernelGGL((partials16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
-                       act, slope, rows, c, stats);
+#define DCN_PT(TY, TD) hipLaunchKernelGGL((partials16_kernel<TY, TD>), g, dim3(256), 0, stream, (const TY*)y, (const TD*)dout, lddo, mean, invstd, gamma, beta, act, slope, rows, c, stats)
+  if (y_f32) { if (dout_f32) DCN_PT(float, float); else DCN_PT(float, __bf16); }
+  else { if (dout_f32) DCN_PT(__bf16, float); else DCN_PT(__bf16, __bf16); }
+#undef DCN_PT
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_reduce_b16");
   return DCN_OK;
 }
 
-extern "C" int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+extern "C" int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int dout_f32, int lddo, const float* mean, const float* invstd,
                                         const float* gamma, const float* beta, int act, float slope, const float* sums, int64_t count,
                                         int64_t rows, int c, void* dy, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (lddo <= 0) lddo = c;
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 8 == 0 && lddo % 8 == 0 && count > 0,
                 "bn_act_bwd_apply_b16: bad argument");
-  const int pid = prof_begin(45, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + 4.0), stream);
+  const int pid = prof_begin(45, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + (dout_f32 ? 4.0 : 2.0) + 2.0), stream);
   const dim3 g(grid_for(rows * (c / 8)));
-  if (y_f32)
-    hipLaunchKernelGGL((bn_bwd_apply16_kernel<float>), g, dim3(256), 0, stream, (const float*)y, (const __bf16*)dout, lddo, mean, invstd, gamma, beta,
-                       act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply16_kernel<__bf16>), g, dim3(256), 0, stream, (const __bf16*)y, (const __bf16*)dout, lddo, mean, invstd, gamma,
-                       beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy);
+#define DCN_AP(TY, TD) hipLaunchKernelGGL((bn_bwd_apply16_kernel<TY, TD>), g, dim3(256), 0, stream, (const TY*)y, (const TD*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy)
+  if (y_f32) { if (dout_f32) DCN_AP(float, float); else DCN_AP(float, __bf16); }
+  else { if (dout_f32) DCN_AP(__bf16, float); else DCN_AP(__bf16, __bf16); }
+#undef DCN_AP
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply_b16");
   return DCN_OK;

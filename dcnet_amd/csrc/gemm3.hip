@@ -333,7 +333,9 @@ void gemm3_set_tuning(int v) { g_gemm3 = v; }
 
 // shapes the kernel takes: rows of 16-byte granularity everywhere, the T operands' tile columns inside their rows
 bool gemm3_applicable(int M, int N, int K, int batch) {
-  return g_gemm3 && igemm_precision() == 4 && M >= 512 && N >= 256 && K >= 64 && batch >= 1;
+  // (precision 2, the bf16 modes: the co-attention keeps its fp32-accurate f16 split — its operands are fp32 tensors either way, and
+  //  these tiles are twice as fast as the fp32-pipe tiles the mode would fall back to)
+  return g_gemm3 && (igemm_precision() == 4 || igemm_precision() == 2) && M >= 512 && N >= 256 && K >= 64 && batch >= 1;
 }
 
 int gemm3_presplit(const float* src, int ld, long long bs, float* dst, int ldd, long long bsd, int batch, int rows, int c,

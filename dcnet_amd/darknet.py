@@ -272,7 +272,7 @@ def _cpad(c: int) -> int:
     return 4 if c <= 4 else ops.pad32(c)
 
 
-def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], banks=None):
+def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], banks=None, taps_b16: bool = False):
     """P[slot] = dict(w=OIHW weight, b=conv bias|None, gamma, beta, rm, rv).  Returns tap tensors.
     banks (ops.FilterBanks, refreshed by the caller): the filter banks of all slots in their GEMM forms."""
     out: Dict[int, torch.Tensor] = {-1: x_nhwc}
@@ -336,8 +336,6 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     if save is not None:
                         save[op.slot] = (x, y, mi, w, None, None)
                 else:
-                    if save is not None:
-                        raise NotImplementedError("bf16 storage: frozen-BatchNorm fine-tuning is not built (train-mode BatchNorm or inference)")
                     if op.bn:
                         ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5)
                         scale, shift = ss[0], ss[1]
@@ -380,8 +378,6 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                         o = ops.scale_act(a, None, None, ops.ACT_NONE, 0.0, residual=res, amax_out=ao)
                     save[op.slot] = (x, a, scale, w, ax, aw)
             if s16:
-                if save is not None and not (op.bn and training):
-                    raise NotImplementedError("bf16 storage: frozen-BatchNorm fine-tuning is not built")
                 o = ops.to_b16(o)          # (the stem in inference: its fused epilogue wrote fp32)
             out[op.dst] = o; amx[op.dst] = ao
         elif isinstance(op, _UpCatOp):
@@ -395,7 +391,8 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             amx[op.dst] = ops.absmax(lat, ops.absmax(up)) if am else None
         else:
             out[op.dst] = out[op.src]; amx[op.dst] = amx.get(op.src)
-    return [ops.to_f32(out[t]) if s16 else out[t] for t in taps], [amx.get(t) for t in taps], early_event
+    # (taps_b16: the caller's first kernels read bf16 — grounding_model's mapping convolutions — so the taps stay as they are)
+    return [ops.to_f32(out[t]) if (s16 and not taps_b16) else out[t] for t in taps], [amx.get(t) for t in taps], early_event
 
 
 def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bucket_bytes: int = 0):
@@ -569,8 +566,11 @@ class _DarknetFn(torch.autograd.Function):
         P = net._param_table(flat)
         x = ops.nchw_to_nhwc(image.contiguous(), 4)
         need_grad = any(ctx.needs_input_grad[3:])
+        if ops.storage_b16() and not training:
+            need_grad = False          # bf16 storage has no frozen-BatchNorm backward: inference only in eval mode (backward() says so)
         save = {} if need_grad else None
-        outs, tap_amax, net._early_event = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P))
+        outs, tap_amax, net._early_event = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P),
+                                                        taps_b16=bool(net.__dict__.get("_taps_b16")))
         net._tap_amax = tap_amax              # abs-max words of the three taps (read by the head's first convolutions)
         if save is not None:
             # outputs must go through save_for_backward (an attribute reference would make a
@@ -587,6 +587,9 @@ class _DarknetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         net = ctx.net
+        if ctx.save is None:
+            raise NotImplementedError("dcnet_amd.Darknet, bf16 storage: no backward in eval mode (frozen-BatchNorm fine-tuning is not built); "
+                                      "train with .train(), or use the fp32 precision mode")
         outs = ctx.saved_tensors
         save = {slot: ((outs[t[0][1]],) + t[1:] if isinstance(t[0], tuple) else t) for slot, t in ctx.save.items()}
         ctx.save = None
@@ -695,7 +698,9 @@ class Darknet(nn.Module):
         fb.pending = prep
         return fb
 
-    def forward_nhwc(self, x: torch.Tensor) -> List[torch.Tensor]:
+    def forward_nhwc(self, x: torch.Tensor, taps_b16: bool = False) -> List[torch.Tensor]:
+        """taps_b16 (bf16-storage mode only): hand the three taps out as the bf16 tensors they are instead of casting them to fp32."""
+        self.__dict__["_taps_b16"] = bool(taps_b16) and ops.storage_b16()
         if not x.is_cuda:
             raise RuntimeError("dcnet_amd.Darknet runs on an MI355X only: move the model and inputs to cuda "
                                "(there is no CPU path; the CPU restatement lives in oracle/ for tests)")

@@ -15,14 +15,34 @@ class ConvBNAct(torch.autograd.Function):
     + ReLU.  x may carry zero-padded channels beyond the weight's Cin (K-padding to 32)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float, amax_x=None, bank=None):
+    def forward(ctx, x, weight, gamma, beta, bn, ksize: int, training: bool, slope: float, amax_x=None, bank=None, out_b16: bool = False):
         """Returns (out, amax_out): amax_* are the abs-max words of ops.amax_* (None outside the f16-split precision).
         bank: this layer's entry of an ops.FilterBanks table refreshed this step (OHWI / split / transposed banks + abs-max word):
-        nothing is transposed, measured or split per launch then."""
+        nothing is transposed, measured or split per launch then.
+        bf16-storage mode (ops.storage_b16(), a bank given): the block runs on bf16 tensors — x bf16 (an fp32 x is cast once), raw result
+        and saved tensors bf16, out bf16 when ``out_b16`` (the consumer is another bf16 block) else fp32, written by the BatchNorm pass
+        itself; the input gradient comes back in x's dtype straight from the data-gradient kernel."""
         cout = weight.shape[0]
         am = ops.use_amax()
         if bank is not None and x.shape[3] != weight.shape[1]:
             bank = None                    # (K-padded input: the per-launch path pads the bank)
+        ctx.b16 = None
+        if ops.storage_b16() and bank is not None:
+            x_f32 = x.dtype == torch.float32
+            x16 = ops.to_b16(x.contiguous())
+            if training:
+                y, stats = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, want_stats=True)
+                mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
+                                     bn.running_mean, bn.running_var)
+                bn.num_batches_tracked += 1
+                out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope, out_f32=not out_b16)
+                ctx.save_for_backward(x16, y, mi, gamma, beta)
+            else:
+                ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
+                out, _ = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
+            ctx.b16 = (bank["tb16"], x_f32)
+            ctx.meta = (ksize, training, slope, tuple(weight.shape))
+            return out, None
         wsp = wtr = None
         if bank is not None:
             w, wsp, wtr = bank["ohwi"], bank["split"], (bank["t"], bank["tsplit"])
@@ -52,6 +72,22 @@ class ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _ga=None):
+        if ctx.b16 is not None:            # bf16 storage: dout bf16 or fp32 (read as it is), dy / saved tensors bf16, dw fp32
+            if not ctx.meta[1]:
+                raise NotImplementedError("ConvBNAct, bf16 storage: no backward in eval mode (frozen-BatchNorm fine-tuning is not built)")
+            x16, y, mi, gamma, beta = ctx.saved_tensors
+            ksize, training, slope, wshape = ctx.meta
+            tb16, x_f32 = ctx.b16
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout.contiguous(), mi[0], mi[1], gamma.detach(), beta.detach(), ops.ACT_LEAKY, slope)
+            dx = None
+            if not ops.WGRAD_AFTER_DGRAD:
+                dwt = ops.wgrad_on_side(x16, dy, ksize, 1, wshape)
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+            if ops.WGRAD_AFTER_DGRAD:
+                dwt = ops.wgrad_on_side(x16, dy, ksize, 1, wshape)
+            ops.join_side(x16.device)
+            return dx, dwt, dgamma, dbeta, None, None, None, None, None, None, None
         x, y, aux, w, gamma, beta = ctx.saved_tensors
         gamma, beta = gamma.detach(), beta.detach()
         ksize, training, slope, wshape = ctx.meta
@@ -74,7 +110,7 @@ class ConvBNAct(torch.autograd.Function):
         if ops.WGRAD_AFTER_DGRAD:
             dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
         ops.join_side(x.device)
-        return dx, dwt, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dwt, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 class ConvBias(torch.autograd.Function):
@@ -89,6 +125,17 @@ class ConvBias(torch.autograd.Function):
         w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3], co_pad=cop)
         b = torch.zeros(cop, dtype=torch.float32, device=x.device)
         b[:cout] = bias.detach()
+        ctx.b16 = None
+        if ops.storage_b16() and weight.shape[2] == 1 and x.shape[3] % 32 == 0:
+            # bf16 storage: x bf16 (an fp32 x is cast once), the 32 x Cin bank in bf16 (8 K elements: converted here), logits fp32
+            x_f32 = x.dtype == torch.float32
+            x16 = ops.to_b16(x.contiguous())
+            w16 = w.reshape(cop, -1).to(torch.bfloat16)
+            y, _ = ops.conv2d_fwd_b16(x16, w16.reshape(-1), cop, 1, 1, None, b, out_f32=True)
+            ctx.save_for_backward(x16, w16)
+            ctx.wshape = tuple(weight.shape)
+            ctx.b16 = x_f32
+            return y
         y, _ = ops.conv2d_fwd(x, w, weight.shape[2], 1, None, b)          # (32 filters: the fp32-pipe tile, no scales)
         ctx.save_for_backward(x, w)
         ctx.wshape = tuple(weight.shape)
@@ -97,6 +144,19 @@ class ConvBias(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.b16 is not None:
+            x16, w16 = ctx.saved_tensors
+            co, ci, k, _ = ctx.wshape
+            dy = dy.contiguous()
+            db = ops.colsum_rows(dy.view(-1, dy.shape[-1]))[:co]
+            dy16 = ops.to_b16(dy)
+            dwt = ops.wgrad_on_side(x16, dy16, 1, 1, ctx.wshape)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv2d_bwd_data_b16(dy16, w16.t().contiguous().reshape(-1), (x16.shape[1], x16.shape[2]), x16.shape[3], 1, 1,
+                                             out_f32=ctx.b16)
+            ops.join_side(x16.device)
+            return dx, dwt, db, None
         x, w = ctx.saved_tensors
         co, ci, k, _ = ctx.wshape
         ax, aw = ctx.amax

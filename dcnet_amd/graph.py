@@ -72,7 +72,10 @@ class GraphedTrainStep:
         self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: only THIS thread's calls are checked against the capture.  In a data-parallel run ProcessGroupNCCL's watchdog
+        # thread polls the events of earlier collectives; under the default (global) mode one such hipEventQuery during the capture
+        # aborts the process ("operation not permitted when stream is capturing": seen on a one-rank RCCL group, intermittently)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.loss, self.parts = self._body(eager=False)
         self.graph = g
         ops._amax_pools.pop(dev.index, None)                  # the capture's private abs-max pool stays with the graph

@@ -132,10 +132,10 @@ SIGNATURES = {
     "dcn_conv2d_bwd_data_b16": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, F, P, I, P, P]),
     "dcn_conv2d_bwd_weight_ws_b16": (L, [I, I, I, I, I, I, I]),
     "dcn_conv2d_bwd_weight_b16": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
-    "dcn_scale_act_b16": (I, [P, I, P, P, I, F, P, I, P, L, I, I, P]),
+    "dcn_scale_act_b16": (I, [P, I, P, P, I, F, P, I, P, I, L, I, I, P]),
     "dcn_bn_act_bwd_reduce_rows_b16": (I, [L]),
-    "dcn_bn_act_bwd_reduce_b16": (I, [P, I, P, I, P, P, P, P, I, F, L, I, P, P]),
-    "dcn_bn_act_bwd_apply_b16": (I, [P, I, P, I, P, P, P, P, I, F, P, L, L, I, P, P]),
+    "dcn_bn_act_bwd_reduce_b16": (I, [P, I, P, I, I, P, P, P, P, I, F, L, I, P, P]),
+    "dcn_bn_act_bwd_apply_b16": (I, [P, I, P, I, I, P, P, P, P, I, F, P, L, L, I, P, P]),
     "dcn_cast_rows": (I, [P, I, I, P, I, I, L, I, I, P]),
     "dcn_upsample2_nhwc_b16": (I, [P, I, P, I, I, I, I, I, P]),
     "dcn_upsample2_nhwc_bwd_b16": (I, [P, I, P, I, I, I, I, I, I, P]),

@@ -71,7 +71,8 @@ class ConvBatchNormReLU(nn.Sequential):
         """``amax`` / the ``_dcn_amax`` attribute of the input: abs-max word of x (ops.amax_*); the output carries its own."""
         amax = amax if amax is not None else getattr(x_nhwc, "_dcn_amax", None)
         out, a = ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
-                                 self.conv.kernel_size[0], self.training, self.slope, amax, self.__dict__.get("_dcn_bank"))
+                                 self.conv.kernel_size[0], self.training, self.slope, amax, self.__dict__.get("_dcn_bank"),
+                                 bool(self.__dict__.get("_dcn_out_b16")))          # (bf16-storage mode: the next block reads bf16)
         out._dcn_amax = a
         return out
 
@@ -245,7 +246,7 @@ class grounding_model(nn.Module):
         refreshed by ONE dcn_prepare_filters call per forward — as the backbone's (Darknet._filter_banks): per layer and step that
         replaces an OIHW->OHWI transpose, an abs-max pass and a pre-split in the forward and a filter transpose + pre-split in the
         backward (~150 launches of 5-10 us).  The first fcn_emb block (1032 input channels: the fusion layer) keeps its own path."""
-        if not ops.FILTER_BANKS or not ops.use_amax():
+        if not ops.FILTER_BANKS or not (ops.use_amax() or ops.storage_b16()):      # (bf16 storage reads the banks' bf16 forms)
             for blk in self._head_blocks():
                 blk.__dict__["_dcn_bank"] = None
             return
@@ -292,7 +293,9 @@ class grounding_model(nn.Module):
         z, za = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
                                       blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training, one)
         z._dcn_amax = za
-        for blk in list(self.fcn_emb[s])[1:] + list(self.fcn_out[s])[:-1]:       # (none of them with light=True)
+        chain = list(self.fcn_emb[s])[1:] + list(self.fcn_out[s])[:-1]           # (none of them with light=True)
+        for blk in chain:
+            blk.__dict__["_dcn_out_b16"] = True          # bf16-storage mode: the chain fcn_emb[1:] -> fcn_out[0] -> bbox head stays in bf16
             z = blk(z)
         last = self.fcn_out[s][-1]
         return ConvBias.apply(z, last.weight, last.bias, getattr(z, "_dcn_amax", None))    # (B,H,W,32): channels 15..31 are zero padding
@@ -512,7 +515,7 @@ class grounding_model(nn.Module):
             side.wait_stream(main)
             word_id, flang, context, embedded, flang_attn, flang_loc = language()
         handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
-        raw = self.visumodel.forward_nhwc(image)                                 # :344  (queued asynchronously)
+        raw = self.visumodel.forward_nhwc(image, taps_b16=True)                  # :344  (queued asynchronously; bf16-storage mode: bf16 taps)
         if late:
             ev = self.visumodel.__dict__.get("_early_event")
             if ev is not None:
@@ -569,7 +572,7 @@ class grounding_model(nn.Module):
         with torch.cuda.stream(side):
             word_id, flang, context, embedded = self._language(word_id)
             flang_attn, flang_loc = self._phrases(context, embedded, word_id)
-        raw = self.visumodel.forward_nhwc(image)
+        raw = self.visumodel.forward_nhwc(image, taps_b16=True)
         self._head_filter_banks()
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):

@@ -695,20 +695,21 @@ def channel_stats(x2d):
     return stats
 
 
-def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None, out_b16=False):
+def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None, out_b16=False, out_f32=False):
     c = y.shape[-1]
     rows = y.numel() // c
     if _b16(y) or out_b16 or _b16(out):
-        # bf16 storage (csrc/b16.hip): y bf16 (fp32 for the stem's raw output), residual / out bf16
+        # bf16 storage (csrc/b16.hip): y bf16 (fp32 for the stem's raw output), residual bf16, out bf16 (fp32 with out_f32: the boundary
+        # to an fp32 consumer)
         if out is None:
-            out = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
-        if not y.is_contiguous() or not _b16(out) or (residual is not None and not _b16(residual)):
-            raise ValueError("scale_act (bf16 storage): contiguous y, bf16 out / residual")
+            out = torch.empty(y.shape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=y.device)
+        if not y.is_contiguous() or (residual is not None and not _b16(residual)):
+            raise ValueError("scale_act (bf16 storage): contiguous y, bf16 residual")
         _rows16(out, "scale_act out")
         if residual is not None:
             _rows16(residual, "scale_act residual")
         lib().scale_act_b16(y.data_ptr(), int(not _b16(y)), _p(scale), _p(shift), act, float(slope), _p(residual),
-                            0 if residual is None else residual.stride(-2), out.data_ptr(), rows, c, out.stride(-2), _s())
+                            0 if residual is None else residual.stride(-2), out.data_ptr(), int(not _b16(out)), rows, c, out.stride(-2), _s())
         return out
     if out is None:
         out = torch.empty_like(y)
@@ -724,10 +725,10 @@ def _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part):
     rows = y.numel() // c
     if part is not None:
         return part, part.shape[0]
-    if _b16(dout):
+    if _b16(dout) or _b16(y):
         r = lib().bn_act_bwd_reduce_rows_b16(rows)
         part = scratch(r * 2 * c, y.device, slot=0)
-        lib().bn_act_bwd_reduce_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), dout.stride(-2), mean.data_ptr(), invstd.data_ptr(),
+        lib().bn_act_bwd_reduce_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), int(not _b16(dout)), dout.stride(-2), mean.data_ptr(), invstd.data_ptr(),
                                     _p(gamma), _p(beta), act, float(slope), rows, c, part.data_ptr(), _s())
         return part, r
     r = lib().channel_stats_rows(rows)
@@ -749,9 +750,9 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, pa
     sums = torch.empty((2, c), dtype=torch.float32, device=dev)
     ws = scratch(lib().bn_ws(c), dev, slot=2)
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
-    if _b16(dout):          # bf16 storage: dy bf16 (y bf16, or the stem's fp32 raw output)
+    if _b16(dout) or _b16(y):          # bf16 storage: dy bf16 (y bf16, or the stem's fp32 raw output; dout bf16, or fp32 at the boundary)
         dy = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
-        lib().bn_act_bwd_apply_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma),
+        lib().bn_act_bwd_apply_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), int(not _b16(dout)), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma),
                                    _p(beta), act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _s())
         return dy, sums[1], sums[0]
     dy = torch.empty_like(y)

@@ -465,16 +465,17 @@ int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt16, void* dx
 int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
-/* out (bf16, pixel stride ldo) = act(scale * y + shift) + residual (bf16): BatchNorm apply + LeakyReLU + shortcut. */
+/* out (bf16, or fp32 with out_f32; pixel stride ldo) = act(scale * y + shift) + residual (bf16): BatchNorm apply + LeakyReLU + shortcut. */
 int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, const float* shift, int act, float slope, const void* residual,
-                      int ldr, void* out, int64_t rows, int c, int ldo, void* stream);
+                      int ldr, void* out, int out_f32, int64_t rows, int c, int ldo, void* stream);
 /* BatchNorm + activation backward on bf16 y / dout / dy: the reduce pass (stats [dcn_bn_act_bwd_reduce_rows_b16(rows)][2][c], to be
- * summed by dcn_bn_bwd_sums) and the apply pass, arithmetic of dcn_bn_act_bwd_reduce / _apply term by term. */
+ * summed by dcn_bn_bwd_sums) and the apply pass, arithmetic of dcn_bn_act_bwd_reduce / _apply term by term.  dout_f32: the incoming
+ * gradient is an fp32 tensor (a head block whose consumer is an fp32 kernel). */
 int dcn_bn_act_bwd_reduce_rows_b16(int64_t rows);
-int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+int dcn_bn_act_bwd_reduce_b16(const void* y, int y_f32, const void* dout, int dout_f32, int lddo, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, int act, float slope, int64_t rows, int c, float* stats,
                               void* stream);
-int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int lddo, const float* mean, const float* invstd,
+int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* dout, int dout_f32, int lddo, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, int act, float slope, const float* sums, int64_t count,
                              int64_t rows, int c, void* dy, void* stream);
 /* dst[r][:c] (+)= src[r][:c], element types by flag (0 fp32, 1 bf16), element strides lds / ldd: casts at the fp32 boundary,
