@@ -348,7 +348,8 @@ def main():
         else:
             if world > 1:
                 broadcast_parameters(model, 0)
-            flat = FlatGradAllReduce(model.parameters()).bind()       # gradients live in one flat buffer: no per-parameter copies
+            # gradients live in one flat buffer: no per-parameter copies; the bf16 modes move it over xGMI as bf16
+            flat = FlatGradAllReduce(model.parameters(), comm_dtype=torch.bfloat16 if args.precision in ("bf16", "bf16s") else None).bind()
             flat.always_collective = args.force_ddp                   # (one-rank RCCL group: the collective is issued all the same)
     from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
     opt = make_optimizer(model, 1e-4)

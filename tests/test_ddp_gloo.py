@@ -96,6 +96,18 @@ def _worker_backbone(rank, world, port, out):
         fl()
         res[f"bound{it}"] = {k: p.grad.clone() for k, p in m3.named_parameters() if p.grad is not None}
     res["bound_views_kept"] = all(p.grad.data_ptr() == ptrs[k] for k, p in m3.named_parameters() if k in ptrs)
+    # the bf16 modes move a bf16 copy of the flat buffer (half the xGMI bytes); gradients stay fp32 on both sides
+    m4 = _Backbone(); m4.load_state_dict(m.state_dict())
+    for i in (3, 17):
+        m4.ws[i].requires_grad_(False)
+    for p in m4.dead:
+        p.requires_grad_(False)
+    fb = FlatGradAllReduce(m4.parameters(), comm_dtype=torch.bfloat16).bind()
+    fb.zero()
+    ((m4(data[idx]) - tgt[idx]) ** 2).mean().backward()
+    fb()
+    res["bound_bf16"] = {k: p.grad.clone() for k, p in m4.named_parameters() if p.grad is not None}
+    res["bound_bf16_dtype"] = (fb._comm.dtype, next(iter(res["bound_bf16"].values())).dtype)
     m2 = _Backbone(); m2.load_state_dict(m.state_dict())
     for i in (3, 17):
         m2.ws[i].requires_grad_(False)
@@ -128,6 +140,13 @@ def test_two_rank_allreduce_with_a_single_node_backbone(tmp_path):
                 assert torch.allclose(r[i][f"bound{it}"][k], mean, atol=1e-6), (it, k)      # (same parameters: the model state is not stepped)
     assert all(gr is None for gr in r[0]["frozen_grads"])
     assert r[0]["bound_views_kept"] and r[1]["bound_views_kept"], "autograd replaced a gradient view of the flat buffer"
+    # bf16 on the wire: each rank's gradient rounded to bf16, summed, rounded again — the mean to ~2^-8 relative, identical on both ranks
+    assert r[0]["bound_bf16_dtype"] == (torch.bfloat16, torch.float32)
+    for k in r[0]["local0"]:
+        mean = (r[0]["local0"][k] + r[1]["local0"][k]) / 2
+        tol = 2.0 ** -7 * max(float(r[0]["local0"][k].abs().max()), float(r[1]["local0"][k].abs().max())) + 1e-8
+        assert float((r[0]["bound_bf16"][k] - mean).abs().max()) <= tol, k
+        assert torch.equal(r[0]["bound_bf16"][k], r[1]["bound_bf16"][k]), k
 
 
 class _PushingGrads(torch.autograd.Function):

@@ -4,7 +4,7 @@ The synthetic random-init network amplifies an operand rounding over ~75 layers,
 with fp32 outputs there (tests/test_model_gpu.py::test_reduced_precision_modes_end_to_end only bounds them).  Here the fp32
 model is first trained with the product's own train step (RMSprop, the five losses) on a small fixed synthetic set whose images
 carry the target — a textured rectangle at the ground-truth box over weak noise — until the confidence map is peaked; then the
-SAME weights are evaluated in fp32, bf16-operand and fp8-operand mode and the decoded boxes compared:
+SAME weights are evaluated in fp32, bf16-operand, bf16-storage ("bf16s") and fp8-operand mode and the decoded boxes compared:
 
     criterion (builder-defined): IoU(box_mode, box_fp32) >= 0.95 and the same arg-max (scale, anchor, cell).
 
@@ -72,7 +72,7 @@ def main():
     res = {}
     m.eval()
     try:
-        for mode in ("fp32", "bf16", "fp8"):
+        for mode in ("fp32", "bf16", "bf16s", "fp8"):
             ops.set_precision(mode)
             with torch.no_grad():
                 outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
@@ -89,7 +89,7 @@ def main():
     out["fp32"] = {"acc_at_0.5_vs_gt": float((f["iou_gt"] > 0.5).float().mean()), "mean_iou_vs_gt": float(f["iou_gt"].mean()),
                    "conf_margin_top1_minus_top2_min": float((top2[:, 0] - top2[:, 1]).min()),
                    "conf_margin_top1_minus_top2_median": float((top2[:, 0] - top2[:, 1]).median())}
-    for mode in ("bf16", "fp8"):
+    for mode in ("bf16", "bf16s", "fp8"):
         r = res[mode]
         iou = losses.bbox_iou(r["boxes"], f["boxes"])
         same = (r["cell"] == f["cell"])
@@ -101,7 +101,7 @@ def main():
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
     # same data and schedule, every step in the mode; evaluated in the mode against the ground truth.
     out["trained_in_mode"] = {}
-    for mode in ("bf16", "fp8"):
+    for mode in ("bf16", "bf16s", "fp8"):
         try:
             ops.set_precision(mode)
             m2 = build_product(size, synth_sd(size), dev)
