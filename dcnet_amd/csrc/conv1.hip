@@ -630,9 +630,12 @@ int conv1_shape(const IgemmParams& p, int gran) {
 }
 
 // bf16 storage: (MI, NI) of a launch; 0 = no tile (Co not a multiple of 32).  One BatchNorm partial row per 128 MI output rows.
+int g_conv1b_wide = 1024; // dcn_set_tuning("bwide", min workgroups; 0 = off): 128 x 256 tiles from that many workgroups on
+int g_conv1b_tall = 0;    // dcn_set_tuning("btall", min workgroups; 0 = off): 256 x 128 tiles (a wave owns 64 rows x 128 filters)
 int conv1b_shape(int M, int Co) {
   if (Co % 32 != 0) return 0;
-  if (Co % 256 == 0 && (long long)cdiv(M, 128) * (Co / 256) >= 1024) return 18;
+  if (g_conv1b_wide && Co % 256 == 0 && (long long)cdiv(M, 128) * (Co / 256) >= g_conv1b_wide) return 18;
+  if (g_conv1b_tall && Co % 128 == 0 && (long long)cdiv(M, 256) * (Co / 128) >= g_conv1b_tall) return 24;
   if (Co % 128 == 0) return 14;
   if (Co % 64 == 0) return 12;
   return 21;
@@ -659,7 +662,10 @@ int launch1b(const IgemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-void conv1_set_tuning(int key, int value) { if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value; else g_conv1_fill = value; }
+void conv1_set_tuning(int key, int value) {
+  if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value;
+  else if (key == 4) g_conv1b_wide = value; else if (key == 5) g_conv1b_tall = value; else g_conv1_fill = value;
+}
 
 // shape part of the decision.  The kernel only takes launches that igemm.hip would run on its f16-split tiles WITH the pre-split
 // bank (b_scale set by conv.hip under igemm_will_presplit): the arithmetic — which products, in which order — is then the same and
@@ -715,6 +721,7 @@ int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
   switch (conv1b_shape(p.M, p.Co)) {
     case 18: return out_f32 ? launch1b<8, 1, true>(p, stream) : launch1b<8, 1, false>(p, stream);
     case 14: return out_f32 ? launch1b<4, 1, true>(p, stream) : launch1b<4, 1, false>(p, stream);
+    case 24: return out_f32 ? launch1b<4, 2, true>(p, stream) : launch1b<4, 2, false>(p, stream);
     case 12: return out_f32 ? launch1b<2, 1, true>(p, stream) : launch1b<2, 1, false>(p, stream);
     case 21: return out_f32 ? launch1b<1, 2, true>(p, stream) : launch1b<1, 2, false>(p, stream);
     default: dcn_set_error("conv1b: Co=%d is not a multiple of 32", p.Co); return DCN_ERR_ARG;

@@ -733,6 +733,7 @@ void wgrad_set_abl(int v);
 void wgrad_set_target(int v);
 void wgrad_set_wide64(int v);
 void wgrad_set_target_small(int v);
+void wgrad_set_w3_b16(int v);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
 void score_set_tuning(int key, int value);
@@ -741,6 +742,9 @@ void wgrad9_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == 'w' && key[1] == '3') { wgrad_set_w3_b16(value); return DCN_OK; }           // "w3b16": bf16-storage 3x3 weight gradients by filter rows (wgrad3.hip)
+  if (k == 'b' && key[1] == 'w') { conv1_set_tuning(4, value); return DCN_OK; }       // "bwide": conv1b 128 x 256 tiles from n workgroups on
+  if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"

@@ -592,6 +592,7 @@ void wgrad_set_abl(int v) { g_wabl = v; }
 void wgrad_set_wide64(int v) { g_wide64 = v; }
 void wgrad_set_target(int v) { g_wg_target = v > 0 ? v : 1024; }
 void wgrad_set_target_small(int v) { g_wg_target_small = v > 0 ? v : 512; }
+void wgrad_set_w3_b16(int v);
 
 // C[b][m][n] (+)= row_scale[b][m] * sum_k A[b][k][m] * B[b][k][n]   ("TN" GEMM: K is the strided dim of
 // both operands).  A may be loaded up to column m_ld (zero padded by its producer).  No split-K.
@@ -746,9 +747,19 @@ Plan make_plan_b16(int n, int h, int wd, int cin, int cout, int ksize, int strid
 }
 }  // namespace
 
+bool wgrad3_b16_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
+int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+                      hipStream_t stream);
+int g_w3_b16 = 0;         // dcn_set_tuning("w3b16", 1): bf16-storage 3x3 stride-1 weight gradients by filter rows (wgrad3.hip, bf16 inputs).  Measured
+                          // (tools/bench_b16.py --set w3b16=0 --ab w3b16=1, N = 64): it LOSES to the per-tap tile here — 128->256 @52 0.170 -> 0.207 ms,
+                          // 256->512 @26 0.167 -> 0.204, 512->512 @52 1.22 -> 1.50: with one MFMA per product both are bound by the bytes they stage per
+                          // FLOP, and the filter-row form stages more (a 16-position step per 3 x 8 MFMAs); off
+
 extern "C" int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
-  return pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  if (wgrad3_b16_ok(n, h, wd, cin, cout, ksize, stride)) { const int64_t w3 = wgrad3_ws(n, h, wd, cin, cout); if (w3 > ws) ws = w3; }
+  return ws;
 }
 
 extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
@@ -759,6 +770,10 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
   DCN_CHECK_ARG(x && dy && dw && geom, "conv2d_bwd_weight_b16: null pointer (geom = table of dcn_conv2d_geom for this geometry)");
   const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
   DCN_CHECK_ARG(lx % 8 == 0 && ly % 8 == 0, "conv2d_bwd_weight_b16: pixel strides must be multiples of 8 elements");
+  // 3x3 stride-1 layers with >= 128 channels on a side: one filter row per workgroup (wgrad3.hip), the dY tile staged once for three taps
+  if (g_w3_b16 && wgrad3_b16_ok(n, h, wd, cin, cout, ksize, stride) && (long long)n * h * wd * lx * 2 < 0x7FFFFFF0LL &&
+      (long long)n * h * wd * ly * 2 < 0x7FFFFFF0LL)
+    return wgrad3_launch_b16(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stream);
   const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.M >= 16, "conv2d_bwd_weight_b16: fewer than 16 output pixels");
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
@@ -777,3 +792,5 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
   if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   return DCN_OK;
 }
+
+void wgrad_set_w3_b16(int v) { g_w3_b16 = v; }

@@ -63,8 +63,12 @@ constexpr int A_PLANE = 16 * 256, B_PLANE = 18 * 256;
 // NP = 2: fp32-accurate f16 two-piece split (three MFMAs per product, per-tensor power-of-two scales from the abs-max words);
 // NP = 1: plain bf16 operands (round to nearest even, one MFMA per product) — the weight gradient of the bf16- and fp8-operand
 // modes (BASELINE.json configs[2] / [4]; ops.set_precision("bf16" | "fp8"))
-template <int NP>
+// IN16 (NP = 1, bf16 storage): x and dy ARE bf16 tensors.  A 16-byte piece is 8 channels of a position and goes to its plane as loaded:
+// waves 0-3 bring in the 256 pieces of the dY tile, waves 4-7 strip rows 0-15, the first 32 threads strip rows 16-17 as well.
+template <int NP, bool IN16 = false>
 __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
+  static_assert(!IN16 || NP == 1, "bf16 inputs: one plane");
+  constexpr int ESZ = IN16 ? 2 : 4;
   constexpr int B_BASE = NP * A_PLANE, BUF = NP * A_PLANE + NP * B_PLANE;
   typedef typename std::conditional<NP == 2, f16x8_t, bf16x8_t>::type frag_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];       // [2 buffers][A: 2 planes x 16 rows | B: 2 planes x 18 rows]
@@ -85,25 +89,29 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
   if constexpr (NP == 2) { s_a = pow2w(amax_read(p.amax_dy)); s_b = pow2w(amax_read(p.amax_x)); }
 
   const long long npix = (long long)p.N * p.H * p.W;
-  const __amdgpu_buffer_rsrc_t a_rs = rsrcw(p.dy, ((npix - 1) * p.lddy + p.Co) * 4);
-  const __amdgpu_buffer_rsrc_t b_rs = rsrcw(p.x, ((npix - 1) * p.ldx + p.Ci) * 4);
+  const __amdgpu_buffer_rsrc_t a_rs = rsrcw(p.dy, ((npix - 1) * p.lddy + p.Co) * ESZ);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrcw(p.x, ((npix - 1) * p.ldx + p.Ci) * ESZ);
   const int nrows = p.N * p.H;                        // image rows in the tensor
 
   // ---- load slots: A = dY row (position p_begin + ra), B0 / B1 = strip rows s (position p_begin - 1 + s, filter row r-1 down) --
-  const int ra = tid >> 5, cch = (tid & 31) * 4;      // row within the K-step, first of 4 channels
+  // fp32 inputs: every thread loads an A piece and a B0 piece (4 channels each).  IN16: a piece is 8 channels — threads 0-255 (waves 0-3) own
+  // the A pieces, 256-511 the B0 pieces (slot 0 = ar below), the first 32 threads the B1 pieces of strip rows 16, 17 (slot 1 = br[1]).
+  const bool role_a = !IN16 || tid < 256;             // (wave-uniform)
+  const int ra = IN16 ? ((tid & 255) >> 4) : (tid >> 5), cch = IN16 ? (tid & 15) * 8 : (tid & 31) * 4;
   const bool a_chan = co0 + cch < p.Co, b_chan = ci0 + cch < p.Ci;
+  const __amdgpu_buffer_rsrc_t s0_rs = role_a ? a_rs : b_rs;
   // state (row index = n*H + y, column in [0, Wp)); A also keeps y for the vertical tap test
   int a_row, a_col, a_y;
   { const int q = p_begin + ra; a_row = q / Wp; a_col = q - a_row * Wp; a_y = a_row % p.H; }
   int b_row[2], b_col[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int q = p_begin - 1 + ra + 16 * j;          // >= -1
+    const int q = p_begin - 1 + (IN16 && j == 1 ? (tid >> 4) : ra) + 16 * j;          // >= -1   (IN16, j = 1: rows 16 + tid / 16 of threads 0-31)
     if (q < 0) { b_row[j] = -1; b_col[j] = Wp + q; }
     else { b_row[j] = q / Wp; b_col[j] = q - b_row[j] * Wp; }
     b_row[j] += r - 1;
   }
-  const bool b1_on = tid < 64;                        // strip rows 16, 17
+  const bool b1_on = tid < (IN16 ? 32 : 64);          // strip rows 16, 17
   int pos_a = p_begin + ra;                           // padded position of the A row (end-of-split test)
 
   // 16 positions further: at most two row wraps (W >= 8), as selects — a loop here puts branches into the K loop
@@ -115,6 +123,26 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     return w1 + w2;
   };
   auto load_into = [&](f32x4& ar, f32x4* br) {
+    if constexpr (IN16) {
+      // slot 0: the A piece (waves 0-3) or the B0 piece (waves 4-7) — one load instruction, the descriptor and the offset chosen per wave
+      const bool vert = (r == 0 && a_y == 0) || (r == 2 && a_y == p.H - 1);
+      const bool ok_a = a_chan && pos_a < p_end && a_col < p.W && !vert;
+      const unsigned off_a = (unsigned)(((a_row * p.W + a_col) * p.lddy + co0 + cch) * 2);
+      const bool ok_b = b_chan && b_col[0] < p.W && (unsigned)b_row[0] < (unsigned)nrows;
+      const unsigned off_b = (unsigned)(((b_row[0] * p.W + b_col[0]) * p.ldx + ci0 + cch) * 2);
+      ar = ldw16(s0_rs, role_a ? (ok_a ? off_a : OOBW) : (ok_b ? off_b : OOBW));
+      a_y += advance(a_row, a_col);
+      a_y -= a_y >= p.H ? p.H : 0; a_y -= a_y >= p.H ? p.H : 0;
+      pos_a += 16;
+      advance(b_row[0], b_col[0]);
+      // slot 1: strip rows 16, 17 (threads 0-31; the others read out of range: zeros, never stored)
+      const int cc1 = (tid & 15) * 8;
+      const bool ok1 = b1_on && ci0 + cc1 < p.Ci && b_col[1] < p.W && (unsigned)b_row[1] < (unsigned)nrows;
+      br[1] = ldw16(b_rs, ok1 ? (unsigned)(((b_row[1] * p.W + b_col[1]) * p.ldx + ci0 + cc1) * 2) : OOBW);
+      advance(b_row[1], b_col[1]);
+      br[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
     {
       const bool vert = (r == 0 && a_y == 0) || (r == 2 && a_y == p.H - 1);
       const bool ok = a_chan && pos_a < p_end && a_col < p.W && !vert;
@@ -145,9 +173,13 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     *reinterpret_cast<uint2*>(plane0 + off) = __builtin_bit_cast(uint2, h);
     *reinterpret_cast<uint2*>(plane0 + plane_stride + off) = __builtin_bit_cast(uint2, l);
   };
-  const int a_st = poff(ra, cch), b_st0 = poff(ra, cch), b_st1 = poff(16 + (ra & 1), cch);   // (b1: rows 16, 17 <- tid < 64: ra in {0, 1})
-  auto store_a = [&](int buf, const f32x4& ar) { split_store(sm3 + buf * BUF, A_PLANE, a_st, ar, s_a); };
+  const int a_st = poff(ra, cch), b_st0 = poff(ra, cch), b_st1 = IN16 ? poff(16 + (tid >> 4), (tid & 15) * 8) : poff(16 + (ra & 1), cch);   // (b1: rows 16, 17)
+  auto store_a = [&](int buf, const f32x4& ar) {
+    if constexpr (IN16) { *reinterpret_cast<f32x4*>(sm3 + buf * BUF + (role_a ? 0 : B_BASE) + a_st) = ar; return; }      // slot 0: 8 bf16 as loaded
+    split_store(sm3 + buf * BUF, A_PLANE, a_st, ar, s_a);
+  };
   auto store_b = [&](int buf, const f32x4* br) {
+    if constexpr (IN16) { if (b1_on) *reinterpret_cast<f32x4*>(sm3 + buf * BUF + B_BASE + b_st1) = br[1]; return; }
     split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st0, br[0], s_b);
     if (b1_on) split_store(sm3 + buf * BUF + B_BASE, B_PLANE, b_st1, br[1], s_b);      // (one wave of the eight: wave-uniform)
   };
@@ -300,6 +332,32 @@ int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout) {
 }
 
 int wgrad_lds_pad();
+
+// bf16 storage: x, dy bf16 tensors (strides in elements), dw / slabs fp32
+int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+                      hipStream_t stream) {
+  const Plan3 pl = plan3(n, h, wd, cin, cout);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
+  W3Params p{};
+  p.x = (const float*)x; p.dy = (const float*)dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy;
+  p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
+  size_t lds = (size_t)2 * (A_PLANE + B_PLANE);
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
+  const int pid = prof_begin(46, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);
+  hipLaunchKernelGGL((wgrad3_kernel<1, true>), dim3(grid), dim3(512), lds, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("wgrad3 b16");
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
+  return DCN_OK;
+}
+bool wgrad3_b16_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  return wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) && cin % 8 == 0 && cout % 8 == 0;
+}
 
 int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
                   const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream) {

@@ -549,19 +549,36 @@ class CoAttentionPairs(torch.autograd.Function):
 class CoAttentionCenter(torch.autograd.Function):
     """Centre-frame co-attention of the inference model (model/test_DCNet_model.py:247-282):
     f1 = centre frame, f2 = another frame of the clip; only f1_attn is consumed.
-    clips (B,T,HW,C); returns [f1 | f1_attn] (B,HW,2C).  Forward only."""
+    clips (B,T,HW,C); returns [f1 | f1_attn] (B,HW,2C).
+    Backward (the reference's train branch of this model, test_DCNet_model.py:480-483, reachable though its scripts never take it): the
+    pair kernels of dcn_coattn_bwd with a zero gradient for the unused f2_attn; the result lands in frames ``ctr`` and ``idx`` of a
+    clips-shaped gradient (autograd sums the T - 1 of them)."""
 
     @staticmethod
     def forward(ctx, clips, ctr: int, idx: int, temperature: float):
         b, t, hw, c = clips.shape
         cat = torch.empty((b, hw, 2 * c), dtype=torch.float32, device=clips.device)
         cat[..., :c].copy_(clips[:, ctr])        # batch-strided source: plain torch copy
-        ops.coattn_fwd(clips[:, ctr], clips[:, idx], cat[..., c:], None, temperature)
+        ctx.meta = (ctr, idx, temperature)
+        if ctx.needs_input_grad[0]:
+            o2 = torch.empty((b, hw, c), dtype=torch.float32, device=clips.device)      # f2_attn: only its backward's bookkeeping reads it
+            E, rc = ops.coattn_fwd(clips[:, ctr], clips[:, idx], cat[..., c:], o2, temperature)
+            ctx.save_for_backward(clips, cat, o2, E, rc)
+        else:
+            ops.coattn_fwd(clips[:, ctr], clips[:, idx], cat[..., c:], None, temperature)
         return cat
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("the n_frame (inference) model has no backward; train with pair semantics")
+        clips, cat, o2, E, rc = ctx.saved_tensors
+        ctr, idx, temperature = ctx.meta
+        b, t, hw, c = clips.shape
+        g = g.contiguous()
+        d = torch.zeros_like(clips)
+        d[:, ctr].copy_(g[..., :c])              # the pass-through half of the concat
+        ops.coattn_bwd(clips[:, ctr], clips[:, idx], g[..., c:], torch.zeros_like(o2), cat[..., c:], o2, E, rc, d[:, ctr], d[:, idx], True,
+                       temperature)
+        return d, None, None, None
 
 
 class ToNCHW(torch.autograd.Function):

@@ -313,9 +313,6 @@ class grounding_model(nn.Module):
     def _scale_nframe(self, s: int, raw_s, flang, flang_attn, B: int, n_frame: int):
         """Scale s of the inference model: centre frame vs every other frame, mean of the normalised
         correspondence features (model/test_DCNet_model.py:299-332), then the shared head."""
-        if self.training and torch.is_grad_enabled() and raw_s.requires_grad:
-            raise NotImplementedError("the n_frame (inference) model is forward-only — its centre-frame co-attention has no backward "
-                                      "kernels; run it under torch.no_grad(), train with the pair-semantics forward(image, word_id, word_mask)")
         one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None
         fv = L2Norm.apply(self.mapping_visu[s](raw_s, self.visumodel._tap_amax[s]))
         _, h, w, e = fv.shape
@@ -325,7 +322,14 @@ class grounding_model(nn.Module):
             if idx == ctr:
                 continue
             cat = CoAttentionCenter.apply(clips, ctr, idx, self.temperature).view(B, h, w, 2 * e)
-            acc = NormAccumulate.apply(self.corr_conv[s][0](cat, one), acc, 1.0 / (n_frame - 1))   # :277-280, mean :324-332
+            z = self.corr_conv[s][0](cat, one)
+            if torch.is_grad_enabled() and z.requires_grad:
+                # the reference's train branch of this model (test_DCNet_model.py:480-483; its scripts never take it): differentiable
+                # mean of the normalised features — L2Norm has a backward, the in-place accumulate of the inference path has none
+                zn = L2Norm.apply(z)
+                acc = zn * (1.0 / (n_frame - 1)) if acc is None else acc + zn * (1.0 / (n_frame - 1))
+            else:
+                acc = NormAccumulate.apply(z, acc, 1.0 / (n_frame - 1))          # :277-280, mean :324-332
         corr = acc
         sim = RowDot.apply(corr, flang_attn, False)                              # :386-391
         return fv, corr, sim, None, self._fusion_head(s, corr, flang)

@@ -36,7 +36,10 @@ CASES = [
     (1, 9, 11, 96, 160, 3, 1),        # ragged M, 160 = 5 x 32 filters
     (3, 8, 8, 256, 256, 1, 1),
     (1, 27, 29, 64, 128, 3, 2),       # odd sizes under stride 2 (ragged parity classes)
-    (2, 52, 52, 128, 256, 3, 1),      # more than one round of tiles
+    (2, 52, 52, 128, 256, 3, 1),      # more than one round of tiles; weight gradient by filter rows (wgrad3.hip, bf16 inputs)
+    (2, 26, 26, 256, 128, 3, 1),      # filter rows again, two channel tiles
+    (1, 40, 33, 160, 192, 3, 1),      # ragged channel tiles (128 + 32 | 128 + 64), odd width: pad crossings inside a K-step
+    (8, 13, 13, 256, 512, 3, 1),      # 13-wide rows: two row wraps per K-step
 ]
 
 
@@ -85,11 +88,17 @@ def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case):
     dx32 = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st, out_f32=True)
     assert float((dx32.double().cpu() - ref_dx).abs().max()) <= 3e-5 * max(1.0, float(ref_dx.abs().max()))
     # ---- weight gradient: fp32 out, fp32 accumulation of exact bf16 products ----
-    dw = ops.conv2d_bwd_weight_b16(x, dy, k, st)
+    from dcnet_amd.lib import lib
     ref_dw = wd.grad.permute(0, 2, 3, 1)
-    assert dw.dtype == torch.float32 and dw.shape == (cout, k, k, cin)
-    assert float((dw.double().cpu() - ref_dw).abs().max()) <= 5e-5 * max(1.0, float(ref_dw.abs().max()))
-    assert torch.equal(ops.conv2d_bwd_weight_b16(x, dy, k, st), dw)
+    try:
+        for knob in (0, 1):                    # the per-tap tile (default) and the filter-row kernel on bf16 inputs (where its shape test admits the layer)
+            lib().set_tuning(b"w3b16", knob)
+            dw = ops.conv2d_bwd_weight_b16(x, dy, k, st)
+            assert dw.dtype == torch.float32 and dw.shape == (cout, k, k, cin)
+            assert float((dw.double().cpu() - ref_dw).abs().max()) <= 5e-5 * max(1.0, float(ref_dw.abs().max())), knob
+            assert torch.equal(ops.conv2d_bwd_weight_b16(x, dy, k, st), dw)
+    finally:
+        lib().set_tuning(b"w3b16", 0)
 
 
 @pytest.mark.parametrize("shape", [(2, 26, 26, 128, 256, 3), (3, 13, 13, 256, 128, 1), (1, 20, 12, 64, 64, 3)])

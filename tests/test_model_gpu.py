@@ -158,6 +158,42 @@ def test_nframe_forward_matches_oracle_and_golden(dev, size, b, t):
     assert float(O.bbox_iou_xyxy(boxes, torch.from_numpy(gold["boxes"])).min()) > 0.999
 
 
+def test_nframe_train_branch_forward_and_gradients_match_the_oracle(dev):
+    """The n_frame model in TRAIN mode (model/test_DCNet_model.py:480-483: batch-statistics BatchNorm, the 5-tuple with corr_feat and
+    flang_attn) — a branch the reference's scripts never take, reachable all the same: outputs against the oracle within 1e-3 and
+    parameter gradients through the centre-frame co-attention (dcn_coattn_bwd with a zero gradient for the unused f2_attn) by cosine."""
+    from dcnet_amd.utils.synth import synth_inputs
+    from oracle import dcnet_oracle as O
+    size, b, t = 256, 2, 3
+    sd = synth_sd(size)
+    image, word_id, word_mask = synth_inputs(b * t, size, n_queries=b, seed=91)
+    m = build_product(size, sd, dev, test_model=True).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    outbox, sim, loc, corr, flang_attn = m(image.to(dev), word_id.to(dev), word_mask.to(dev), t)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    params = {k: sdo[k].requires_grad_(True) for k, _ in m.named_parameters()}
+    o = O.grounding_forward_nframe(sdo, image, word_id, t, training=True)
+    for s_ in range(3):
+        assert maxdiff(outbox[s_], o["outbox"][s_]) < TOL and maxdiff(sim[s_], o["sim_score"][s_]) < TOL
+        assert maxdiff(loc[s_], o["loc_score"][s_]) < TOL and maxdiff(corr[s_], o["corr_feat"][s_]) < TOL
+    assert maxdiff(flang_attn.view(b, -1), o["flang_attn"].view(b, -1)) < TOL
+    gen = torch.Generator().manual_seed(3)
+    gs = [torch.randn(x.shape, generator=gen) for x in outbox] + [torch.randn(x.shape, generator=gen) for x in sim]
+    (sum((a * g.to(dev)).sum() for a, g in zip(outbox, gs[:3])) + sum((a * g.to(dev)).sum() for a, g in zip(sim, gs[3:]))).backward()
+    (sum((a * g).sum() for a, g in zip(o["outbox"], gs[:3])) + sum((a * g).sum() for a, g in zip(o["sim_score"], gs[3:]))).backward()
+    checked = 0
+    for k, p in m.named_parameters():
+        og = params[k].grad
+        if og is None or p.grad is None or float(og.abs().max()) < 1e-4 or "loc_" in k:
+            continue
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.cpu().flatten().double(), og.flatten().double(), dim=0))
+        assert cos > 0.99, (k, cos)           # (train-mode BatchNorm over 6 images through 75 layers: LeakyReLU sign flips)
+        checked += 1
+    assert checked > 150
+
+
 @pytest.mark.parametrize("size,n", [(256, 4), (416, 4)])
 def test_train_forward_backward_matches_oracle(dev, size, n):
     """Train mode (batch-stat BN, p_dropout = 0), N = 4 (the well-conditioned golden case): the 11

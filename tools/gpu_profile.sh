@@ -23,6 +23,11 @@ echo "stats done"
 BENCHE="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 2 --graph off --no-side-streams"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o bench -- python3 $BENCHE > "$OUT/bench_eager_under_rocprof.json" 2> "$OUT/stats_eager.err"
 echo "eager stats done"
+# the bf16-storage mode (BASELINE configs[2] on one GPU): the timed line, then its graph replays under the tracer
+python3 "$ROOT/bench.py" --precision bf16s --steps 20 --warmup 5 --no-cpu-baseline --alt-steps 0 > "$OUT/bench_bf16s.json" 2> "$OUT/bench_bf16s.err"
+cp "$ROOT/gpurun_out/bench_full_latest.json" "$OUT/bench_full_bf16s.json" 2>/dev/null || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_bf16s" -o bench -- python3 $BENCH --precision bf16s > "$OUT/bench_bf16s_under_rocprof.json" 2> "$OUT/stats_bf16s.err"
+echo "bf16s stats done"
 BENCH1="$ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --alt-steps 0 --profile-steps 1 --graph off"      # (counter collection serialises dispatches: the eager step)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 $BENCH1 > /dev/null 2> "$OUT/pmc_fetch.err"
 echo "pmc fetch done"
