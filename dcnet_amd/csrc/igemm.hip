@@ -734,6 +734,7 @@ void wgrad_set_target(int v);
 void wgrad_set_wide64(int v);
 void wgrad_set_target_small(int v);
 void wgrad_set_w3_b16(int v);
+void wgrad_set_target_b16(int v, int small);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
 void score_set_tuning(int key, int value);
@@ -742,6 +743,8 @@ void wgrad9_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == 'q' && key[1] == 't') { wgrad_set_target_b16(value, 0); return DCN_OK; }     // "qtargetb16": workgroups a bf16-storage 3x3 stride-1 weight gradient aims for
+  if (k == 'q' && key[1] == 's') { wgrad_set_target_b16(value, 1); return DCN_OK; }     // "qsmallb16": the same for its 1x1 / stride-2 layers
   if (k == 'w' && key[1] == '3') { wgrad_set_w3_b16(value); return DCN_OK; }           // "w3b16": bf16-storage 3x3 weight gradients by filter rows (wgrad3.hip)
   if (k == 'b' && key[1] == 'w') { conv1_set_tuning(4, value); return DCN_OK; }       // "bwide": conv1b 128 x 256 tiles from n workgroups on
   if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on

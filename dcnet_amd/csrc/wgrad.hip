@@ -487,6 +487,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 struct Plan { int tm, tn, tiles_co, tiles_ci, T, splits, kchunk, M, ld_out; };
 int g_wide64 = 1;           // dcn_set_tuning("cwide64", 0): 64-channel sides back on the narrow fp32-pipe tiles
 int g_wg_target = 1024;    // dcn_set_tuning("xwgtarget", n): workgroups a 3x3 stride-1 weight-gradient launch aims for (split-K sizing)
+int g_wg_target_small_b16 = 512;   // ("qsmallb16")
+int g_wg_target_b16 = 768;     // dcn_set_tuning("qtargetb16", n): the same for the bf16-storage 3x3 stride-1 layers (make_plan_b16)
 int g_wg_target_small = 512;   // dcn_set_tuning("zwgsmall", n): the same for 1x1 and stride-2 layers
 int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hipStream_t stream);
 
@@ -733,7 +735,13 @@ Plan make_plan_b16(int n, int h, int wd, int cin, int cout, int ksize, int strid
   pl.T = ksize * ksize; pl.ld_out = pl.T * cin;
   const int base = pl.tiles_co * pl.tiles_ci * pl.T;
   const int max_splits = pl.M / 256 > 0 ? pl.M / 256 : 1;
-  const int target = (ksize == 1 || stride == 2) ? g_wg_target_small : g_wg_target;
+  // (3x3 stride-1 layers: with one MFMA per product the kernel is twice as fast as the f16-split tile while a slab costs the same, so fewer,
+  //  longer splits win — tools/bench_b16.py --ab qtargetb16=..., N = 64: 1024 -> 768 workgroups 128->256 @52 0.169 -> 0.146 ms, 512->512 @52
+  //  1.25 -> 1.02, 64->128 @104 0.311 -> 0.243; 512 loses again on the 13-wide maps; the 1x1 / stride-2 layers keep 512: 256 costs 15-70 %)
+  // (1x1 / stride-2 layers: one full round of 768 as well once the launch is large — 1024->512 @52 0.303 -> 0.249 ms, 128->256 s2 @104
+  //  0.177 -> 0.151 —, 512 for the small residual 1x1 layers, whose slabs weigh more: 256->128 @52 0.048 vs 0.052)
+  const bool small_cls = ksize == 1 || stride == 2;
+  const int target = small_cls ? (2.0 * pl.M * (double)cin * cout * pl.T >= 3e10 ? g_wg_target_b16 : g_wg_target_small_b16) : g_wg_target_b16;
   int splits = target / base;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -794,3 +802,4 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
 }
 
 void wgrad_set_w3_b16(int v) { g_w3_b16 = v; }
+void wgrad_set_target_b16(int v, int small) { if (small) g_wg_target_small_b16 = v > 0 ? v : 512; else g_wg_target_b16 = v > 0 ? v : 768; }

@@ -561,7 +561,7 @@ class CoAttentionCenter(torch.autograd.Function):
         cat[..., :c].copy_(clips[:, ctr])        # batch-strided source: plain torch copy
         ctx.meta = (ctr, idx, temperature)
         if ctx.needs_input_grad[0]:
-            o2 = torch.empty((b, hw, c), dtype=torch.float32, device=clips.device)      # f2_attn: only its backward's bookkeeping reads it
+            o2 = torch.empty((b, hw, 2 * c), dtype=torch.float32, device=clips.device)[..., c:]      # f2_attn (strides of out1): only the backward's bookkeeping reads it
             E, rc = ops.coattn_fwd(clips[:, ctr], clips[:, idx], cat[..., c:], o2, temperature)
             ctx.save_for_backward(clips, cat, o2, E, rc)
         else:
@@ -576,8 +576,8 @@ class CoAttentionCenter(torch.autograd.Function):
         g = g.contiguous()
         d = torch.zeros_like(clips)
         d[:, ctr].copy_(g[..., :c])              # the pass-through half of the concat
-        ops.coattn_bwd(clips[:, ctr], clips[:, idx], g[..., c:], torch.zeros_like(o2), cat[..., c:], o2, E, rc, d[:, ctr], d[:, idx], True,
-                       temperature)
+        z2 = torch.zeros((b, hw, 2 * c), dtype=torch.float32, device=g.device)[..., c:]        # d f2_attn = 0, in the strides of d f1_attn
+        ops.coattn_bwd(clips[:, ctr], clips[:, idx], g[..., c:], z2, cat[..., c:], o2, E, rc, d[:, ctr], d[:, idx], True, temperature)
         return d, None, None, None
 
 

@@ -186,7 +186,9 @@ def test_nframe_train_branch_forward_and_gradients_match_the_oracle(dev):
     checked = 0
     for k, p in m.named_parameters():
         og = params[k].grad
-        if og is None or p.grad is None or float(og.abs().max()) < 1e-4 or "loc_" in k:
+        # (loc branch: min-max amplification; a Linear bias in front of a train-mode BatchNorm1d has a gradient of exact zero
+        #  in exact arithmetic: what both sides hold there is rounding noise)
+        if og is None or p.grad is None or float(og.abs().max()) < 1e-4 or "loc_" in k or k in ("mapping_lang.0.bias", "mapping_lang.4.bias"):
             continue
         cos = float(torch.nn.functional.cosine_similarity(p.grad.cpu().flatten().double(), og.flatten().double(), dim=0))
         assert cos > 0.99, (k, cos)           # (train-mode BatchNorm over 6 images through 75 layers: LeakyReLU sign flips)
