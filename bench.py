@@ -73,10 +73,10 @@ PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if
                else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33, 41, 42) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
-RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2>"],
+RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>"],
             26: ["igemm_kernel<256,64,4,1,0,false,16,true,0,2,", "igemm_kernel<256,32,4,1,0,false,16,true,0,2,"],
             27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"],
-            29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2>"], 35: ["conv1_kernel<"],
+            29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
             36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
 FAMILY = {28: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)"}
 NT = 48            # DCN_PROF_TAGS
@@ -121,8 +121,8 @@ def compact_line(res: dict) -> str:
         for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "bf16s_ms", "fp8_ms"):
             rf[k] = alt.get(k)
         rf["alone_ms"] = alt.get("exclusive_ms")
-    if "sclk_mhz" in out:
-        rf["sclk_mhz"] = out.pop("sclk_mhz")
+    if "sclk_mhz" in out and rf:
+        rf["sclk_mhz"] = out.pop("sclk_mhz")       # (no roofline object — a run without the profiled pass —: the clock stays at top level)
     if rf:
         rf["note"] = "kernel alone (HIP events); in_step: rocprofv3 of replays"
         out["roofline"] = rf
