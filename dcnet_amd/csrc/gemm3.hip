@@ -60,7 +60,9 @@ struct G3Params {
 // T-form swizzle of a k-row's 16-byte chunks: rows k, k+1, k+2, k+3 of a transposed read land in four disjoint bank sets
 __device__ __forceinline__ int g3_tswz(int krow) { return (krow & 1) | ((krow & 2) << 1); }
 
-template <bool AT, bool BT>
+// H1 (the bf16 precision modes): only the HIGH piece of each operand is read and multiplied — f16 operands with the tensor's power-of-two
+// scale, 11 significant bits (three more than bf16), ONE MFMA per product instead of three; same tiles, same DMA, same schedule.
+template <bool AT, bool BT, bool H1 = false>
 __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem3g[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -213,13 +215,13 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
     } else {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        if (BT) { bh[ni] = tfrag(st, b_rd[ni][0], b_rd[ni][1], 0); bl[ni] = tfrag(st, b_rd[ni][0], b_rd[ni][1], 1); }
-        else { bh[ni] = *reinterpret_cast<const f16x8_t*>(st + b_rd[ni][0]); bl[ni] = *reinterpret_cast<const f16x8_t*>(st + b_rd[ni][1]); }
+        if (BT) { bh[ni] = tfrag(st, b_rd[ni][0], b_rd[ni][1], 0); if constexpr (!H1) bl[ni] = tfrag(st, b_rd[ni][0], b_rd[ni][1], 1); }
+        else { bh[ni] = *reinterpret_cast<const f16x8_t*>(st + b_rd[ni][0]); if constexpr (!H1) bl[ni] = *reinterpret_cast<const f16x8_t*>(st + b_rd[ni][1]); }
       }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        if (AT) { ah[mi] = tfrag(st, a_rd[mi][0], a_rd[mi][1], 0); al[mi] = tfrag(st, a_rd[mi][0], a_rd[mi][1], 1); }
-        else { ah[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd[mi][0]); al[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd[mi][1]); }
+        if (AT) { ah[mi] = tfrag(st, a_rd[mi][0], a_rd[mi][1], 0); if constexpr (!H1) al[mi] = tfrag(st, a_rd[mi][0], a_rd[mi][1], 1); }
+        else { ah[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd[mi][0]); if constexpr (!H1) al[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd[mi][1]); }
       }
     }
     // slice it + 3, into the stage of slice it - 1.  BEHIND the fragment reads: the memory path is the narrow one here (a CU gets
@@ -243,15 +245,17 @@ __global__ __launch_bounds__(512, 1) void gemm3_kernel(const G3Params p) {
     } else {
       // smallest terms first: (l,h) (h,l) (h,h); eight independent accumulators between two uses of one
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (!H1) {
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-      if (p.var == 2) issue_b();
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        if (p.var == 2) issue_b();
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+      } else if (p.var == 2) issue_b();
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -317,19 +321,28 @@ __global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__
 
 int g_gemm3 = 1;          // dcn_set_tuning("Gemm3", 0): the co-attention products back on the implicit-GEMM / weight-gradient tiles
 
-template <bool AT, bool BT>
-int launch3g(const G3Params& p, int grid, hipStream_t stream) {
+int g_gemm3_h1 = 1;       // dcn_set_tuning("H1gemm3", 0): the bf16 precision modes multiply both pieces as well (fp32-accurate co-attention)
+
+template <bool AT, bool BT, bool H1>
+int launch3g_(const G3Params& p, int grid, hipStream_t stream) {
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<AT, BT, H1>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
   }
-  hipLaunchKernelGGL((gemm3_kernel<AT, BT>), dim3(grid), dim3(512), G3_LDS, stream, p);
+  hipLaunchKernelGGL((gemm3_kernel<AT, BT, H1>), dim3(grid), dim3(512), G3_LDS, stream, p);
   return DCN_OK;
+}
+template <bool AT, bool BT>
+int launch3g(const G3Params& p, int grid, hipStream_t stream) {
+  // precision 2 = the bf16 modes: one f16 piece per operand (11 significant bits: finer than the bf16 those modes are defined by)
+  if (g_gemm3_h1 && igemm_precision() == 2) return launch3g_<AT, BT, true>(p, grid, stream);
+  return launch3g_<AT, BT, false>(p, grid, stream);
 }
 
 }  // namespace
 
 void gemm3_set_tuning(int v) { g_gemm3 = v; }
+void gemm3_set_h1(int v) { g_gemm3_h1 = v; }
 
 // shapes the kernel takes: rows of 16-byte granularity everywhere, the T operands' tile columns inside their rows
 bool gemm3_applicable(int M, int N, int K, int batch) {

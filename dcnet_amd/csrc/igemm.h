@@ -95,6 +95,7 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
 void nconv_set_tuning(int v);
 // gemm3.hip: batched GEMM on pre-split operands (the co-attention products)
 void gemm3_set_tuning(int v);
+void gemm3_set_h1(int v);
 bool gemm3_applicable(int M, int N, int K, int batch);
 int gemm3_presplit(const float* src, int ld, long long bs, float* dst, int ldd, long long bsd, int batch, int rows, int c,
                    const unsigned* amax, hipStream_t stream);

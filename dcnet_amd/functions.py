@@ -465,6 +465,19 @@ class FusionConvBNAct(torch.autograd.Function):
         coord2d = coord.reshape(h * w, -1).contiguous()
         # the pre-filled term W2.flang[n] + W3.coord[p] (csrc/fusion.hip; W2, W3 are column slices of the parameter: no copies)
         y = ops.fusion_prefill(ops.gemm_nt(flang.detach().contiguous(), w2), coord2d, w3).view(n, h, w, co)
+        ctx.b16 = False
+        if ops.storage_b16() and training and e % 32 == 0 and co % 32 == 0:
+            # bf16 storage: the K = E convolution on bf16 operands (corr cast once, the 512 x 512 bank converted here), accumulated onto the
+            # fp32 pre-fill in the kernel's epilogue — raw result and statistics fp32 —, the activation written as bf16 for the next block
+            corr16 = ops.to_b16(corr)
+            w16 = w1.view(co, e).to(torch.bfloat16)
+            y, stats = ops.conv2d_fwd_b16(corr16, w16.reshape(-1), co, 1, 1, out=y, want_stats=True, accumulate=True, out_f32=True)
+            mi = ops.bn_finalize(stats, n * h * w, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+            bn.num_batches_tracked += 1
+            out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0, out_b16=True)
+            ctx.save_for_backward(corr16, y, mi, w16, gamma, beta, flang, weight)
+            ctx.training, ctx.coord2d, ctx.b16, ctx.amax = True, coord2d, True, (None, None)
+            return out, None
         wk = ops.weight_to_ohwi(w1)
         aw = ops.absmax(wk) if am else None
         if training:
@@ -492,6 +505,17 @@ class FusionConvBNAct(torch.autograd.Function):
         co = weight.shape[0]
         ax, aw = ctx.amax
         dout = dout.contiguous()
+        if ctx.b16:
+            dy16, dgamma, dbeta = ops.bn_act_bwd(y, dout, aux[0], aux[1], gamma, beta, ops.ACT_LEAKY, 0.0)      # y fp32, dout bf16 | fp32 -> dy bf16
+            dw1 = ops.wgrad_on_side(corr, dy16, 1, 1, (co, e, 1, 1)).view(co, e)
+            dcorr = ops.conv2d_bwd_data_b16(dy16, wk.t().contiguous().reshape(-1), (h, w), e, 1, 1, out_f32=True) if ctx.needs_input_grad[0] else None
+            ops.join_side(corr.device)
+            wd = weight.detach().view(co, -1)
+            dweight = torch.empty((co, wd.shape[1]), dtype=torch.float32, device=dy16.device)
+            d_img = ops.fusion_bwd(ops.to_f32(dy16), ctx.coord2d, flang.detach().contiguous(), dweight, e)     # (the per-image / per-position terms read fp32)
+            ops.copy_slice(dw1, dweight[:, :e])
+            dflang = ops.gemm_nn(d_img, wd[:, e:2 * e]) if ctx.needs_input_grad[1] else None
+            return dcorr, dflang, None, dweight.view_as(weight), dgamma, dbeta, None, None, None
         ady = None
         if ctx.training:
             ady = ops.amax_slot(dout.device) if ops.use_amax() else None

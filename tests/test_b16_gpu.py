@@ -227,3 +227,34 @@ def test_b16_backbone_training_step_against_the_fp32_run():
         worst = max(worst, d_sto)
         assert d_sto < max(5 * d_ops, 0.25), (k_, d_ops, d_sto)
     assert worst > 1e-4          # it IS reduced precision
+
+
+def test_coattention_on_one_f16_piece_in_the_bf16_modes():
+    """In the bf16 precision modes the nine co-attention products per scale run on gemm3.hip with ONE f16 piece per operand (the high piece of
+    the split form: 11 significant bits, one MFMA per product).  Forward and backward stay within f16-operand rounding of the fp32-accurate
+    run (two pieces), differ from it (the mode is live), and the knob `H1gemm3=0` gives the two-piece result back bit for bit."""
+    from dcnet_amd import ops
+    from dcnet_amd.functions import CoAttentionPairs
+    from dcnet_amd.lib import lib
+    dev = torch.device("cuda:0")
+    n, h, w, c = 4, 26, 26, 512
+    fv0 = torch.nn.functional.normalize(_rand(n, h, w, c, seed=1), dim=3).to(dev)
+    g = (_rand(n, h, w, 2 * c, seed=2) / (h * w) ** 0.5).to(dev)
+    res = {}
+    try:
+        for tag, mode, knob in (("fp32", "fp32", 1), ("h1", "bf16s", 1), ("two", "bf16s", 0)):
+            ops.set_precision(mode); lib().set_tuning(b"H1gemm3", knob)
+            fv = fv0.clone().requires_grad_(True)
+            out = CoAttentionPairs.apply(fv, 10.0)
+            out.backward(g)
+            res[tag] = (out.detach().clone(), fv.grad.clone())
+    finally:
+        ops.set_precision("fp32"); lib().set_tuning(b"H1gemm3", 1)
+    assert lib().gemm3_supported(h * w, c, h * w, n // 2) == 1
+    for k_ in (0, 1):
+        assert torch.equal(res["two"][k_], res["fp32"][k_])                          # the two-piece path is the fp32 one
+        ref = res["fp32"][k_].double(); got = res["h1"][k_].double()
+        err = float((got - ref).abs().max()); scale = float(ref.abs().max())
+        assert 1e-7 * scale < err < 4e-3 * scale, (k_, err, scale)                   # live, and within f16-operand rounding (2^-11 per operand)
+        cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+        assert cos > 0.99999, (k_, cos)
