@@ -340,7 +340,7 @@ int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* d
 extern "C" int dcn_conv2d_stats_rows_b16(int n, int h, int wd, int cout, int ksize, int stride) {
   const int pad = (ksize - 1) / 2;
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
-  return conv1b_grid_m(n * ho * wo, cout);
+  return conv1b_grid_m(n * ho * wo, cout, ksize * ksize);
 }
 
 extern "C" int dcn_conv2d_fwd_b16(const void* x, const void* w16, void* y, int y_f32, int n, int h, int wd, int cin, int cout, int ksize,
@@ -394,7 +394,7 @@ extern "C" int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt1
         p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
       }
     if (tap_y && tap_stats && tap_mean && tap_invstd) {
-      const int rows = conv1b_grid_m(p.M, cin);
+      const int rows = conv1b_grid_m(p.M, cin, T);
       if (rows > 0 && tap_stats_rows >= rows) {
         p.stats = tap_stats; p.bt_y = (const float*)tap_y; p.bt_mean = tap_mean; p.bt_invstd = tap_invstd; p.bt_gamma = tap_gamma;
         p.bt_beta = tap_beta; p.bt_act = tap_act; p.bt_slope = tap_slope;

@@ -704,7 +704,8 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
 }
 
 // ---- bf16 storage ------------------------------------------------------------------------------------------------------
-int conv1b_grid_m(int M, int Co) {
+int conv1b_grid_m(int M, int Co, int ntaps) {
+  if (conv2b_takes(M, Co, ntaps)) return cdiv(M, 256);              // conv2b.hip's 256 x 256 tile
   const int sh = conv1b_shape(M, Co);
   return sh ? cdiv(M, 128 * (sh / 10)) : 0;
 }
@@ -718,6 +719,7 @@ int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
   if (p.Hs * p.Ws < 1 || (256 / (p.Hs * p.Ws) + 2) * (long long)p.Hi * p.Wi * p.ldi * 2 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 2 >= 0x7FFFFFF0LL) {
     dcn_set_error("conv1b: tensor beyond the 2 GiB buffer window"); return DCN_ERR_ARG;
   }
+  if (conv2b_takes(p.M, p.Co, p.ntaps)) return conv2b_launch(p, out_f32, stream);      // >= 256 filters on a long grid: 256 x 256 tiles, eight waves
   switch (conv1b_shape(p.M, p.Co)) {
     case 18: return out_f32 ? launch1b<8, 1, true>(p, stream) : launch1b<8, 1, false>(p, stream);
     case 14: return out_f32 ? launch1b<4, 1, true>(p, stream) : launch1b<4, 1, false>(p, stream);

@@ -75,8 +75,12 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv1_set_tuning(int key, int value);
 // ... and its bf16-storage form (activations, gradients and filter banks bf16 in HBM): every forward / data-gradient launch with
 // Ci % 32 == 0.  conv1b_grid_m = BatchNorm partial rows (M-tiles) of a launch.
-int conv1b_grid_m(int M, int Co);
+int conv1b_grid_m(int M, int Co, int ntaps);
 int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
+// conv2b.hip: the same on 256 x 256 tiles (eight waves, gemm3.hip's two-group schedule) for launches with Co % 256 == 0 and enough tiles
+bool conv2b_takes(int M, int Co, int ntaps);
+int conv2b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
+void conv2b_set_tuning(int v);
 
 
 // stem.hip: the 4-channel 3x3 stride-1 stem directly on the vector ALU (forward).  scratch: >= 27*32 floats.

@@ -743,6 +743,7 @@ void wgrad9_set_tuning(int key, int value);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == '2') { conv2b_set_tuning(value); return DCN_OK; }                             // "2btile": min 256 x 256 tiles for conv2b.hip (0 = off)
   if (k == 'H') { gemm3_set_h1(value); return DCN_OK; }                                  // "H1gemm3": one f16 piece per operand in the bf16 modes (gemm3.hip)
   if (k == 'q' && key[1] == 't') { wgrad_set_target_b16(value, 0); return DCN_OK; }     // "qtargetb16": workgroups a bf16-storage 3x3 stride-1 weight gradient aims for
   if (k == 'q' && key[1] == 's') { wgrad_set_target_b16(value, 1); return DCN_OK; }     // "qsmallb16": the same for its 1x1 / stride-2 layers

@@ -476,7 +476,7 @@ def conv2d_bwd_data_b16(dy, wt16, in_hw, cin, ksize, stride, out=None, accumulat
     rows = ctypes.c_int(0)
     cap = 0
     if tap is not None and stride == 1 and _b16(tap["y"]) and tap["y"].is_contiguous():
-        cap = lib().conv2d_stats_rows_b16(n, h, wd, cin, 1, 1)            # M-tiles of the launch (rows = n*h*wd, filters = cin)
+        cap = lib().conv2d_stats_rows_b16(n, h, wd, cin, ksize, 1)        # M-tiles of the launch (rows = n*h*wd, filters = cin, k*k taps: stride 1 keeps h x wd)
         part = torch.empty((max(cap, 1), 2, cin), dtype=torch.float32, device=dy.device)
     lib().conv2d_bwd_data_b16(dy.data_ptr(), dy.stride(2), wt16.data_ptr(), out.data_ptr(), int(out_f32), n, h, wd, cin, cout, ksize, stride,
                               int(accumulate), tap["y"].data_ptr() if cap else 0, tap["mean"].data_ptr() if cap else 0,

@@ -40,11 +40,28 @@ CASES = [
     (2, 26, 26, 256, 128, 3, 1),      # filter rows again, two channel tiles
     (1, 40, 33, 160, 192, 3, 1),      # ragged channel tiles (128 + 32 | 128 + 64), odd width: pad crossings inside a K-step
     (8, 13, 13, 256, 512, 3, 1),      # 13-wide rows: two row wraps per K-step
+    (1, 28, 28, 128, 256, 3, 2),      # stride 2 into 256 filters (the 256 x 256 tile with a strided gather)
+    (1, 20, 20, 256, 256, 3, 2),      # ... and its parity classes into 256 channels (strided output)
 ]
 
 
+@pytest.mark.parametrize("tile2b", [0, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case):
+def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case, tile2b):
+    """tile2b = 1: every launch with a multiple of 256 filters is forced onto conv2b.hip's 256 x 256 eight-wave tile (knob `2btile`: it takes
+    them from 256 tiles on by default, which only the full-size layers reach); 0: conv1.hip's conv1b tiles."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    if tile2b and case[3] % 256 and case[4] % 256:
+        pytest.skip("no launch of this case has a multiple of 256 filters")
+    lib().set_tuning(b"2btile", -1 if tile2b else 0)
+    try:
+        _conv_case(case)
+    finally:
+        lib().set_tuning(b"2btile", 256)
+
+
+def _conv_case(case):
     from dcnet_amd import ops
     dev = torch.device("cuda:0")
     n, h, w, cin, cout, k, st = case
