@@ -101,3 +101,63 @@ def test_reduced_precision_config_at_full_workload(dev, mode, n_img):
                 assert d_mode > 1e-3 and d_inv < 0.25 * d_mode, (s, d_inv, d_mode)
     finally:
         ops.set_precision("fp32")
+
+
+def test_bf16_storage_config_at_full_workload(dev):
+    """configs[2] proper — bf16 STORAGE (``ops.set_precision("bf16s")``) — at its workload: 64 images of 416x416 through a full training step.
+    Layer level at this batch size: the bf16-tensor kernels (conv1b / conv2b tiles, bf16 weight gradient) against their exact model — the same
+    convolution in the fp32-exact split pipe on the bf16 values, which tests/test_ops_gpu.py pins against fp64 — on the layer shapes that
+    carry most of the step; then the whole step: finite, bitwise repeatable, bf16 on the inside (memory well below the fp32 step's), and in
+    eval mode a clip run alone agrees with its slice of the full batch far better than the mode differs from fp32."""
+    from dcnet_amd import ops
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n_img = 416, 64
+    sd = synth_sd(size)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n_img, size, seed=n_img))
+    bbox = synth_boxes(n_img, size, seed=n_img).to(dev)
+    try:
+        g = torch.Generator().manual_seed(1)
+        for (h, cin, cout, k, st) in ((52, 128, 256, 3, 1), (26, 512, 256, 1, 1), (104, 128, 256, 3, 2), (52, 512, 512, 3, 1)):
+            T = k * k
+            x = torch.randn(n_img, h, h, cin, generator=g).to(dev).bfloat16()
+            w = (torch.randn(cout, k, k, cin, generator=g) / (cin * T) ** 0.5).to(dev).bfloat16()
+            ho = h // st
+            dy = (torch.randn(n_img, ho, ho, cout, generator=g) / 8).to(dev).bfloat16()
+            ops.set_precision("fp32")
+            ref_fwd = ops.conv2d_fwd(x.float(), w.float(), k, st)[0]
+            ref_dx = ops.conv2d_bwd_data(dy.float(), w.float(), (h, h), k, st)
+            ref_dw = ops.conv2d_bwd_weight(x.float(), dy.float(), k, st)
+            got_fwd, _ = ops.conv2d_fwd_b16(x, w.reshape(-1), cout, k, st, out_f32=True)
+            got_fwd16, stats = ops.conv2d_fwd_b16(x, w.reshape(-1), cout, k, st, want_stats=True)
+            wt_t = w.reshape(cout, T, cin).permute(2, 1, 0).contiguous().reshape(-1)
+            got_dx = ops.conv2d_bwd_data_b16(dy, wt_t, (h, h), cin, k, st, out_f32=True)
+            got_dw = ops.conv2d_bwd_weight_b16(x, dy, k, st)
+            for name, a, b in (("fwd", got_fwd, ref_fwd), ("dgrad", got_dx, ref_dx), ("wgrad", got_dw, ref_dw)):
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 1e-4 * scale, (name, (h, cin, cout, k, st), float((a - b).abs().max()), scale)
+            assert torch.equal(got_fwd16, got_fwd.bfloat16())                       # the bf16 store is the rounding of the same accumulators
+            s = stats.double().sum(0); yf = got_fwd16.double().reshape(-1, cout)
+            assert torch.allclose(s[0], yf.sum(0), rtol=1e-5, atol=1e-3 * float(yf.abs().sum(0).max()))
+            del x, w, dy, ref_fwd, ref_dx, ref_dw, got_fwd, got_fwd16, got_dx, got_dw, stats, yf
+        torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats(dev)
+        ops.set_precision("bf16s")
+        m = build_product(size, sd, dev).train()
+        a, finite_a, parts = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        b, finite_b, _ = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        assert finite_a and finite_b and all(v == v and abs(v) < 1e6 for v in parts.values()), parts
+        for x, y in zip(a, b):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+        assert torch.cuda.max_memory_allocated(dev) / 2 ** 30 < 26.0               # (the fp32 step peaks at 30 GB)
+        del a, b
+        m.eval()
+        with torch.no_grad():
+            full = m(image, word_id, word_mask)
+            one = m(image[24:32], word_id[24:32], word_mask[24:32])
+            ops.set_precision("fp32")
+            ref = m(image[24:32], word_id[24:32], word_mask[24:32])
+        for s_ in range(3):
+            d_mode = maxdiff(one[0][s_], ref[0][s_])
+            d_inv = maxdiff(full[0][s_][24:32], one[0][s_])
+            assert d_mode > 1e-3 and d_inv < 0.25 * d_mode, (s_, d_inv, d_mode)
+    finally:
+        ops.set_precision("fp32")
