@@ -110,6 +110,8 @@ def compact_line(res: dict) -> str:
     if ce:
         rf["conv_engine_frac"] = ce["frac_of_838.9"]; rf["conv_engine_tflops"] = ce["tflops_over_kernel_time"]
         rf["conv_tflop_per_step"] = ce["tflop_per_step"]
+        if "binding_frac" in ce:
+            rf["conv_engine_binding_frac"] = ce["binding_frac"]
     hs = out.pop("hbm_scoring", None)
     if hs:
         rf["hbm_scoring_frac"] = hs["frac"]; rf["hbm_scoring_gbs"] = hs["achieved"]
@@ -637,7 +639,10 @@ def main():
                                   "tflops_over_kernel_time": round(mfma_work / (mfma_ms * 1e-3) / 1e12, 1),
                                   "frac_of_838.9": round(mfma_work / (mfma_ms * 1e-3) / 1e12 / PEAK_H2_TFLOPS, 4),
                                   "frac_of_fp32_mfma_157.3": round(mfma_work / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
-                                  "tflops_over_step_wall": round(mfma_work / prof["steps"] / 1e12 / (dt / args.steps), 1)}
+                                  "tflops_over_step_wall": round(mfma_work / prof["steps"] / 1e12 / (dt / args.steps), 1),
+                                  # time the binding roofline of every launch allows (max of FLOP / MFMA peak of its arithmetic, bytes / 8 TB/s) over
+                                  # the time taken: what the HBM-bound layers of the stack (1x1 residual layers, 32-128-channel maps) can be held to
+                                  "binding_frac": round(sum(prof["bound"][t] for t in mm_tags) / mfma_ms, 4)}
             bn = sum(prof["ms"][t] for t in (10, 11, 22)) / prof["steps"]
             res["bn_passes_ms_per_step"] = round(bn, 2)
             per_shape = []
