@@ -83,8 +83,37 @@ NT = 48            # DCN_PROF_TAGS
 
 
 def read_sclk_mhz(device_index: int = 0):
-    """Shader clock (MHz) the card holds right now, from rocm-smi; None when the tool or the line is missing."""
+    """Shader clock (MHz) the card holds right now; None when it cannot be read.  From sysfs (`pp_dpm_sclk` of the device's PCI node: the
+    level marked `*`) — no process is started.  Only when sysfs has nothing and no profiler library is preloaded does it fall back to
+    `rocm-smi` in a child process (under `rocprofv3 --pmc` the preloaded library initialises the GPU in every child, and the `env python3`
+    hop of the rocm-smi script is then an exec of a GPU process, which the GPU boxes refuse)."""
+    import glob
     import re
+
+    def parse(path):
+        try:
+            with open(path) as f:
+                txt = f.read()
+        except OSError:
+            return None
+        m = re.search(r"(\d+)\s*Mhz\s*\*", txt, flags=re.I)
+        return int(m.group(1)) if m else None
+
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        node = "/sys/bus/pci/devices/%04x:%02x:%02x.0/pp_dpm_sclk" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        v = parse(node)
+        if v is not None:
+            return v
+    except (AttributeError, RuntimeError, AssertionError):
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+    if len(cards) == 1:
+        v = parse(cards[0])
+        if v is not None:
+            return v
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
     try:
         r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks"], capture_output=True, text=True, timeout=20)
     except (OSError, subprocess.SubprocessError):
