@@ -37,7 +37,7 @@ def test_single_gpu_line_is_compact_and_complete():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "ms_per_step", "binding_frac",
               "conv_engine_frac", "hbm_scoring_frac", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz"):
         assert k in rf, k
-    assert rf["sclk_mhz"] is None or 300 <= rf["sclk_mhz"] <= 3000
+    assert rf["sclk_mhz"] is None or 50 <= rf["sclk_mhz"] <= 3000
     assert 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = res["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["gpu_vs_oracle_max_abs_err"] < 1e-3
