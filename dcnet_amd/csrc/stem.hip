@@ -169,7 +169,8 @@ namespace {
 struct StemWParams {
   const float* x;                  // [M][4]
   const float* y;                  // raw convolution output [M][32]
-  const float* dout; int lddo;     // gradient w.r.t. the activation
+  const float* dout; int lddo;     // gradient w.r.t. the activation (lddo in elements)
+  int dout_b16;                    // bf16 storage: dout is a bf16 tensor (the data gradient of the layer behind the stem writes bf16)
   const float* mean; const float* invstd; const float* gamma; const float* beta; const float* sums;    // sums: [2][Co] = sum g, sum g*xhat
   float inv_count; int act; float slope;
   float* out;                      // slabs [grid][32][64]
@@ -213,6 +214,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_bn_kernel(const StemWParams p)
       const bool ok = ca_on && col < p.W && q_step + pa < p_end;
       const size_t pix = (size_t)row * p.W + col;
       yv = ok ? *reinterpret_cast<const f32x4*>(p.y + pix * 32 + ca) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.dout_b16) {
+        typedef __bf16 bf16x4s_t __attribute__((ext_vector_type(4)));
+        const bf16x4s_t b = ok ? *reinterpret_cast<const bf16x4s_t*>(reinterpret_cast<const __bf16*>(p.dout) + pix * p.lddo + ca) : bf16x4s_t{0, 0, 0, 0};
+        dv = f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+      } else
       dv = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.dout + pix * p.lddo + ca)) : f32x4{0.f, 0.f, 0.f, 0.f};
       a_ok = ok;
     }
@@ -302,10 +308,29 @@ PlanSW plan_sw(int n, int h, int wd) {
 
 extern "C" int64_t dcn_stem_bwd_weight_bn_ws(int n, int h, int wd) { return (int64_t)plan_sw(n, h, wd).grid * 32 * 64; }
 
+static int stem_bwd_impl(const float* x, const float* y, const float* dout, int dout_b16, int lddo,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         int act, float slope, const float* sums, int64_t count,
+                         int n, int h, int wd, int cout, float* dw, float* ws, void* stream_);
+
 extern "C" int dcn_stem_bwd_weight_bn(const float* x, const float* y, const float* dout, int lddo,
                                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                                       int act, float slope, const float* sums, int64_t count,
                                       int n, int h, int wd, int cout, float* dw, float* ws, void* stream_) {
+  return stem_bwd_impl(x, y, dout, 0, lddo, mean, invstd, gamma, beta, act, slope, sums, count, n, h, wd, cout, dw, ws, stream_);
+}
+// the same with dout as a bf16 tensor (bf16 storage: the stem's raw output y stays fp32, the gradient that reaches it is bf16)
+extern "C" int dcn_stem_bwd_weight_bn_b16(const float* x, const float* y, const void* dout16, int lddo,
+                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                          int act, float slope, const float* sums, int64_t count,
+                                          int n, int h, int wd, int cout, float* dw, float* ws, void* stream_) {
+  return stem_bwd_impl(x, y, (const float*)dout16, 1, lddo, mean, invstd, gamma, beta, act, slope, sums, count, n, h, wd, cout, dw, ws, stream_);
+}
+
+static int stem_bwd_impl(const float* x, const float* y, const float* dout, int dout_b16, int lddo,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                         int act, float slope, const float* sums, int64_t count,
+                         int n, int h, int wd, int cout, float* dw, float* ws, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG(x && y && dout && mean && invstd && sums && dw && ws, "stem_bwd_weight_bn: null pointer");
   DCN_CHECK_ARG(n > 0 && h >= 2 && wd >= 32 && cout > 0 && cout <= 32 && cout % 4 == 0 && count > 0,
@@ -318,7 +343,7 @@ extern "C" int dcn_stem_bwd_weight_bn(const float* x, const float* y, const floa
   DCN_CHECK_ARG((long long)n * h * (wd + 1) < 0x7FFFFFF0LL && (long long)n * h * wd * 16 < 0x7FFFFFF0LL, "stem_bwd_weight_bn: tensor too large");
   const PlanSW pl = plan_sw(n, h, wd);
   StemWParams p{};
-  p.x = x; p.y = y; p.dout = dout; p.lddo = lddo; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.sums = sums;
+  p.x = x; p.y = y; p.dout = dout; p.dout_b16 = dout_b16; p.lddo = lddo; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.sums = sums;
   p.inv_count = 1.f / (float)count; p.act = act; p.slope = slope; p.out = ws;
   p.N = n; p.H = h; p.W = wd; p.Co = cout; p.Mp = pl.Mp; p.kchunk = pl.kchunk;
   const int pid = prof_begin(39, 4.0 * ((double)n * h * wd * (32 + 32 + 4) + (double)pl.grid * 2048), stream);      // HBM-priced

@@ -450,8 +450,10 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
         else:
             p = P[op.slot]
             x, y, aux, w, ax, aw = save.pop(op.slot)
-            if s16 and torch.is_tensor(x) and x.dtype == torch.float32 and dout.dtype == torch.bfloat16:
-                dout = ops.to_f32(dout)           # bf16 storage: the 3-channel stem's kernels (BatchNorm backward, weight gradient) stay fp32
+            stem_fused = (op.bn and training and not op.need_dx and ops.STEM_FUSED_BWD and torch.is_tensor(x) and x.shape[3] == 4 and op.cout == 32
+                          and op.k == 3 and op.stride == 1 and op.res is None and torch.is_tensor(y) and y.is_contiguous() and x.shape[2] >= 32)
+            if s16 and torch.is_tensor(x) and x.dtype == torch.float32 and dout.dtype == torch.bfloat16 and not stem_fused:
+                dout = ops.to_f32(dout)           # bf16 storage: the 3-channel stem's generic kernels stay fp32 (its fused backward reads bf16 itself)
             shape = tuple(p["w"].shape)
             d = {}
             ady = ops.amax_slot(dout.device) if ops.use_amax() else None

@@ -45,6 +45,7 @@ SIGNATURES = {
     "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
     "dcn_stem_bwd_weight_bn": (I, [P, P, P, I, P, P, P, P, I, F, P, L, I, I, I, I, P, P, P]),
     "dcn_stem_bwd_weight_bn_ws": (L, [I, I, I]),
+    "dcn_stem_bwd_weight_bn_b16": (I, [P, P, P, I, P, P, P, P, I, F, P, L, I, I, I, I, P, P, P]),
     "dcn_bn_ws": (L, [I]),
     "dcn_bn_finalize": (I, [P, I, I, L, P, P, F, F, P, P, P, P, P, P, P, P]),
     "dcn_bn_fold": (I, [P, P, P, P, F, I, P, P, P]),

@@ -775,8 +775,9 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
     dw = torch.empty((c, 64), dtype=torch.float32, device=dev)
     slabs = scratch(lib().stem_bwd_weight_bn_ws(n, h, wd), dev, slot=0)          # (slot 0's partials have been reduced by then; slot 3 belongs to the side stream)
-    lib().stem_bwd_weight_bn(x.data_ptr(), y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
-                             act, float(slope), sums.data_ptr(), rows, n, h, wd, c, dw.data_ptr(), slabs.data_ptr(), _s())
+    fn = lib().stem_bwd_weight_bn_b16 if _b16(dout) else lib().stem_bwd_weight_bn      # (bf16 storage: the gradient arrives as bf16, y is fp32)
+    fn(x.data_ptr(), y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta),
+       act, float(slope), sums.data_ptr(), rows, n, h, wd, c, dw.data_ptr(), slabs.data_ptr(), _s())
     return dw, sums[1], sums[0]
 
 

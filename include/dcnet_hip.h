@@ -186,6 +186,11 @@ int dcn_stem_bwd_weight_bn(const float* x, const float* y, const float* dout, in
                            int act, float slope, const float* sums, int64_t count,
                            int n, int h, int wd, int cout, float* dw, float* ws, void* stream);
 int64_t dcn_stem_bwd_weight_bn_ws(int n, int h, int wd);
+/* the same with dout as a bf16 tensor (bf16 storage, ABI 305: y stays fp32, the gradient that reaches the stem is bf16; lddo in elements) */
+int dcn_stem_bwd_weight_bn_b16(const float* x, const float* y, const void* dout16, int lddo,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta,
+                               int act, float slope, const float* sums, int64_t count,
+                               int n, int h, int wd, int cout, float* dw, float* ws, void* stream);
 
 /* ---- batched GEMM on pre-split operands (gemm3.hip) ----------------------------------- */
 /* The torch.bmm products of the inter-frame co-attention (model/DCNet_model.py:449-459: affinity, the two attended features; and

@@ -308,3 +308,22 @@ def test_b16_inference_models_run_on_bf16_storage():
         assert a.dtype == torch.float32 and bool(torch.isfinite(a).all())
         d = maxdiff(a, r)
         assert 1e-4 < d < 0.5 * float(r.abs().max()), (s_, d)
+
+
+def test_stem_backward_reads_a_bf16_gradient_as_it_is():
+    """bf16 storage: the gradient that reaches the 3-channel stem is a bf16 tensor (the data gradient of the layer behind it), its raw output y
+    stays fp32.  The fused stem backward (BatchNorm + LeakyReLU backward + weight gradient in one pass) reads the bf16 gradient directly:
+    bitwise what it computes from the same values cast to fp32 first."""
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w = 2, 40, 48
+    x = _rand(n, h, w, 4, seed=1).to(dev); x[..., 3] = 0
+    y = _rand(n, h, w, 32, seed=2).to(dev)
+    dout16 = _bf(_rand(n, h, w, 32, seed=3)).to(dev)
+    mean = _rand(32, seed=4, scale=0.1).to(dev); invstd = (_rand(32, seed=5).abs() + 0.5).to(dev)
+    gamma = _rand(32, seed=6).to(dev); beta = _rand(32, seed=7, scale=0.3).to(dev)
+    a = ops.stem_bwd_weight_bn(x, y, dout16, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1)
+    b = ops.stem_bwd_weight_bn(x, y, dout16.float(), mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1)
+    assert torch.equal(a[0], b[0])                                           # the weight gradient: same values, same order
+    for u, v in zip(a[1:], b[1:]):                                           # d gamma, d beta: the reduce passes differ in their block shape only
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-5 * float(v.abs().max()))
