@@ -567,7 +567,10 @@ class _DarknetFn(torch.autograd.Function):
         plan, taps = net._plan, net._taps
         P = net._param_table(flat)
         x = ops.nchw_to_nhwc(image.contiguous(), 4)
-        need_grad = any(ctx.needs_input_grad[3:])
+        # (needs_input_grad speaks about the parameters, not about the caller's grad mode: under torch.no_grad() — inference — nothing is
+        #  saved and every layer is ONE kernel with BatchNorm, activation and shortcut in its epilogue; forward_nhwc notes the mode, since
+        #  inside a Function's forward grad mode is always off)
+        need_grad = any(ctx.needs_input_grad[3:]) and bool(net.__dict__.get("_grad_on", True))
         if ops.storage_b16() and not training:
             need_grad = False          # bf16 storage has no frozen-BatchNorm backward: inference only in eval mode (backward() says so)
         save = {} if need_grad else None
@@ -703,6 +706,7 @@ class Darknet(nn.Module):
     def forward_nhwc(self, x: torch.Tensor, taps_b16: bool = False) -> List[torch.Tensor]:
         """taps_b16 (bf16-storage mode only): hand the three taps out as the bf16 tensors they are instead of casting them to fp32."""
         self.__dict__["_taps_b16"] = bool(taps_b16) and ops.storage_b16()
+        self.__dict__["_grad_on"] = torch.is_grad_enabled()
         if not x.is_cuda:
             raise RuntimeError("dcnet_amd.Darknet runs on an MI355X only: move the model and inputs to cuda "
                                "(there is no CPU path; the CPU restatement lives in oracle/ for tests)")
