@@ -431,6 +431,17 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 first_use.setdefault(s_, i)
     index_of = {id(op): i for i, op in enumerate(plan)}
     tapped: Dict[int, torch.Tensor] = {}
+    held = None          # (gradient dict, slot, ops.HeldWgrad): the weight gradient of the layer before, launched behind this layer's passes
+
+    def release():
+        nonlocal held, pending_bytes
+        if held is not None:
+            d_, slot_, hw_ = held
+            held = None
+            d_["w"] = hw_.issue()
+            if sink is not None:
+                pending.append((slot_, "w", d_["w"])); pending_bytes += d_["w"].numel() * 4
+
     for op in reversed(plan):
         dout = g.pop(op.dst, None)
         if dout is None:
@@ -498,6 +509,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 ady = None            # (frozen-BN path: the GEMMs below compute the abs-max of dy themselves)
             if op.res is not None:
                 add(op.res, dout)
+            release()                  # (behind this layer's BatchNorm passes: the main chain stays the first dependent of the data gradient before)
             if not ops.WGRAD_AFTER_DGRAD:
                 d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)     # overlaps with the data gradient below
             if op.need_dx and s16 and dy.dtype == torch.bfloat16:
@@ -543,7 +555,10 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 if cur is None:
                     g[op.src] = res_
             if ops.WGRAD_AFTER_DGRAD:      # (schedule experiment: queued behind the data gradient, beside the next layer's BatchNorm passes)
-                d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)
+                if ops.WGRAD_SIDE and ops.WGRAD_HELD:
+                    held = (d, op.slot, ops.HeldWgrad(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady))
+                else:
+                    d["w"] = ops.wgrad_on_side(x, dy, op.k, op.stride, shape, amax_x=ax, amax_dy=ady)
             pg[op.slot] = d
             if sink is not None:
                 for k_, t_ in d.items():
@@ -551,6 +566,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                         pending.append((op.slot, k_, t_)); pending_bytes += t_.numel() * 4
                 if pending_bytes >= bucket_bytes:
                     sink(pending); pending = []; pending_bytes = 0
+    release()
     if sink is not None and pending:
         sink(pending)
     if pg:

@@ -96,13 +96,20 @@ class GraphedTrainStep:
         # the forward reads this step's draws from the static buffers (draw_samples filled them); only for this call — an eager
         # forward of the same model elsewhere keeps drawing for itself
         self.core.static_samples = self.samples
+        defer = ops.LANGUAGE_BWD_DEFERRED and hasattr(self.core, "finish_backward")
+        if defer:
+            self.core.defer_language_backward = True
         try:
             out = self.model(self.image, self.word_id, self.word_mask)
         finally:
             self.core.static_samples = None
+            if defer:
+                self.core.defer_language_backward = False
         loss, parts = losses.total_loss(out, self.bbox, self.size)
         self._zero_grads()
         loss.backward()
+        if defer:
+            self.core.finish_backward()          # the language branch's backward, beside the backbone's (model.finish_backward)
         if self.reducer is None:
             self.opt.step()
         elif eager:

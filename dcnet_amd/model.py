@@ -229,12 +229,59 @@ class grounding_model(nn.Module):
         self.presample_ahead = True
         # the language branch (embedding, MLP, BiLSTM, mapping_lang, phrase attention) on its own stream under the backbone
         self.language_stream = True
+        # a step driver that calls finish_backward() after loss.backward() sets this (graph.GraphedTrainStep): the language branch's
+        # backward is then NOT part of loss.backward() — the head hands its gradients to detached leaves and finish_backward() runs the
+        # branch's backward on its stream from the point where the last of them was written.  In a captured step that makes it the LAST
+        # captured dependent of that point: the graph executor keeps it off the main chain's queue (tools/graph_sched.py) and its
+        # latency-bound kernels (the persistent BiLSTM backward: 1.5 ms alone) run beside the backbone's backward, not in front of it
+        self.defer_language_backward = False
         # discrete choices of the last forward (top-k / arg-max indices and the sampled negatives):
         # exposed so that parity tests can replay them through the oracle (near-tie orderings differ
         # between fp32 implementations) and so that a caller can log what was sampled
         self.last_choices = {}
 
     # ------------------------------------------------------------------------------------------
+    def finish_backward(self) -> None:
+        """Second half of a backward pass when ``defer_language_backward`` is set: the language branch's backward, on its own stream,
+        from the gradients loss.backward() left on the detached leaves.  The caller's stream waits for it."""
+        st = self.__dict__.pop("_lang_pending", None)
+        if st is None:
+            return
+        side = st["side"]
+        main = torch.cuda.current_stream()
+        pairs = [(t_, l_.grad) for t_, l_ in zip(st["live"], st["leaves"]) if t_.requires_grad and l_.grad is not None]
+        hops = []
+        if st["event"] is not None:
+            # (captured steps: the graph executor gives the k-th dependent of a node the node's queue + k, of four — tools/graph_sched.py.
+            #  The main chain is dependent 0, the weight-gradient stream sits on queue + 1: LANGUAGE_BWD_HOPS one-word memsets on streams of
+            #  their own, waiting on the same event, take the places in between so that this branch gets a queue to itself)
+            if torch.cuda.is_current_stream_capturing():
+                for i_ in range(int(ops.LANGUAGE_BWD_HOPS)):
+                    h_ = self._side_stream(main.device, "hop%d" % i_)
+                    h_.wait_event(st["event"])
+                    with torch.cuda.stream(h_):
+                        self._hop_word(main.device).zero_()
+                    hops.append(h_)
+            side.wait_event(st["event"])
+        else:
+            side.wait_stream(main)
+        if pairs:
+            with torch.cuda.stream(side):
+                for _, g_ in pairs:
+                    g_.record_stream(side)
+                torch.autograd.backward([t_ for t_, _ in pairs], [g_ for _, g_ in pairs])
+        main.wait_stream(side)
+        for h_ in hops:
+            main.wait_stream(h_)
+        for l_ in st["leaves"]:
+            l_.grad = None
+
+    def _hop_word(self, device):
+        key = ("hop_word", str(device))
+        if key not in self._streams:
+            self._streams[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._streams[key]
+
     def _side_stream(self, device, name: str = "lang"):
         key = (str(device), name)
         if key not in self._streams:
@@ -530,6 +577,20 @@ class grounding_model(nn.Module):
         main.wait_stream(side)
         for t_ in (flang, context, embedded, flang_attn, flang_loc):
             t_.record_stream(main)
+        self.__dict__.pop("_lang_pending", None)
+        if self.defer_language_backward and self.training and torch.is_grad_enabled() and side is not main:
+            live = (flang, context, embedded, flang_attn, flang_loc)
+            leaves = tuple(t_.detach().requires_grad_(t_.requires_grad) for t_ in live)
+            state = {"live": live, "leaves": leaves, "event": None, "side": side}
+
+            def _written(_leaf, st=state):       # (runs on the stream of the leaf's AccumulateGrad: the head's)
+                ev_ = torch.cuda.Event(); ev_.record(torch.cuda.current_stream()); st["event"] = ev_
+
+            for l_ in leaves:
+                if l_.requires_grad:
+                    l_.register_post_accumulate_grad_hook(_written)
+            self.__dict__["_lang_pending"] = state
+            flang, context, embedded, flang_attn, flang_loc = leaves
         sampling = self.training
         samp = None
         r0 = self._scale_pairs(0, raw[0], flang, flang_attn)

@@ -639,6 +639,43 @@ WGRAD_AFTER_DGRAD = True    # the side stream also waits for the layer's DATA gr
                             # False = round 2's order; a lowest-priority side stream: +-0)
 
 
+WGRAD_HELD = True      # A/B switch (darknet._run_backward): a layer's weight gradient is LAUNCHED behind the next layer's BatchNorm passes (its
+                       # dependency stays the event recorded behind its own data gradient).  Same DAG; in a captured step the main chain
+                       # then is the first dependent of every data gradient and the graph executor keeps it on ONE queue, the weight
+                       # gradients on another (without it the main chain hops queues layer by layer and meets the weight-gradient queue —
+                       # and whatever else runs beside it — every fourth layer: tools/graph_sched.py)
+
+
+class HeldWgrad:
+    """A weight gradient on the side stream whose launch is held back: the constructor records (on the current stream) the event it
+    depends on, issue() launches it.  issue() must run with the same current stream."""
+
+    def __init__(self, x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
+        self.args = (x, dy, ksize, stride, wshape, amax_x, amax_dy)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream())
+
+    def issue(self):
+        x, dy, ksize, stride, wshape, amax_x, amax_dy = self.args
+        self.args = None
+        main = torch.cuda.current_stream()
+        side = side_stream(x.device)
+        side.wait_event(self.event)                  # dy (and x) are produced on the main stream, in front of the event
+        return _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy)
+
+
+def _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy):
+    with torch.cuda.stream(side):
+        dw = conv2d_bwd_weight(x, dy, ksize, stride, slot=3, amax_x=amax_x, amax_dy=amax_dy)
+        if wshape[0] != dw.shape[0]:
+            dw = dw[:wshape[0]].contiguous()
+        out = weight_grad_to_oihw(dw, wshape)
+    for t in ((x.y, x.scale, x.shift) if isinstance(x, PreAct) else (x,)) + (dy,):
+        t.record_stream(side)                    # keep the allocator from recycling them under the side kernels
+    out.record_stream(main)
+    return out
+
+
 def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
     """Launch the weight gradient (+ its OHWI->OIHW conversion) on the side stream.  Returns the OIHW
     gradient; the caller must make the main stream wait for side_stream() before the result is consumed."""
@@ -650,15 +687,7 @@ def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
     main = torch.cuda.current_stream()
     side = side_stream(x.device)
     side.wait_stream(main)                       # dy (and x) are produced on the main stream
-    with torch.cuda.stream(side):
-        dw = conv2d_bwd_weight(x, dy, ksize, stride, slot=3, amax_x=amax_x, amax_dy=amax_dy)
-        if wshape[0] != dw.shape[0]:
-            dw = dw[:wshape[0]].contiguous()
-        out = weight_grad_to_oihw(dw, wshape)
-    for t in ((x.y, x.scale, x.shift) if isinstance(x, PreAct) else (x,)) + (dy,):
-        t.record_stream(side)                    # keep the allocator from recycling them under the side kernels
-    out.record_stream(main)
-    return out
+    return _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy)
 
 
 def join_side(device) -> None:
@@ -782,6 +811,8 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
 
 
 LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
+LANGUAGE_BWD_HOPS = 1             # (model.finish_backward: queue steering in captured steps)
+LANGUAGE_BWD_DEFERRED = True      # A/B switch (graph.GraphedTrainStep): the language branch's backward as its own stage behind loss.backward()
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
 BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
 BN_TAP_TRUNK = os.environ.get("DCN_BN_TAP_TRUNK", "1") != "0"
