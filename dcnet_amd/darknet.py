@@ -435,6 +435,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
 
     def release():
         nonlocal held, pending_bytes
+        ops.release_held_wgrads()        # (ops.WGRAD_DIRECT: the head's last block)
         if held is not None:
             d_, slot_, hw_ = held
             held = None

@@ -27,6 +27,7 @@ class ConvBNAct(torch.autograd.Function):
         if bank is not None and x.shape[3] != weight.shape[1]:
             bank = None                    # (K-padded input: the per-launch path pads the bank)
         ctx.b16 = None
+        ctx.wparam = weight if (ops.WGRAD_DIRECT and ops.WGRAD_SIDE and training and isinstance(weight, torch.nn.Parameter)) else None
         if ops.storage_b16() and bank is not None:
             x_f32 = x.dtype == torch.float32
             x16 = ops.to_b16(x.contiguous())
@@ -80,6 +81,12 @@ class ConvBNAct(torch.autograd.Function):
             tb16, x_f32 = ctx.b16
             dy, dgamma, dbeta = ops.bn_act_bwd(y, dout.contiguous(), mi[0], mi[1], gamma.detach(), beta.detach(), ops.ACT_LEAKY, slope)
             dx = None
+            if ctx.wparam is not None:     # (ops.WGRAD_DIRECT: the block before's weight gradient goes out behind this block's passes)
+                ops.release_held_wgrads()
+                if ctx.needs_input_grad[0]:
+                    dx = ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+                ops.hold_wgrad_into(ctx.wparam, x16, dy, ksize, 1, wshape)
+                return dx, None, dgamma, dbeta, None, None, None, None, None, None, None
             if not ops.WGRAD_AFTER_DGRAD:
                 dwt = ops.wgrad_on_side(x16, dy, ksize, 1, wshape)
             if ctx.needs_input_grad[0]:
@@ -104,6 +111,11 @@ class ConvBNAct(torch.autograd.Function):
             z = y if slope == 0 else torch.where(y > 0, y, y / slope)
             gs = torch.where(gamma == 0, torch.ones_like(gamma), gamma)
             dgamma = (dz * (z - beta) / gs).reshape(-1, wshape[0]).sum(0)
+        if ctx.wparam is not None and training:
+            ops.release_held_wgrads()
+            dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw, wt_ready=ctx.wtr) if ctx.needs_input_grad[0] else None
+            ops.hold_wgrad_into(ctx.wparam, x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
+            return dx, None, dgamma, dbeta, None, None, None, None, None, None, None
         if not ops.WGRAD_AFTER_DGRAD:
             dwt = ops.wgrad_on_side(x, dy, ksize, 1, wshape, amax_x=ax, amax_dy=ady)
         dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), ksize, 1, amax_dy=ady, amax_w=aw, wt_ready=ctx.wtr) if ctx.needs_input_grad[0] else None

@@ -97,19 +97,25 @@ class GraphedTrainStep:
         # forward of the same model elsewhere keeps drawing for itself
         self.core.static_samples = self.samples
         defer = ops.LANGUAGE_BWD_DEFERRED and hasattr(self.core, "finish_backward")
+        direct = ops.HEAD_WGRAD_DIRECT and not getattr(self.reducer, "uses_parameter_hooks", False)
+        was_direct = ops.WGRAD_DIRECT
         if defer:
             self.core.defer_language_backward = True
+        ops.WGRAD_DIRECT = direct
         try:
             out = self.model(self.image, self.word_id, self.word_mask)
+            loss, parts = losses.total_loss(out, self.bbox, self.size)
+            self._zero_grads()
+            loss.backward()
+            if defer:
+                self.core.finish_backward()      # the language branch's backward, beside the backbone's (model.finish_backward)
+            if direct:
+                ops.finish_wgrads(self.image.device)     # the head's weight gradients went into .grad on the side stream (ops.WGRAD_DIRECT)
         finally:
             self.core.static_samples = None
+            ops.WGRAD_DIRECT = was_direct
             if defer:
                 self.core.defer_language_backward = False
-        loss, parts = losses.total_loss(out, self.bbox, self.size)
-        self._zero_grads()
-        loss.backward()
-        if defer:
-            self.core.finish_backward()          # the language branch's backward, beside the backbone's (model.finish_backward)
         if self.reducer is None:
             self.opt.step()
         elif eager:

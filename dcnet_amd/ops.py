@@ -690,6 +690,43 @@ def wgrad_on_side(x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
     return _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy)
 
 
+WGRAD_DIRECT = False   # set by a step driver that calls finish_wgrads() behind loss.backward() (graph.GraphedTrainStep).  The head's conv blocks
+                       # (functions.ConvBNAct / ConvBias) then do NOT hand their weight gradient to autograd — that needs the main stream to
+                       # wait for the side stream in every block: dgrad -> wgrad -> next block, nothing beside anything — but add it to
+                       # the parameter's .grad themselves, ON the side stream, launched behind the next block's BatchNorm passes like the
+                       # backbone's (WGRAD_HELD); the main stream joins once, in finish_wgrads().  Same sums into the same buffers.
+                       # (Parameter hooks do not fire for these gradients: drivers whose reducer hangs on hooks leave it off.)
+HEAD_WGRAD_DIRECT = True    # A/B switch: graph.GraphedTrainStep sets WGRAD_DIRECT for its step
+_held_direct: list = []
+
+
+def hold_wgrad_into(param, x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None) -> None:
+    """The weight gradient of (x, dy), to be added to param.grad on the side stream; launched by the next release_held_wgrads()."""
+    _held_direct.append((HeldWgrad(x, dy, ksize, stride, wshape, amax_x=amax_x, amax_dy=amax_dy), param))
+
+
+def release_held_wgrads() -> None:
+    while _held_direct:
+        hw, param = _held_direct.pop(0)
+        dev = hw.args[0].device if not isinstance(hw.args[0], PreAct) else hw.args[0].y.device
+        out = hw.issue()
+        with torch.cuda.stream(side_stream(dev)):
+            if param.grad is None:
+                param.grad = out.view_as(param)
+            else:
+                param.grad.add_(out.view_as(param))
+
+
+def finish_wgrads(device) -> None:
+    """Launch what is still held and make the current stream wait for every weight-gradient stream of the device."""
+    release_held_wgrads()
+    cur = torch.cuda.current_stream(device)
+    idx = torch.device(device).index
+    for key, st in _side.items():
+        if key[0] == idx and st is not cur:
+            cur.wait_stream(st)
+
+
 def join_side(device) -> None:
     if WGRAD_SIDE:
         torch.cuda.current_stream().wait_stream(side_stream(device))
