@@ -82,3 +82,30 @@ def test_new_inputs_reach_the_captured_step(dev):
     out = m(img2, wid2, word_mask)
     b = float(losses.total_loss(out, box2, size)[0])
     assert a == b, (a, b)
+
+
+def test_graph_queues_of_the_captured_step(tmp_path):
+    """The stream schedule of the captured step leans on how the hipGraph executor maps branches to its four queues (the k-th dependent of
+    a node gets the node's queue + k; tools/graph_sched.py models it).  The runtime's own dump of the captured DAG
+    (DEBUG_HIP_GRAPH_DOT_PRINT, in a child process: the flag is read when the runtime loads) must agree with that model on every node,
+    and show what the schedule is built for: the backbone's data-gradient chain on ONE queue, its weight gradients on another, the
+    language branch's backward on a third."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dot = str(tmp_path / "step.dot")
+    env = dict(os.environ, DEBUG_HIP_GRAPH_DOT_PRINT="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_dot.py"), "--out", dot, "--clips", "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_sched.py"), dot, "--chains"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = json.loads(r.stdout.strip().splitlines()[-1])
+    assert c["agree"] == c["nodes"] and c["nodes"] > 1000, c
+    assert len(c["data_gradients"]) == 1, c
+    main_q = next(iter(c["data_gradients"]))
+    wq = max(c["weight_gradients"], key=c["weight_gradients"].get)
+    assert wq != main_q and c["weight_gradients"][wq] >= 0.9 * sum(c["weight_gradients"].values()), c
+    assert len(c["language"]) == 1 and next(iter(c["language"])) not in (main_q, wq), c

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def capture(path, clips, precision, switches=""):
+def capture(path, clips, precision, switches="", size=416):
     from dcnet_amd import ops
     for kv in switches.split(","):
         if kv:
@@ -30,15 +30,15 @@ def capture(path, clips, precision, switches=""):
     ops.set_precision(precision)
     torch.manual_seed(1234)
     model = grounding_model(corpus=list(range(1000)), light=False, emb_size=512, coordmap=True, bert_model="bert-base-uncased",
-                            dataset="vid", img_size=416, config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None).to(dev)
+                            dataset="vid", img_size=size, config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None).to(dev)
     model.train(); freeze_gradless(model)
     opt = make_optimizer(model, 1e-4)
     n = clips * 8
-    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n, 416, seed=100))
-    bbox = synth_boxes(n, 416, seed=100).to(dev)
+    image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n, size, seed=100))
+    bbox = synth_boxes(n, size, seed=100).to(dev)
     random.seed(13)
     cwd = os.getcwd(); os.chdir("/tmp")
-    GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, 416, warmup=2)
+    GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, size, warmup=2)
     torch.cuda.synchronize()
     os.chdir(cwd)
     import glob
@@ -93,11 +93,12 @@ def main():
     ap.add_argument("--from", dest="src", default="bilstm_bwd"); ap.add_argument("--to", dest="dst", default="dA_kernel")
     ap.add_argument("--clips", type=int, default=8); ap.add_argument("--precision", default="fp32")
     ap.add_argument("--analyse-only", action="store_true")
+    ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--ops", default="", help="switches of dcnet_amd.ops for the capture, NAME=int[,NAME=int]")
     a = ap.parse_args()
     if not a.analyse_only:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
-        capture(a.out, a.clips, a.precision, a.ops)
+        capture(a.out, a.clips, a.precision, a.ops, a.size)
     analyse(a.out, a.src, a.dst)
 
 

@@ -43,7 +43,34 @@ def simulate(nodes, order, edges, nq=4):
     return sid
 
 
+def chains(path):
+    """Queue ids (as the runtime assigned them) of the step's chains: the backbone's data-gradient chain, its weight gradients, the
+    language branch's backward; and how many nodes the model of simulate() gets right."""
+    nodes, order, edges = parse(path)
+    sim = simulate(nodes, order, edges)
+    idx = {n: nodes[n]["idx"] for n in order}
+    name = lambda n: nodes[n]["name"]
+    lang0 = min(idx[n] for n in order if "phrase_bwd" in name(n))
+    lang1 = max(idx[n] for n in order if "embedding_bwd" in name(n))
+    loss = min(idx[n] for n in order if "dense_loss_bwd" in name(n))
+    in_lang = lambda n: lang0 <= idx[n] <= lang1
+    # the backbone's backward: everything behind the head's backward that is not the language chain; its convolutions' data gradients
+    # (conv3 / conv1 / igemm / dgrad2 / nconv kernels) against its weight-gradient kernels
+    stem = max(idx[n] for n in order if "stem_wgrad" in name(n) or "wgrad9" in name(n))
+    body = [n for n in order if loss + 300 < idx[n] <= stem and not in_lang(n)]
+    is_w = lambda n: "wgrad" in name(n)
+    is_d = lambda n: any(k in name(n) for k in ("conv3_kernel", "conv1_kernel", "dgrad2_kernel"))
+    cnt = lambda ns: dict(collections.Counter(nodes[n]["sid"] for n in ns))
+    return dict(agree=sum(1 for n in order if sim.get(n) == nodes[n]["sid"]), nodes=len(order),
+                language=cnt([n for n in order if in_lang(n)]), data_gradients=cnt([n for n in body if is_d(n)]),
+                weight_gradients=cnt([n for n in body if is_w(n)]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--chains":
+        import json
+        print(json.dumps(chains(sys.argv[1])))
+        sys.exit(0)
     nodes, order, edges = parse(sys.argv[1])
     print("nodes", len(nodes), "edges", len(edges), "roots", sum(1 for n in order if not any(b == n for a, b in edges)))
     sim = simulate(nodes, order, edges)
