@@ -139,6 +139,8 @@ def compact_line(res: dict) -> str:
     if ce:
         rf["conv_engine_frac"] = ce["frac_of_838.9"]; rf["conv_engine_tflops"] = ce["tflops_over_kernel_time"]
         rf["conv_tflop_per_step"] = ce["tflop_per_step"]
+        if "tflops_over_step_wall" in ce:          # the whole replayed step against the MFMA ceiling: moves with the step, whatever shares the GPU
+            rf["step_tflops"] = ce["tflops_over_step_wall"]; rf["step_frac"] = round(ce["tflops_over_step_wall"] / PEAK_H2_TFLOPS, 4)
         if "binding_frac" in ce:
             rf["conv_engine_binding_frac"] = ce["binding_frac"]
     hs = out.pop("hbm_scoring", None)
@@ -155,7 +157,7 @@ def compact_line(res: dict) -> str:
     if "sclk_mhz" in out and rf:
         rf["sclk_mhz"] = out.pop("sclk_mhz")       # (no roofline object — a run without the profiled pass —: the clock stays at top level)
     if rf:
-        rf["note"] = "kernel alone (HIP events); in_step: rocprofv3 of replays"
+        rf["note"] = "alone: HIP events; in_step: rocprofv3, 2 queues share GPU"
         out["roofline"] = rf
     line = json.dumps(out, separators=(",", ":"))
     for path in (("roofline", "rocprof_match"), ("roofline", "alg_bytes_per_launch"), ("roofline", "hbm_frac_algorithmic"),

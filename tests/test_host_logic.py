@@ -302,9 +302,11 @@ def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
         assert k in out, k
     rf = out["roofline"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "in_step_frac", "in_step_ms", "conv_engine_frac",
-              "hbm_scoring_frac", "hbm_scoring_gbs", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz", "rocprof_match"):
+              "hbm_scoring_frac", "hbm_scoring_gbs", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz", "rocprof_match",
+              "step_tflops", "step_frac"):
         assert k in rf, k
     assert rf["in_step_frac"] == 0.3642 and rf["hbm_scoring_frac"] == 0.6485 and rf["conv_engine_frac"] == 0.3086 and rf["sclk_mhz"] == 2104
+    assert rf["step_tflops"] == 190.6 and abs(rf["step_frac"] - 190.6 / 838.9) < 1e-3        # the replayed step's FLOP over its wall time
     assert all(len(v) <= 120 for v in (out["config"]["workload"], rf["kernel"], rf["note"], out["cpu_baseline"]["sample"]))   # the driver cuts strings
     # an absurdly long line sheds bookkeeping keys, never the contract or the north_star numbers
     res["config"]["workload"] = "x" * 700
