@@ -256,7 +256,7 @@ class grounding_model(nn.Module):
             #  The main chain is dependent 0, the weight-gradient stream sits on queue + 1: LANGUAGE_BWD_HOPS one-word memsets on streams of
             #  their own, waiting on the same event, take the places in between so that this branch gets a queue to itself)
             if torch.cuda.is_current_stream_capturing():
-                for i_ in range(int(ops.LANGUAGE_BWD_HOPS)):
+                for i_ in range(int(ops.LANGUAGE_BWD_HOPS_B16 if ops.storage_b16() else ops.LANGUAGE_BWD_HOPS)):
                     h_ = self._side_stream(main.device, "hop%d" % i_)
                     h_.wait_event(st["event"])
                     with torch.cuda.stream(h_):

@@ -848,7 +848,8 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
 
 
 LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
-LANGUAGE_BWD_HOPS = 1             # (model.finish_backward: queue steering in captured steps)
+LANGUAGE_BWD_HOPS = 1             # (model.finish_backward: queue steering in captured steps; fp32: 97.7 / 95.6 / 96.6 ms with 0 / 1 / 2)
+LANGUAGE_BWD_HOPS_B16 = 0         # bf16 storage: the branch shares the weight gradients' queue (59.9 ms against 60.7 with a queue of its own)
 LANGUAGE_BWD_DEFERRED = True      # A/B switch (graph.GraphedTrainStep): the language branch's backward as its own stage behind loss.backward()
 STEM_FUSED_BWD = True      # A/B switch: False = bn_act_bwd (writes dy) + conv2d_bwd_weight for the stem
 BN_TAP = True              # A/B switch: False = never ask a data gradient for the partial sums of the BatchNorm in front
