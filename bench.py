@@ -135,6 +135,8 @@ def compact_line(res: dict) -> str:
     ins = rf.pop("in_step", None)
     if ins:
         rf["in_step_frac"] = ins["frac"]; rf["in_step_ms"] = ins["avg_launch_ms"]
+        if "shared" in ins:
+            rf["in_step_shared"] = ins["shared"]
     ce = out.pop("conv_engine", None)
     if ce:
         rf["conv_engine_frac"] = ce["frac_of_838.9"]; rf["conv_engine_tflops"] = ce["tflops_over_kernel_time"]
@@ -658,6 +660,8 @@ def main():
                     fl_per_launch = fam_sum(prof, dom, "work") / fam_sum(prof, dom, "c")
                     roofline["in_step"] = {"avg_launch_ms": round(k_["avg_launch_ms"], 4),
                                            "frac": round(fl_per_launch / (k_["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_OF[dom], 4)}
+                    if "shared_frac_of_time" in k_:      # part of that time with a kernel of another graph queue resident as well
+                        roofline["in_step"]["shared"] = k_["shared_frac_of_time"]
             res["roofline"] = roofline
             fe = entry(prof, fdom)
             res["flop_dominant"] = {k: fe[k] for k in ("kernel", "frac", "ms_per_step", "binding_frac")}

@@ -50,6 +50,54 @@ def norm(name):
     return name.replace(" ", "").replace("void", "").replace("(anonymousnamespace)::", "")
 
 
+def residency(trace_csv, fam, kernels):
+    ev = []; rows = []
+    with open(trace_csv, newline="") as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), norm(r["Kernel_Name"])))
+    # the replays only: from the first launch of the first replayed step's first kernel (the capture's eager passes come before)
+    rows.sort()
+    firsts = [s for s, e, n in rows if "image_to_nhwc4" in n]
+    opt = [e for s, e, n in rows if "rmsprop_kernel" in n]
+    if len(firsts) < 3 or not opt:
+        return None
+    t0, t1 = firsts[-3], max(opt)                 # the last three steps of the run are replays (bench.py --steps 3)
+    rows = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+    for i, (s, e, n) in enumerate(rows):
+        ev.append((s, 1, i)); ev.append((e, 0, i))
+    ev.sort()
+    active = set(); last = ev[0][0]
+    conc = {1: 0.0, 2: 0.0, 3: 0.0}
+    shared = [0.0] * len(rows)
+    for t, kind, i in ev:
+        dt = t - last
+        if dt > 0 and active:
+            conc[min(len(active), 3)] += dt
+            if len(active) > 1:
+                for j in active:
+                    shared[j] += dt
+        last = t
+        if kind:
+            active.add(i)
+        else:
+            active.discard(i)
+    steps = 3
+    res = {"steps": steps, "ms_per_step_with_1_2_3plus_kernels_resident": [round(conc[k] / steps / 1e6, 2) for k in (1, 2, 3)], "families": {}}
+    for k_, pats in fam.items():
+        tot = sh = 0.0; solo_n = 0; solo_t = 0.0
+        for (s, e, n), sh_ in zip(rows, shared):
+            if any(p_ in n for p_ in pats):
+                tot += e - s; sh += sh_
+                if sh_ < 0.05 * (e - s):
+                    solo_n += 1; solo_t += e - s
+        if tot:
+            res["families"][k_] = {"shared_frac_of_time": round(sh / tot, 3), "launches_alone": solo_n,
+                                   "avg_launch_ms_alone": round(solo_t / solo_n / 1e6, 4) if solo_n else None}
+            if k_ in kernels:
+                kernels[k_]["shared_frac_of_time"] = round(sh / tot, 3)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
@@ -110,6 +158,12 @@ def main():
                     calls += int(r["Calls"]); tot += float(r["TotalDurationNs"])
             if calls:
                 out["kernels"][k_] = {"calls": calls, "avg_launch_ms": tot / calls / 1e6}
+        # who shares the chip: from the kernel trace of the same run, per family the part of its time during which a kernel of
+        # another graph queue was resident too (a launch beside the weight-gradient queue is longer than the same launch alone —
+        # the step is shorter for it), and the replays' time with one / two / three+ kernels resident
+        trace = find(os.path.join(a.dir, "stats"), "*kernel_trace.csv")
+        if trace:
+            out["residency"] = residency(trace, fam, out["kernels"])
         with open(os.path.join(prof, "in_step_latest.json"), "w") as f:
             json.dump(out, f, indent=1)
     tables = {}
