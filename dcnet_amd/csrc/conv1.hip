@@ -582,7 +582,9 @@ int launch1(const IgemmParams& p, hipStream_t stream) {
   const int gm = cdiv(p.M, BM), gn = p.Co / BN;
   const double k_alg = (double)p.ntaps * p.Ci;
   // algorithmic bytes: the gathered tensor once (its N*Hi*Wi pixels of Ci), the filter bank, the output
-  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co);
+  // (every operand the launch must read once: gathered tensor, bank, and — where the epilogue asks for them — the tensor accumulated
+  //  onto, the shortcut, the tapped BatchNorm input)
+  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
   const int pid = prof_begin(35, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((conv1_kernel<SA, SB, NI, MI>), dim3(gm * gn), dim3(256), lds, stream, p);
   prof_end(pid, stream);
@@ -652,7 +654,8 @@ int launch1b(const IgemmParams& p, hipStream_t stream) {
   }
   const int gm = cdiv(p.M, BM), gn = p.Co / BN;
   const double k_alg = (double)p.ntaps * p.Ci;
-  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) + (O32 ? 4.0 : 2.0) * (double)p.M * p.Co;
+  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
+                           ((O32 ? 4.0 : 2.0) * (1.0 + (p.accumulate ? 1.0 : 0.0) + (p.residual ? 1.0 : 0.0)) + (p.bt_y ? 2.0 : 0.0)) * (double)p.M * p.Co;
   const int pid = prof_begin(41, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((conv1b_kernel<SA, SB, NI, MI, O32>), dim3(gm * gn), dim3(256), lds, stream, p);
   prof_end(pid, stream);

@@ -270,7 +270,8 @@ int launch2b(const IgemmParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2b_kernel<O32>), hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS);
   const int grid = cdiv(p.M, C2_BM) * (p.Co / C2_BN);
   const double k_alg = (double)p.ntaps * p.Ci;
-  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) + (O32 ? 4.0 : 2.0) * (double)p.M * p.Co;
+  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
+                           ((O32 ? 4.0 : 2.0) * (1.0 + (p.accumulate ? 1.0 : 0.0) + (p.residual ? 1.0 : 0.0)) + (p.bt_y ? 2.0 : 0.0)) * (double)p.M * p.Co;
   const int pid = prof_begin(47, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((conv2b_kernel<O32>), dim3(grid), dim3(512), C2_LDS, stream, p);
   prof_end(pid, stream);

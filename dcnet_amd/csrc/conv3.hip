@@ -415,7 +415,7 @@ int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   }
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const double k_alg = 9.0 * p.Ci;
-  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co);
+  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
   const int pid = prof_begin(NP == 1 ? 33 : (WM == 4 ? 28 : 29), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);

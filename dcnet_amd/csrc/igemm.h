@@ -53,6 +53,9 @@ struct IgemmParams {
   const float* bt_y; const float* bt_mean; const float* bt_invstd; const float* bt_gamma; const float* bt_beta;
   int bt_act; float bt_slope;
 };
+// [M][Co] tensors a launch's epilogue touches, in units of the output: the store, plus one read each for accumulate / shortcut / tapped
+// BatchNorm input (the "algorithmic bytes" of a launch count every operand it must move once)
+inline double epilogue_reads(const IgemmParams& p) { return 1.0 + (p.accumulate ? 1.0 : 0.0) + (p.residual ? 1.0 : 0.0) + (p.bt_y ? 1.0 : 0.0); }
 // can this launch take a BatchNorm tap (i.e. does it run on conv1.hip / conv3.hip, whose statistics epilogues know the tap)?
 bool igemm_tap_capable(const IgemmParams& p);
 

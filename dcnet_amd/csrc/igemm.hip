@@ -631,7 +631,7 @@ int launch_bk(const IgemmParams& p0, hipStream_t stream) {
   // algorithmic bytes: the gathered tensor once (rows actually addressed: N*Hi*Wi pixels of Ci), the filter bank, the output
   double m_out = p.M;
   if (p.ncls) { m_out = 0; for (int c = 0; c < p.ncls; ++c) m_out += p.cls_M[c]; }
-  const double alg_bytes = 4.0 * nb * ((double)p.N * p.Hi * p.Wi * (p.c4 ? 4 : p.Ci) + (double)p.Co * k_alg + m_out * p.Co);
+  const double alg_bytes = 4.0 * nb * ((double)p.N * p.Hi * p.Wi * (p.c4 ? 4 : p.Ci) + (double)p.Co * k_alg + m_out * p.Co * epilogue_reads(p));
   const int pid = prof_begin(tag, 2.0 * nb * mk * p.Co, stream, alg_bytes);
   hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, BMODE, C4, BK, SP, ABL, NP, OCC, F8, BPRE>), dim3(gm * gn, nb), dim3(256), lds, stream, p);
   prof_end(pid, stream);
