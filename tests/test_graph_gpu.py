@@ -109,3 +109,44 @@ def test_graph_queues_of_the_captured_step(tmp_path):
     wq = max(c["weight_gradients"], key=c["weight_gradients"].get)
     assert wq != main_q and c["weight_gradients"][wq] >= 0.9 * sum(c["weight_gradients"].values()), c
     assert len(c["language"]) == 1 and next(iter(c["language"])) not in (main_q, wq), c
+
+
+def test_staged_backward_gives_the_gradients_of_a_plain_backward(dev):
+    """What GraphedTrainStep switches on for its step — the language branch's backward as its own stage (model.finish_backward) and the
+    head blocks adding their weight gradients to .grad on the side stream (ops.WGRAD_DIRECT, ops.finish_wgrads) — run eagerly against
+    a plain loss.backward() of the same model state, batch and draws: every gradient bitwise equal, none missing."""
+    from dcnet_amd import losses, ops
+    size, n = 256, 4
+    m, _, image, word_id, word_mask, bbox = _setup(dev, size, n, 33)
+    m.train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads(staged):
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        random.seed(7)
+        was = ops.WGRAD_DIRECT
+        m.defer_language_backward = staged
+        ops.WGRAD_DIRECT = staged
+        try:
+            out = m(image, word_id, word_mask)
+            loss, _ = losses.total_loss(out, bbox, size)
+            loss.backward()
+            if staged:
+                m.finish_backward()
+                ops.finish_wgrads(dev)
+        finally:
+            ops.WGRAD_DIRECT = was
+            m.defer_language_backward = False
+        torch.cuda.synchronize()
+        return float(loss), {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert l0 == l1
+    assert sum(v is not None for v in g0.values()) > 100
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), k
