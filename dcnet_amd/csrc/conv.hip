@@ -69,6 +69,8 @@ void base_params(IgemmParams& p) {
 }  // namespace
 
 void conv_set_merge(int v) { g_merge_classes = v; }
+int g_d2_b16 = 1;           // dcn_set_tuning("Db16", 0): bf16-storage stride-2 data gradients of the narrow layers back on the gathered parity classes
+void conv_set_d2_b16(int v) { g_d2_b16 = v; }
 
 extern "C" int dcn_conv2d_stats_rows(int n, int h, int wd, int cout, int ksize, int stride) {
   const int pad = (ksize - 1) / 2;
@@ -405,6 +407,10 @@ extern "C" int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt1
     }
     return conv1b_launch(p, dx_f32, stream);
   }
+  // the 32 <- 64 / 64 <- 128 stride-2 layers on the 416 / 208-wide maps: the register-bank kernel (nconv.hip), all four parity classes of a
+  // position stored by the workgroup that computed them (the four gathered launches below: 1.14 ms against 0.2 ms of HBM traffic)
+  if (g_d2_b16 && !dx_f32 && lddy == cout && dgrad2_applicable(n, h, wd, cin, cout, ksize, stride, accumulate))
+    return dgrad2_launch_b16(dy, lddy, wt16, dx, n, h, wd, cin, accumulate, stream);
   if (ksize == 1 && !accumulate &&
       hipMemsetAsync(dx, 0, (size_t)n * h * wd * cin * (dx_f32 ? 4 : 2), stream) != hipSuccess) {
     dcn_set_error("conv2d_bwd_data_b16: memset failed"); return DCN_ERR_LAUNCH;

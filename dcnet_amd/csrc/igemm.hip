@@ -734,9 +734,11 @@ void wgrad_set_target(int v);
 void wgrad_set_wide64(int v);
 void wgrad_set_target_small(int v);
 void wgrad_set_w3_b16(int v);
+void wgrad_set_w9_b16(int v);
 void wgrad_set_target_b16(int v, int small);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
+void conv_set_d2_b16(int v);
 void score_set_tuning(int key, int value);
 void bn_set_tuning(int v);
 void wgrad9_set_tuning(int key, int value);
@@ -752,6 +754,8 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'D') { conv_set_d2_b16(value); return DCN_OK; }                            // "Db16": bf16-storage register-bank stride-2 data gradient (nconv.hip)
+  if (k == '9' && key[1] == 'b') { wgrad_set_w9_b16(value); return DCN_OK; }          // "9b16": bf16-storage nine-tap weight gradient (wgrad9.hip)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"
   if (k == 'G') { gemm3_set_tuning(value); return DCN_OK; }       // "Gemm3": the co-attention products on pre-split operands (gemm3.hip)
   if (k == 'N') { nconv_set_tuning(value); return DCN_OK; }       // "Nconv": register-bank kernels of the 32 <-> 64 channel layers (nconv.hip)

@@ -99,8 +99,13 @@ __device__ __forceinline__ void walk_step(Walk& w, int step, int Wp, int Ho) {  
   if (w.col >= Wp) { w.col -= Wp; ++w.row; if (++w.r == Ho) w.r = 0; }
 }
 
-template <int ROLE, int CK, int CN, bool TAP>
+// IN16 (bf16 storage): dY, the transposed bank and dX are bf16 — 8-byte pieces staged as they are (one plane), the bank's 16-byte runs
+// are MFMA operands, one v_mfma_f32_32x32x16_bf16 per product, dX rounded to bf16 where it is stored (no tap in this form).
+template <int ROLE, int CK, int CN, bool TAP, bool IN16 = false>
 __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm) {
+  static_assert(!(TAP && IN16), "no BatchNorm tap in the bf16 form");
+  constexpr int ESZ = IN16 ? 2 : 4;
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
   typedef Taps<ROLE> T;
   typedef Geo<CK, CN> G;
   constexpr int NT = T::N, KS = CK / 16, CH = G::CH, NE = G::NE, PLANE = G::PLANE, BUFB = G::BUFB, NSLOT = G::NSLOT;
@@ -108,27 +113,33 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   const int mb = CN == 32 ? (wave & 1) : 0, nb = CN == 32 ? 0 : (wave & 1);
   const int m = lane & 31, kg = lane >> 5;
   const int Wp = p.Wo + 1, NR = p.N * p.Ho, W = 2 * p.Wo;
-  const float s_a = pow2n(amax_read(p.amax_dy)), s_b = pow2n(amax_read(p.amax_w));
+  float s_a = 1.f, s_b = 1.f;
+  if constexpr (!IN16) { s_a = pow2n(amax_read(p.amax_dy)); s_b = pow2n(amax_read(p.amax_w)); }
   // Buffer descriptors start at the first dY row of THIS workgroup's range (row0): byte offsets stay 32-bit whatever the tensor size
   const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
   const int row0 = (c_begin * CH) / Wp;
-  const long long a_skip = (long long)row0 * p.Wo * p.lddy * 4, a_all = (((long long)NR * p.Wo - 1) * p.lddy + CK) * 4;
-  const long long o_skip = (long long)row0 * 4 * p.Wo * p.ldo * 4, o_all = (((long long)NR * 4 * p.Wo - 1) * p.ldo + CN) * 4;
+  const long long a_skip = (long long)row0 * p.Wo * p.lddy * ESZ, a_all = (((long long)NR * p.Wo - 1) * p.lddy + CK) * ESZ;
+  const long long o_skip = (long long)row0 * 4 * p.Wo * p.ldo * ESZ, o_all = (((long long)NR * 4 * p.Wo - 1) * p.ldo + CN) * ESZ;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.dy + a_skip), 0, span32(a_all - a_skip), 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.dx + o_skip), 0, span32(o_all - o_skip), 0x00020000);
 
   // ---- the wave's filter fragments, split once: B[k = co][n = ci = lane % 32], 8 consecutive co per lane ------------------
-  f16x8_t bh[NT][KS], bl[NT][KS];
+  f16x8_t bh[NT][KS], bl[IN16 ? 1 : NT][IN16 ? 1 : KS];
   auto load_b = [&](auto ic) {
     constexpr int i = decltype(ic)::value;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
+      if constexpr (IN16) {
+        const unsigned short* src16 = reinterpret_cast<const unsigned short*>(p.wt) + ((size_t)((nb * 32 + m) * 9 + T::ky[i] * 3 + T::kx[i]) * CK + kk * 16 + 8 * kg);
+        bh[i][kk] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const f32x4*>(src16));
+        continue;
+      }
       const float* src = p.wt + ((size_t)((nb * 32 + m) * 9 + T::ky[i] * 3 + T::kx[i]) * CK + kk * 16 + 8 * kg);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s_b, v1 = *reinterpret_cast<const f32x4*>(src + 4) * s_b;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bh[i][kk][e] = (_Float16)v0[e]; bh[i][kk][4 + e] = (_Float16)v1[e];
-        bl[i][kk][e] = (_Float16)(v0[e] - (float)bh[i][kk][e]); bl[i][kk][4 + e] = (_Float16)(v1[e] - (float)bh[i][kk][4 + e]);
+        if constexpr (!IN16) { bl[i][kk][e] = (_Float16)(v0[e] - (float)bh[i][kk][e]); bl[i][kk][4 + e] = (_Float16)(v1[e] - (float)bh[i][kk][4 + e]); }
       }
     }
   };
@@ -150,7 +161,7 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
     const int e = rem / (CK / 4), co = (rem % (CK / 4)) * 4;
     meta[j] = strip | (e << 1);
     st_off[j] = G::off(strip, e, co);
-    k_off[j] = ((strip * p.Wo + e) * p.lddy + co) * 4;
+    k_off[j] = ((strip * p.Wo + e) * p.lddy + co) * ESZ;
   }
 
   Walk wl, wc;                                       // chunk being LOADED / being computed; rows count from row0
@@ -163,10 +174,16 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       const int strip = meta[j] & 1, e = meta[j] >> 1;
       const int t = wl.col + e;                                       // == Wo: the pad entry; beyond: the next padded row
       const int r = t > p.Wo ? (wl.r + 1 == p.Ho ? 0 : wl.r + 1) : wl.r;
-      const int base = (wl.row * p.Wo + wl.col) * p.lddy * 4;         // (scalar)
-      unsigned off = (unsigned)(base + k_off[j] - (t > p.Wo ? p.lddy * 4 : 0));
+      const int base = (wl.row * p.Wo + wl.col) * p.lddy * ESZ;         // (scalar)
+      unsigned off = (unsigned)(base + k_off[j] - (t > p.Wo ? p.lddy * ESZ : 0));
       if (t == p.Wo || (strip == 1 && r + 1 >= p.Ho)) off = OOBN;     // (rows past the tensor: out of the descriptor's range, read as zero)
-      v[j] = ldn(a_rs, off);
+      if constexpr (IN16) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, off, 0, 0));
+        v[j] = f32x4{__uint_as_float(w2[0]), __uint_as_float(w2[1]), 0.f, 0.f};
+      } else {
+        v[j] = ldn(a_rs, off);
+      }
     }
     walk_step(wl, CH, Wp, p.Ho);
   };
@@ -174,6 +191,10 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       if (j == NSLOT - 1 && !last_on) continue;
+      if constexpr (IN16) {
+        *reinterpret_cast<uint2*>(sm + buf * BUFB + st_off[j]) = uint2{__float_as_uint(v[j][0]), __float_as_uint(v[j][1])};
+        continue;
+      }
       const f32x4 t = v[j] * s_a;
       const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
       const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
@@ -227,6 +248,10 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       for (int kk = 0; kk < KS; ++kk) {
         const int ao = a_base[dyo][dxo] + 16 * ((2 * kk + kg) ^ a_x[dxo]);
         const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + ao);
+        if constexpr (IN16) {
+          acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[i][kk]), acc[T::ac[i]], 0, 0, 0);
+          continue;
+        }
         const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + ao);
         acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][kk], acc[T::ac[i]], 0, 0, 0);      // smallest terms first
         acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][kk], acc[T::ac[i]], 0, 0, 0);
@@ -267,8 +292,13 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
       for (int a = 0; a < 2; ++a) {               // (32-bit byte offsets through a buffer descriptor: one address register per store)
         bool ok; const int pix = pix_of(q, a, ok);
         if (!ok) continue;
-        const int off = (pix * p.ldo + nb * 32 + m) * 4;
+        const int off = (pix * p.ldo + nb * 32 + m) * ESZ;
         float v = acc[a][q] * dq;
+        if constexpr (IN16) {
+          if (p.accumulate) v += __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(o_rs, off, 0, 0) << 16);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (__bf16)v), o_rs, off, 0, 0);
+          continue;
+        }
         if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_rs, off, 0, 0));
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, off, 0, 0);
         if constexpr (tapped) {                   // the terms of channel_partials_kernel<1> (bn.hip), on the value just stored
@@ -297,11 +327,11 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
   }
 }
 
-template <int CK, int CN, bool TAP>
+template <int CK, int CN, bool TAP, bool IN16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dgrad2_kernel(const D2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smn[];       // [2 buffers][high | low][strip r | strip r+1]
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN, TAP>(p, smn);
-  else dgrad2_body<1, CK, CN, TAP>(p, smn);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) dgrad2_body<0, CK, CN, TAP, IN16>(p, smn);
+  else dgrad2_body<1, CK, CN, TAP, IN16>(p, smn);
 }
 
 // =====================================================================================================================
@@ -603,15 +633,15 @@ bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int s
   return (long long)n * h * wd >= 65536;                                               // (a persistent grid wants work for every CU)
 }
 
-template <int CK, int CN, bool TAP>
+template <int CK, int CN, bool TAP, bool IN16 = false>
 int launch_d2(D2Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo<CK, CN> G;
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN, TAP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad2_kernel<CK, CN, TAP, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G::BUFB);
   }
   const int pid = prof_begin(37, flop, stream, bytes);
-  hipLaunchKernelGGL((dgrad2_kernel<CK, CN, TAP>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
+  hipLaunchKernelGGL((dgrad2_kernel<CK, CN, TAP, IN16>), dim3(grid), dim3(256), 2 * G::BUFB, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("dgrad2");
   return DCN_OK;
@@ -651,6 +681,27 @@ int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, 
   const double flop = 2.0 * (double)n * p.Ho * p.Wo * ck * 9.0 * cin;
   if (cin == 32) return tap ? launch_d2<64, 32, true>(p, grid, flop, bytes, stream) : launch_d2<64, 32, false>(p, grid, flop, bytes, stream);
   return launch_d2<128, 64, false>(p, grid, flop, bytes, stream);
+}
+
+// bf16 storage: dY, the transposed bank [Cin][9][Cout] and dX are bf16 (dense dX, no tap)
+int dgrad2_launch_b16(const void* dy, int lddy, const void* wt16, void* dx, int n, int h, int wd, int cin, int accumulate, hipStream_t stream) {
+  const int g_ncus = dcn_device_cus();
+  if (!g_ncus) { dcn_set_error("dgrad2: device query failed"); return DCN_ERR_LAUNCH; }
+  const int ch = cin == 32 ? 64 : 32, ck = 2 * cin;
+  D2Params p{};
+  p.dy = (const float*)dy; p.wt = (const float*)wt16; p.dx = (float*)dx; p.N = n; p.Ho = h / 2; p.Wo = wd / 2; p.lddy = lddy; p.ldo = cin;
+  p.accumulate = accumulate;
+  p.Mp = n * p.Ho * (p.Wo + 1);
+  p.nchunks = cdiv(p.Mp, ch);
+  int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
+  p.per_wg = cdiv(p.nchunks, grid);
+  grid = cdiv(p.nchunks, p.per_wg);
+  DCN_CHECK_ARG(((long long)p.per_wg * ch / (p.Wo + 1) + 4) * 4 * p.Wo * (lddy > cin ? lddy : cin) * 2 < 0x7FFFFFF0LL,
+                "conv2d_bwd_data_b16: the rows of one workgroup exceed 32-bit byte offsets");
+  const double bytes = 2.0 * ((double)n * p.Ho * p.Wo * ck + (double)n * h * wd * cin * (accumulate ? 2 : 1) + (double)cin * 9 * ck);
+  const double flop = 2.0 * (double)n * p.Ho * p.Wo * ck * 9.0 * cin;
+  if (cin == 32) return launch_d2<64, 32, false, true>(p, grid, flop, bytes, stream);
+  return launch_d2<128, 64, false, true>(p, grid, flop, bytes, stream);
 }
 
 // ---- 3x3 layers between 32 and 64 channels (forward S = 1 | 2, data gradient S = 1) ---------------------------------------------

@@ -763,9 +763,14 @@ int g_w3_b16 = 0;         // dcn_set_tuning("w3b16", 1): bf16-storage 3x3 stride
                           // 256->512 @26 0.167 -> 0.204, 512->512 @52 1.22 -> 1.50: with one MFMA per product both are bound by the bytes they stage per
                           // FLOP, and the filter-row form stages more (a 16-position step per 3 x 8 MFMAs); off
 
+int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+                      hipStream_t stream);
+int g_w9_b16 = 1;         // dcn_set_tuning("9b16", 0): the 32 -> 64 / 64 -> 128 3x3 layers of the bf16-storage mode back on the per-tap tile
+
 extern "C" int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
   int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
+  if (wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride)) { const int64_t w9 = wgrad9_ws(n, h, wd, cin, cout, stride); if (w9 > ws) ws = w9; }
   if (wgrad3_b16_ok(n, h, wd, cin, cout, ksize, stride)) { const int64_t w3 = wgrad3_ws(n, h, wd, cin, cout); if (w3 > ws) ws = w3; }
   return ws;
 }
@@ -778,6 +783,9 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
   DCN_CHECK_ARG(x && dy && dw && geom, "conv2d_bwd_weight_b16: null pointer (geom = table of dcn_conv2d_geom for this geometry)");
   const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
   DCN_CHECK_ARG(lx % 8 == 0 && ly % 8 == 0, "conv2d_bwd_weight_b16: pixel strides must be multiples of 8 elements");
+  // the 32 -> 64 (either stride) and 64 -> 128 (stride 1) 3x3 layers: all nine taps per workgroup (wgrad9.hip), dY and X read once
+  if (g_w9_b16 && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride))
+    return wgrad9_launch_b16(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, stream);
   // 3x3 stride-1 layers with >= 128 channels on a side: one filter row per workgroup (wgrad3.hip), the dY tile staged once for three taps
   if (g_w3_b16 && wgrad3_b16_ok(n, h, wd, cin, cout, ksize, stride) && (long long)n * h * wd * lx * 2 < 0x7FFFFFF0LL &&
       (long long)n * h * wd * ly * 2 < 0x7FFFFFF0LL)
@@ -802,4 +810,5 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
 }
 
 void wgrad_set_w3_b16(int v) { g_w3_b16 = v; }
+void wgrad_set_w9_b16(int v) { g_w9_b16 = v; }
 void wgrad_set_target_b16(int v, int small) { if (small) g_wg_target_small_b16 = v > 0 ? v : 512; else g_wg_target_b16 = v > 0 ? v : 768; }

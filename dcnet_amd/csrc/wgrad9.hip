@@ -40,6 +40,16 @@ struct W9Params {
 __device__ __forceinline__ f32x4 ld9(__amdgpu_buffer_rsrc_t r, unsigned voff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
+// a piece of four channels: 16 bytes of fp32, or (IN16) 8 bytes of bf16 carried in the first two lanes of the register set
+template <bool IN16> __device__ __forceinline__ f32x4 ld9x(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  if constexpr (IN16) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0));
+    return f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), 0.f, 0.f};
+  } else {
+    return ld9(r, voff);
+  }
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc9(const float* base, long long bytes) {
   const unsigned n = bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0u : (unsigned)(bytes < 0 ? 0 : bytes);
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, n, 0x00020000);
@@ -86,9 +96,13 @@ template <int S, int CO, int CI> struct G9 {
   static __device__ __forceinline__ int x_off(int fr, int row, int c) { return fr * FROWB + X_ROWB * row + 64 * seg_swz<X_ROWB>(c >> 5, row) + 2 * (c & 31); }
 };
 
-template <int S, int CO, int CI, bool PRE = false>
+// IN16 (bf16 storage, BASELINE.json configs[2]): x and dy ARE bf16 tensors — a piece of four channels is an 8-byte load that goes to LDS
+// as it is (one plane, no scales, no split), the transposed reads hand the MFMA its bf16 operands, one v_mfma_f32_32x32x16_bf16 per product.
+template <int S, int CO, int CI, bool PRE = false, bool IN16 = false>
 __global__ __launch_bounds__(64 * (CO == 64 ? 6 : 8)) __attribute__((amdgpu_waves_per_eu(CO == 64 ? 3 : 2, CO == 64 ? 3 : 2)))
 void wgrad9_kernel(const W9Params p) {
+  static_assert(!(PRE && IN16), "the loader-side activation exists for fp32 tensors only");
+  constexpr int ESZ = IN16 ? 2 : 4;
   typedef G9<S, CO, CI> G;
   constexpr int NT = G::NT, NR = G::NR, NU = G::NU, A_PLANE = G::A_PLANE, B_PLANE = G::B_PLANE, B_BASE = G::B_BASE, BUF = G::BUF;
   constexpr int NA = G::NA, NX = G::NX, NSLOT = G::NSLOT;
@@ -102,10 +116,11 @@ void wgrad9_kernel(const W9Params p) {
   const int p_begin = split * p.kchunk;
   const int p_end = min(p.Mp, p_begin + p.kchunk);
   const int iters = (p_end - p_begin + KS - 1) / KS;
-  const float s_a = pow2_9(amax_read(p.amax_dy)), s_b = pow2_9(amax_read(p.amax_x));
+  float s_a = 1.f, s_b = 1.f;
+  if constexpr (!IN16) { s_a = pow2_9(amax_read(p.amax_dy)); s_b = pow2_9(amax_read(p.amax_x)); }
 
-  const __amdgpu_buffer_rsrc_t a_rs = rsrc9(p.dy, (((long long)p.N * p.Ho * p.Wo - 1) * p.lddy + CO) * 4);
-  const __amdgpu_buffer_rsrc_t b_rs = rsrc9(p.x, (((long long)p.N * p.H * p.W - 1) * p.ldx + CI) * 4);
+  const __amdgpu_buffer_rsrc_t a_rs = rsrc9(p.dy, (((long long)p.N * p.Ho * p.Wo - 1) * p.lddy + CO) * ESZ);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrc9(p.x, (((long long)p.N * p.H * p.W - 1) * p.ldx + CI) * ESZ);
 
   // ---- load slots: element e = slot*NT + tid of the K-step's staging list (dY pieces first, then X pieces) ------------------
   // dY piece: position q0 + idx, filters c..c+3;  X piece: filter row fr, entry idx of the staged range, channels c..c+3.
@@ -154,15 +169,15 @@ void wgrad9_kernel(const W9Params p) {
       if (is_a[j]) {
         int col = g_col + idx, row = g_row;
         if (col >= Wp) { col -= Wp; ++row; }
-        if (col < p.Wo && q_step + idx < p_end) off = (unsigned)(((row * p.Wo + col) * p.lddy + c) * 4);      // (< 2^31: checked by the launcher)
-        v[j] = ld9(a_rs, off);
+        if (col < p.Wo && q_step + idx < p_end) off = (unsigned)(((row * p.Wo + col) * p.lddy + c) * ESZ);      // (< 2^31: checked by the launcher)
+        v[j] = ld9x<IN16>(a_rs, off);
       } else {
         int u = S * g_col + idx, oy = g_oy, nb = g_nb;
         if (u >= RL) { u -= RL; if (++oy == p.Ho) { oy = 0; nb += p.H; } }
         const int iy = S * oy + ((meta[j] >> 2) & 3) - 1, ix = u - 1;
         if ((unsigned)ix < (unsigned)p.W && (unsigned)iy < (unsigned)p.H && nb < rows_x)
-          off = (unsigned)((((nb + iy) * p.W + ix) * p.ldx + c) * 4);
-        v[j] = ld9(b_rs, off);
+          off = (unsigned)((((nb + iy) * p.W + ix) * p.ldx + c) * ESZ);
+        v[j] = ld9x<IN16>(b_rs, off);
         if constexpr (PRE) vmask = off != OOB9 ? (vmask | (1u << j)) : (vmask & ~(1u << j));
       }
     }
@@ -173,6 +188,10 @@ void wgrad9_kernel(const W9Params p) {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
       if (PRE && j == NSLOT - 1 && !is_a[j] && dead_last) continue;
+      if constexpr (IN16) {                                  // four bf16 channels, as loaded (pads and rows past the end loaded zeros)
+        *reinterpret_cast<uint2*>(sm9 + buf * BUF + st_off[j]) = uint2{__float_as_uint(v[j][0]), __float_as_uint(v[j][1])};
+        continue;
+      }
       f32x4 t;
       if (PRE && !is_a[j]) {
         // scale_act_kernel's arithmetic (bn.hip) on operands that carry the power-of-two operand scale already (psc, psh = s_b * scale,
@@ -228,6 +247,18 @@ void wgrad9_kernel(const W9Params p) {
     return __builtin_bit_cast(f16x8_t, v);
   };
   auto k_step = [&](int buf, int ks) {
+    if constexpr (IN16) {
+      typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+      const bf16x8_t a16 = __builtin_bit_cast(bf16x8_t, frag(buf * BUF + a_tr[ks][0], buf * BUF + a_tr[ks][1]));
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const bf16x8_t b16 = __builtin_bit_cast(bf16x8_t, frag(buf * BUF + rr * G::FROWB + b_tr[ks][d][0], buf * BUF + rr * G::FROWB + b_tr[ks][d][1]));
+          acc[rr * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a16, b16, acc[rr * 3 + d], 0, 0, 0);
+        }
+      return;
+    }
     f16x8_t af[2];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) af[pl] = frag(buf * BUF + pl * A_PLANE + a_tr[ks][0], buf * BUF + pl * A_PLANE + a_tr[ks][1]);
@@ -295,15 +326,15 @@ Plan9 plan9(int n, int ho, int wo) {
 
 template <int S, int CO, int CI> size_t lds9() { return (size_t)2 * G9<S, CO, CI>::BUF; }
 
-template <int S, int CO, int CI, bool PRE = false>
+template <int S, int CO, int CI, bool PRE = false, bool IN16 = false>
 int launch9(const W9Params& p, int splits, hipStream_t stream) {
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad9_kernel<S, CO, CI, PRE, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds9<S, CO, CI>());
   }
   const int threads = G9<S, CO, CI>::NT;
   const size_t lds = lds9<S, CO, CI>();
-  hipLaunchKernelGGL((wgrad9_kernel<S, CO, CI, PRE>), dim3(splits), dim3(threads), lds, stream, p);
+  hipLaunchKernelGGL((wgrad9_kernel<S, CO, CI, PRE, IN16>), dim3(splits), dim3(threads), lds, stream, p);
   return DCN_OK;
 }
 
@@ -354,6 +385,29 @@ int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   else { if (stride == 1) launch9<1, 128, 64>(p, pl.splits, stream); else launch9<2, 128, 64>(p, pl.splits, stream); }
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad9");
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
+  return DCN_OK;
+}
+
+// bf16 storage: the same two layer forms on bf16 tensors (x, dy bf16 NHWC; dw fp32 [Cout][3][3][Cin]); the per-tap tile of wgrad.hip reads
+// dY and X nine times for them (32 -> 64 @208: 0.85 ms against 0.11 ms of HBM traffic).
+int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+                      hipStream_t stream) {
+  const int ho = h / stride, wo = wd / stride;
+  const Plan9 pl = plan9(n, ho, wo);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
+  DCN_CHECK_ARG((long long)n * ho * wo * lddy * 2 < 0x7FFFFFF0LL && (long long)n * h * wd * ldx * 2 < 0x7FFFFFF0LL,
+                "conv2d_bwd_weight_b16: a sliced operand exceeds the 32-bit byte offsets of the nine-tap kernel");
+  W9Params p{};
+  p.x = (const float*)x; p.dy = (const float*)dy; p.out = pl.splits > 1 ? ws : dw;
+  p.N = n; p.H = h; p.W = wd; p.Ho = ho; p.Wo = wo; p.ldx = ldx; p.lddy = lddy;
+  p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  const double bytes = 2.0 * ((double)n * ho * wo * cout + (double)n * h * wd * cin) + 4.0 * (double)pl.splits * cout * 9 * cin;
+  const int pid = prof_begin(36, 2.0 * (double)n * ho * wo * cout * 9.0 * cin, stream, bytes);
+  if (cin == 32) { if (stride == 1) launch9<1, 64, 32, false, true>(p, pl.splits, stream); else launch9<2, 64, 32, false, true>(p, pl.splits, stream); }
+  else { if (stride == 1) launch9<1, 128, 64, false, true>(p, pl.splits, stream); else launch9<2, 128, 64, false, true>(p, pl.splits, stream); }
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("wgrad9 (bf16)");
   if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
   return DCN_OK;
 }

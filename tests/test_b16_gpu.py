@@ -42,6 +42,11 @@ CASES = [
     (8, 13, 13, 256, 512, 3, 1),      # 13-wide rows: two row wraps per K-step
     (1, 28, 28, 128, 256, 3, 2),      # stride 2 into 256 filters (the 256 x 256 tile with a strided gather)
     (1, 20, 20, 256, 256, 3, 2),      # ... and its parity classes into 256 channels (strided output)
+    (2, 48, 48, 32, 64, 3, 1),        # the narrow layers: weight gradient with all nine taps per workgroup (wgrad9.hip, bf16 inputs)
+    (1, 64, 80, 32, 64, 3, 2),        # ... at stride 2 (even / odd entry planes)
+    (1, 64, 66, 64, 128, 3, 1),       # ... and its 64 -> 128 form
+    (4, 128, 128, 32, 64, 3, 2),      # the stride-2 data gradient of the narrow layers on the register-bank kernel (nconv.hip dgrad2, bf16 form)
+    (2, 128, 256, 64, 128, 3, 2),     # ... its 64 <- 128 form
 ]
 
 
@@ -63,6 +68,7 @@ def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case, tile2b):
 
 def _conv_case(case):
     from dcnet_amd import ops
+    from dcnet_amd.lib import lib
     dev = torch.device("cuda:0")
     n, h, w, cin, cout, k, st = case
     T = k * k
@@ -102,6 +108,12 @@ def _conv_case(case):
     acc = base.clone()
     ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st, out=acc, accumulate=True)
     _ulp_close(acc, ref_dx + base.double().cpu(), "dgrad accumulate")
+    lib().set_tuning(b"Db16", 0)               # (the register-bank stride-2 kernel off: the gathered parity classes)
+    try:
+        _ulp_close(ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st), ref_dx, "dgrad, gathered classes")
+    finally:
+        lib().set_tuning(b"Db16", 1)
+    assert torch.equal(ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st), dx)      # bitwise repeatable
     dx32 = ops.conv2d_bwd_data_b16(dy, wt_t, (h, w), cin, k, st, out_f32=True)
     assert float((dx32.double().cpu() - ref_dx).abs().max()) <= 3e-5 * max(1.0, float(ref_dx.abs().max()))
     # ---- weight gradient: fp32 out, fp32 accumulation of exact bf16 products ----
@@ -114,8 +126,13 @@ def _conv_case(case):
             assert dw.dtype == torch.float32 and dw.shape == (cout, k, k, cin)
             assert float((dw.double().cpu() - ref_dw).abs().max()) <= 5e-5 * max(1.0, float(ref_dw.abs().max())), knob
             assert torch.equal(ops.conv2d_bwd_weight_b16(x, dy, k, st), dw)
+        lib().set_tuning(b"w3b16", 0)
+        lib().set_tuning(b"9b16", 0)           # (the nine-tap kernel off: the per-tap tile for the narrow layers too)
+        dw0 = ops.conv2d_bwd_weight_b16(x, dy, k, st)
+        assert float((dw0.double().cpu() - ref_dw).abs().max()) <= 5e-5 * max(1.0, float(ref_dw.abs().max()))
     finally:
         lib().set_tuning(b"w3b16", 0)
+        lib().set_tuning(b"9b16", 1)
 
 
 @pytest.mark.parametrize("shape", [(2, 26, 26, 128, 256, 3), (3, 13, 13, 256, 128, 1), (1, 20, 12, 64, 64, 3)])
