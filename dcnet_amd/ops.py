@@ -652,16 +652,16 @@ class HeldWgrad:
 
     def __init__(self, x, dy, ksize, stride, wshape, amax_x=None, amax_dy=None):
         self.args = (x, dy, ksize, stride, wshape, amax_x, amax_dy)
+        self.main = torch.cuda.current_stream()
+        self.side = side_stream(x.device)            # the companion of the stream that produced dy, whoever launches the gradient later
         self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream())
+        self.event.record(self.main)
 
     def issue(self):
         x, dy, ksize, stride, wshape, amax_x, amax_dy = self.args
         self.args = None
-        main = torch.cuda.current_stream()
-        side = side_stream(x.device)
-        side.wait_event(self.event)                  # dy (and x) are produced on the main stream, in front of the event
-        return _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy)
+        self.side.wait_event(self.event)             # dy (and x) are produced on the main stream, in front of the event
+        return _wgrad_side_launch(self.main, self.side, x, dy, ksize, stride, wshape, amax_x, amax_dy)
 
 
 def _wgrad_side_launch(main, side, x, dy, ksize, stride, wshape, amax_x, amax_dy):
@@ -708,9 +708,8 @@ def hold_wgrad_into(param, x, dy, ksize, stride, wshape, amax_x=None, amax_dy=No
 def release_held_wgrads() -> None:
     while _held_direct:
         hw, param = _held_direct.pop(0)
-        dev = hw.args[0].device if not isinstance(hw.args[0], PreAct) else hw.args[0].y.device
         out = hw.issue()
-        with torch.cuda.stream(side_stream(dev)):
+        with torch.cuda.stream(hw.side):
             if param.grad is None:
                 param.grad = out.view_as(param)
             else:
