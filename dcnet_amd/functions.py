@@ -35,7 +35,7 @@ class ConvBNAct(torch.autograd.Function):
                 y, stats = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, want_stats=True)
                 mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                      bn.running_mean, bn.running_var)
-                bn.num_batches_tracked += 1
+                ops.bump_batches(bn)
                 out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope, out_f32=not out_b16)
                 ctx.save_for_backward(x16, y, mi, gamma, beta)
             else:
@@ -58,7 +58,7 @@ class ConvBNAct(torch.autograd.Function):
             y, stats = ops.conv2d_fwd(x, w, ksize, 1, want_stats=True, amax_x=ax, amax_w=aw, w_split_ready=wsp)
             mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                  bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bump_batches(bn)
             out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope, amax_out=ao)
             ctx.save_for_backward(x, y, mi, w, gamma, beta)
         else:
@@ -319,7 +319,7 @@ class HeadTail(torch.autograd.Function):
         loc_map = ops.locmod_fwd(e8, Mp, bp, q_loc)                                                       # :585-594
         outbox, loc, mm = ops.head_final_fwd(logits, sims, loc_map)                                       # :597-621
         if training:
-            bn_le.num_batches_tracked += 1; bn_lt.num_batches_tracked += 1
+            ops.bump_batches(bn_le); ops.bump_batches(bn_lt)
         ctx.save_for_backward(*logits, *sims, *loc, *only, q_loc, coord, w_le, g_le, be_le, b_lt, g_lt, e8, xh, stat, mom, obj_map, objn, X,
                               wp, M, Mp, bp, saved, mm, bn_lt.running_mean)
         ctx.training = training
@@ -485,7 +485,7 @@ class FusionConvBNAct(torch.autograd.Function):
             w16 = w1.view(co, e).to(torch.bfloat16)
             y, stats = ops.conv2d_fwd_b16(corr16, w16.reshape(-1), co, 1, 1, out=y, want_stats=True, accumulate=True, out_f32=True)
             mi = ops.bn_finalize(stats, n * h * w, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bump_batches(bn)
             out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0, out_b16=True)
             ctx.save_for_backward(corr16, y, mi, w16, gamma, beta, flang, weight)
             ctx.training, ctx.coord2d, ctx.b16, ctx.amax = True, coord2d, True, (None, None)
@@ -495,7 +495,7 @@ class FusionConvBNAct(torch.autograd.Function):
         if training:
             y, stats = ops.conv2d_fwd(corr, wk, 1, 1, out=y, want_stats=True, accumulate=True, amax_x=ax, amax_w=aw)
             mi = ops.bn_finalize(stats, n * h * w, gamma.detach(), beta.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bump_batches(bn)
             out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, 0.0, amax_out=ao)
             ctx.save_for_backward(corr, y, mi, wk, gamma, beta, flang, weight)
         else:
@@ -666,7 +666,7 @@ class BatchNormRowsAct(torch.autograd.Function):
         if training:
             mi = ops.bn_finalize(ops.channel_stats(x), x.shape[0], gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                  bn.running_mean, bn.running_var)
-            bn.num_batches_tracked += 1
+            ops.bump_batches(bn)
             out = ops.scale_act(x, mi[2], mi[3], act, 0.0)
             ctx.save_for_backward(x, mi, gamma, beta)
         else:

@@ -537,6 +537,15 @@ class grounding_model(nn.Module):
             raise RuntimeError("dcnet_amd.grounding_model runs on an MI355X only (HIP kernels, no CPU path)")
         if n_frame is not None:
             return self._forward_nframe(image, word_id, n_frame)
+        if not self.training:
+            return self._forward_pairs(image, word_id, word_mask)
+        ops.batches_begin()                      # (the head's num_batches_tracked counters: one launch at the end instead of 23)
+        try:
+            return self._forward_pairs(image, word_id, word_mask)
+        finally:
+            ops.batches_end()
+
+    def _forward_pairs(self, image, word_id, word_mask=None):
         N = image.size(0)
         if N % 2:
             raise ValueError("the training model consumes frame pairs: batch must be even (model/DCNet_model.py:365)")

@@ -846,6 +846,30 @@ def stem_bwd_weight_bn(x, y, dout, mean, invstd, gamma, beta, act, slope, part=N
     return dw, sums[1], sums[0]
 
 
+# BatchNorm's num_batches_tracked counters of a forward: one kernel each when bumped where the layer runs (23 six-microsecond launches on
+# the head's chain); a forward that calls batches_begin() / batches_end() bumps them with ONE _foreach_add_ at its end
+_nbt = None
+
+
+def bump_batches(bn) -> None:
+    if _nbt is not None:
+        _nbt.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
+def batches_begin() -> None:
+    global _nbt
+    _nbt = []
+
+
+def batches_end() -> None:
+    global _nbt
+    pend, _nbt = _nbt, None
+    if pend:
+        torch._foreach_add_(pend, 1)
+
+
 LANGUAGE_LATE = True       # A/B switch (captured steps): the language branch starts behind the backbone's register-bank layers
 LANGUAGE_BWD_HOPS = 1             # (model.finish_backward: queue steering in captured steps; fp32: 97.7 / 95.6 / 96.6 ms with 0 / 1 / 2)
 LANGUAGE_BWD_HOPS_B16 = 0         # bf16 storage: the branch shares the weight gradients' queue (59.9 ms against 60.7 with a queue of its own)
