@@ -216,9 +216,15 @@ void gemm_params(IgemmParams& p, const float* A, int lda, long long a_bs, const 
 static bool on_gemm3(int b, int hw, int c) { return c % 32 == 0 && gemm3_applicable(hw, c, hw, b) && gemm3_applicable(hw, hw, c, b); }
 
 extern "C" int64_t dcn_coattn_fwd_ws(int b, int hw, int c) {
-  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw) + AM_SLOTS * DCN_AMAX_WORDS + (on_gemm3(b, hw, c) ? (int64_t)2 * b * hw * c : 0);
+  (void)c;
+  return (int64_t)cdiv(hw, EXP_ROWS) * b * ld_pad(hw) + AM_SLOTS * DCN_AMAX_WORDS;
 }
 extern "C" int64_t dcn_coattn_e_size(int b, int hw) { return (int64_t)b * hw * ld_pad(hw); }
+// what the forward keeps for the backward in the caller's E buffer: E, and — on gemm3.hip — the split forms of f1 and f2 behind it (the
+// backward multiplies by them four more times; it used to split them again: two passes over both tensors per scale)
+extern "C" int64_t dcn_coattn_saved_size(int b, int hw, int c) {
+  return dcn_coattn_e_size(b, hw) + (on_gemm3(b, hw, c) ? (int64_t)2 * b * hw * c : 0);
+}
 
 extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t bsf, float* f1_attn, float* f2_attn, int ldo,
                               int64_t bso, float* E, float* rinv, float* cinv, float* ws,
@@ -241,7 +247,7 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
   const long long bsE = (long long)hw * ldE;
   if (on_gemm3(b, hw, c)) {
     // every product on gemm3.hip: f1, f2 split once (unit norm: the constant word), E written in split form by its own pass
-    float* f1s = ws + (int64_t)nrb * b * ldE + AM_SLOTS * DCN_AMAX_WORDS;
+    float* f1s = E + dcn_coattn_e_size(b, hw);               // (kept for the backward: dcn_coattn_saved_size)
     float* f2s = f1s + (int64_t)b * hw * c;
     const long long bss = (long long)hw * c;
     int rc = gemm3_presplit(f1, ldf, bsf, f1s, c, bss, b, hw, c, one, stream);
@@ -289,7 +295,7 @@ extern "C" int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t
 
 extern "C" int64_t dcn_coattn_bwd_ws(int b, int hw, int c) {
   return (int64_t)2 * b * hw * ld_pad(hw) + (int64_t)2 * b * hw * c + (int64_t)2 * b * hw + AM_SLOTS * DCN_AMAX_WORDS +
-         (on_gemm3(b, hw, c) ? (int64_t)4 * b * hw * c + 4 : 0);
+         (on_gemm3(b, hw, c) ? (int64_t)2 * b * hw * c + 4 : 0);
 }
 
 extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t bsf,
@@ -337,14 +343,12 @@ extern "C" int dcn_coattn_bwd(const float* f1, const float* f2, int ldf, int64_t
     // every product on gemm3.hip (E arrives in split form from dcn_coattn_fwd): the six narrow operands are split once each, dA in place
     float* dO1p = reinterpret_cast<float*>(((uintptr_t)(am + AM_SLOTS * DCN_AMAX_WORDS) + 15) & ~(uintptr_t)15);      // (b * hw may be odd)
     float* dO2p = dO1p + rows * c;
-    float* f1s = dO2p + rows * c;
-    float* f2s = f1s + rows * c;
+    const float* f1s = E + dcn_coattn_e_size(b, hw);         // the forward's split forms of f1, f2 (unit norm: the constant abs-max word)
+    const float* f2s = f1s + rows * c;
     const long long bss = (long long)hw * c;
     int rc;
     if ((rc = gemm3_presplit(d_f1_attn, lddo, bsdo, dO1p, c, bss, b, hw, c, slot(AM_DO1), stream))) return rc;
     if ((rc = gemm3_presplit(d_f2_attn, lddo, bsdo, dO2p, c, bss, b, hw, c, slot(AM_DO2), stream))) return rc;
-    if ((rc = gemm3_presplit(f1, ldf, bsf, f1s, c, bss, b, hw, c, slot(AM_ONE), stream))) return rc;
-    if ((rc = gemm3_presplit(f2, ldf, bsf, f2s, c, bss, b, hw, c, slot(AM_ONE), stream))) return rc;
     if ((rc = gemm3_presplit(dO1s, c, bss, dO1s, c, bss, b, hw, c, slot(AM_DO1S), stream))) return rc;
     if ((rc = gemm3_presplit(dO2s, c, bss, dO2s, c, bss, b, hw, c, slot(AM_DO2S), stream))) return rc;
     // 2. dP1[i,j] = <dO1_i, f2_j>,  dP2[i,j] = <f1_i, dO2_j>                (NT x2)

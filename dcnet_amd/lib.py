@@ -57,6 +57,7 @@ SIGNATURES = {
     "dcn_bn_act_bwd_apply": (I, [P, P, I, P, P, P, P, I, F, P, L, L, I, P, P, P]),
     "dcn_act_bwd": (I, [P, P, I, F, L, I, P, P]),
     "dcn_coattn_e_size": (L, [I, I]),
+    "dcn_coattn_saved_size": (L, [I, I, I]),
     "dcn_coattn_fwd_ws": (L, [I, I, I]),
     "dcn_coattn_fwd": (I, [P, P, I, L, P, P, I, L, P, P, P, P, I, I, I, F, P]),
     "dcn_coattn_bwd_ws": (L, [I, I, I]),
@@ -146,7 +147,7 @@ SIGNATURES = {
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
                 "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records",
                 "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16"}
-ABI_VERSION = 305        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+ABI_VERSION = 306        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

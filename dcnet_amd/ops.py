@@ -896,7 +896,7 @@ def coattn_fwd(f1, f2, out1, out2, temperature):
     stride ldo (out2 may be None).  Returns the saved (E, rinv, cinv)."""
     b, hw, c = f1.shape
     dev = f1.device
-    E = torch.empty(lib().coattn_e_size(b, hw), dtype=torch.float32, device=dev)
+    E = torch.empty(lib().coattn_saved_size(b, hw, c), dtype=torch.float32, device=dev)
     rc = torch.empty((2, b, hw), dtype=torch.float32, device=dev)
     ws = scratch(lib().coattn_fwd_ws(b, hw, c), dev, slot=0)
     assert f1.stride() == f2.stride() and (out2 is None or out1.stride() == out2.stride())

@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 305
+#define DCN_ABI_VERSION 306
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -258,7 +258,8 @@ int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int6
 /* f1,f2: [b][hw][c] NHWC (pixel stride ldf), unit L2 norm over c.  With A[i,j] = <f1_i, f2_j>:
  *   f1_attn[i,:] = sum_j softmax_j(t*A[i,j]) * f2[j,:]
  *   f2_attn[j,:] = sum_i softmax_i(t*A[i,j]) * f1[i,:]      (f2_attn may be NULL: inference model)
- * E (dcn_coattn_e_size floats) receives exp(t*A - t), rinv/cinv ([b][hw]) the inverse row / column
+ * E (dcn_coattn_saved_size floats: the hw x ld_pad(hw) matrices of dcn_coattn_e_size and, behind them, the split forms of f1 and f2 where
+ * the products run on gemm3.hip) receives exp(t*A - t), rinv/cinv ([b][hw]) the inverse row / column
  * sums; all three are kept for the backward.  E is OPAQUE to the caller: at the large scales (hw >= 512, c >= 256, default precision)
  * it holds the f16 two-piece split form the products on gemm3.hip read (dcn_gemm3_presplit's layout), otherwise fp32; dcn_coattn_bwd
  * decides the same way, so precision mode and the "Gemm3" knob must not change between a forward and its backward.
@@ -269,6 +270,7 @@ int dcn_act_bwd(const float* out, const float* dout, int lddo, float slope, int6
  * batch, so f1 = x[0::2], f2 = x[1::2] without a copy; <= 0 means densely packed.
  * Replaces the 3 bmm + 2 softmax of model/DCNet_model.py:449-459 / model/test_DCNet_model.py:259-274. */
 int64_t dcn_coattn_e_size(int b, int hw);
+int64_t dcn_coattn_saved_size(int b, int hw, int c);
 int64_t dcn_coattn_fwd_ws(int b, int hw, int c);
 int dcn_coattn_fwd(const float* f1, const float* f2, int ldf, int64_t bsf, float* f1_attn, float* f2_attn, int ldo,
                    int64_t bso, float* E, float* rinv, float* cinv, float* ws,
