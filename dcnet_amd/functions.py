@@ -27,7 +27,8 @@ class ConvBNAct(torch.autograd.Function):
         if bank is not None and x.shape[3] != weight.shape[1]:
             bank = None                    # (K-padded input: the per-launch path pads the bank)
         ctx.b16 = None
-        ctx.wparam = weight if (ops.WGRAD_DIRECT and ops.WGRAD_SIDE and training and isinstance(weight, torch.nn.Parameter)) else None
+        ctx.wparam = weight if (ops.WGRAD_DIRECT and ops.WGRAD_SIDE and training and isinstance(weight, torch.nn.Parameter)
+                                and weight.requires_grad) else None
         if ops.storage_b16() and bank is not None:
             x_f32 = x.dtype == torch.float32
             x16 = ops.to_b16(x.contiguous())

@@ -102,6 +102,7 @@ class GraphedTrainStep:
         if defer:
             self.core.defer_language_backward = True
         ops.WGRAD_DIRECT = direct
+        ops.reset_held_wgrads()
         try:
             out = self.model(self.image, self.word_id, self.word_mask)
             loss, parts = losses.total_loss(out, self.bbox, self.size)

@@ -705,6 +705,11 @@ def hold_wgrad_into(param, x, dy, ksize, stride, wshape, amax_x=None, amax_dy=No
     _held_direct.append((HeldWgrad(x, dy, ksize, stride, wshape, amax_x=amax_x, amax_dy=amax_dy), param))
 
 
+def reset_held_wgrads() -> None:
+    """Drop what a backward that did not finish (an exception between hold and release) left behind."""
+    _held_direct.clear()
+
+
 def release_held_wgrads() -> None:
     while _held_direct:
         hw, param = _held_direct.pop(0)
