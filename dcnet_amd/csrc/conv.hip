@@ -69,6 +69,8 @@ void base_params(IgemmParams& p) {
 }  // namespace
 
 void conv_set_merge(int v) { g_merge_classes = v; }
+int g_n1_b16 = 1;           // dcn_set_tuning("Nb16", 0): bf16-storage 32 <-> 64 3x3 layers back on the gathered tiles of conv1.hip
+void conv_set_n1_b16(int v) { g_n1_b16 = v; }
 int g_d2_b16 = 1;           // dcn_set_tuning("Db16", 0): bf16-storage stride-2 data gradients of the narrow layers back on the gathered parity classes
 void conv_set_d2_b16(int v) { g_d2_b16 = v; }
 
@@ -368,6 +370,11 @@ extern "C" int dcn_conv2d_fwd_b16(const void* x, const void* w16, void* y, int y
       const int t = r * ksize + s;
       p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
     }
+  // the raw forward of the 32 -> 64 layers on the 416 / 208-wide maps: the register-bank kernel (nconv.hip), x read once instead of nine times
+  if (g_n1_b16 && !y_f32 && !scale && !shift && act == DCN_ACT_NONE && !residual && !accumulate && p.ldo == cout &&
+      nconv1_applicable(0, n, h, wd, cin, cout, ksize, stride))
+    return nconv1_launch_b16(0, x, cin, w16, y, cout, stats, stats ? dcn_conv2d_stats_rows_b16(n, h, wd, cout, ksize, stride) : 0, n, h, wd, stride,
+                             (hipStream_t)stream);
   return conv1b_launch(p, y_f32, (hipStream_t)stream);
 }
 
@@ -388,6 +395,9 @@ extern "C" int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt1
   p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = lddy;
   p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
   p.accumulate = accumulate;
+  // the data gradient 64 -> 32 of the stride-1 layer on the 208-wide map: the register-bank kernel (no tap there: the caller reduces)
+  if (g_n1_b16 && stride == 1 && !dx_f32 && !accumulate && lddy == cout && nconv1_applicable(1, n, h, wd, cin, cout, ksize, stride))
+    return nconv1_launch_b16(1, dy, lddy, wt16, dx, cin, nullptr, 0, n, h, wd, 1, stream);
   if (stride == 1) {
     p.Hs = h; p.Ws = wd; p.M = n * h * wd; p.ntaps = T;
     for (int r = 0; r < ksize; ++r)

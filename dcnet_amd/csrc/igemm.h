@@ -96,6 +96,8 @@ bool dgrad2_applicable(int n, int h, int wd, int cin, int cout, int ksize, int s
 // tap (optional): the BatchNorm + activation in front of this convolution — the kernel also writes the partial sums its backward starts with
 struct DcnBnTap { const float* y; const float* mean; const float* invstd; const float* gamma; const float* beta; int act; float slope;
                   float* stats; int stats_rows; };
+int nconv1_launch_b16(int mode, const void* x, int ldi, const void* w16, void* y, int ldo, float* stats, int stats_rows,
+                      int n, int h, int wd, int stride, hipStream_t stream);
 int dgrad2_launch_b16(const void* dy, int lddy, const void* wt16, void* dx, int n, int h, int wd, int cin, int accumulate, hipStream_t stream);
 int dgrad2_grid(int n, int h, int wd, int cin);      // workgroups (= statistics rows of a tap) of a launch, -1: device query failed
 int dgrad2_launch(const float* dy, int lddy, const float* wt, float* dx, int n, int h, int wd, int cin, int accumulate,

@@ -739,6 +739,7 @@ void wgrad_set_target_b16(int v, int small);
 void wgrad3_set_tuning(int key, int value);
 void conv_set_merge(int v);
 void conv_set_d2_b16(int v);
+void conv_set_n1_b16(int v);
 void score_set_tuning(int key, int value);
 void bn_set_tuning(int v);
 void wgrad9_set_tuning(int key, int value);
@@ -754,6 +755,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on
   if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256)
+  if (k == 'N' && key[1] == 'b') { conv_set_n1_b16(value); return DCN_OK; }           // "Nb16": bf16-storage register-bank forward / data gradient 32 <-> 64 (nconv.hip)
   if (k == 'D') { conv_set_d2_b16(value); return DCN_OK; }                            // "Db16": bf16-storage register-bank stride-2 data gradient (nconv.hip)
   if (k == '9' && key[1] == 'b') { wgrad_set_w9_b16(value); return DCN_OK; }          // "9b16": bf16-storage nine-tap weight gradient (wgrad9.hip)
   if (k == '9') { wgrad9_set_tuning(key[1] == 't' && key[2] == 'a' && key[3] == 'r' ? 1 : 0, value); return DCN_OK; }   // "9tap" (0/1), "9target"

@@ -378,8 +378,14 @@ template <int S, int CK> struct Geo1 {
 // Eight waves: waves 0-3 compute (MFMAs + epilogue, the filter registers), waves 4-7 stage (global loads, split, LDS stores) — two
 // waves per SIMD, one of each kind, so the staging's vector work and memory latency run under the other wave's MFMAs.  (With four
 // waves doing both, timing ablations showed the three parts adding up: 0.57 ms = 0.38 without MFMAs + 0.19 of MFMAs.)
-template <int S, int CK, int CN, bool FLIP, bool PRE = false>
+// IN16 (bf16 storage): x, the bank [CN][9][CK] and y are bf16 — 8-byte pieces staged as loaded (one plane), the bank's 16-byte runs are
+// MFMA operands, one v_mfma_f32_32x32x16_bf16 per product, y rounded to bf16 where it is stored and the BatchNorm partial sums taken of
+// the ROUNDED values (the statistics of the stored tensor, as in conv1.hip's bf16 kernel).
+template <int S, int CK, int CN, bool FLIP, bool PRE = false, bool IN16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nconv1_kernel(const N1Params p) {
+  static_assert(!(PRE && IN16), "the loader-side activation exists for fp32 tensors only");
+  constexpr int ESZ = IN16 ? 2 : 4;
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
   typedef Geo1<S, CK> G;
   constexpr int CH = G::CH, NE = G::NE, PLANE = G::PLANE, BUFB = G::BUFB, NSLOT = G::NSLOT;
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];       // [2 buffers][high | low][3 strips]  (+ CN = 32: the K-halves' exchange)
@@ -390,31 +396,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nb = CN == 64 ? hb : 0, kofs = CN == 64 ? 0 : hb * 32;
   const int m = lane & 31, kg = lane >> 5;
   const int Wp = p.Wo + 1, RL = S * Wp, NR = p.N * p.Ho, W = S * p.Wo, H = S * p.Ho;
-  const float s_a = pow2n(amax_read(p.amax_x)), s_b = pow2n(amax_read(p.amax_w));
+  float s_a = 1.f, s_b = 1.f;
+  if constexpr (!IN16) { s_a = pow2n(amax_read(p.amax_x)); s_b = pow2n(amax_read(p.amax_w)); }
   // Buffer descriptors start at this workgroup's first output row (row0) and, for the input, one input row above S*row0 (the top
   // strip; `bias` is that row in bytes — zero for row0 = 0, where the row above does not exist and its offsets go negative = out of
   // range): byte offsets stay 32-bit whatever the tensor size
   const int c_begin = blockIdx.x * p.per_wg, c_end = min(p.nchunks, c_begin + p.per_wg);
   const int row0 = (c_begin * CH) / Wp;
-  const int bias = row0 > 0 ? W * p.ldi * 4 : 0;
-  const long long a_skip = (long long)S * row0 * W * p.ldi * 4 - bias, a_all = (((long long)p.N * H * W - 1) * p.ldi + CK) * 4;
-  const long long o_skip = (long long)row0 * p.Wo * p.ldo * 4, o_all = (((long long)NR * p.Wo - 1) * p.ldo + CN) * 4;
+  const int bias = row0 > 0 ? W * p.ldi * ESZ : 0;
+  const long long a_skip = (long long)S * row0 * W * p.ldi * ESZ - bias, a_all = (((long long)p.N * H * W - 1) * p.ldi + CK) * ESZ;
+  const long long o_skip = (long long)row0 * p.Wo * p.ldo * ESZ, o_all = (((long long)NR * p.Wo - 1) * p.ldo + CN) * ESZ;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x + a_skip), 0, span32(a_all - a_skip), 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.y + o_skip), 0, span32(o_all - o_skip), 0x00020000);
 
   // ---- the wave's filter fragments (tap t = 3 j + kx of strip j, entry offset kx; FLIP: the data gradient reads bank tap 8 - t) ----
-  f16x8_t bh[9][2], bl[9][2];
+  f16x8_t bh[9][2], bl[IN16 ? 1 : 9][IN16 ? 1 : 2];
   if (!loader)
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (IN16) {
+        const unsigned short* src16 = reinterpret_cast<const unsigned short*>(p.w) + ((size_t)((nb * 32 + m) * 9 + (FLIP ? 8 - t : t)) * CK + kofs + kk * 16 + 8 * kg);
+        bh[t][kk] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const f32x4*>(src16));
+        continue;
+      }
       const float* src = p.w + ((size_t)((nb * 32 + m) * 9 + (FLIP ? 8 - t : t)) * CK + kofs + kk * 16 + 8 * kg);
       const f32x4 v0 = *reinterpret_cast<const f32x4*>(src) * s_b, v1 = *reinterpret_cast<const f32x4*>(src + 4) * s_b;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bh[t][kk][e] = (_Float16)v0[e]; bh[t][kk][4 + e] = (_Float16)v1[e];
-        bl[t][kk][e] = (_Float16)(v0[e] - (float)bh[t][kk][e]); bl[t][kk][4 + e] = (_Float16)(v1[e] - (float)bh[t][kk][4 + e]);
+        if constexpr (!IN16) { bl[t][kk][e] = (_Float16)(v0[e] - (float)bh[t][kk][e]); bl[t][kk][4 + e] = (_Float16)(v1[e] - (float)bh[t][kk][4 + e]); }
       }
     }
 
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int e = rem / (CK / 4), c = (rem % (CK / 4)) * 4;
     meta[j] = strip | (e << 2);
     st_off[j] = G::off(strip, G::row_of(e), c);
-    k_off[j] = ((((strip - 1) * W + e - 1) * p.ldi) + c) * 4;
+    k_off[j] = ((((strip - 1) * W + e - 1) * p.ldi) + c) * ESZ;
   }
   // PRE: every piece of a thread holds the same four channels (256 and the piece counts per row are multiples of CK/4) — except
   // the repeats of the list's last piece, which are switched off instead (dead_last)
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     psc = *reinterpret_cast<const f32x4*>(p.pre_scale + c) * s_a; psh = *reinterpret_cast<const f32x4*>(p.pre_shift + c) * s_a;
   }
   const bool leaky_max = p.pre_slope >= 0.f && p.pre_slope <= 1.f;
-  const int wrap_delta = (S * W - RL) * p.ldi * 4;          // an output row further: S input rows on, one padded row of entries back
+  const int wrap_delta = (S * W - RL) * p.ldi * ESZ;        // an output row further: S input rows on, one padded row of entries back
 
   Walk wl, wc;                                       // chunk being LOADED / being computed: (row n*Ho + oy - row0, column, oy)
   walk_to(wl, c_begin * CH, Wp, p.Ho); wl.row -= row0; wc = wl;
@@ -461,10 +473,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int u = u0 + e - (wrapped ? RL : 0);                      // entry within its padded row: image column u - 1
     const int oy = wrapped ? (wl.r + 1 == p.Ho ? 0 : wl.r + 1) : wl.r;
     const bool row_out = (strip == 0 && oy == 0) || (S == 1 && strip == 2 && oy == p.Ho - 1);
-    const int base = (S * wl.row * W + u0) * p.ldi * 4 + bias;      // (scalar)
+    const int base = (S * wl.row * W + u0) * p.ldi * ESZ + bias;      // (scalar)
     unsigned off = (unsigned)(base + k_off[j] + (wrapped ? wrap_delta : 0));
     if ((unsigned)(u - 1) >= (unsigned)W || row_out || NCONV_ABL == 3) off = OOBN;    // (rows past the tensor: out of the descriptor's range, read as zero)
-    v[j] = ldn(a_rs, off);
+    if constexpr (IN16) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(a_rs, off, 0, 0));
+      v[j] = f32x4{__uint_as_float(w2[0]), __uint_as_float(w2[1]), 0.f, 0.f};
+    } else {
+      v[j] = ldn(a_rs, off);
+    }
     if constexpr (PRE) {                             // (a piece past the tensor's end is a pad as well: its rows do not exist)
       const bool in = off != OOBN && (S * (wl.row + row0 + (wrapped ? 1 : 0)) + strip - 1) < p.N * H;
       vmask = in ? (vmask | (1u << j)) : (vmask & ~(1u << j));
@@ -473,6 +491,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto store_slot = [&](int j, int buf, const f32x4* v, unsigned vmask) {
     if (j >= FULL && !last_on) return;
     if (PRE && j >= FULL && dead_last) return;
+    if constexpr (IN16) {
+      *reinterpret_cast<uint2*>(sm + buf * BUFB + st_off[j]) = uint2{__float_as_uint(v[j][0]), __float_as_uint(v[j][1])};
+      return;
+    }
     f32x4 t;
     if constexpr (PRE) {
       // scale_act_kernel's arithmetic (bn.hip) on operands that carry the power-of-two operand scale already (psc, psh = s_a * scale,
@@ -559,20 +581,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       {
         const int ao = buf * BUFB + j * G::STRIP + a_addr[kx][0];
         const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + ao);
+        if constexpr (IN16) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[t][0]), acc, 0, 0, 0);
+        } else {
         const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + ao + PLANE);
         if (NCONV_ABL == 2) { acc[0] += (float)al[0] + (float)ah[0]; } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t][0], acc, 0, 0, 0);      // smallest terms first
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][0], acc, 0, 0, 0); }
+        }
       }
       {
         const int ao = buf * BUFB + j * G::STRIP + a_addr[kx][1];
         const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + ao);
+        if constexpr (IN16) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[t][1]), acc1, 0, 0, 0);
+        } else {
         const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + ao + PLANE);
         if (NCONV_ABL == 2) { acc1[0] += (float)al[0] + (float)ah[0]; } else {
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[t][1], acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[t][1], acc1, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t][1], acc1, 0, 0, 0); }
+        }
       }
     }
 #pragma unroll
@@ -594,15 +624,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (CN == 64 || hb == 0) {
       // output pixel of position pos: row*Wo + col + pos, minus one behind the pad entry (col + pos == Wo: the pad itself, no pixel)
       const int q0 = c * CH;
-      const int obase = ((wc.row * p.Wo + wc.col) * p.ldo + nb * 32 + m) * 4;
+      const int obase = ((wc.row * p.Wo + wc.col) * p.ldo + nb * 32 + m) * ESZ;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int pos = mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * kg;
         const int t = wc.col + pos;
         if (t == p.Wo || q0 + pos >= p.Mp) continue;
-        const float v = acc[q] * dq;
-        if (NCONV_ABL != 1 || v == 123.f)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, obase + (pos - (t > p.Wo ? 1 : 0)) * p.ldo * 4, 0, 0);
+        float v = acc[q] * dq;
+        if constexpr (IN16) {
+          const __bf16 v16 = (__bf16)v;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v16), o_rs, obase + (pos - (t > p.Wo ? 1 : 0)) * p.ldo * ESZ, 0, 0);
+          v = (float)v16;
+        } else {
+          if (NCONV_ABL != 1 || v == 123.f)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), o_rs, obase + (pos - (t > p.Wo ? 1 : 0)) * p.ldo * 4, 0, 0);
+        }
         st_s += v; st_ss += v * v;
       }
     }
@@ -715,16 +751,16 @@ bool nconv1_applicable(int mode, int n, int h, int wd, int cin, int cout, int ks
   return (long long)n * (h / stride) * (wd / stride) >= 65536;                                // (a persistent grid wants work for every CU)
 }
 
-template <int S, int CK, int CN, bool FLIP, bool PRE = false>
+template <int S, int CK, int CN, bool FLIP, bool PRE = false, bool IN16 = false>
 int launch_n1(N1Params& p, int grid, double flop, double bytes, hipStream_t stream) {
   typedef Geo1<S, CK> G;
   const int lds = 2 * G::BUFB + (CN == 32 ? 2 * 16 * 64 * 4 : 0);
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nconv1_kernel<S, CK, CN, FLIP, PRE, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   const int pid = prof_begin(38, flop, stream, bytes);
-  hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP, PRE>), dim3(grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL((nconv1_kernel<S, CK, CN, FLIP, PRE, IN16>), dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("nconv1");
   return DCN_OK;
@@ -765,4 +801,32 @@ int nconv1_launch(int mode, const float* x, int ldi, const float* w, float* y, i
   if (mode == 1) return launch_n1<1, 64, 32, true>(p, grid, flop, bytes, stream);
   if (pre) return stride == 1 ? launch_n1<1, 32, 64, false, true>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false, true>(p, grid, flop, bytes, stream);
   return stride == 1 ? launch_n1<1, 32, 64, false>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false>(p, grid, flop, bytes, stream);
+}
+
+// bf16 storage: x, the bank and y are bf16 (mode 0: forward 32 -> 64 with the OHWI bank [64][9][32]; mode 1: data gradient 64 -> 32 of the
+// stride-1 layer with the transposed bank [32][9][64]); stats as in nconv1_launch
+int nconv1_launch_b16(int mode, const void* x, int ldi, const void* w16, void* y, int ldo, float* stats, int stats_rows,
+                      int n, int h, int wd, int stride, hipStream_t stream) {
+  const int g_ncus = dcn_device_cus();
+  if (!g_ncus) { dcn_set_error("nconv1: device query failed"); return DCN_ERR_LAUNCH; }
+  const int ck = mode == 0 ? 32 : 64, cn = mode == 0 ? 64 : 32;
+  N1Params p{};
+  p.x = (const float*)x; p.w = (const float*)w16; p.y = (float*)y; p.stats = stats; p.N = n; p.Ho = h / stride; p.Wo = wd / stride; p.ldi = ldi; p.ldo = ldo;
+  p.Mp = n * p.Ho * (p.Wo + 1);
+  p.nchunks = cdiv(p.Mp, 64);
+  int grid = g_ncus < p.nchunks ? g_ncus : p.nchunks;
+  p.per_wg = cdiv(p.nchunks, grid);
+  grid = cdiv(p.nchunks, p.per_wg);
+  DCN_CHECK_ARG(((long long)p.per_wg * 64 / (p.Wo + 1) + 4) * stride * wd * (ldi > ldo ? ldi : ldo) * 2 < 0x7FFFFFF0LL,
+                "conv2d (bf16): the rows of one workgroup exceed 32-bit byte offsets");
+  if (stats) {
+    DCN_CHECK_ARG(stats_rows >= grid, "conv2d_fwd_b16: %d statistics rows for %d workgroups", stats_rows, grid);
+    if (stats_rows > grid && hipMemsetAsync(stats + (size_t)grid * 2 * cn, 0, (size_t)(stats_rows - grid) * 2 * cn * sizeof(float), stream) != hipSuccess) {
+      dcn_set_error("conv2d_fwd_b16: memset of the statistics rows failed"); return DCN_ERR_LAUNCH;
+    }
+  }
+  const double bytes = 2.0 * ((double)n * h * wd * ck + (double)n * p.Ho * p.Wo * cn + 64.0 * 9 * 32);
+  const double flop = 2.0 * (double)n * p.Ho * p.Wo * 64 * 9.0 * 32;
+  if (mode == 1) return launch_n1<1, 64, 32, true, false, true>(p, grid, flop, bytes, stream);
+  return stride == 1 ? launch_n1<1, 32, 64, false, false, true>(p, grid, flop, bytes, stream) : launch_n1<2, 32, 64, false, false, true>(p, grid, flop, bytes, stream);
 }

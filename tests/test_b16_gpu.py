@@ -47,6 +47,8 @@ CASES = [
     (1, 64, 66, 64, 128, 3, 1),       # ... and its 64 -> 128 form
     (4, 128, 128, 32, 64, 3, 2),      # the stride-2 data gradient of the narrow layers on the register-bank kernel (nconv.hip dgrad2, bf16 form)
     (2, 128, 256, 64, 128, 3, 2),     # ... its 64 <- 128 form
+    (4, 128, 128, 32, 64, 3, 1),      # forward 32 -> 64 and data gradient 64 -> 32 on the register-bank kernel (nconv.hip nconv1, bf16 form)
+    (4, 256, 256, 32, 64, 3, 2),      # ... the stride-2 forward (even / odd entry planes)
 ]
 
 
@@ -93,6 +95,15 @@ def _conv_case(case):
     assert y32.dtype == torch.float32 and float((y32.double().cpu() - ref_y).abs().max()) <= 3e-5 * max(1.0, float(ref_y.abs().max()))
     again, _ = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st)
     assert torch.equal(again, y)                                                      # bitwise repeatable
+    lib().set_tuning(b"Nb16", 0)               # (the register-bank kernel of the 32 <-> 64 layers off: conv1.hip's gathered tiles)
+    try:
+        y0, stats0 = ops.conv2d_fwd_b16(x, wt.reshape(-1), cout, k, st, want_stats=True)
+        _ulp_close(y0, ref_y, "fwd, gathered tiles")
+        assert torch.allclose(stats0.double().sum(0).cpu()[0], yf.sum(0), rtol=1e-5, atol=1e-4 * float(yf.abs().sum(0).max())) or not torch.equal(y0, y)
+        _ulp_close(ops.conv2d_bwd_data_b16(_bf(_rand(n, ho, wo, cout, seed=3) / 8).to(dev), wt.reshape(cout, T, cin).permute(2, 1, 0).contiguous().reshape(-1),
+                                           (h, w), cin, k, st), xd.grad.permute(0, 2, 3, 1), "dgrad, gathered tiles")
+    finally:
+        lib().set_tuning(b"Nb16", 1)
     # ---- epilogue: scale / shift / LeakyReLU / shortcut (bf16) ----
     sc = (_rand(cout, seed=4).abs() + 0.5).to(dev); sh = _rand(cout, seed=5).to(dev)
     res = _bf(_rand(n, ho, wo, cout, seed=6)).to(dev)
