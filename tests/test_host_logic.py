@@ -312,3 +312,36 @@ def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
     res["config"]["workload"] = "x" * 700
     out = json.loads(bench.compact_line(res))
     assert "rocprof_match" not in out["roofline"] and out["roofline"]["hbm_scoring_frac"] == 0.6485 and "cpu_baseline" in out
+
+
+def test_graph_queue_model_on_a_small_dag(tmp_path):
+    """tools/graph_sched.py on a hand-written dump in the runtime's format: depth first from the root, the first dependent of a node keeps
+    its queue, the k-th gets queue + k (mod 4), a node reached twice keeps its first queue — the rule the captured step's stream
+    schedule is built on (the GPU test checks it against the runtime's own dump of the real step)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("graph_sched", os.path.join(root, "tools", "graph_sched.py"))
+    gs = importlib.util.module_from_spec(spec); spec.loader.exec_module(gs)
+
+    def node(i, name, sid):
+        return f'"graph_1_node_{i}"[style="bold"shape="octagon"label="{i}\n{name}\nStreamId:{sid}\nSignalIsRequired: false\nDeviceId:0"];\n'
+
+    # 0 -> 1 -> 2 -> 5 (main chain), 1 -> 3 -> 4 -> 5 (a side branch captured behind the main continuation), 2 -> 6 and 2 -> 7 (two more forks)
+    edges = [(0, 1), (1, 2), (1, 3), (2, 5), (2, 6), (2, 7), (3, 4), (4, 5), (6, 5), (7, 5)]
+    want = {0: 0, 1: 0, 2: 0, 5: 0, 3: 1, 4: 1, 6: 1, 7: 2}
+    text = "digraph dot {\nsubgraph cluster_1 {\n" + "".join(node(i, f"k{i}", want[i]) for i in range(8))
+    text += "".join(f'"graph_1_node_{a}" -> "graph_1_node_{b}";\n' for a, b in edges) + "}\n}\n"
+    path = tmp_path / "small.dot"
+    path.write_text(text)
+    nodes, order, ed = gs.parse(str(path))
+    assert len(nodes) == 8 and len(ed) == len(edges)
+    sim = gs.simulate(nodes, order, ed)
+    assert {nodes[n]["idx"]: s for n, s in sim.items()} == want
+    # the same DAG with the side branch captured FIRST: it inherits the main chain's queue and the main chain moves on
+    edges2 = [(0, 1), (1, 3), (1, 2)] + [e for e in edges if e not in ((0, 1), (1, 2), (1, 3))]
+    text2 = text.split('"graph_1_node_0" ->')[0] + "".join(f'"graph_1_node_{a}" -> "graph_1_node_{b}";\n' for a, b in edges2) + "}\n}\n"
+    path.write_text(text2)
+    nodes, order, ed = gs.parse(str(path))
+    sim2 = {nodes[n]["idx"]: s for n, s in gs.simulate(nodes, order, ed).items()}
+    assert sim2[3] == 0 and sim2[4] == 0 and sim2[5] == 0 and sim2[2] == 1
