@@ -135,6 +135,7 @@ class ConvBias(torch.autograd.Function):
     def forward(ctx, x, weight, bias, amax_x=None):
         cout = weight.shape[0]
         cop = ops.pad32(cout)
+        ctx.wparam = weight if (ops.WGRAD_DIRECT and ops.WGRAD_SIDE and isinstance(weight, torch.nn.Parameter) and weight.requires_grad) else None
         w = ops.weight_to_ohwi(weight, ci_pad=x.shape[3], co_pad=cop)
         b = torch.zeros(cop, dtype=torch.float32, device=x.device)
         b[:cout] = bias.detach()
@@ -163,8 +164,15 @@ class ConvBias(torch.autograd.Function):
             dy = dy.contiguous()
             db = ops.colsum_rows(dy.view(-1, dy.shape[-1]))[:co]
             dy16 = ops.to_b16(dy)
-            dwt = ops.wgrad_on_side(x16, dy16, 1, 1, ctx.wshape)
             dx = None
+            if ctx.wparam is not None:      # (ops.WGRAD_DIRECT: added to .grad on the side stream, no join here)
+                ops.release_held_wgrads()
+                if ctx.needs_input_grad[0]:
+                    dx = ops.conv2d_bwd_data_b16(dy16, w16.t().contiguous().reshape(-1), (x16.shape[1], x16.shape[2]), x16.shape[3], 1, 1,
+                                                 out_f32=ctx.b16)
+                ops.hold_wgrad_into(ctx.wparam, x16, dy16, 1, 1, ctx.wshape)
+                return dx, None, db, None
+            dwt = ops.wgrad_on_side(x16, dy16, 1, 1, ctx.wshape)
             if ctx.needs_input_grad[0]:
                 dx = ops.conv2d_bwd_data_b16(dy16, w16.t().contiguous().reshape(-1), (x16.shape[1], x16.shape[2]), x16.shape[3], 1, 1,
                                              out_f32=ctx.b16)
@@ -175,6 +183,12 @@ class ConvBias(torch.autograd.Function):
         ax, aw = ctx.amax
         dy = dy.contiguous()
         ady = ops.absmax(dy) if ops.use_amax() else None
+        if ctx.wparam is not None:
+            ops.release_held_wgrads()
+            db = ops.colsum_rows(dy.view(-1, dy.shape[-1]))[:co]
+            dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
+            ops.hold_wgrad_into(ctx.wparam, x, dy, k, 1, ctx.wshape, amax_x=ax, amax_dy=ady)
+            return dx, None, db, None
         dwt = ops.wgrad_on_side(x, dy, k, 1, ctx.wshape, amax_x=ax, amax_dy=ady)
         db = ops.colsum_rows(dy.view(-1, dy.shape[-1]))[:co]
         dx = ops.conv2d_bwd_data(dy, w, (x.shape[1], x.shape[2]), k, 1, amax_dy=ady, amax_w=aw) if ctx.needs_input_grad[0] else None
