@@ -136,9 +136,14 @@ def main():
                 shutil.copy(est, os.path.join(prof, f"{tag}_{a.name}_eager_kernel_stats.csv"))
                 if os.path.exists(eager_json):
                     shutil.copy(eager_json, os.path.join(prof, f"{tag}_{a.name}_eager_under_rocprof.json"))
-            for extra in ("bench.json", "bench_full.json"):
+            for extra in ("bench.json", "bench_full.json", "bench_bf16s.json", "bench_full_bf16s.json"):
                 if os.path.exists(os.path.join(a.dir, extra)):
                     shutil.copy(os.path.join(a.dir, extra), os.path.join(prof, f"{tag}_{extra}"))
+            b16 = find(os.path.join(a.dir, "stats_bf16s"), "*kernel_stats.csv")      # the bf16-storage mode's replays under the tracer
+            if b16:
+                shutil.copy(b16, os.path.join(prof, f"{tag}_{a.name}_bf16s_kernel_stats.csv"))
+                if os.path.exists(os.path.join(a.dir, "bench_bf16s_under_rocprof.json")):
+                    shutil.copy(os.path.join(a.dir, "bench_bf16s_under_rocprof.json"), os.path.join(prof, f"{tag}_{a.name}_bf16s_under_rocprof.json"))
     # in-step launch durations of the replayed graph (real stream concurrency), per kernel family: bench.py cannot time launches
     # inside a hipGraph (events recorded in a captured graph cannot be read: tools/graph_event_probe.hip), so it quotes these beside
     # its live event-pair numbers
