@@ -132,6 +132,7 @@ def compact_line(res: dict) -> str:
     line still came out long, bookkeeping keys go first and the contract keys never."""
     out = dict(res)
     rf = dict(out.get("roofline") or {})
+    rf.pop("rocprof_match", None)              # (kept in the full JSON: tools/summarize_profile.py reads it there)
     ins = rf.pop("in_step", None)
     if ins:
         rf["in_step_frac"] = ins["frac"]; rf["in_step_ms"] = ins["avg_launch_ms"]
@@ -162,7 +163,7 @@ def compact_line(res: dict) -> str:
         rf["note"] = "alone: HIP events; in_step: rocprofv3, 2 queues share GPU"
         out["roofline"] = rf
     line = json.dumps(out, separators=(",", ":"))
-    for path in (("roofline", "rocprof_match"), ("roofline", "alg_bytes_per_launch"), ("roofline", "hbm_frac_algorithmic"),
+    for path in (("loss_hex",), ("roofline", "alg_bytes_per_launch"), ("roofline", "hbm_frac_algorithmic"),
                  ("roofline", "flop_dominant"), ("roofline", "flop_dominant_frac"), ("bn_passes_ms_per_step",), ("host_queue_ms_per_step",),
                  ("loss",), ("roofline", "conv_tflop_per_step"), ("roofline", "launches_per_step"), ("roofline", "note")):
         if len(line) < LINE_LIMIT:
@@ -195,6 +196,10 @@ def parse():
     ap.add_argument("--alt-steps", "--exclusive-steps", type=int, default=2, dest="alt_steps",
                     help="untimed eager steps per alternative-arithmetic pass, side streams off (bf16x3 / native "
                          "fp32 / bf16 / fp8 arithmetic).  0 = skip, e.g. under rocprofv3 so its averages speak about the timed step")
+    ap.add_argument("--bf16s-leg", choices=["auto", "on", "off"], default="auto",
+                    help="after the fp32 timed region: the SAME step on bf16 storage (BASELINE configs[2] on this GPU), captured and replayed "
+                         "in this process with the same --steps / --warmup -> roofline.bf16s_clips_s / bf16s_ms_per_step (auto: on for the "
+                         "single-GPU fp32 graph run)")
     ap.add_argument("--schedules", type=int, default=0,
                     help="N > 0: after the timed region capture the step under three stream schedules (no side streams; the default: "
                          "weight gradient beside the data-gradient chain; weight gradient queued behind its layer's data gradient) "
@@ -464,6 +469,40 @@ def main():
         sclk = read_sclk_mhz(local_rank)
     barrier()
 
+    # ---- configs[2] on this GPU: the same step on bf16 storage, captured again and replayed (its own timed region, never `value`) ----
+    bf16s_leg = None
+    want_leg = args.bf16s_leg == "on" or (args.bf16s_leg == "auto" and args.precision == "fp32" and not use_dist)
+    if want_leg and use_graph and step is not eager_step and args.precision != "bf16s":
+        from dcnet_amd.graph import GraphedTrainStep
+        ops.set_precision("bf16s")
+        g2 = None
+        try:
+            g2 = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=max(1, min(args.warmup, 2)))
+            for _ in range(args.warmup):
+                g2()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l2 = g2()
+            barrier()
+            dt2 = time.perf_counter() - t1
+            ops.check_bilstm(dev)
+            l2 = float(l2.detach())
+            if not np.isfinite(l2):
+                raise RuntimeError(f"bf16-storage leg: loss {l2}")
+            bf16s_leg = {"ms_per_step": dt2 / args.steps * 1e3, "clips_s": args.clips * args.steps / dt2, "steps": args.steps,
+                         "warmup": args.warmup, "loss": l2, "step": "hipGraph replay (fwd+losses+bwd+RMSprop), bf16 storage"}
+        except Exception as e:       # the fp32 line must not die with the extra leg: say so on stderr and in the line
+            print(f"bench.py: bf16-storage leg failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            bf16s_leg = {"error": type(e).__name__}
+        finally:
+            ops.set_precision(args.precision)
+            del g2
+            model.static_samples = None
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+
     # ---- untimed passes (every rank runs them, so collectives stay in step) -------------------------------------------
     # from here on the eager step: the profiler wraps each launch in a HIP event pair, which a captured graph cannot hold
     model.static_samples = None
@@ -573,6 +612,8 @@ def main():
         dist.barrier()                           # every rank got here: only now may rank 0 print the line
 
     if rank == 0:
+        from dcnet_amd.utils.srchash import kernel_sources_hash
+        src_hash = kernel_sources_hash()
         clips_total = args.clips * world * args.steps
 
         def table(r):
@@ -604,7 +645,7 @@ def main():
                                     "fp8": "fp8 e4m3 operands, fp32 accumulate"}[args.precision], "parallelism": f"dp{world}",
                           "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4),
-               "loss_hex": float(last_loss).hex()}
+               "loss_hex": float(last_loss).hex(), "src": src_hash}     # src: hash of the kernel + host sources (dcnet_amd.utils.srchash)
         if use_dist:
             res["config"]["collectives"] = (flat.collectives if flat is not None else red.buckets_last_step if red is not None else None)
         if step is not eager_step:
@@ -638,11 +679,14 @@ def main():
 
             e = entry(prof, dom)
             traffic = None
+            stale = []
             pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc_file):     # HBM bytes per launch from the last rocprofv3 --pmc passes (not measurable live)
                 with open(pmc_file) as f:
                     pmc = json.load(f)
-                if pmc.get("kernel", "").split(" (")[0] == e["kernel"].split(" (")[0]:
+                if pmc.get("src_hash") != src_hash:      # taken on other sources than the ones running: not quoted
+                    stale.append("pmc")
+                elif pmc.get("kernel", "").split(" (")[0] == e["kernel"].split(" (")[0]:
                     traffic = pmc.get("hbm_bytes_per_launch")
             roofline = {"bound": "mfma", "kernel": e["kernel"], "rocprof_match": RP_MATCH.get(dom), "achieved": e["achieved"], "peak": e["peak"], "unit": "TFLOP/s",
                         "frac": e["frac"], "traffic": traffic,
@@ -656,12 +700,16 @@ def main():
                     ins = json.load(f)
                 key = {28: "conv3", 29: "conv3", 32: "wgrad3", 35: "conv1", 25: "wgrad<128,128>", 24: "igemm<128,128> NT"}.get(dom)
                 k_ = ins.get("kernels", {}).get(key)
+                if ins.get("src_hash") != src_hash:
+                    stale.append("in_step"); k_ = None
                 if k_:
                     fl_per_launch = fam_sum(prof, dom, "work") / fam_sum(prof, dom, "c")
                     roofline["in_step"] = {"avg_launch_ms": round(k_["avg_launch_ms"], 4),
                                            "frac": round(fl_per_launch / (k_["avg_launch_ms"] * 1e-3) / 1e12 / PEAK_OF[dom], 4)}
                     if "shared_frac_of_time" in k_:      # part of that time with a kernel of another graph queue resident as well
                         roofline["in_step"]["shared"] = k_["shared_frac_of_time"]
+            if stale:
+                roofline["stale_profiles"] = stale    # committed profiles of OTHER sources: their numbers are left out (null)
             res["roofline"] = roofline
             fe = entry(prof, fdom)
             res["flop_dominant"] = {k: fe[k] for k in ("kernel", "frac", "ms_per_step", "binding_frac")}
@@ -700,6 +748,20 @@ def main():
             res["cpu_baseline"] = {"value": round(cb["value"], 4), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                    "sample": cb["sample"], "gpu_vs_oracle_max_abs_err": round(cb["parity"]["max_abs_err_outbox"], 6),
                                    "acc_at_0.5_vs_oracle_boxes": cb["parity"]["acc_at_iou_0.5_vs_oracle_boxes"]}
+        if bf16s_leg is not None:
+            full["bf16_storage_replayed"] = bf16s_leg
+            rf_ = res.setdefault("roofline", {})
+            if "error" in bf16s_leg:
+                rf_["bf16s_leg"] = bf16s_leg["error"]
+            else:
+                rf_["bf16s_clips_s"] = round(bf16s_leg["clips_s"], 2); rf_["bf16s_ms_per_step"] = round(bf16s_leg["ms_per_step"], 2)
+            crit_file = os.path.join(ROOT, "profiles", "precision_criterion_latest.json")
+            if os.path.exists(crit_file):    # SURVEY 8(c) box criterion of the mode on trained weights (tools/precision_criterion.py; also a -m gpu test)
+                with open(crit_file) as f:
+                    cr = json.load(f)
+                m_ = cr.get("modes", {}).get("bf16s")
+                if m_ and "criterion_met_frac" in m_:
+                    rf_["bf16s_criterion"] = "%d/%d" % (round(m_["criterion_met_frac"] * cr.get("images", 16)), cr.get("images", 16))
         res["full"] = "profiles/bench_full_latest.json"
         res["sclk_mhz"] = sclk
         full["bench_line"] = res

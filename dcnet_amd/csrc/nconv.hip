@@ -250,14 +250,14 @@ __device__ __forceinline__ void dgrad2_body(const D2Params& p, unsigned char* sm
         const f16x8_t ah = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + ao);
         if constexpr (IN16) {
           acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ah), __builtin_bit_cast(bf16x8_t, bh[i][kk]), acc[T::ac[i]], 0, 0, 0);
-          continue;
+        } else {
+          const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + ao);
+          acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][kk], acc[T::ac[i]], 0, 0, 0);      // smallest terms first
+          acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][kk], acc[T::ac[i]], 0, 0, 0);
+          acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][kk], acc[T::ac[i]], 0, 0, 0);
+          // (320 filter registers at CK = 128: keep the scheduler from reading all eight K-steps' fragments ahead of the MFMAs)
+          if constexpr (KS > 4) { if (kk & 1) __builtin_amdgcn_sched_barrier(0); }
         }
-        const f16x8_t al = *reinterpret_cast<const f16x8_t*>(sm + buf * BUFB + PLANE + ao);
-        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[i][kk], acc[T::ac[i]], 0, 0, 0);      // smallest terms first
-        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[i][kk], acc[T::ac[i]], 0, 0, 0);
-        acc[T::ac[i]] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[i][kk], acc[T::ac[i]], 0, 0, 0);
-        // (320 filter registers at CK = 128: keep the scheduler from reading all eight K-steps' fragments ahead of the MFMAs)
-        if constexpr (KS > 4) { if (kk & 1) __builtin_amdgcn_sched_barrier(0); }
       }
     };
     const int q0 = c * CH;

@@ -149,7 +149,7 @@ extern "C" int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int ne
                 "mt_sample_crossmodal: bad argument");
   const int setsz = set_size(neg_n);
   const int bits = bit_length((uint32_t)rows);
-  if (rows - 1 > setsz && bits == bit_length((uint32_t)(rows - 1)) && neg_n <= 8) {
+  if (rows - 1 > setsz && bits == bit_length((uint32_t)(rows - 1)) && neg_n <= 8 && bits <= 16) {     // (survivors are kept as uint16_t)
     // both populations (rows, rows - 1 entries) take the rejection branch with the same bit count: the block form.
     // A draw is compared with the <= 7 earlier ones of its sample instead of a set; only the n-th sample of a
     // (ii, jj) is written, the others just advance the stream.

@@ -588,8 +588,11 @@ class _DarknetFn(torch.autograd.Function):
         #  saved and every layer is ONE kernel with BatchNorm, activation and shortcut in its epilogue; forward_nhwc notes the mode, since
         #  inside a Function's forward grad mode is always off)
         need_grad = any(ctx.needs_input_grad[3:]) and bool(net.__dict__.get("_grad_on", True))
+        ctx.no_backward_reason = None if need_grad else "nothing was saved: the forward ran with gradients off (or no parameter requires one)"
         if ops.storage_b16() and not training:
             need_grad = False          # bf16 storage has no frozen-BatchNorm backward: inference only in eval mode (backward() says so)
+            ctx.no_backward_reason = ("bf16 storage has no backward in eval mode (frozen-BatchNorm fine-tuning is not built); "
+                                      "train with .train(), or use the fp32 precision mode")
         save = {} if need_grad else None
         outs, tap_amax, net._early_event = _run_forward(plan, taps, x, P, training, save, net._filter_banks(P),
                                                         taps_b16=bool(net.__dict__.get("_taps_b16")))
@@ -610,8 +613,9 @@ class _DarknetFn(torch.autograd.Function):
     def backward(ctx, *grads):
         net = ctx.net
         if ctx.save is None:
-            raise NotImplementedError("dcnet_amd.Darknet, bf16 storage: no backward in eval mode (frozen-BatchNorm fine-tuning is not built); "
-                                      "train with .train(), or use the fp32 precision mode")
+            why = getattr(ctx, "no_backward_reason", None) or ("this node's saved tensors were consumed by an earlier backward "
+                                                               "(one backward per forward; retain_graph is not supported)")
+            raise (NotImplementedError if "bf16" in why else RuntimeError)("dcnet_amd.Darknet: " + why)
         outs = ctx.saved_tensors
         save = {slot: ((outs[t[0][1]],) + t[1:] if isinstance(t[0], tuple) else t) for slot, t in ctx.save.items()}
         ctx.save = None

@@ -42,6 +42,8 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: HIP only (no CPU path)")
         self.model, self.opt, self.size, self.reducer = model, optimizer, size, reducer
         self.core = model.module if hasattr(model, "module") else model
+        self._hooked = (self.core is not model or getattr(reducer, "uses_parameter_hooks", False)
+                        or any(getattr(p_, "_post_accumulate_grad_hooks", None) for p_ in self.core.parameters()))
         dev = image.device
         self.image, self.word_id, self.bbox = image.clone(), word_id.clone(), bbox.clone()
         self.word_mask = None if word_mask is None else word_mask.clone()
@@ -97,7 +99,9 @@ class GraphedTrainStep:
         # forward of the same model elsewhere keeps drawing for itself
         self.core.static_samples = self.samples
         defer = ops.LANGUAGE_BWD_DEFERRED and hasattr(self.core, "finish_backward")
-        direct = ops.HEAD_WGRAD_DIRECT and not getattr(self.reducer, "uses_parameter_hooks", False)
+        # direct = the head's conv blocks add their weight gradient to .grad themselves (autograd sees None): only where nobody listens
+        # on the parameters — a DDP wrapper or a hook-based reducer would never see those gradients
+        direct = ops.HEAD_WGRAD_DIRECT and not self._hooked
         was_direct = ops.WGRAD_DIRECT
         if defer:
             self.core.defer_language_backward = True

@@ -70,6 +70,8 @@ class ConvBatchNormReLU(nn.Sequential):
     def forward(self, x_nhwc, amax=None):
         """``amax`` / the ``_dcn_amax`` attribute of the input: abs-max word of x (ops.amax_*); the output carries its own."""
         amax = amax if amax is not None else getattr(x_nhwc, "_dcn_amax", None)
+        if x_nhwc.dtype == torch.bfloat16 and not ops.storage_b16():
+            x_nhwc = ops.to_f32(x_nhwc)          # (a bf16 producer in front of an fp32 block: mixed-precision experiments, ops.region)
         out, a = ConvBNAct.apply(x_nhwc, self.conv.weight, self.bn.weight, self.bn.bias, self.bn,
                                  self.conv.kernel_size[0], self.training, self.slope, amax, self.__dict__.get("_dcn_bank"),
                                  bool(self.__dict__.get("_dcn_out_b16")))          # (bf16-storage mode: the next block reads bf16)
@@ -251,6 +253,10 @@ class grounding_model(nn.Module):
         main = torch.cuda.current_stream()
         pairs = [(t_, l_.grad) for t_, l_ in zip(st["live"], st["leaves"]) if t_.requires_grad and l_.grad is not None]
         hops = []
+        # one event per leaf, each recorded on the stream its AccumulateGrad ran on: `context` is also read by the sampling heads on
+        # their stream, so its gradient is complete behind THAT stream's kernels, not behind the head's on the main one
+        events = list(st["events"].values())
+        st["event"] = events[-1] if events else None     # the last one written: the point the branch (and the hops) fork from
         if st["event"] is not None:
             # (captured steps: the graph executor gives the k-th dependent of a node the node's queue + k, of four — tools/graph_sched.py.
             #  The main chain is dependent 0, the weight-gradient stream sits on queue + 1: LANGUAGE_BWD_HOPS one-word memsets on streams of
@@ -262,7 +268,8 @@ class grounding_model(nn.Module):
                     with torch.cuda.stream(h_):
                         self._hop_word(main.device).zero_()
                     hops.append(h_)
-            side.wait_event(st["event"])
+            for ev_ in reversed(events):
+                side.wait_event(ev_)
         else:
             side.wait_stream(main)
         if pairs:
@@ -335,24 +342,35 @@ class grounding_model(nn.Module):
     def _fusion_head(self, s: int, corr, flang):
         """fcn_emb[s] + fcn_out[s] on one scale: corr (B,H,W,E) -> outbox logits (B,H,W,32 = 15 + padding)  (:491-506)."""
         h, w = corr.shape[1], corr.shape[2]
+        ops.region("fusion")
         blk0 = self.fcn_emb[s][0]                                                # [corr | tile(flang) | coord] -> 1x1
         one = ops.amax_const(corr.device, 1.0) if ops.use_amax() else None        # corr is L2-normalised: |x| <= 1
         z, za = FusionConvBNAct.apply(corr.contiguous(), flang, self._coord(h, w, corr.device), blk0.conv.weight,
                                       blk0.bn.weight, blk0.bn.bias, blk0.bn, self.training, one)
         z._dcn_amax = za
         chain = list(self.fcn_emb[s])[1:] + list(self.fcn_out[s])[:-1]           # (none of them with light=True)
-        for blk in chain:
+        if ops.storage_b16() and self.training and chain and (not ops.FILTER_BANKS or (self.emb_size // 2) % 32):
+            raise RuntimeError("bf16 storage: the head chain fcn_emb -> fcn_out runs on bf16 tensors and needs the prepared filter banks "
+                               f"(ops.FILTER_BANKS) and emb_size // 2 a multiple of 32 (emb_size = {self.emb_size})")
+        n_emb = len(self.fcn_emb[s]) - 1
+        for i_, blk in enumerate(chain):
+            if i_ == n_emb:
+                ops.region("out")
             blk.__dict__["_dcn_out_b16"] = True          # bf16-storage mode: the chain fcn_emb[1:] -> fcn_out[0] -> bbox head stays in bf16
             z = blk(z)
         last = self.fcn_out[s][-1]
+        if z.dtype == torch.bfloat16 and not ops.storage_b16():
+            z = ops.to_f32(z)
         return ConvBias.apply(z, last.weight, last.bias, getattr(z, "_dcn_amax", None))    # (B,H,W,32): channels 15..31 are zero padding
 
     def _scale_pairs(self, s: int, raw_s, flang, flang_attn):
         """Everything of scale s that depends only on its backbone tap (pair semantics): mapping + norm
         (:356-359), co-attention + corr_conv (:449-468), normalise + sim (:469,530-535), fusion head.
         Returns (fv, corr, sim, neg_sim|None, logits (B,H,W,32))."""
-        one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None       # unit-norm features and their convex combinations
+        ops.region("mapping")
         fv = L2Norm.apply(self.mapping_visu[s](raw_s, self.visumodel._tap_amax[s]))
+        ops.region("corr")
+        one = ops.amax_const(raw_s.device, 1.0) if ops.use_amax() else None       # unit-norm features and their convex combinations
         corr_raw = self.corr_conv[s][0](CoAttentionPairs.apply(fv, self.temperature), one)
         corr, sim, neg_sim = NormScore.apply(corr_raw, flang_attn, self.training)
         return fv, corr, sim, neg_sim, self._fusion_head(s, corr, flang)
@@ -573,8 +591,10 @@ class grounding_model(nn.Module):
 
         if not late:
             side.wait_stream(main)
+            ops.region("language")
             word_id, flang, context, embedded, flang_attn, flang_loc = language()
         handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
+        ops.region("backbone")
         raw = self.visumodel.forward_nhwc(image, taps_b16=True)                  # :344  (queued asynchronously; bf16-storage mode: bf16 taps)
         if late:
             ev = self.visumodel.__dict__.get("_early_event")
@@ -590,10 +610,11 @@ class grounding_model(nn.Module):
         if self.defer_language_backward and self.training and torch.is_grad_enabled() and side is not main:
             live = (flang, context, embedded, flang_attn, flang_loc)
             leaves = tuple(t_.detach().requires_grad_(t_.requires_grad) for t_ in live)
-            state = {"live": live, "leaves": leaves, "event": None, "side": side}
+            state = {"live": live, "leaves": leaves, "events": {}, "side": side}
 
-            def _written(_leaf, st=state):       # (runs on the stream of the leaf's AccumulateGrad: the head's)
-                ev_ = torch.cuda.Event(); ev_.record(torch.cuda.current_stream()); st["event"] = ev_
+            def _written(leaf, st=state):        # (runs on the stream of the leaf's AccumulateGrad: the head's, or the sampling heads')
+                ev_ = torch.cuda.Event(); ev_.record(torch.cuda.current_stream())
+                st["events"].pop(id(leaf), None); st["events"][id(leaf)] = ev_       # insertion order = order of completion
 
             for l_ in leaves:
                 if l_.requires_grad:
@@ -621,6 +642,7 @@ class grounding_model(nn.Module):
         res = [r0, self._scale_pairs(1, raw[1], flang, flang_attn), self._scale_pairs(2, raw[2], flang, flang_attn)]
         corr_feat = [r[1] for r in res]
         sim = OutputList([r[2] for r in res], neg_sim=[r[3] for r in res] if sampling else None)
+        ops.region("tail")
         outbox, loc, only_obj = self._head(sim, [r[4] for r in res], flang_loc)
         if not self.training:
             return outbox, sim, loc, only_obj

@@ -89,6 +89,17 @@ def get_precision() -> str:
     return _precision
 
 
+# Experiments only (tools/precision_criterion.py --regions): a precision mode per region of the model's forward, to localise where a
+# reduced-precision mode loses the box criterion.  None (the product's state) = one mode for everything, region() is a no-op.
+REGION_PRECISION = None
+
+
+def region(name: str) -> None:
+    """Called by grounding_model at the start of a region (language, backbone, mapping, corr, fusion, out, tail)."""
+    if REGION_PRECISION is not None:
+        set_precision(REGION_PRECISION.get(name, REGION_PRECISION.get("default", "fp32")))
+
+
 # ---- abs-max words of GEMM operands (the f16 two-piece split derives its power-of-two scales from them) --------------
 # A word holds the float bits of max|tensor| and is written with order-independent atomic maxima by the kernels that
 # produce the tensor (scale_act, bn_act_bwd, the conv epilogue) or by absmax().  Words come zeroed from a pool (one per

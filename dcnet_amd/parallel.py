@@ -182,6 +182,8 @@ class OverlappedGradReducer:
     into an existing ``.grad`` would be averaged while the old content is not (DDP has the same contract under no_sync).
     On CPU tensors (gloo, tests) the same calls run synchronously."""
 
+    uses_parameter_hooks = False      # (reads .grad in finish(): graph.GraphedTrainStep may let the head add its weight gradients directly)
+
     def __init__(self, model_or_params, bucket_bytes: int = 48 << 20, group=None):
         params = model_or_params.parameters() if hasattr(model_or_params, "parameters") else model_or_params
         self.params = [p for p in params if p.requires_grad]

@@ -279,17 +279,18 @@ def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
            "config": {"workload": "T=8 416x416 bs8/GPU L=20 fp32, 64 img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
                       "arith": "f16x2-split MFMA, fp32 accumulate", "parallelism": "dp1", "ranks_seen": 1, "reducer": "none",
                       "step": "hipGraph replay (fwd+losses+bwd+RMSprop)"},
-           "host_queue_ms_per_step": 89.53, "mem_gb": 30.1, "loss": 123.4567, "host_ms_per_step": {"launch": 5.01, "sampler_thread": 18.2, "gpu_wait": 84.42},
+           "host_queue_ms_per_step": 89.53, "mem_gb": 30.1, "loss": 123.4567, "loss_hex": "0x1.1d65820000000p+4", "src": "9246e1312c10", "host_ms_per_step": {"launch": 5.01, "sampler_thread": 18.2, "gpu_wait": 84.42},
            "roofline": {"bound": "mfma", "kernel": bench.FAMILY[28], "rocprof_match": bench.RP_MATCH[28], "achieved": 334.0, "peak": 838.9,
                         "unit": "TFLOP/s", "frac": 0.3982, "traffic": 389711014.40000004, "traffic_ratio": 1.933, "avg_launch_ms": 0.382,
                         "ms_per_step": 22.92, "launches_per_step": 60.0, "alg_bytes_per_launch": 201624781, "hbm_frac_algorithmic": 0.066,
-                        "binding_frac": 0.3982, "in_step": {"avg_launch_ms": 0.4176, "frac": 0.3642}},
+                        "binding_frac": 0.3982, "in_step": {"avg_launch_ms": 0.4176, "frac": 0.3642, "shared": 0.411},
+                        "bf16s_clips_s": 138.52, "bf16s_ms_per_step": 57.75, "bf16s_criterion": "15/16"},
            "flop_dominant": {"kernel": bench.FAMILY[28], "frac": 0.3982, "ms_per_step": 22.92, "binding_frac": 0.3982},
            "hbm_scoring": {"kernel": bench.NAMES[8], "achieved": 5188.3, "peak": 8000.0, "unit": "GB/s", "frac": 0.6485},
            "conv_engine": {"tflop_per_step": 18.87, "tflops_over_kernel_time": 258.9, "frac_of_838.9": 0.3086, "frac_of_fp32_mfma_157.3": 1.646,
                            "tflops_over_step_wall": 190.6},
            "bn_passes_ms_per_step": 13.71,
-           "alt": {"exclusive_ms": 112.0, "bf16x3_ms": 152.6, "native_fp32_ms": 221.8, "bf16_ms": 102.7, "fp8_ms": 109.1},
+           "alt": {"exclusive_ms": 112.0, "bf16x3_ms": 152.6, "native_fp32_ms": 221.8, "bf16_ms": 102.7, "bf16s_ms": 67.9, "fp8_ms": 109.1},
            "cpu_baseline": {"value": 0.2383, "unit": "clips/s", "cores": 8, "kind": "port",
                             "sample": "oracle port fwd+5 losses+bwd, 1 clip T=8 416x416, median of 3 steps, 128 cpus on host",
                             "gpu_vs_oracle_max_abs_err": 0.00019, "acc_at_0.5_vs_oracle_boxes": 1.0},
@@ -302,16 +303,18 @@ def test_bench_line_keeps_north_star_numbers_at_benchmark_size():
         assert k in out, k
     rf = out["roofline"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "in_step_frac", "in_step_ms", "conv_engine_frac",
-              "hbm_scoring_frac", "hbm_scoring_gbs", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz", "rocprof_match",
-              "step_tflops", "step_frac"):
+              "hbm_scoring_frac", "hbm_scoring_gbs", "native_fp32_ms", "bf16x3_ms", "bf16_ms", "fp8_ms", "alone_ms", "sclk_mhz",
+              "step_tflops", "step_frac", "bf16s_clips_s", "bf16s_ms_per_step", "bf16s_criterion"):
         assert k in rf, k
+    assert "rocprof_match" not in rf and out["src"] == "9246e1312c10"      # (the match strings live in the full JSON; the line names its sources)
     assert rf["in_step_frac"] == 0.3642 and rf["hbm_scoring_frac"] == 0.6485 and rf["conv_engine_frac"] == 0.3086 and rf["sclk_mhz"] == 2104
     assert rf["step_tflops"] == 190.6 and abs(rf["step_frac"] - 190.6 / 838.9) < 1e-3        # the replayed step's FLOP over its wall time
     assert all(len(v) <= 120 for v in (out["config"]["workload"], rf["kernel"], rf["note"], out["cpu_baseline"]["sample"]))   # the driver cuts strings
     # an absurdly long line sheds bookkeeping keys, never the contract or the north_star numbers
     res["config"]["workload"] = "x" * 700
     out = json.loads(bench.compact_line(res))
-    assert "rocprof_match" not in out["roofline"] and out["roofline"]["hbm_scoring_frac"] == 0.6485 and "cpu_baseline" in out
+    assert "loss_hex" not in out and out["roofline"]["hbm_scoring_frac"] == 0.6485 and "cpu_baseline" in out
+    assert out["roofline"]["bf16s_ms_per_step"] == 57.75
 
 
 def test_graph_queue_model_on_a_small_dag(tmp_path):

@@ -50,6 +50,10 @@ def main():
     ap.add_argument("--size", type=int, default=256); ap.add_argument("--images", type=int, default=16)
     ap.add_argument("--steps", type=int, default=300); ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--out", type=str, default=os.path.join(ROOT, "gpurun_out", "criterion.json"))
+    ap.add_argument("--regions", action="store_true",
+                    help="localise the bf16-storage drift: evaluate with ONE region of the forward at a time in fp32 (rest bf16s) and with one "
+                         "region at a time in bf16s (rest fp32) — ops.REGION_PRECISION")
+    ap.add_argument("--no-train-in-mode", action="store_true", help="skip the three trainings IN the reduced modes")
     args = ap.parse_args()
     from dcnet_amd import losses, ops, train as T
     from dcnet_amd.parallel import freeze_gradless
@@ -98,10 +102,35 @@ def main():
                               "iou_vs_fp32_min": float(iou.min()), "iou_vs_fp32_mean": float(iou.mean()),
                               "same_argmax_cell_frac": float(same.float().mean()), "criterion_met_frac": float(ok.float().mean()),
                               "max_abs_conf_diff": float((r["conf"] - f["conf"]).abs().max())}
+    if args.regions:
+        names = ("language", "backbone", "mapping", "corr", "fusion", "out", "tail")
+        table = {}
+        try:
+            cases = {"all_bf16s": {"default": "bf16s"}, "all_fp32": {"default": "fp32"}}
+            for r_ in names:
+                cases[f"fp32_only_{r_}"] = {"default": "bf16s", r_: "fp32"}
+                cases[f"bf16s_only_{r_}"] = {"default": "fp32", r_: "bf16s"}
+            cases["fp32_fusion+out"] = {"default": "bf16s", "fusion": "fp32", "out": "fp32"}
+            cases["fp32_head(all_but_backbone)"] = {"default": "fp32", "backbone": "bf16s"}
+            for cname, rp in cases.items():
+                ops.REGION_PRECISION = rp
+                with torch.no_grad():
+                    outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
+                boxes = losses.decode_boxes(outbox, size)
+                cell, conf = argmax_cells(outbox)
+                iou = losses.bbox_iou(boxes, f["boxes"])
+                same = (cell == f["cell"])
+                table[cname] = {"met": int(((iou >= 0.95) & same).sum()), "iou_min": round(float(iou.min()), 4), "iou_mean": round(float(iou.mean()), 4),
+                                "same_cell": int(same.sum())}
+                print(f"regions {cname:34s} {table[cname]}", flush=True)
+        finally:
+            ops.REGION_PRECISION = None
+            ops.set_precision("fp32")
+        out["regions"] = table
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
     # same data and schedule, every step in the mode; evaluated in the mode against the ground truth.
     out["trained_in_mode"] = {}
-    for mode in ("bf16", "bf16s", "fp8"):
+    for mode in (() if args.no_train_in_mode else ("bf16", "bf16s", "fp8")):
         try:
             ops.set_precision(mode)
             m2 = build_product(size, synth_sd(size), dev)

@@ -112,15 +112,21 @@ def main():
     dominant = None
     match = None
     eager_json = os.path.join(a.dir, "bench_eager_under_rocprof.json")
+    src_hash = None
     for cand in (bench_json, eager_json, os.path.join(a.dir, "bench.json")):      # (the graph-replay run carries no live roofline)
         if os.path.exists(cand) and os.path.getsize(cand):
             with open(cand) as f:
                 line = [l for l in f if l.startswith("{")][-1]
-            rf = json.loads(line).get("roofline")
-            if rf and rf.get("kernel"):
+            rec_ = json.loads(line)
+            src_hash = src_hash or rec_.get("src")      # the sources the profiled runs used: bench.py quotes a profile only on the same ones
+            rf = rec_.get("roofline")
+            if rf and rf.get("kernel") and dominant is None:
                 dominant = rf["kernel"]
                 match = rf.get("rocprof_match")
-                break
+    full_json = os.path.join(a.dir, "bench_full.json")
+    if match is None and os.path.exists(full_json):      # (the compact line no longer carries the match strings)
+        with open(full_json) as f:
+            match = ((json.load(f).get("bench_line") or {}).get("roofline") or {}).get("rocprof_match")
     if stats:
         with open(stats, newline="") as f:
             rows = list(csv.DictReader(f))
@@ -154,7 +160,7 @@ def main():
                "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel"], "channel_partials": ["channel_partials_kernel"],
                "l2norm_score_fwd": ["l2norm_score_fwd_kernel"], "dgrad2": ["dgrad2_kernel<"], "nconv1": ["nconv1_kernel<"],
                "wgrad9": ["wgrad9_kernel<"], "stem_wgrad_bn": ["stem_wgrad_bn_kernel"]}
-        out = {"round": a.round, "source": f"profiles/{tag}_{a.name}_kernel_stats.csv", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
+        out = {"round": a.round, "src_hash": src_hash, "source": f"profiles/{tag}_{a.name}_kernel_stats.csv", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
                "--warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0 (graph replays only)", "kernels": {}}
         for k_, pats in fam.items():
             calls = 0; tot = 0.0
@@ -192,7 +198,7 @@ def main():
             nf = sum(tables["fetch"][h][0] for h in hit); sf = sum(tables["fetch"][h][1] for h in hit)
             nw = sum(tables["write"].get(h, [0, 0.0])[0] for h in hit); sw = sum(tables["write"].get(h, [0, 0.0])[1] for h in hit)
             fetch_kb, write_kb = sf / nf, sw / max(nw, 1)
-            rec = {"round": a.round, "kernel": dominant, "rocprof_name": k, "launches_in_pass": nf,
+            rec = {"round": a.round, "src_hash": src_hash, "kernel": dominant, "rocprof_name": k, "launches_in_pass": nf,
                    "FETCH_SIZE_KB_avg_per_launch": fetch_kb, "WRITE_SIZE_KB_avg_per_launch": write_kb,
                    "gfx950_correction": "FETCH_SIZE doubled (16-B/lane coalesced reads are tallied at half their bytes, "
                                         "MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
