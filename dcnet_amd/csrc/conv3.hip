@@ -52,7 +52,12 @@ __device__ __forceinline__ int row32(int pos, int half) { return pos * 32 + (((h
 // NP = 2: fp32-accurate f16 two-piece split (pre-split filter bank, three MFMAs per product).  NP = 1: bf16 operands, one plane,
 // one MFMA per product — the bf16-operand mode (BASELINE.json configs[2]); the filter bank arrives converted to bf16
 // (IgemmParams::wt16, dcn_prepare_filters), activations are rounded when the strip is staged.
-template <int WM, int WN, int A_LD, int NP = 2>
+// ABL (builds with -DC3_ABL=1 only, dcn_set_tuning("3abl", bits); results are WRONG, timing experiments): 1 = no filter loads in the loop,
+// 2 = no strip loads in the loop, 4 = no filter / strip LDS stores in the loop, 8 = no epilogue, 16 = one of the three MFMA terms
+#ifndef C3_ABL
+#define C3_ABL 0
+#endif
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParams p, const int S, const int gran) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   constexpr int CHB = 2 * NP;                 // 16-B chunks per filter row and tap (16 k: 64 B pre-split, 32 B bf16)
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     // older stage's stores conservative (it then also waits for the loads just issued).  Past the end of the K loop the loads
     // take the out-of-range offset (they return zero without touching memory) and the stores fill a buffer nobody reads.
     {
-      const bool in_b = it + 2 < iters;
+      const bool in_b = (ABL & 1) ? false : it + 2 < iters;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const unsigned soff = (unsigned)(p.tap_w[3 * G2 + j] + (cc + C2) * 16) * (unsigned)ESZ;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       }
     }
     if constexpr (G == 0) {
-      const bool in_a = cc + 1 < nch;
+      const bool in_a = (ABL & 2) ? false : cc + 1 < nch;
 #pragma unroll
       for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, in_a ? a_off[j] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
     }
@@ -265,12 +270,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       const int st = (IP + j) & 1;
       read_frags(G, CP, IP, j + 1, st ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_term(st, 0);
+      if constexpr (!(ABL & 16)) mfma_term(st, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (j == 0) { store_b_tap(bnx, bold, 0); store_b_tap(bnx, bold, 1); } else store_b_tap(bnx, bold, 2);
-      mfma_term(st, 1);
+      if constexpr (!(ABL & 4)) { if (j == 0) { store_b_tap(bnx, bold, 0); store_b_tap(bnx, bold, 1); } else store_b_tap(bnx, bold, 2); }
+      if constexpr (!(ABL & 16)) mfma_term(st, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (G == 2) {
+      if constexpr (G == 2 && !(ABL & 4)) {
 #pragma unroll
         for (int q = j * (A_LD / 2); q < (j + 1) * (A_LD / 2); ++q) store_a_piece(an, q);
       }
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     __syncthreads();
     read_frags(GN, CPN, IP ^ 1, 0, IP ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_term(IP, 0); mfma_term(IP, 1); mfma_term(IP, 2);
+    if constexpr (!(ABL & 16)) { mfma_term(IP, 0); mfma_term(IP, 1); }
+    mfma_term(IP, 2);
     __builtin_amdgcn_sched_barrier(0);
   };
   read_frags(0, 0, 0, 0, 0);
@@ -292,6 +298,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     }
   }
   __syncthreads();                            // (the statistics reduction below reuses LDS)
+  if constexpr ((ABL & 8) != 0) {             // (timing only: one store per lane keeps the accumulators alive)
+    float t_ = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t_ += acc[mi][ni][r];
+    if (t_ == 12345.678f) p.out[tid] = t_;
+    return;
+  }
 
   const float dq = 1.f / (sa * sb);           // powers of two: exact
 #pragma unroll
@@ -403,21 +420,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 
 int g_conv3 = 1;          // dcn_set_tuning("3x3strip", 0): 3x3 stride-1 layers back on the implicit-GEMM tile
 int g_conv3_bm = 0;       // dcn_set_tuning("3bm", 128|256): force the strip kernel's M tile (0 = automatic)
+int g_conv3_abl = 0;      // dcn_set_tuning("3abl", bits): timing ablations (C3_ABL builds only)
 
-template <int WM, int WN, int A_LD, int NP = 2>
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0>
 int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   const int S = BM + 2 * p.Wi + 2;
   const size_t lds = (size_t)2 * NP * (S + 2) * 32 + (size_t)2 * 3 * (NP * BN * 32 + 128);
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const double k_alg = 9.0 * p.Ci;
   const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
   const int pid = prof_begin(NP == 1 ? 33 : (WM == 4 ? 28 : 29), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
+  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv3");
   return DCN_OK;
@@ -428,6 +446,17 @@ constexpr int A_LD_MAX = 4;   // strip loads per thread: S <= threads pixels.  (
 template <int WM, int WN>
 int launch3_ld(const IgemmParams& p, int gran, hipStream_t stream) {
   if (p.wt16) return launch3<WM, WN, A_LD_MAX, 1>(p, gran, stream);       // bf16 operands
+#if C3_ABL
+  switch (g_conv3_abl) {
+    case 1: return launch3<WM, WN, A_LD_MAX, 2, 1>(p, gran, stream);
+    case 3: return launch3<WM, WN, A_LD_MAX, 2, 3>(p, gran, stream);
+    case 7: return launch3<WM, WN, A_LD_MAX, 2, 7>(p, gran, stream);
+    case 8: return launch3<WM, WN, A_LD_MAX, 2, 8>(p, gran, stream);
+    case 15: return launch3<WM, WN, A_LD_MAX, 2, 15>(p, gran, stream);
+    case 16: return launch3<WM, WN, A_LD_MAX, 2, 16>(p, gran, stream);
+    default: break;
+  }
+#endif
   return launch3<WM, WN, A_LD_MAX>(p, gran, stream);
 }
 
@@ -450,7 +479,7 @@ int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
 
 }  // namespace
 
-void conv3_set_tuning(int key, int value) { if (key == 0) g_conv3 = value; else g_conv3_bm = value; }
+void conv3_set_tuning(int key, int value) { if (key == 0) g_conv3 = value; else if (key == 1) g_conv3_bm = value; else g_conv3_abl = value; }
 
 // can this launch run on the strip kernel?  (gran = rows per statistics partial the caller sized its buffer for)
 bool conv3_applicable(const IgemmParams& p, int precision, int gran) {

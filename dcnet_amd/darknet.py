@@ -326,6 +326,35 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             ao = ops.amax_slot(x.device) if am else None
             res = out[op.res] if op.res is not None else None
             act = ops.ACT_LEAKY if op.leaky else ops.ACT_NONE
+            if s16 and ops.B16_DIAG is not None and not training and op.cin > 4:
+                # experiments (tools/precision_criterion.py --backbone): which part of the bf16-storage backbone costs the box criterion.
+                # "layers": predicate on the conv slot — True = this layer on bf16 tensors, False = on fp32 tensors at fp32 accuracy;
+                # "res32": the shortcut sums are kept in fp32 (the convolutions read a bf16 copy)
+                diag = ops.B16_DIAG
+                on16 = diag.get("layers", lambda s_: True)(op.slot)
+                if not on16:
+                    ops.set_precision("fp32")
+                    try:
+                        ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5) if op.bn else (None, p["b"])
+                        # (no abs-max words: the launch takes the bf16 three-piece split — fp32 accuracy all the same)
+                        o, _ = ops.conv2d_fwd(ops.to_f32(x), w, op.k, op.stride, ss[0], ss[1], act, 0.1,
+                                              residual=None if res is None else ops.to_f32(diag.get("_r32", {}).get(op.res, res)))
+                    finally:
+                        ops.set_precision("bf16s")
+                    if res is not None and diag.get("res32"):
+                        diag.setdefault("_r32", {})[op.dst] = o
+                    out[op.dst] = o; amx[op.dst] = None
+                    continue
+                x = ops.to_b16(x)
+                if res is not None and diag.get("res32"):
+                    ss = ops.bn_fold(p["gamma"], p["beta"], p["rm"], p["rv"], 1e-5)
+                    o32, _ = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, ss[0], ss[1], act, 0.1, out_f32=True)
+                    r32 = diag.setdefault("_r32", {})
+                    o32 = o32 + (r32[op.res] if op.res in r32 else ops.to_f32(res))
+                    r32[op.dst] = o32
+                    out[op.dst] = ops.to_b16(o32); amx[op.dst] = None
+                    continue
+                res = None if res is None else ops.to_b16(res)
             if s16 and x.dtype == torch.bfloat16:
                 if bank is None:
                     raise RuntimeError("bf16 storage needs the prepared filter banks (ops.FILTER_BANKS) for every layer behind the stem")
@@ -382,6 +411,8 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             out[op.dst] = o; amx[op.dst] = ao
         elif isinstance(op, _UpCatOp):
             up, lat = out[op.up_src], out[op.lat_src]
+            if up.dtype != lat.dtype:              # (mixed-precision experiments only)
+                up = ops.to_b16(up) if lat.dtype == torch.bfloat16 else ops.to_f32(up)
             n, h, w_, _ = lat.shape
             buf = torch.empty((n, h, w_, op.c_up + op.c_lat), dtype=lat.dtype, device=lat.device)
             ops.upsample2_into(up, buf[..., :op.c_up])

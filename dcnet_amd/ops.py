@@ -94,6 +94,9 @@ def get_precision() -> str:
 REGION_PRECISION = None
 
 
+B16_DIAG = None      # experiments: {"layers": slot -> bool, "res32": bool} for the bf16-storage backbone in eval mode (darknet._run_forward)
+
+
 def region(name: str) -> None:
     """Called by grounding_model at the start of a region (language, backbone, mapping, corr, fusion, out, tail)."""
     if REGION_PRECISION is not None:

@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--regions", action="store_true",
                     help="localise the bf16-storage drift: evaluate with ONE region of the forward at a time in fp32 (rest bf16s) and with one "
                          "region at a time in bf16s (rest fp32) — ops.REGION_PRECISION")
+    ap.add_argument("--backbone", action="store_true",
+                    help="localise the drift INSIDE the bf16-storage backbone (eval): fp32 shortcut sums, fp32 for the layers before / from a "
+                         "stage boundary — ops.B16_DIAG")
     ap.add_argument("--no-train-in-mode", action="store_true", help="skip the three trainings IN the reduced modes")
     args = ap.parse_args()
     from dcnet_amd import losses, ops, train as T
@@ -127,6 +130,30 @@ def main():
             ops.REGION_PRECISION = None
             ops.set_precision("fp32")
         out["regions"] = table
+    if args.backbone:
+        table = {}
+        cases = {"bf16s": None, "res32": {"res32": True}}
+        for k_ in (5, 12, 37, 62, 75):          # first conv slot of the 104^2 / 52^2 / 26^2 / 13^2 stages, end of the trunk
+            cases[f"fp32_before_{k_}"] = {"layers": (lambda s_, k=k_: s_ >= k)}
+            cases[f"fp32_from_{k_}"] = {"layers": (lambda s_, k=k_: s_ < k)}
+            cases[f"res32+fp32_before_{k_}"] = {"layers": (lambda s_, k=k_: s_ >= k), "res32": True}
+        try:
+            ops.set_precision("bf16s")
+            for cname, dg in cases.items():
+                ops.B16_DIAG = None if dg is None else dict(dg)
+                with torch.no_grad():
+                    outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
+                boxes = losses.decode_boxes(outbox, size)
+                cell, conf = argmax_cells(outbox)
+                iou = losses.bbox_iou(boxes, f["boxes"])
+                same = (cell == f["cell"])
+                table[cname] = {"met": int(((iou >= 0.95) & same).sum()), "iou_min": round(float(iou.min()), 4), "iou_mean": round(float(iou.mean()), 4),
+                                "same_cell": int(same.sum())}
+                print(f"backbone {cname:34s} {table[cname]}", flush=True)
+        finally:
+            ops.B16_DIAG = None
+            ops.set_precision("fp32")
+        out["backbone"] = table
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
     # same data and schedule, every step in the mode; evaluated in the mode against the ground truth.
     out["trained_in_mode"] = {}
