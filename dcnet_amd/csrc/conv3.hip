@@ -57,7 +57,10 @@ __device__ __forceinline__ int row32(int pos, int half) { return pos * 32 + (((h
 #ifndef C3_ABL
 #define C3_ABL 0
 #endif
-template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0>
+// LS ("load spread"): the global loads of an iteration are issued one by one BEHIND its MFMA groups instead of all at its start — every wave
+// leaves the barrier at the same time, and a burst of 7-10 loads per thread from all of them fills the memory path's queue: a load then sits in
+// the issue stage with no MFMA behind it (gemm3.hip measured the same for its LDS-DMA: 0.92 -> 0.70 ms with the DMA behind the fragment reads)
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParams p, const int S, const int gran) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   constexpr int CHB = 2 * NP;                 // 16-B chunks per filter row and tap (16 k: 64 B pre-split, 32 B bf16)
@@ -249,19 +252,34 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     // Every load and store below is unconditional: a load inside a (wave-uniform) branch makes the s_waitcnt in front of the
     // older stage's stores conservative (it then also waits for the loads just issued).  Past the end of the K loop the loads
     // take the out-of-range offset (they return zero without touching memory) and the stores fill a buffer nobody reads.
-    {
-      const bool in_b = (ABL & 1) ? false : it + 2 < iters;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
+    const bool in_b = (ABL & 1) ? false : it + 2 < iters;
+    const bool in_a = (ABL & 2) ? false : cc + 1 < nch;
+    // load q of this iteration: the 3 B_LD filter pieces of iteration it + 2 first (stored one iteration from now), then — G == 0 — the
+    // A_LD strip pieces of channel step cc + 1 (stored at G == 2)
+    constexpr int NLOAD = 3 * B_LD + (G == 0 ? A_LD : 0);
+    auto load_q = [&](const int q) {
+      if (q < 3 * B_LD) {
+        const int j = q / B_LD, l = q - j * B_LD;
         const unsigned soff = (unsigned)(p.tap_w[3 * G2 + j] + (cc + C2) * 16) * (unsigned)ESZ;
-#pragma unroll
-        for (int l = 0; l < B_LD; ++l) bnew[j * B_LD + l] = ld16(b_rs, in_b ? b_off[l] : OOB3, in_b ? soff : 0u);
+        bnew[q] = ld16(b_rs, in_b ? b_off[l] : OOB3, in_b ? soff : 0u);
+      } else if (q < NLOAD) {
+        a_reg[q - 3 * B_LD] = ld16(a_rs, in_a ? a_off[q - 3 * B_LD] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
       }
-    }
-    if constexpr (G == 0) {
-      const bool in_a = (ABL & 2) ? false : cc + 1 < nch;
+    };
+    // LS: slot s of the iteration's nine MFMA groups takes loads [lo(s), lo(s + 1)): the filter pieces behind the first groups (they are
+    // stored early in the next iteration), the strip pieces behind the later ones
+    constexpr int BSL = 3 * B_LD <= 4 ? 3 * B_LD : 4;             // slots the filter loads spread over
+    auto slot_loads = [&](const int sl) {
+      if constexpr (LS == 0) return;
 #pragma unroll
-      for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, in_a ? a_off[j] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
+      for (int q = 0; q < NLOAD; ++q) {
+        const int home = q < 3 * B_LD ? q * BSL / (3 * B_LD) : BSL + (q - 3 * B_LD) * (9 - BSL) / (A_LD > 0 ? A_LD : 1);
+        if (home == sl) load_q(q);
+      }
+    };
+    if constexpr (LS == 0) {
+#pragma unroll
+      for (int q = 0; q < NLOAD; ++q) load_q(q);
     }
     unsigned char* an = Abase + (CP ^ 1) * NP * PA;
     unsigned char* bnx = Bbase + (IP ^ 1) * 3 * SLOT;
@@ -271,22 +289,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
       read_frags(G, CP, IP, j + 1, st ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(ABL & 16)) mfma_term(st, 0);
+      slot_loads(3 * j);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(ABL & 4)) { if (j == 0) { store_b_tap(bnx, bold, 0); store_b_tap(bnx, bold, 1); } else store_b_tap(bnx, bold, 2); }
       if constexpr (!(ABL & 16)) mfma_term(st, 1);
+      slot_loads(3 * j + 1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (G == 2 && !(ABL & 4)) {
 #pragma unroll
         for (int q = j * (A_LD / 2); q < (j + 1) * (A_LD / 2); ++q) store_a_piece(an, q);
       }
       mfma_term(st, 2);
+      slot_loads(3 * j + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     read_frags(GN, CPN, IP ^ 1, 0, IP ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!(ABL & 16)) { mfma_term(IP, 0); mfma_term(IP, 1); }
-    mfma_term(IP, 2);
+    if constexpr (!(ABL & 16)) {
+      mfma_term(IP, 0); slot_loads(6); __builtin_amdgcn_sched_barrier(0);
+      mfma_term(IP, 1); slot_loads(7); __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_term(IP, 2); slot_loads(8);
     __builtin_amdgcn_sched_barrier(0);
   };
   read_frags(0, 0, 0, 0, 0);
@@ -421,21 +445,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 int g_conv3 = 1;          // dcn_set_tuning("3x3strip", 0): 3x3 stride-1 layers back on the implicit-GEMM tile
 int g_conv3_bm = 0;       // dcn_set_tuning("3bm", 128|256): force the strip kernel's M tile (0 = automatic)
 int g_conv3_abl = 0;      // dcn_set_tuning("3abl", bits): timing ablations (C3_ABL builds only)
+int g_conv3_ls = 0;       // dcn_set_tuning("3ls", 1): global loads spread behind the MFMA groups (LS)
 
-template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0>
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0>
 int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   const int S = BM + 2 * p.Wi + 2;
   const size_t lds = (size_t)2 * NP * (S + 2) * 32 + (size_t)2 * 3 * (NP * BN * 32 + 128);
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP, ABL, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const double k_alg = 9.0 * p.Ci;
   const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
   const int pid = prof_begin(NP == 1 ? 33 : (WM == 4 ? 28 : 29), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
+  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL, LS>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv3");
   return DCN_OK;
@@ -457,6 +482,7 @@ int launch3_ld(const IgemmParams& p, int gran, hipStream_t stream) {
     default: break;
   }
 #endif
+  if (g_conv3_ls) return launch3<WM, WN, A_LD_MAX, 2, 0, 1>(p, gran, stream);
   return launch3<WM, WN, A_LD_MAX>(p, gran, stream);
 }
 
@@ -479,7 +505,9 @@ int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
 
 }  // namespace
 
-void conv3_set_tuning(int key, int value) { if (key == 0) g_conv3 = value; else if (key == 1) g_conv3_bm = value; else g_conv3_abl = value; }
+void conv3_set_tuning(int key, int value) {
+  if (key == 0) g_conv3 = value; else if (key == 1) g_conv3_bm = value; else if (key == 2) g_conv3_abl = value; else g_conv3_ls = value;
+}
 
 // can this launch run on the strip kernel?  (gran = rows per statistics partial the caller sized its buffer for)
 bool conv3_applicable(const IgemmParams& p, int precision, int gran) {

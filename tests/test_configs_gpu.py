@@ -160,3 +160,47 @@ def test_bf16_storage_config_at_full_workload(dev):
             assert d_mode > 1e-3 and d_inv < 0.25 * d_mode, (s_, d_inv, d_mode)
     finally:
         ops.set_precision("fp32")
+
+
+def test_bf16_storage_box_criterion_on_trained_weights(dev):
+    """SURVEY.md 8(c), the builder-defined acceptance of the bf16 mode (the reference has no bf16 semantics): on weights that localise —
+    the fp32 model trained by the product's own step for 300 RMSprop iterations on 16 synthetic 256 x 256 images that carry their target,
+    tools/precision_criterion.py — the boxes decoded from the bf16-storage forward must keep the fp32 arg-max cell on every image and
+    reach IoU >= 0.95 against the fp32 box on >= 15 of 16 (as shipped: inference keeps the stem and ops.B16_FP32_FIRST convolutions on fp32
+    tensors; the same with every layer on bf16 tensors is measured and only bounded).  The training is bitwise repeatable, so is the count."""
+    import importlib.util
+    import os
+    from dcnet_amd import losses, ops, train as T
+    from dcnet_amd.parallel import freeze_gradless
+    from util import ROOT
+    spec = importlib.util.spec_from_file_location("precision_criterion", os.path.join(ROOT, "tools", "precision_criterion.py"))
+    pc = importlib.util.module_from_spec(spec); spec.loader.exec_module(pc)
+    size, n, steps, lr = 256, 16, 300, 1e-4
+    ops.set_precision("fp32")
+    m = build_product(size, synth_sd(size), dev)
+    freeze_gradless(m)
+    opt = T.make_optimizer(m, lr)
+    image, word_id, word_mask, bbox = (t.to(dev) for t in pc.make_set(n, size, 5))
+    random.seed(0)
+    for it in range(steps):
+        T.adjust_learning_rate(opt, it, lr, steps, 0.9)
+        T.train_step(m, opt, image, word_id, word_mask, bbox, size)
+    m.eval()
+    res = {}
+    first = ops.B16_FP32_FIRST
+    try:
+        for tag, mode, k in (("fp32", "fp32", first), ("bf16s", "bf16s", first), ("all", "bf16s", 0)):
+            ops.set_precision(mode); ops.B16_FP32_FIRST = k
+            with torch.no_grad():
+                outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
+            res[tag] = (losses.decode_boxes(outbox, size), pc.argmax_cells(outbox)[0])
+    finally:
+        ops.set_precision("fp32"); ops.B16_FP32_FIRST = first
+    gt = torch.clamp(bbox, min=0, max=size - 1)
+    assert float((losses.bbox_iou(res["fp32"][0], gt) > 0.5).float().mean()) == 1.0        # the fp32 model localises its training set
+    iou = losses.bbox_iou(res["bf16s"][0], res["fp32"][0])
+    same = res["bf16s"][1] == res["fp32"][1]
+    assert bool(same.all()), same
+    assert int(((iou >= 0.95) & same).sum()) >= 15, iou
+    iou_all = losses.bbox_iou(res["all"][0], res["fp32"][0])
+    assert bool((res["all"][1] == res["fp32"][1]).all()) and float(iou_all.min()) > 0.85 and float(iou_all.mean()) > 0.95, iou_all

@@ -79,8 +79,12 @@ def main():
     res = {}
     m.eval()
     try:
-        for mode in ("fp32", "bf16", "bf16s", "fp8"):
-            ops.set_precision(mode)
+        first_default = ops.B16_FP32_FIRST
+        for mode in ("fp32", "bf16", "bf16s", "bf16s_all_layers", "fp8"):
+            # "bf16s" = the mode as shipped (inference keeps the stem + ops.B16_FP32_FIRST convolutions on fp32 tensors);
+            # "bf16s_all_layers" = every layer behind the stem on bf16 tensors, as in the mode's training step
+            ops.B16_FP32_FIRST = 0 if mode == "bf16s_all_layers" else first_default
+            ops.set_precision("bf16s" if mode == "bf16s_all_layers" else mode)
             with torch.no_grad():
                 outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
             boxes = losses.decode_boxes(outbox, size)
@@ -89,6 +93,7 @@ def main():
             res[mode] = dict(boxes=boxes, cell=cell, conf=conf, iou_gt=iou_gt)
     finally:
         ops.set_precision("fp32")
+        ops.B16_FP32_FIRST = first_default
     out = {"size": size, "images": n, "train_steps": args.steps, "train_seconds": train_s, "loss_history": hist,
            "criterion": "IoU(box_mode, box_fp32) >= 0.95 and same arg-max (scale, anchor, cell)", "modes": {}}
     f = res["fp32"]
@@ -96,7 +101,8 @@ def main():
     out["fp32"] = {"acc_at_0.5_vs_gt": float((f["iou_gt"] > 0.5).float().mean()), "mean_iou_vs_gt": float(f["iou_gt"].mean()),
                    "conf_margin_top1_minus_top2_min": float((top2[:, 0] - top2[:, 1]).min()),
                    "conf_margin_top1_minus_top2_median": float((top2[:, 0] - top2[:, 1]).median())}
-    for mode in ("bf16", "bf16s", "fp8"):
+    out["bf16s_fp32_first_layers"] = int(first_default)
+    for mode in ("bf16", "bf16s", "bf16s_all_layers", "fp8"):
         r = res[mode]
         iou = losses.bbox_iou(r["boxes"], f["boxes"])
         same = (r["cell"] == f["cell"])
@@ -137,8 +143,13 @@ def main():
             cases[f"fp32_before_{k_}"] = {"layers": (lambda s_, k=k_: s_ >= k)}
             cases[f"fp32_from_{k_}"] = {"layers": (lambda s_, k=k_: s_ < k)}
             cases[f"res32+fp32_before_{k_}"] = {"layers": (lambda s_, k=k_: s_ >= k), "res32": True}
+        for set_ in ((1,), (1, 2), (1, 2, 3), (1, 2, 3, 4), (2, 3, 4), (3, 4), (4,), (1, 4), (1, 2, 3, 4, 5), (5, 6, 7, 8, 9, 10, 11)):
+            cases["fp32_slots_" + "_".join(map(str, set_))] = {"layers": (lambda s_, q=set_: s_ not in q)}
+        for set_ in ((1, 2, 3, 4), (1,), (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)):
+            cases["fp32tensors_bf16ops_slots_" + "_".join(map(str, set_))] = {"layers": (lambda s_, q=set_: s_ not in q), "arith": "bf16"}
         try:
             ops.set_precision("bf16s")
+            ops.B16_FP32_FIRST = 0
             for cname, dg in cases.items():
                 ops.B16_DIAG = None if dg is None else dict(dg)
                 with torch.no_grad():
@@ -152,6 +163,7 @@ def main():
                 print(f"backbone {cname:34s} {table[cname]}", flush=True)
         finally:
             ops.B16_DIAG = None
+            ops.B16_FP32_FIRST = first_default
             ops.set_precision("fp32")
         out["backbone"] = table
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
