@@ -257,6 +257,101 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
   }
 }
 
+// ---- the two passes above with the channel fixed per thread (round 5) ---------------------------------------------------------------
+// c / 4 a power of two <= 256 (every BatchNorm width of the network but the 1056-channel fusion tensor): quad t of a 256-quad group lies
+// in channel quad t % (c / 4) whatever the group, so a thread's per-channel vectors (scale / shift; mean, invstd, gamma, beta and the two
+// sums) are read ONCE instead of once per element quad — the grid-stride form issued 2 + 6 loads per 16-byte store in the backward pass, the
+// L1 busy with parameter re-reads —, the 64-bit division per element is a shift, and a workgroup takes 16-KB chunks (PC_UNR groups) with
+// PC_UNR independent streaming loads per tensor in flight per thread (the grid-stride loop had one: 16-32 KB per CU against the ~64 KB that
+// 8 TB/s x 2 us ask for).  Same arithmetic per element, order-independent abs-max: bitwise the same tensors and words.
+constexpr int PC_UNR = 4;
+__global__ __launch_bounds__(256) void scale_act_pc_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, float slope,
+                                                           const float* __restrict__ residual, float* __restrict__ out,
+                                                           int64_t total, int lg_c4, int ldo, unsigned* __restrict__ amax) {
+  const int c4 = 1 << lg_c4;
+  const int ch = (threadIdx.x & (c4 - 1)) * 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (scale) sc = *reinterpret_cast<const f32x4*>(scale + ch);
+  if (shift) sh = *reinterpret_cast<const f32x4*>(shift + ch);
+  float vmax = 0.f;
+  const int64_t nchunk = (total + 256 * PC_UNR - 1) / (256 * PC_UNR);
+  for (int64_t cidx = blockIdx.x; cidx < nchunk; cidx += gridDim.x) {
+    const int64_t i0 = cidx * (256 * PC_UNR) + threadIdx.x;
+    f32x4 v[PC_UNR], rs[PC_UNR];
+#pragma unroll
+    for (int k = 0; k < PC_UNR; ++k) {
+      const int64_t i = i0 + k * 256;
+      const bool ok = i < total;
+      v[k] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + i * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (residual) rs[k] = ok ? *reinterpret_cast<const f32x4*>(residual + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < PC_UNR; ++k) {
+      const int64_t i = i0 + k * 256;
+      if (i >= total) continue;
+      f32x4 t = v[k] * sc + sh;
+      if (act == DCN_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * slope;
+      }
+      if (residual) t += rs[k];
+      *reinterpret_cast<f32x4*>(out + (i >> lg_c4) * ldo + ch) = t;
+      vmax = fmaxf(fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3]))), vmax);
+    }
+  }
+  if (amax) {
+    __shared__ float red[4];
+    amax_update_block(amax, vmax, red);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_pc_kernel(const float* __restrict__ y, const float* __restrict__ dout, int lddo,
+                                                                  const float* mean, const float* invstd, const float* gamma,
+                                                                  const float* beta, int act, float slope, const float* sums,
+                                                                  float inv_count, int64_t total, int lg_c4, float* __restrict__ dy,
+                                                                  unsigned* __restrict__ amax) {
+  const int c4 = 1 << lg_c4, c = c4 * 4;
+  const int ch = (threadIdx.x & (c4 - 1)) * 4;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch), is = *reinterpret_cast<const f32x4*>(invstd + ch);
+  f32x4 g = {1.f, 1.f, 1.f, 1.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + ch);
+  if (beta) b = *reinterpret_cast<const f32x4*>(beta + ch);
+  const f32x4 sg = *reinterpret_cast<const f32x4*>(sums + ch), sgx = *reinterpret_cast<const f32x4*>(sums + c + ch);
+  float vmax = 0.f;
+  const int64_t nchunk = (total + 256 * PC_UNR - 1) / (256 * PC_UNR);
+  for (int64_t cidx = blockIdx.x; cidx < nchunk; cidx += gridDim.x) {
+    const int64_t i0 = cidx * (256 * PC_UNR) + threadIdx.x;
+    f32x4 v[PC_UNR], d[PC_UNR];
+#pragma unroll
+    for (int k = 0; k < PC_UNR; ++k) {
+      const int64_t i = i0 + k * 256;
+      const bool ok = i < total;
+      v[k] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(y + i * 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      d[k] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dout + (i >> lg_c4) * lddo + ch)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < PC_UNR; ++k) {
+      const int64_t i = i0 + k * 256;
+      if (i >= total) continue;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (v[k][e] - mu[e]) * is[e];
+        float dd = d[k][e];
+        if (act == DCN_ACT_LEAKY && (g[e] * xh + b[e]) <= 0.f) dd *= slope;
+        o[e] = g[e] * is[e] * (dd - sg[e] * inv_count - xh * sgx[e] * inv_count);
+      }
+      *reinterpret_cast<f32x4*>(dy + i * 4) = o;
+      vmax = fmaxf(fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))), vmax);
+    }
+  }
+  if (amax) {
+    __shared__ float red[4];
+    amax_update_block(amax, vmax, red);
+  }
+}
+
 // plain activation backward (eval-style affine, no batch statistics): dy = dout*act'(scale*y+shift)*scale
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ outv, const float* __restrict__ dout, int lddo,
                                                       float slope, int64_t rows, int c, float* __restrict__ dy) {
@@ -276,7 +371,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // from the last row to the first): a pass that starts where its producer stopped finds the producer's last lines in the
 // memory-side cache.
 int g_bn_rev = 0;
-
+int g_bn_pc = 1;          // dcn_set_tuning("Bpc", 0): the apply passes back on their grid-stride forms (A/B switch)
+// log2(c / 4) when the per-thread-channel kernels take the width (c / 4 a power of two <= 256), else -1
+inline int pc_lg(int c) {
+  const int c4 = c / 4;
+  if (c % 4 || c4 < 1 || c4 > 256 || (c4 & (c4 - 1))) return -1;
+  int lg = 0;
+  while ((1 << lg) < c4) ++lg;
+  return lg;
+}
 inline int stream_grid(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -286,6 +389,7 @@ inline int row_slices(int rows) { int rs = (rows + 63) / 64; return rs < 1 ? 1 :
 }  // namespace
 
 void bn_set_tuning(int v) { g_bn_rev = v; }
+void bn_set_pc(int v) { g_bn_pc = v; }
 
 extern "C" int64_t dcn_bn_ws(int c) { return (int64_t)RS_MAX * 2 * c * 2; }   // doubles stored in a float-typed scratch
 
@@ -362,8 +466,15 @@ extern "C" int dcn_scale_act(const float* y, const float* scale, const float* sh
   DCN_CHECK_ARG(ldo % 4 == 0, "scale_act: ldo=%d must be a multiple of 4", ldo);
   const int pid = prof_begin(10, (double)rows * c * 4.0 * (residual ? 3 : 2), (hipStream_t)stream);
   // (with an abs-max word: at most 1024 workgroups, i.e. 1024 atomics over 64 words; they all finish together)
-  hipLaunchKernelGGL(scale_act_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, scale, shift, act, slope, residual, out, rows, c, ldo, amax, g_bn_rev & 1);
+  const int want = amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4));
+  const int lg = (g_bn_pc && !(g_bn_rev & 1)) ? pc_lg(c) : -1;
+  if (lg >= 0) {
+    const int64_t total = rows * (c / 4), nchunk = (total + 256 * PC_UNR - 1) / (256 * PC_UNR);
+    hipLaunchKernelGGL(scale_act_pc_kernel, dim3((int)(nchunk < want ? nchunk : want)), dim3(256), 0, (hipStream_t)stream,
+                       y, scale, shift, act, slope, residual, out, total, lg, ldo, amax);
+  } else
+    hipLaunchKernelGGL(scale_act_kernel, dim3(want), dim3(256), 0, (hipStream_t)stream,
+                       y, scale, shift, act, slope, residual, out, rows, c, ldo, amax, g_bn_rev & 1);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("scale_act");
   return DCN_OK;
@@ -407,8 +518,17 @@ extern "C" int dcn_bn_act_bwd_apply(const float* y, const float* dout, int lddo,
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && rows > 0 && c > 0 && c % 4 == 0, "bn_act_bwd_apply: bad argument");
   if (lddo <= 0) lddo = c;
   const int pid = prof_begin(11, (double)rows * c * 4.0 * 3, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4))), dim3(256), 0, (hipStream_t)stream,
-                     y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax, (g_bn_rev >> 2) & 1);
+  const int want = amax ? min(stream_grid(rows * (c / 4)), 1024) : stream_grid(rows * (c / 4));
+  const int lg = (g_bn_pc && !((g_bn_rev >> 2) & 1) && (((uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)sums | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0)
+                     ? pc_lg(c) : -1;
+  if (lg >= 0) {
+    const int64_t total = rows * (c / 4), nchunk = (total + 256 * PC_UNR - 1) / (256 * PC_UNR);
+    hipLaunchKernelGGL(bn_act_bwd_apply_pc_kernel, dim3((int)(nchunk < want ? nchunk : want)), dim3(256), 0, (hipStream_t)stream,
+                       y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, total, lg, dy, amax);
+  }
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(want), dim3(256), 0, (hipStream_t)stream,
+                       y, dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, dy, amax, (g_bn_rev >> 2) & 1);
   prof_end(pid, (hipStream_t)stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply");
   return DCN_OK;

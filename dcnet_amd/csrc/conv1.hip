@@ -46,10 +46,7 @@ __device__ __forceinline__ float c1_pow2_scale(unsigned amax_bits) {      // = i
 // along M), BN = 32 NI filters: (1,4) wide layers, (1,2) / (2,2) 64 filters, (2,1) 32 filters.
 // K runs over (tap, 16-channel step); a tap that leaves the image for a row is that lane's out-of-range offset (zeros), exactly
 // like the buffer loads of igemm.hip: per row a byte offset and a bit mask of in-image taps, computed once.
-// PS: the gathered tensor is in the SPLIT form (gemm3.hip: each run of 8 channels stored as [8 f16 h | 8 f16 l] of s*x, same bytes and
-// strides as fp32; s = the power of two of its abs-max word): chunk 2 kh of a row's 64 bytes IS the h operand of MFMA k-half kh, chunk
-// 2 kh + 1 its l operand — no vector ALU in the loop; same products in the same order as the in-register split: bitwise equal results.
-template <int SA, int SB, int NI, int MI, bool PS = false>
+template <int SA, int SB, int NI, int MI>
 __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
   constexpr int BM = 128 * MI, BN = 32 * NI;
   constexpr int ASTAGE = BM * 64, BPLANE = BN * 32, BSTAGE = 2 * BPLANE;
@@ -185,10 +182,6 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
     f16x8_t ah[MI], al[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      if constexpr (PS) {
-        ah[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd0[mi]); al[mi] = *reinterpret_cast<const f16x8_t*>(st + a_rd1[mi]);
-        continue;
-      }
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + a_rd0[mi]), x1 = *reinterpret_cast<const f32x4*>(st + a_rd1[mi]);
       // x * s = h + l, two f16 (round to nearest): 11 + 11 significant bits
       const f32x4 t0 = x0 * sa, t1 = x1 * sa;
@@ -578,13 +571,13 @@ int g_conv1 = 1;          // dcn_set_tuning("1x1dma", 0): back on the implicit-G
 int g_conv1_stages = 32;  // dcn_set_tuning("1stages", 10 * SA + SB): ring depths.  Default 3 activation + 2 filter K-steps = 40 KB at the 128 x 128 tile:
                           // FOUR workgroups per CU (measured per layer, tools/bench_convs.py --set 1stages=..: 32 < 33 < 42 < 44 ~ 63 << 84: occupancy beats ring depth)
 
-template <int SA, int SB, int NI, int MI, bool PS = false>
+template <int SA, int SB, int NI, int MI>
 int launch1(const IgemmParams& p, hipStream_t stream) {
   constexpr int BM = 128 * MI, BN = 32 * NI;
   static DcnPerDeviceFlag attr_once;
   const size_t lds = (size_t)SA * BM * 64 + (size_t)SB * 2 * BN * 32;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_kernel<SA, SB, NI, MI, PS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_kernel<SA, SB, NI, MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const int gm = cdiv(p.M, BM), gn = p.Co / BN;
   const double k_alg = (double)p.ntaps * p.Ci;
@@ -593,17 +586,14 @@ int launch1(const IgemmParams& p, hipStream_t stream) {
   //  onto, the shortcut, the tapped BatchNorm input)
   const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
   const int pid = prof_begin(35, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv1_kernel<SA, SB, NI, MI, PS>), dim3(gm * gn), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv1_kernel<SA, SB, NI, MI>), dim3(gm * gn), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv1");
   return DCN_OK;
 }
 
-int g_conv1_ps = 0;       // dcn_set_tuning("1ps", 1): EXPERIMENT — the gathered tensor of every conv1 launch is taken to be in split form
-
 template <int NI, int MI>
 int launch1_ring(const IgemmParams& p, hipStream_t stream) {
-  if (g_conv1_ps) return launch1<3, 2, NI, MI, true>(p, stream);
   if constexpr (NI == 4 && MI == 1) {
     switch (g_conv1_stages) {
       case 33: return launch1<3, 3, NI, MI>(p, stream);
@@ -677,7 +667,7 @@ int launch1b(const IgemmParams& p, hipStream_t stream) {
 
 void conv1_set_tuning(int key, int value) {
   if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value;
-  else if (key == 4) g_conv1b_wide = value; else if (key == 5) g_conv1b_tall = value; else if (key == 6) g_conv1_ps = value; else g_conv1_fill = value;
+  else if (key == 4) g_conv1b_wide = value; else if (key == 5) g_conv1b_tall = value; else g_conv1_fill = value;
 }
 
 // shape part of the decision.  The kernel only takes launches that igemm.hip would run on its f16-split tiles WITH the pre-split

@@ -737,6 +737,7 @@ void wgrad_set_w3_b16(int v);
 void wgrad_set_w9_b16(int v);
 void wgrad_set_target_b16(int v, int small);
 void wgrad3_set_tuning(int key, int value);
+void bn_set_pc(int v);
 void conv_set_merge(int v);
 void conv_set_d2_b16(int v);
 void conv_set_n1_b16(int v);
@@ -753,7 +754,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'w' && key[1] == '3') { wgrad_set_w3_b16(value); return DCN_OK; }           // "w3b16": bf16-storage 3x3 weight gradients by filter rows (wgrad3.hip)
   if (k == 'b' && key[1] == 'w') { conv1_set_tuning(4, value); return DCN_OK; }       // "bwide": conv1b 128 x 256 tiles from n workgroups on
   if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on
-  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : (key[1] == 'p' ? 6 : 0))), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
+  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { conv3_set_tuning(key[1] == 'b' ? 1 : key[1] == 'a' ? 2 : key[1] == 'l' ? 3 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256), "3abl", "3ls"
   if (k == 'N' && key[1] == 'b') { conv_set_n1_b16(value); return DCN_OK; }           // "Nb16": bf16-storage register-bank forward / data gradient 32 <-> 64 (nconv.hip)
   if (k == 'D') { conv_set_d2_b16(value); return DCN_OK; }                            // "Db16": bf16-storage register-bank stride-2 data gradient (nconv.hip)
@@ -769,6 +770,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"
+  if (k == 'B') { bn_set_pc(value); return DCN_OK; }              // "Bpc": BatchNorm apply passes with the channel fixed per thread (bn.hip; 0 = grid-stride forms)
   if (k == 'z') { wgrad_set_target_small(value); return DCN_OK; }   // "zwgsmall"
   if (k == 'c') { wgrad_set_wide64(value); return DCN_OK; }        // "cwide64"
   if (k == 'x') { wgrad_set_target(value); return DCN_OK; }   // "xwgtarget"

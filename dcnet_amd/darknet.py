@@ -282,10 +282,6 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
     # bf16 storage (ops.set_precision("bf16s")): every activation / raw conv output behind the stem is a bf16 tensor; the three taps are
     # cast to fp32 for the head (and their gradients back to bf16 in _run_backward)
     s16 = ops.storage_b16()
-    am0, s16_0, in32 = am, s16, False
-    fp32_first = int(ops.B16_FP32_FIRST) if (s16 and not training and save is None) else 0
-    if fp32_first > 0:
-        ops.amax_begin_step(x_nhwc.device)     # (the fp32 layers track abs-max words; the mode's own forward does not begin a step)
     amx: Dict[int, Optional[torch.Tensor]] = {-1: None}
     # outputs with exactly ONE reader, a train-mode conv + BatchNorm whose kernels can apply the activation while loading
     # (ops.pre_supported): they are handed on as ops.PreAct — no scale_act pass, no activation tensor
@@ -316,14 +312,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             early_event = torch.cuda.Event(); early_event.record()
         if isinstance(op, _ConvOp):
             p = P[op.slot]
-            # bf16-storage INFERENCE: the stem and the ops.B16_FP32_FIRST convolutions behind it stay on fp32 tensors at fp32 accuracy
-            keep32 = fp32_first > 0 and op.slot <= fp32_first
-            if keep32 != in32:
-                ops.set_precision("fp32" if keep32 else "bf16s"); in32 = keep32
-            am, s16 = (True, False) if keep32 else (am0, s16_0)
             x = out[op.src]; ax = amx.get(op.src)
-            if s16 and fp32_first > 0 and x.dtype == torch.float32 and op.cin > 4:
-                x = ops.to_b16(x)                  # (the first bf16 layer behind the fp32 ones: one cast pass)
             bank = banks.get(op.slot, p["w"]) if banks is not None else None
             if bank is not None and getattr(banks, "pending", None) is not None:
                 torch.cuda.current_stream().wait_stream(banks.pending)      # the refresh launched by Darknet._filter_banks
@@ -366,8 +355,6 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     out[op.dst] = ops.to_b16(o32); amx[op.dst] = None
                     continue
                 res = None if res is None else ops.to_b16(res)
-            if s16 and res is not None and res.dtype == torch.float32:
-                res = ops.to_b16(res)
             if s16 and x.dtype == torch.bfloat16:
                 if bank is None:
                     raise RuntimeError("bf16 storage needs the prepared filter banks (ops.FILTER_BANKS) for every layer behind the stem")
@@ -435,9 +422,6 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             amx[op.dst] = ops.absmax(lat, ops.absmax(up)) if am else None
         else:
             out[op.dst] = out[op.src]; amx[op.dst] = amx.get(op.src)
-    if in32:
-        ops.set_precision("bf16s")
-    am, s16 = am0, s16_0
     # (taps_b16: the caller's first kernels read bf16 — grounding_model's mapping convolutions — so the taps stay as they are)
     return [ops.to_f32(out[t]) if (s16 and not taps_b16) else out[t] for t in taps], [amx.get(t) for t in taps], early_event
 

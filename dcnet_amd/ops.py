@@ -94,12 +94,6 @@ def get_precision() -> str:
 REGION_PRECISION = None
 
 
-# bf16 storage, INFERENCE (no_grad eval forward): the stem and this many convolutions behind it keep fp32 tensors and fp32-accurate arithmetic.
-# Measured on trained weights (tools/precision_criterion.py --backbone, profiles/r05_precision_localise.json): the box criterion of SURVEY 8(c)
-# (IoU >= 0.95 against the fp32 box, same arg-max cell) is lost in the backbone, not in the head, and there in the first residual stage — K = 288
-# and 64-channel contractions average the bf16 rounding least: 12/16 images with every layer on bf16 tensors, 16/16 with slots 1-3 on fp32.
-# The training step of the mode is unchanged (every layer behind the stem on bf16 tensors).
-B16_FP32_FIRST = 3
 B16_DIAG = None      # experiments: {"layers": slot -> bool, "res32": bool} for the bf16-storage backbone in eval mode (darknet._run_forward)
 
 

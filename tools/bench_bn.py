@@ -22,6 +22,9 @@ def timeit(fn, iters=10):
 
 def main():
     dev = torch.device("cuda:0")
+    for kv in [t for t in (sys.argv[1] if len(sys.argv) > 1 else "").split(",") if t]:       # knobs: python tools/bench_bn.py Bpc=0
+        from dcnet_amd.lib import lib
+        k_, v_ = kv.split("="); lib().set_tuning(k_.encode(), int(v_))
     shapes = [(416, 32, 1), (208, 64, 2), (208, 32, 1), (104, 128, 3), (104, 64, 2), (52, 256, 9), (52, 128, 8), (26, 512, 9), (26, 256, 8),
               (13, 1024, 5), (13, 512, 4), (52, 512, 6)]
     tot = {"scale_act": 0.0, "partials": 0.0, "apply": 0.0, "copy": 0.0, "copy3": 0.0}

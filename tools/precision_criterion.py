@@ -79,12 +79,8 @@ def main():
     res = {}
     m.eval()
     try:
-        first_default = ops.B16_FP32_FIRST
-        for mode in ("fp32", "bf16", "bf16s", "bf16s_all_layers", "fp8"):
-            # "bf16s" = the mode as shipped (inference keeps the stem + ops.B16_FP32_FIRST convolutions on fp32 tensors);
-            # "bf16s_all_layers" = every layer behind the stem on bf16 tensors, as in the mode's training step
-            ops.B16_FP32_FIRST = 0 if mode == "bf16s_all_layers" else first_default
-            ops.set_precision("bf16s" if mode == "bf16s_all_layers" else mode)
+        for mode in ("fp32", "bf16", "bf16s", "fp8"):
+            ops.set_precision(mode)
             with torch.no_grad():
                 outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
             boxes = losses.decode_boxes(outbox, size)
@@ -93,7 +89,6 @@ def main():
             res[mode] = dict(boxes=boxes, cell=cell, conf=conf, iou_gt=iou_gt)
     finally:
         ops.set_precision("fp32")
-        ops.B16_FP32_FIRST = first_default
     out = {"size": size, "images": n, "train_steps": args.steps, "train_seconds": train_s, "loss_history": hist,
            "criterion": "IoU(box_mode, box_fp32) >= 0.95 and same arg-max (scale, anchor, cell)", "modes": {}}
     f = res["fp32"]
@@ -101,8 +96,7 @@ def main():
     out["fp32"] = {"acc_at_0.5_vs_gt": float((f["iou_gt"] > 0.5).float().mean()), "mean_iou_vs_gt": float(f["iou_gt"].mean()),
                    "conf_margin_top1_minus_top2_min": float((top2[:, 0] - top2[:, 1]).min()),
                    "conf_margin_top1_minus_top2_median": float((top2[:, 0] - top2[:, 1]).median())}
-    out["bf16s_fp32_first_layers"] = int(first_default)
-    for mode in ("bf16", "bf16s", "bf16s_all_layers", "fp8"):
+    for mode in ("bf16", "bf16s", "fp8"):
         r = res[mode]
         iou = losses.bbox_iou(r["boxes"], f["boxes"])
         same = (r["cell"] == f["cell"])
@@ -149,7 +143,6 @@ def main():
             cases["fp32tensors_bf16ops_slots_" + "_".join(map(str, set_))] = {"layers": (lambda s_, q=set_: s_ not in q), "arith": "bf16"}
         try:
             ops.set_precision("bf16s")
-            ops.B16_FP32_FIRST = 0
             for cname, dg in cases.items():
                 ops.B16_DIAG = None if dg is None else dict(dg)
                 with torch.no_grad():
@@ -163,7 +156,6 @@ def main():
                 print(f"backbone {cname:34s} {table[cname]}", flush=True)
         finally:
             ops.B16_DIAG = None
-            ops.B16_FP32_FIRST = first_default
             ops.set_precision("fp32")
         out["backbone"] = table
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
