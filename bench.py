@@ -67,10 +67,13 @@ NAMES = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,
          40: "gemm3_kernel (co-attention products on pre-split operands, f16 split)",
          41: "conv1b_kernel (bf16 storage: forward / data gradient, both tiles by LDS-DMA)",
          42: "wgrad_kernel<128,128,16,true,0,1,true> (bf16 storage)", 43: "scale_act16_kernel (bf16 storage)",
-         44: "partials16_kernel (bf16 storage)", 45: "bn_bwd_apply16_kernel (bf16 storage)"}
-FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40, 41, 42}
+         44: "partials16_kernel (bf16 storage)", 45: "bn_bwd_apply16_kernel (bf16 storage)",
+         46: "wgrad3_kernel<1,true> (bf16 storage, filter rows)", 47: "conv3_kernel<*,2,*,1,..,IN16> (bf16 storage: 3x3 stride-1 strip)",
+         48: "conv1b_kernel<..,F8> (fp8 storage: e4m3 + row scales, block-scaled MFMA)"}
+FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40, 41, 42, 46, 47, 48}
 PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38, 40)
-               else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33, 41, 42) else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
+               else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33, 41, 42, 46, 47) else 2 * PEAK_BF16_MFMA_TFLOPS if t == 48
+               else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
 RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>"],
@@ -79,7 +82,7 @@ RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_k
             29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
             36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
 FAMILY = {28: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)"}
-NT = 48            # DCN_PROF_TAGS
+NT = 56            # DCN_PROF_TAGS
 
 
 def read_sclk_mhz(device_index: int = 0):
@@ -154,7 +157,7 @@ def compact_line(res: dict) -> str:
         rf["flop_dominant"] = fd["kernel"][:40]; rf["flop_dominant_frac"] = fd["frac"]
     alt = out.pop("alt", None)
     if alt:
-        for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "bf16s_ms", "fp8_ms"):
+        for k in ("native_fp32_ms", "bf16x3_ms", "bf16_ms", "bf16s_ms", "fp8_ms", "fp8s_ms"):
             rf[k] = alt.get(k)
         rf["alone_ms"] = alt.get("exclusive_ms")
     if "sclk_mhz" in out and rf:
@@ -185,7 +188,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="T")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s", "fp8"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16s", "fp8", "fp8s"], default="fp32",
                     help="arithmetic of the TIMED region (default fp32 = BASELINE configs[1]; bf16s = bf16 storage, configs[2] on one GPU; "
                          "reduced-precision runs say so in dtype / config.arith)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -389,7 +392,7 @@ def main():
             if world > 1:
                 broadcast_parameters(model, 0)
             # gradients live in one flat buffer: no per-parameter copies; the bf16 modes move it over xGMI as bf16
-            flat = FlatGradAllReduce(model.parameters(), comm_dtype=torch.bfloat16 if args.precision in ("bf16", "bf16s") else None).bind()
+            flat = FlatGradAllReduce(model.parameters(), comm_dtype=torch.bfloat16 if args.precision in ("bf16", "bf16s", "fp8s") else None).bind()
             flat.always_collective = args.force_ddp                   # (one-rank RCCL group: the collective is issued all the same)
     from dcnet_amd.train import make_optimizer     # the reference's two RMSprop groups (train_DCNet.py:519-534), fused HIP step
     opt = make_optimizer(model, 1e-4)
@@ -469,39 +472,43 @@ def main():
         sclk = read_sclk_mhz(local_rank)
     barrier()
 
-    # ---- configs[2] on this GPU: the same step on bf16 storage, captured again and replayed (its own timed region, never `value`) ----
-    bf16s_leg = None
+    # ---- configs[2] / configs[4] on this GPU: the same step on bf16 storage and on fp8 storage, each captured again and replayed (their own
+    #      timed regions, never `value`)
+    legs = {}
     want_leg = args.bf16s_leg == "on" or (args.bf16s_leg == "auto" and args.precision == "fp32" and not use_dist)
-    if want_leg and use_graph and step is not eager_step and args.precision != "bf16s":
+    if want_leg and use_graph and step is not eager_step:
         from dcnet_amd.graph import GraphedTrainStep
-        ops.set_precision("bf16s")
-        g2 = None
-        try:
-            g2 = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=max(1, min(args.warmup, 2)))
-            for _ in range(args.warmup):
-                g2()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                l2 = g2()
-            barrier()
-            dt2 = time.perf_counter() - t1
-            ops.check_bilstm(dev)
-            l2 = float(l2.detach())
-            if not np.isfinite(l2):
-                raise RuntimeError(f"bf16-storage leg: loss {l2}")
-            bf16s_leg = {"ms_per_step": dt2 / args.steps * 1e3, "clips_s": args.clips * args.steps / dt2, "steps": args.steps,
-                         "warmup": args.warmup, "loss": l2, "step": "hipGraph replay (fwd+losses+bwd+RMSprop), bf16 storage"}
-        except Exception as e:       # the fp32 line must not die with the extra leg: say so on stderr and in the line
-            print(f"bench.py: bf16-storage leg failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
-            bf16s_leg = {"error": type(e).__name__}
-        finally:
-            ops.set_precision(args.precision)
-            del g2
-            model.static_samples = None
-            opt.zero_grad(set_to_none=True)
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
+        for mode_ in ("bf16s", "fp8s"):
+            if mode_ == args.precision:
+                continue
+            ops.set_precision(mode_)
+            g2 = None
+            try:
+                g2 = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=max(1, min(args.warmup, 2)))
+                for _ in range(args.warmup):
+                    g2()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    l2 = g2()
+                barrier()
+                dt2 = time.perf_counter() - t1
+                ops.check_bilstm(dev)
+                l2 = float(l2.detach())
+                if not np.isfinite(l2):
+                    raise RuntimeError(f"{mode_} leg: loss {l2}")
+                legs[mode_] = {"ms_per_step": dt2 / args.steps * 1e3, "clips_s": args.clips * args.steps / dt2, "steps": args.steps,
+                               "warmup": args.warmup, "loss": l2, "step": "hipGraph replay (fwd+losses+bwd+RMSprop), " + mode_}
+            except Exception as e:       # the fp32 line must not die with an extra leg: say so on stderr and in the line
+                print(f"bench.py: {mode_} leg failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+                legs[mode_] = {"error": type(e).__name__}
+            finally:
+                ops.set_precision(args.precision)
+                del g2
+                model.static_samples = None
+                opt.zero_grad(set_to_none=True)
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
 
     # ---- untimed passes (every rank runs them, so collectives stay in step) -------------------------------------------
     # from here on the eager step: the profiler wraps each launch in a HIP event pair, which a captured graph cannot hold
@@ -608,6 +615,7 @@ def main():
         alts["bf16_operands"] = run_pass(args.alt_steps, "bf16", False)
         alts["bf16_storage"] = run_pass(args.alt_steps, "bf16s", False)
         alts["fp8_operands"] = run_pass(args.alt_steps, "fp8", False)
+        alts["fp8_storage"] = run_pass(args.alt_steps, "fp8s", False)
     if use_dist:
         dist.barrier()                           # every rank got here: only now may rank 0 print the line
 
@@ -638,11 +646,13 @@ def main():
         res = {"metric": f"clips/sec (T={args.frames}, {args.size}x{args.size}, bs{args.clips}) fwd+bwd", "value": clips_total / dt,
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-               "dtype": {"fp32": "f32", "bf16": "bf16", "bf16s": "bf16", "fp8": "fp8"}[args.precision],
+               "dtype": {"fp32": "f32", "bf16": "bf16", "bf16s": "bf16", "fp8": "fp8", "fp8s": "fp8"}[args.precision],
                "config": {"workload": f"T={args.frames} {args.size}x{args.size} bs{args.clips}/GPU L=20 {args.precision}, {n_img} img/GPU/step as pairs, fwd+5 losses+bwd+RMSprop",
                           "arith": {"fp32": "f16x2-split MFMA, fp32 accumulate", "bf16": "bf16 operands, fp32 tensors, fp32 accumulate",
                                     "bf16s": "bf16 storage (conv stacks), fp32 accumulate + master weights",
-                                    "fp8": "fp8 e4m3 operands, fp32 accumulate"}[args.precision], "parallelism": f"dp{world}",
+                                    "fp8": "fp8 e4m3 operands, fp32 accumulate",
+                                    "fp8s": "fp8 storage (e4m3 + row scales, block-scaled MFMA) for the 3x3 convs' fwd/dgrad on bf16 storage"}[args.precision],
+                          "parallelism": f"dp{world}",
                           "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4),
                "loss_hex": float(last_loss).hex(), "src": src_hash}     # src: hash of the kernel + host sources (dcnet_amd.utils.srchash)
@@ -739,7 +749,7 @@ def main():
         if alts:
             res["alt"] = {"exclusive_ms": round(prof["ms_per_step"], 1) if prof else None, "bf16x3_ms": round(alts["fp32_bf16x3"]["ms_per_step"], 1),
                           "native_fp32_ms": round(alts["native_fp32"]["ms_per_step"], 1), "bf16_ms": round(alts["bf16_operands"]["ms_per_step"], 1), "bf16s_ms": round(alts["bf16_storage"]["ms_per_step"], 1),
-                          "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1)}
+                          "fp8_ms": round(alts["fp8_operands"]["ms_per_step"], 1), "fp8s_ms": round(alts["fp8_storage"]["ms_per_step"], 1)}
             for k_, r_ in alts.items():
                 full[k_] = {"ms_per_step": r_["ms_per_step"], "kernels": table(r_)}
         if world == 1 and not args.no_cpu_baseline:
@@ -748,20 +758,22 @@ def main():
             res["cpu_baseline"] = {"value": round(cb["value"], 4), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                    "sample": cb["sample"], "gpu_vs_oracle_max_abs_err": round(cb["parity"]["max_abs_err_outbox"], 6),
                                    "acc_at_0.5_vs_oracle_boxes": cb["parity"]["acc_at_iou_0.5_vs_oracle_boxes"]}
-        if bf16s_leg is not None:
-            full["bf16_storage_replayed"] = bf16s_leg
+        for mode_, leg in legs.items():
+            full[mode_ + "_replayed"] = leg
             rf_ = res.setdefault("roofline", {})
-            if "error" in bf16s_leg:
-                rf_["bf16s_leg"] = bf16s_leg["error"]
+            if "error" in leg:
+                rf_[mode_ + "_leg"] = leg["error"]
             else:
-                rf_["bf16s_clips_s"] = round(bf16s_leg["clips_s"], 2); rf_["bf16s_ms_per_step"] = round(bf16s_leg["ms_per_step"], 2)
+                rf_[mode_ + "_clips_s"] = round(leg["clips_s"], 2); rf_[mode_ + "_ms_per_step"] = round(leg["ms_per_step"], 2)
+        if legs:
             crit_file = os.path.join(ROOT, "profiles", "precision_criterion_latest.json")
-            if os.path.exists(crit_file):    # SURVEY 8(c) box criterion of the mode on trained weights (tools/precision_criterion.py; also a -m gpu test)
+            if os.path.exists(crit_file):    # SURVEY 8(c) box criterion of the modes on trained weights (tools/precision_criterion.py; also a -m gpu test)
                 with open(crit_file) as f:
                     cr = json.load(f)
-                m_ = cr.get("modes", {}).get("bf16s")
-                if m_ and "criterion_met_frac" in m_:
-                    rf_["bf16s_criterion"] = "%d/%d" % (round(m_["criterion_met_frac"] * cr.get("images", 16)), cr.get("images", 16))
+                for mode_ in legs:
+                    m_ = cr.get("modes", {}).get(mode_)
+                    if m_ and "criterion_met_frac" in m_:
+                        res["roofline"][mode_ + "_criterion"] = "%d/%d" % (round(m_["criterion_met_frac"] * cr.get("images", 16)), cr.get("images", 16))
         res["full"] = "profiles/bench_full_latest.json"
         res["sclk_mhz"] = sclk
         full["bench_line"] = res

@@ -311,3 +311,77 @@ extern "C" int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc,
   DCN_CHECK_LAUNCH("upsample2_bwd_b16");
   return DCN_OK;
 }
+
+// ---- fp8 storage (BASELINE.json configs[4]): bf16 rows -> OCP e4m3 bytes + ONE e8m0 scale per row ---------------------------------------
+// The operand format of conv1.hip's conv1b_kernel<..., F8>: a row is a pixel's channel vector (activations, gradients) or a filter's
+// k*k*Cin coefficients (banks).  Scale as in the OCP MX formats, with the block = the row: e = floor(log2(max|row|)) - 8 (e4m3's largest
+// binade), q = e4m3(x * 2^-e) rounded to nearest even and clamped to +-448, scale byte = e + 127; an all-zero row gets byte 127.
+namespace {
+__global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const __bf16* __restrict__ x, int ld, int64_t rows, int c, int lanes,
+                                                              unsigned char* __restrict__ q, int ldq, unsigned char* __restrict__ scales) {
+  // `lanes` (a power of two <= 64) lanes per row, 8 channels per lane and pass
+  const int lane = threadIdx.x & 63, sub = lane & (lanes - 1);
+  const int64_t rows_per_wave = 64 / lanes;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave * rows_per_wave; r0 < rows; r0 += nwaves * rows_per_wave) {
+    const int64_t r = r0 + lane / lanes;
+    const bool ok = r < rows;
+    const __bf16* xr = x + (ok ? r : 0) * ld;
+    float amax = 0.f;
+    for (int ch = sub * 8; ch < c; ch += lanes * 8) {
+      const uint4 v = ok ? *reinterpret_cast<const uint4*>(xr + ch) : uint4{0u, 0u, 0u, 0u};
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        amax = fmaxf(amax, fabsf(__uint_as_float(w[k] << 16)));
+        amax = fmaxf(amax, fabsf(__uint_as_float(w[k] & 0xFFFF0000u)));
+      }
+    }
+    for (int d = 1; d < lanes; d <<= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    int e = 0;
+    const unsigned ab = __float_as_uint(amax);
+    if (amax > 0.f && (ab >> 23) != 0xFFu) e = (int)(ab >> 23) - 127 - 8;         // floor(log2(amax)) - 8 (bf16 inputs are never fp32-subnormal unless zero)
+    e = e < -126 ? -126 : (e > 126 ? 126 : e);
+    const float inv = __uint_as_float((unsigned)(127 - e) << 23);                 // 2^-e, exact
+    if (ok && sub == 0) scales[r] = (unsigned char)(e + 127);
+    unsigned char* qr = q + (ok ? r : 0) * ldq;
+    for (int ch = sub * 8; ch < c; ch += lanes * 8) {
+      if (!ok) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(xr + ch);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[2 * k] = fminf(fmaxf(__uint_as_float(w[k] << 16) * inv, -448.f), 448.f);
+        f[2 * k + 1] = fminf(fmaxf(__uint_as_float(w[k] & 0xFFFF0000u) * inv, -448.f), 448.f);
+      }
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+      lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+      int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+      hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+      *reinterpret_cast<uint2*>(qr + ch) = uint2{(unsigned)lo, (unsigned)hi};
+    }
+  }
+}
+}  // namespace
+
+// x: bf16 [rows][c] (row stride ld elements) -> q: e4m3 bytes [rows][c] (row stride ldq), scales: e8m0 [rows]
+extern "C" int dcn_quant_rows_e4m3(const void* x, int ld, int64_t rows, int c, void* q, int ldq, void* scales, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ld <= 0) ld = c;
+  if (ldq <= 0) ldq = c;
+  DCN_CHECK_ARG(x && q && scales && rows > 0 && c > 0 && c % 8 == 0 && ld % 8 == 0 && ldq % 8 == 0 && ld >= c && ldq >= c,
+                "quant_rows_e4m3: bad argument (c=%d ld=%d ldq=%d must be multiples of 8)", c, ld, ldq);
+  DCN_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0, "quant_rows_e4m3: x must be 16-byte, q 8-byte aligned");
+  int lanes = 1;
+  while (lanes < 64 && lanes * 8 < c) lanes <<= 1;
+  const int64_t rows_per_block = 4 * (64 / lanes);
+  int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+  if (g > 8192) g = 8192;
+  const int pid = prof_begin(49, (double)rows * c * 3.0, stream);
+  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3((int)g), dim3(256), 0, stream, (const __bf16*)x, ld, rows, c, lanes, (unsigned char*)q, ldq,
+                     (unsigned char*)scales);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("quant_rows_e4m3");
+  return DCN_OK;
+}

@@ -344,7 +344,7 @@ int bwd_data_impl(const float* dy, int lddy, const float* w, float* wt, float* d
 extern "C" int dcn_conv2d_stats_rows_b16(int n, int h, int wd, int cout, int ksize, int stride) {
   const int pad = (ksize - 1) / 2;
   const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
-  return conv1b_grid_m(n * ho * wo, cout, ksize * ksize);
+  return conv1b_grid_m(n * ho * wo, cout, ksize * ksize, (ksize == 3 && stride == 1) ? wd : 0);
 }
 
 extern "C" int dcn_conv2d_fwd_b16(const void* x, const void* w16, void* y, int y_f32, int n, int h, int wd, int cin, int cout, int ksize,
@@ -406,7 +406,7 @@ extern "C" int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt1
         p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
       }
     if (tap_y && tap_stats && tap_mean && tap_invstd) {
-      const int rows = conv1b_grid_m(p.M, cin, T);
+      const int rows = conv1b_grid_m(p.M, cin, T, ksize == 3 ? wd : 0);
       if (rows > 0 && tap_stats_rows >= rows) {
         p.stats = tap_stats; p.bt_y = (const float*)tap_y; p.bt_mean = tap_mean; p.bt_invstd = tap_invstd; p.bt_gamma = tap_gamma;
         p.bt_beta = tap_beta; p.bt_act = tap_act; p.bt_slope = tap_slope;
@@ -443,6 +443,106 @@ extern "C" int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt1
         }
       if (q.ntaps == 0) continue;
       const int rc = conv1b_launch(q, dx_f32, stream);
+      if (rc != DCN_OK) return rc;
+    }
+  return DCN_OK;
+}
+
+// ---- fp8 storage (BASELINE.json configs[4]): forward / data gradient on e4m3 operands with one e8m0 scale per pixel / per filter ---------
+// x8 / dy8: e4m3 bytes NHWC (dense), xs / dys: e8m0 [pixels] (dcn_quant_rows_e4m3); w8: the bank [Cout][k*k*Cin] (forward) or the
+// transposed bank [Cin][k*k*Cout] (data gradient) as e4m3 bytes with ws: e8m0 per bank row.  y / dx, residual, the BatchNorm tap: bf16
+// tensors exactly as in dcn_conv2d_*_b16 (fp32 accumulate, fp32 statistics of the values as stored).  cin, cout multiples of 64 / 32.
+extern "C" int dcn_conv2d_stats_rows_f8(int n, int h, int wd, int cout, int ksize, int stride) {
+  const int pad = (ksize - 1) / 2;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  return conv1q_grid_m(n * ho * wo, cout);
+}
+
+extern "C" int dcn_conv2d_fwd_f8(const void* x8, const void* xs, const void* w8, const void* ws, void* y, int y_f32, int n, int h, int wd, int cin,
+                                 int cout, int ksize, int stride, const float* scale, const float* shift, int act, float slope,
+                                 const void* residual, int ldr, int ldy, float* stats, int accumulate, void* stream) {
+  DCN_CHECK_ARG(x8 && xs && w8 && ws && y, "conv2d_fwd_f8: null pointer");
+  DCN_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_fwd_f8: ksize=%d stride=%d", ksize, stride);
+  DCN_CHECK_ARG(n > 0 && h > 0 && wd > 0 && cin > 0 && cin % 64 == 0 && cout > 0 && cout % 32 == 0,
+                "conv2d_fwd_f8: cin=%d must be a multiple of 64, cout=%d of 32", cin, cout);
+  const int pad = (ksize - 1) / 2;
+  IgemmParams p; base_params(p);
+  p.in = (const float*)x8; p.wt = (const float*)w8; p.out = (float*)y; p.scale = scale; p.shift = shift; p.residual = (const float*)residual;
+  p.a_scale8 = (const unsigned char*)xs; p.b_scale8 = (const unsigned char*)ws;
+  p.stats = stats;
+  p.N = n; p.Hi = h; p.Wi = wd; p.Ci = cin; p.ldi = cin;
+  p.Ho = (h + 2 * pad - ksize) / stride + 1; p.Wo = (wd + 2 * pad - ksize) / stride + 1;
+  p.Hs = p.Ho; p.Ws = p.Wo; p.isy = p.isx = stride;
+  p.Co = cout; p.ldo = ldy > 0 ? ldy : cout; p.ldr = ldr > 0 ? ldr : cout;
+  DCN_CHECK_ARG(p.ldo >= cout, "conv2d_fwd_f8: ldy=%d < cout=%d", ldy, cout);
+  p.M = n * p.Ho * p.Wo; p.ntaps = ksize * ksize; p.ldw = p.ntaps * cin;
+  p.act = act; p.slope = slope; p.accumulate = accumulate;
+  for (int r = 0; r < ksize; ++r)
+    for (int s = 0; s < ksize; ++s) {
+      const int t = r * ksize + s;
+      p.tap_dy[t] = r - pad; p.tap_dx[t] = s - pad; p.tap_w[t] = t * cin;
+    }
+  return conv1q_launch(p, y_f32, (hipStream_t)stream);
+}
+
+extern "C" int dcn_conv2d_bwd_data_f8(const void* dy8, const void* dys, const void* wt8, const void* wts, void* dx, int dx_f32, int n, int h, int wd,
+                                      int cin, int cout, int ksize, int stride, int accumulate, const void* tap_y, const float* tap_mean,
+                                      const float* tap_invstd, const float* tap_gamma, const float* tap_beta, int tap_act, float tap_slope,
+                                      float* tap_stats, int tap_stats_rows, int* tap_rows, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(dy8 && dys && wt8 && wts && dx, "conv2d_bwd_data_f8: null pointer");
+  DCN_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_bwd_data_f8: ksize=%d stride=%d", ksize, stride);
+  DCN_CHECK_ARG(cout % 64 == 0 && cin % 32 == 0, "conv2d_bwd_data_f8: cout=%d must be a multiple of 64, cin=%d of 32", cout, cin);
+  if (tap_rows) *tap_rows = 0;
+  const int pad = (ksize - 1) / 2, T = ksize * ksize;
+  const int ho = (h + 2 * pad - ksize) / stride + 1, wo = (wd + 2 * pad - ksize) / stride + 1;
+  IgemmParams p; base_params(p);
+  p.in = (const float*)dy8; p.wt = (const float*)wt8; p.out = (float*)dx;
+  p.a_scale8 = (const unsigned char*)dys; p.b_scale8 = (const unsigned char*)wts;
+  p.N = n; p.Hi = ho; p.Wi = wo; p.Ci = cout; p.ldi = cout;
+  p.Ho = h; p.Wo = wd; p.Co = cin; p.ldo = cin; p.ldr = cin; p.ldw = T * cout;
+  p.accumulate = accumulate;
+  if (stride == 1) {
+    p.Hs = h; p.Ws = wd; p.M = n * h * wd; p.ntaps = T;
+    for (int r = 0; r < ksize; ++r)
+      for (int s = 0; s < ksize; ++s) {
+        const int t = r * ksize + s;
+        p.tap_dy[t] = pad - r; p.tap_dx[t] = pad - s; p.tap_w[t] = t * cout;
+      }
+    if (tap_y && tap_stats && tap_mean && tap_invstd) {
+      const int rows = conv1q_grid_m(p.M, cin);
+      if (rows > 0 && tap_stats_rows >= rows) {
+        p.stats = tap_stats; p.bt_y = (const float*)tap_y; p.bt_mean = tap_mean; p.bt_invstd = tap_invstd; p.bt_gamma = tap_gamma;
+        p.bt_beta = tap_beta; p.bt_act = tap_act; p.bt_slope = tap_slope;
+        const int rc = conv1q_launch(p, dx_f32, stream);
+        if (rc == DCN_OK && tap_rows) *tap_rows = rows;
+        return rc;
+      }
+    }
+    return conv1q_launch(p, dx_f32, stream);
+  }
+  if (ksize == 1 && !accumulate &&
+      hipMemsetAsync(dx, 0, (size_t)n * h * wd * cin * (dx_f32 ? 4 : 2), stream) != hipSuccess) {
+    dcn_set_error("conv2d_bwd_data_f8: memset failed"); return DCN_ERR_LAUNCH;
+  }
+  // stride 2: four dense parity classes with 1 / 2 / 2 / 4 taps (see dcn_conv2d_bwd_data_b16)
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      IgemmParams q = p;
+      q.dense_out = 0; q.oy0 = a; q.ox0 = b; q.osy = q.osx = 2;
+      q.Hs = (h - a + 1) / 2; q.Ws = (wd - b + 1) / 2;
+      if (q.Hs <= 0 || q.Ws <= 0) continue;
+      q.M = n * q.Hs * q.Ws;
+      q.ntaps = 0;
+      for (int r = 0; r < ksize; ++r)
+        for (int s = 0; s < ksize; ++s) {
+          if (((a + pad - r) & 1) || ((b + pad - s) & 1)) continue;
+          q.tap_dy[q.ntaps] = (a + pad - r) / 2; q.tap_dx[q.ntaps] = (b + pad - s) / 2;
+          q.tap_w[q.ntaps] = (r * ksize + s) * cout;
+          ++q.ntaps;
+        }
+      if (q.ntaps == 0) continue;
+      const int rc = conv1q_launch(q, dx_f32, stream);
       if (rc != DCN_OK) return rc;
     }
   return DCN_OK;

@@ -329,9 +329,23 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 template <bool O32> struct OutT { typedef __bf16 type; };
 template <> struct OutT<true> { typedef float type; };
 
-template <int SA, int SB, int NI, int MI, bool O32>
+// F8 (fp8 STORAGE, BASELINE.json configs[4]; round 5): the gathered tensor and the bank are OCP e4m3 bytes with ONE e8m0 scale per row —
+// per pixel of the gathered tensor (p.a_scale8[pixel]) and per filter (p.b_scale8[filter]) — and the products run on the block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 (2 x the bf16 rate; every 32-k block of a row is handed the row's scale).  A K-step is 64 channels = the
+// same 64 bytes per row, so the rings, the swizzle and the epilogue are conv1b's; a lane's fragment is the 32 bytes of its k-half.  The
+// scale bytes a lane needs — its rows' pixel under each tap, its four filters — are read once, before the first LDS-DMA is issued.
+// tools/fp8_probe.hip measured this loop at 1.5-2.1 x the bf16 loop on the step's layer shapes (half the staged bytes per FLOP).
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <int I> struct IC1 { static constexpr int value = I; };
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for1(F&& f) {
+  if constexpr (I < N) { f(IC1<I>{}); static_for1<N, I + 1>(f); }
+}
+
+template <int SA, int SB, int NI, int MI, bool O32, bool F8 = false>
 __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
   typedef typename OutT<O32>::type out_t;
+  constexpr int ESZ = F8 ? 1 : 2, KSTEP = 64 / ESZ;        // bytes per element, channels per K-step
   constexpr int BM = 128 * MI, BN = 32 * NI;
   constexpr int ASTAGE = BM * 64, BSTAGE = BN * 64;
   constexpr int AP = 4 * MI;                      // A pieces (16 rows x 64 B) per loader wave and K-step
@@ -343,20 +357,18 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = lin / gn, bn = lin - bm * gn;
   const int M = p.M, m0 = bm * BM;
-  const int cpt = p.Ci >> 5;                      // 32-channel steps per tap
+  const int cpt = p.Ci / KSTEP;                   // 32-channel (fp8: 64-channel) steps per tap
   const int kiters = p.ntaps * cpt;
   const int hsws = p.Hs * p.Ws;
   const bool plain = p.ntaps == 1 && p.dense_out && p.isy == 1 && p.isx == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 &&
                      p.Ws == p.Wi && p.Hs == p.Hi;
-  const __bf16* in16 = reinterpret_cast<const __bf16*>(p.in);
-  const __bf16* wt16 = reinterpret_cast<const __bf16*>(p.wt);
 
   const int n0 = m0 / hsws;
   const long long img = (long long)p.Hi * p.Wi * p.ldi;               // elements per image of the gathered tensor
-  const __bf16* a_base = in16 + (long long)n0 * img;
-  const long long a_bytes = ((long long)(p.N - n0) * img - p.ldi + p.Ci) * 2;
+  const char* a_base = reinterpret_cast<const char*>(p.in) + (long long)n0 * img * ESZ;
+  const long long a_bytes = ((long long)(p.N - n0) * img - p.ldi + p.Ci) * ESZ;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, a_bytes > 0x7FFFFFF0LL ? 0x7FFFFFF0 : (int)a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)wt16, 0, (int)((long long)p.Co * p.ldw * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, (int)((long long)p.Co * p.ldw * ESZ), 0x00020000);
 
   // per-lane source offsets of this wave's 1-KiB pieces: LDS position (row, c') = (16 j + lane / 4, lane % 4) of a tile with 64-byte
   // rows holds the row's 16-byte chunk c = c' ^ ((row >> 2) & 3) — activations (waves 0-1) and filters (waves 2-3) alike
@@ -371,12 +383,12 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
       const int row = 16 * j + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
       const int m = m0 + row;
       if (m < M) {
-        if (plain) { voff[e] = (unsigned)((m - n0 * hsws) * p.ldi * 2 + c * 16); msk[e] = 1u; }
+        if (plain) { voff[e] = (unsigned)((m - n0 * hsws) * p.ldi * ESZ + c * 16); msk[e] = 1u; }
         else {
           const int n = m / hsws, rem = m - n * hsws;
           const int i = rem / p.Ws, jx = rem - i * p.Ws;
           const int iy0 = i * p.isy, ix0 = jx * p.isx;
-          voff[e] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * 2 + c * 16);
+          voff[e] = (unsigned)((((n - n0) * p.Hi + iy0) * p.Wi + ix0) * p.ldi * ESZ + c * 16);
           unsigned mk = 0;
           for (int t = 0; t < p.ntaps; ++t)
             if ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.Hi && (unsigned)(ix0 + p.tap_dx[t]) < (unsigned)p.Wi) mk |= 1u << t;
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
     for (int e = 0; e < NI; ++e) {
       const int j = NI * (wave & 1) + e;
       const int row = 16 * j + (lane >> 2), cp = lane & 3, c = cp ^ ((row >> 2) & 3);
-      voff[e] = (unsigned)((bn * BN + row) * p.ldw * 2 + c * 16);
+      voff[e] = (unsigned)((bn * BN + row) * p.ldw * ESZ + c * 16);
       msk[e] = 0xFFFFu;
     }
   }
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
     const unsigned bit = 1u << k_tap;
     int delta = 0; unsigned soff = 0;
     if (live) {
-      if (loads_a) { delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * 2; soff = (unsigned)k_c * 64u; }
-      else soff = (unsigned)(p.tap_w[k_tap] + k_c * 32) * 2u;
+      if (loads_a) { delta = (p.tap_dy[k_tap] * p.Wi + p.tap_dx[k_tap]) * p.ldi * ESZ; soff = (unsigned)k_c * 64u; }
+      else soff = (unsigned)(p.tap_w[k_tap] + k_c * KSTEP) * (unsigned)ESZ;
     }
     unsigned char* st = smem1 + (loads_a ? (k_done % SA) * ASTAGE : (k_done % SB) * BSTAGE) + my_dst;
 #pragma unroll
@@ -424,14 +436,63 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int ar = (wave * MI + mi) * 32 + (lane & 31);
-      a_rd[mi][kb] = ar * 64 + (((2 * kb + kh) ^ ((ar >> 2) & 3)) << 4);
+      a_rd[mi][kb] = ar * 64 + ((((F8 ? 2 * kh + kb : 2 * kb + kh)) ^ ((ar >> 2) & 3)) << 4);
     }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int row = ni * 32 + (lane & 31);
-      b_rd[ni][kb] = SA * ASTAGE + row * 64 + (((2 * kb + kh) ^ ((row >> 2) & 3)) << 4);
+      b_rd[ni][kb] = SA * ASTAGE + row * 64 + ((((F8 ? 2 * kh + kb : 2 * kb + kh)) ^ ((row >> 2) & 3)) << 4);
     }
   }
+  // fp8: the e8m0 scale bytes this lane's MFMAs take — per accumulator block row its pixel's byte under every tap (packed four to a
+  // register; a tap outside the image gathers zeros: any scale), per filter block its filter's byte.  Plain loads, before any LDS-DMA.
+  unsigned sa_pk[MI][3], sb_pk[2];
+  if constexpr (F8) {
+    const unsigned char* as8 = reinterpret_cast<const unsigned char*>(p.a_scale8);
+    const unsigned char* bs8 = reinterpret_cast<const unsigned char*>(p.b_scale8);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + (wave * MI + mi) * 32 + (lane & 31);
+      long long pix = -1; int iy0 = 0, ix0 = 0;
+      if (m < M) {
+        if (plain) pix = m;
+        else {
+          const int n = m / hsws, rem = m - n * hsws;
+          const int i = rem / p.Ws, jx = rem - i * p.Ws;
+          iy0 = i * p.isy; ix0 = jx * p.isx;
+          pix = ((long long)n * p.Hi + iy0) * p.Wi + ix0;
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        unsigned pk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int t = 4 * w + b;
+          unsigned v = 127u;
+          if (t < p.ntaps && pix >= 0 && (plain || ((unsigned)(iy0 + p.tap_dy[t]) < (unsigned)p.Hi && (unsigned)(ix0 + p.tap_dx[t]) < (unsigned)p.Wi)))
+            v = as8[pix + p.tap_dy[t] * p.Wi + p.tap_dx[t]];
+          pk |= v << (8 * b);
+        }
+        sa_pk[mi][w] = pk;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      unsigned pk = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { const int ni = 4 * w + b; if (ni < NI) pk |= (unsigned)bs8[bn * BN + ni * 32 + (lane & 31)] << (8 * b); }
+      sb_pk[w] = pk;
+    }
+    // (the values leave this block as fresh definitions: the compiler's wait for the loads stays here, in front of the loop, instead of
+    //  becoming a vmcnt(0) at their first use while LDS-DMA pieces are in flight)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int w = 0; w < 3; ++w) asm volatile("" : "+v"(sa_pk[mi][w]));
+    asm volatile("" : "+v"(sb_pk[0]), "+v"(sb_pk[1]));
+  }
+  int c_tap = 0, c_kc = 0;                        // (tap, channel step) of the K-step being MULTIPLIED (the loads run ahead)
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -459,12 +520,34 @@ __global__ __launch_bounds__(256, 2) void conv1b_kernel(const IgemmParams p) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[mi][kb] = *reinterpret_cast<const bf16x8_t*>(st + a_rd[mi][kb]);
     }
+    if constexpr (F8) {
+      // this K-step's tap is wave-uniform: the pixel's scale byte under it, from the packed registers
+      unsigned sa_now[MI];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned w = c_tap < 4 ? sa_pk[mi][0] : (c_tap < 8 ? sa_pk[mi][1] : sa_pk[mi][2]);
+        sa_now[mi] = (w >> (8 * (c_tap & 3))) & 0xFFu;
+      }
+      if (++c_kc == cpt) { c_kc = 0; ++c_tap; }
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi) {
+        const v4i_t a0 = __builtin_bit_cast(v4i_t, af[mi][0]), a1 = __builtin_bit_cast(v4i_t, af[mi][1]);
+        const v8i_t a8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        static_for1<NI>([&](auto nic) {
+          constexpr int ni = decltype(nic)::value;
+          const v4i_t b0 = __builtin_bit_cast(v4i_t, bf[ni][0]), b1 = __builtin_bit_cast(v4i_t, bf[ni][1]);
+          const v8i_t b8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[mi][ni], 0, 0, 0, (int)sa_now[mi], ni & 3, (int)sb_pk[ni >> 2]);
+        });
+      }
+    } else {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][kb], bf[ni][kb], acc[mi][ni], 0, 0, 0);
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][kb], bf[ni][kb], acc[mi][ni], 0, 0, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -643,21 +726,21 @@ int conv1b_shape(int M, int Co) {
   return 21;
 }
 
-template <int NI, int MI, bool O32>
+template <int NI, int MI, bool O32, bool F8 = false>
 int launch1b(const IgemmParams& p, hipStream_t stream) {
   constexpr int SA = 3, SB = 2;
   constexpr int BM = 128 * MI, BN = 32 * NI;
   static DcnPerDeviceFlag attr_once;
   const size_t lds = (size_t)SA * BM * 64 + (size_t)SB * BN * 64;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1b_kernel<SA, SB, NI, MI, O32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1b_kernel<SA, SB, NI, MI, O32, F8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   const int gm = cdiv(p.M, BM), gn = p.Co / BN;
   const double k_alg = (double)p.ntaps * p.Ci;
-  const double alg_bytes = 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
+  const double alg_bytes = (F8 ? 1.0 : 2.0) * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
                            ((O32 ? 4.0 : 2.0) * (1.0 + (p.accumulate ? 1.0 : 0.0) + (p.residual ? 1.0 : 0.0)) + (p.bt_y ? 2.0 : 0.0)) * (double)p.M * p.Co;
-  const int pid = prof_begin(41, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv1b_kernel<SA, SB, NI, MI, O32>), dim3(gm * gn), dim3(256), lds, stream, p);
+  const int pid = prof_begin(F8 ? 48 : 41, 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  hipLaunchKernelGGL((conv1b_kernel<SA, SB, NI, MI, O32, F8>), dim3(gm * gn), dim3(256), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv1b");
   return DCN_OK;
@@ -707,7 +790,8 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
 }
 
 // ---- bf16 storage ------------------------------------------------------------------------------------------------------
-int conv1b_grid_m(int M, int Co, int ntaps) {
+int conv1b_grid_m(int M, int Co, int ntaps, int s1_w) {
+  if (ntaps == 9 && s1_w > 0) { const int bm3 = conv3b_bm(M, Co, s1_w); if (bm3) return cdiv(M, bm3); }      // conv3.hip's strip kernel
   if (conv2b_takes(M, Co, ntaps)) return cdiv(M, 256);              // conv2b.hip's 256 x 256 tile
   const int sh = conv1b_shape(M, Co);
   return sh ? cdiv(M, 128 * (sh / 10)) : 0;
@@ -722,6 +806,7 @@ int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
   if (p.Hs * p.Ws < 1 || (256 / (p.Hs * p.Ws) + 2) * (long long)p.Hi * p.Wi * p.ldi * 2 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 2 >= 0x7FFFFFF0LL) {
     dcn_set_error("conv1b: tensor beyond the 2 GiB buffer window"); return DCN_ERR_ARG;
   }
+  if (conv3b_takes(p)) return conv3b_launch(p, out_f32, stream);                          // 3x3 stride 1: the strip kernel (every row staged once, not nine times)
   if (conv2b_takes(p.M, p.Co, p.ntaps)) return conv2b_launch(p, out_f32, stream);      // >= 256 filters on a long grid: 256 x 256 tiles, eight waves
   switch (conv1b_shape(p.M, p.Co)) {
     case 18: return out_f32 ? launch1b<8, 1, true>(p, stream) : launch1b<8, 1, false>(p, stream);
@@ -730,5 +815,31 @@ int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
     case 12: return out_f32 ? launch1b<2, 1, true>(p, stream) : launch1b<2, 1, false>(p, stream);
     case 21: return out_f32 ? launch1b<1, 2, true>(p, stream) : launch1b<1, 2, false>(p, stream);
     default: dcn_set_error("conv1b: Co=%d is not a multiple of 32", p.Co); return DCN_ERR_ARG;
+  }
+}
+
+// ---- fp8 storage ---------------------------------------------------------------------------------------------------------
+// p.in / p.wt point at e4m3 bytes (strides in elements = bytes), p.a_scale8 / p.b_scale8 at the e8m0 row scales, p.residual / p.bt_y at
+// bf16 data, p.out at bf16 (out_f32 = 0) or fp32 data.  One BatchNorm partial row per 128 MI output rows (conv1q_grid_m).
+int conv1q_grid_m(int M, int Co) {
+  const int sh = conv1b_shape(M, Co);
+  return sh ? cdiv(M, 128 * (sh / 10)) : 0;
+}
+
+int conv1q_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
+  if (p.Ci % 64 != 0 || !p.a_scale8 || !p.b_scale8 || p.c4 || p.bmode != 0 || p.batch > 1 || p.row_scale || p.ncls || p.ntaps < 1 || p.ntaps > 12 ||
+      (long long)p.M != (long long)p.N * p.Hs * p.Ws) {
+    dcn_set_error("conv1q: launch form not supported on fp8 storage (Ci=%d taps=%d)", p.Ci, p.ntaps); return DCN_ERR_ARG;
+  }
+  if (p.Hs * p.Ws < 1 || (256 / (p.Hs * p.Ws) + 2) * (long long)p.Hi * p.Wi * p.ldi >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw >= 0x7FFFFFF0LL) {
+    dcn_set_error("conv1q: tensor beyond the 2 GiB buffer window"); return DCN_ERR_ARG;
+  }
+  switch (conv1b_shape(p.M, p.Co)) {
+    case 18: return out_f32 ? launch1b<8, 1, true, true>(p, stream) : launch1b<8, 1, false, true>(p, stream);
+    case 14: return out_f32 ? launch1b<4, 1, true, true>(p, stream) : launch1b<4, 1, false, true>(p, stream);
+    case 24: return out_f32 ? launch1b<4, 2, true, true>(p, stream) : launch1b<4, 2, false, true>(p, stream);
+    case 12: return out_f32 ? launch1b<2, 1, true, true>(p, stream) : launch1b<2, 1, false, true>(p, stream);
+    case 21: return out_f32 ? launch1b<1, 2, true, true>(p, stream) : launch1b<1, 2, false, true>(p, stream);
+    default: dcn_set_error("conv1q: Co=%d is not a multiple of 32", p.Co); return DCN_ERR_ARG;
   }
 }

@@ -60,8 +60,13 @@ __device__ __forceinline__ int row32(int pos, int half) { return pos * 32 + (((h
 // LS ("load spread"): the global loads of an iteration are issued one by one BEHIND its MFMA groups instead of all at its start — every wave
 // leaves the barrier at the same time, and a burst of 7-10 loads per thread from all of them fills the memory path's queue: a load then sits in
 // the issue stage with no MFMA behind it (gemm3.hip measured the same for its LDS-DMA: 0.92 -> 0.70 ms with the DMA behind the fragment reads)
-template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0>
+// IN16 (NP = 1, bf16 STORAGE — BASELINE.json configs[2]): the gathered tensor, the shortcut, the accumulated-onto tensor and the tapped
+// BatchNorm input ARE bf16 tensors (strides in elements), the bank is the bf16 bank; a 16-byte strip piece is 8 channels and goes to its
+// half of the position's 32-byte row as loaded (no conversion, two pieces per position and channel step instead of four); the result is
+// stored as bf16 (O32: fp32), and the BatchNorm partial sums are those of the values as stored (conv1.hip conv1b_kernel's epilogue).
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0, bool IN16 = false, bool O32 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParams p, const int S, const int gran) {
+  static_assert(!IN16 || NP == 1, "bf16 storage: one plane");
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   constexpr int CHB = 2 * NP;                 // 16-B chunks per filter row and tap (16 k: 64 B pre-split, 32 B bf16)
   constexpr int B_LD = (BN * CHB + NT - 1) / NT;          // 16-B filter loads per thread and tap (the last may be predicated off)
@@ -89,8 +94,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   // ---- descriptors ---------------------------------------------------------------------------------
   const int lin0 = m0 - W - 1;                                     // pixel of strip position 0
   const int base_px = lin0 > 0 ? lin0 : 0;
-  const float* a_base = p.in + (long long)base_px * p.ldi;
-  const __amdgpu_buffer_rsrc_t a_rs = rsrc3(a_base, ((long long)(M - base_px - 1) * p.ldi + p.Ci) * 4);
+  constexpr int AESZ = IN16 ? 2 : 4;           // bytes per element of the gathered tensor
+  constexpr int PPP = IN16 ? 2 : 4;            // 16-byte pieces per strip position and 16-channel step
+  const float* a_base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in) + (long long)base_px * p.ldi * AESZ);
+  const __amdgpu_buffer_rsrc_t a_rs = rsrc3(a_base, ((long long)(M - base_px - 1) * p.ldi + p.Ci) * AESZ);
   const __amdgpu_buffer_rsrc_t b_rs = NP == 2 ? rsrc3(p.wt, (long long)p.Co * p.ldw * 4)
                                               : rsrc3(reinterpret_cast<const float*>(p.wt16), (long long)p.Co * p.ldw * 2);
   constexpr int ESZ = NP == 2 ? 4 : 2;         // bytes per filter element in the bank
@@ -99,10 +106,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   unsigned a_off[A_LD]; int a_st[A_LD];      // global byte offset (channel step 0) / LDS byte offset inside plane 0
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int idx = tid + j * NT, pos = idx >> 2, q = idx & 3;
+    const int idx = tid + j * NT, pos = idx / PPP, q = idx % PPP;
     const int px = lin0 + pos;
-    a_off[j] = (pos < S && px >= 0 && px < M) ? (unsigned)((px - base_px) * p.ldi * 4 + q * 16) : OOB3;
-    a_st[j] = pos < S ? row32(pos, q >> 1) + (q & 1) * 8 : (S + 1) * 32 + q * 8;      // (no branch in the loop: beyond the strip -> dump row)
+    a_off[j] = (pos < S && px >= 0 && px < M) ? (unsigned)((px - base_px) * p.ldi * AESZ + q * 16) : OOB3;
+    if constexpr (IN16) a_st[j] = pos < S ? row32(pos, q) : (S + 1) * 32 + q * 16;
+    else a_st[j] = pos < S ? row32(pos, q >> 1) + (q & 1) * 8 : (S + 1) * 32 + q * 8;      // (no branch in the loop: beyond the strip -> dump row)
   }
   unsigned b_off[B_LD]; int b_st[B_LD];
 #pragma unroll
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
   f32x4 a_reg[A_LD], b_r0[3 * B_LD], b_r1[3 * B_LD];
   auto load_a = [&](int cc) {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, a_off[j], (unsigned)cc * 64u);
+    for (int j = 0; j < A_LD; ++j) a_reg[j] = ld16(a_rs, a_off[j], (unsigned)cc * (16u * AESZ));
   };
   auto load_b = [&](f32x4* br, int it) {      // the three taps of iteration `it`
     const int cc = it / 3, g = it - 3 * cc;
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
     }
   };
   auto store_a_piece = [&](unsigned char* abuf, int j) {            // x*s = h + l, two f16 planes (NP = 1: one bf16 plane)
+    if constexpr (IN16) { *reinterpret_cast<f32x4*>(abuf + a_st[j]) = a_reg[j]; return; }      // 8 bf16 channels as loaded
     if constexpr (NP == 1) {
       typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
       const bf16x4_t b = {(__bf16)a_reg[j][0], (__bf16)a_reg[j][1], (__bf16)a_reg[j][2], (__bf16)a_reg[j][3]};
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
         const unsigned soff = (unsigned)(p.tap_w[3 * G2 + j] + (cc + C2) * 16) * (unsigned)ESZ;
         bnew[q] = ld16(b_rs, in_b ? b_off[l] : OOB3, in_b ? soff : 0u);
       } else if (q < NLOAD) {
-        a_reg[q - 3 * B_LD] = ld16(a_rs, in_a ? a_off[q - 3 * B_LD] : OOB3, in_a ? (unsigned)(cc + 1) * 64u : 0u);
+        a_reg[q - 3 * B_LD] = ld16(a_rs, in_a ? a_off[q - 3 * B_LD] : OOB3, in_a ? (unsigned)(cc + 1) * (16u * AESZ) : 0u);
       }
     };
     // LS: slot s of the iteration's nine MFMA groups takes loads [lo(s), lo(s + 1)): the filter pieces behind the first groups (they are
@@ -331,6 +340,98 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) t_ += acc[mi][ni][r];
     if (t_ == 12345.678f) p.out[tid] = t_;
+    return;
+  }
+
+  if constexpr (IN16) {
+    // ---- epilogue on bf16 tensors (conv1.hip conv1b_kernel's): accumulate, partial sums of the values AS STORED, scale/shift, activation,
+    //      shortcut, bf16 | fp32 store; one partial row per M-tile (gran = BM) ----------------------------------------------------------
+    typedef typename std::conditional<O32, float, __bf16>::type out_t;
+    out_t* __restrict__ gout16 = reinterpret_cast<out_t*>(p.out);
+    auto row_of = [&](int mi, int r) { return m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; };
+    if (p.accumulate) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(mi, r);
+          if (m >= M) continue;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int co = bn * BN + wn * 64 + ni * 32 + (lane & 31);
+            if (co < p.Co) acc[mi][ni][r] += (float)gout16[(size_t)m * p.ldo + co];
+          }
+        }
+    }
+    if (p.stats) {
+      float* red = reinterpret_cast<float*>(smem3);       // [2][WM][BN]
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        float s_ = 0.f, ss_ = 0.f;
+        const int co = bn * BN + wn * 64 + ni * 32 + (lane & 31);
+        if (p.bt_y && co < p.Co) {                         // BatchNorm tap: the terms of bn_act_bwd's reduce pass, y bf16
+          const float mu = p.bt_mean[co], is = p.bt_invstd[co], ga = p.bt_gamma ? p.bt_gamma[co] : 1.f, be = p.bt_beta ? p.bt_beta[co] : 0.f;
+          const __bf16* yb = reinterpret_cast<const __bf16*>(p.bt_y) + co;
+          float yv[2][16];
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const int m = row_of(mi, r); yv[mi][r] = (float)yb[(size_t)(m < M ? m : M - 1) * p.Co]; }
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = row_of(mi, r);
+              const float xh = (yv[mi][r] - mu) * is;
+              float g = O32 ? acc[mi][ni][r] : (float)(__bf16)acc[mi][ni][r];      // (the gradient as it is stored)
+              if (p.bt_act == DCN_ACT_LEAKY) g = (ga * xh + be <= 0.f) ? g * p.bt_slope : g;
+              g = m < M ? g : 0.f;
+              s_ += g; ss_ += g * xh;
+            }
+        } else if (!p.bt_y) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = O32 ? acc[mi][ni][r] : (float)(__bf16)acc[mi][ni][r];
+              s_ += v; ss_ = __builtin_fmaf(v, v, ss_);
+            }
+        }
+        s_ += __shfl_xor(s_, 32); ss_ += __shfl_xor(ss_, 32);
+        if (lane < 32) {
+          const int col = wn * 64 + ni * 32 + lane;
+          red[(0 * WM + wm) * BN + col] = s_;
+          red[(1 * WM + wm) * BN + col] = ss_;
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 2 * BN; idx += NT) {
+        const int which = idx / BN, col = idx - which * BN;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) t += red[(which * WM + w) * BN + col];
+        const int co = bn * BN + col;
+        if (co < p.Co) p.stats[((size_t)bm * 2 + which) * p.Co + co] = t;
+      }
+    }
+    const __bf16* res16 = reinterpret_cast<const __bf16*>(p.residual);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int co = bn * BN + wn * 64 + ni * 32 + (lane & 31);
+      if (co >= p.Co) continue;
+      const float sc = p.scale ? p.scale[co] : 1.f, sh = p.shift ? p.shift[co] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = row_of(mi, r);
+          if (m >= M) continue;
+          float v = acc[mi][ni][r] * sc + sh;
+          if (p.act == DCN_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+          if (res16) v += (float)res16[(size_t)m * p.ldr + co];
+          gout16[(size_t)m * p.ldo + co] = (out_t)v;
+        }
+    }
     return;
   }
 
@@ -447,20 +548,22 @@ int g_conv3_bm = 0;       // dcn_set_tuning("3bm", 128|256): force the strip ker
 int g_conv3_abl = 0;      // dcn_set_tuning("3abl", bits): timing ablations (C3_ABL builds only)
 int g_conv3_ls = 1;       // dcn_set_tuning("3ls", 0): every global load of an iteration at its start again (A/B switch; LS = 1 measured 1-6 % faster per layer)
 
-template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0>
+template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0, bool IN16 = false, bool O32 = false>
 int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
   const int S = BM + 2 * p.Wi + 2;
   const size_t lds = (size_t)2 * NP * (S + 2) * 32 + (size_t)2 * 3 * (NP * BN * 32 + 128);
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP, ABL, LS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_kernel<WM, WN, A_LD, NP, ABL, LS, IN16, O32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   const int gm = cdiv(p.M, BM), gn = cdiv(p.Co, BN);
   const double k_alg = 9.0 * p.Ci;
-  const double alg_bytes = 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
-  const int pid = prof_begin(NP == 1 ? 33 : (WM == 4 ? 28 : 29), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
-  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL, LS>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
+  const double alg_bytes = IN16 ? 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
+                                      ((O32 ? 4.0 : 2.0) * (1.0 + (p.accumulate ? 1.0 : 0.0)) + (p.residual ? 2.0 : 0.0) + (p.bt_y ? 2.0 : 0.0)) * (double)p.M * p.Co
+                                : 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
+  const int pid = prof_begin(IN16 ? 47 : (NP == 1 ? 33 : (WM == 4 ? 28 : 29)), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL, LS, IN16, O32>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv3");
   return DCN_OK;
@@ -531,6 +634,56 @@ bool conv3_applicable(const IgemmParams& p, int precision, int gran) {
   // 32-bit strip offsets: S pixels of ldi floats
   if ((long long)S * p.ldi * 4 >= 0x7FFFFFF0LL || (long long)p.Co * p.ldw * 4 >= 0x7FFFFFF0LL) return false;
   return true;
+}
+
+// ---- bf16 storage: the 3x3 stride-1 launches of conv1b_launch (conv1.hip) ------------------------------------------------------------
+// OFF by default: built as the round-4 plan's "bf16 strip kernel" and measured against the gathered tiles it was meant to replace
+// (tools/bench_b16.py --set 3h16=0 --ab 3h16=1, N = 64, forward / data gradient, ms): 128->256 @52 0.160 -> 0.187 / 0.162 -> 0.147, 256->512 @26 0.150 ->
+// 0.148 / 0.139 -> 0.159, 512->1024 @13 0.137 -> 0.155 / 0.173 -> 0.172, 64->128 @104 0.184 -> 0.253 / 0.227 -> 0.229, 512->512 @52 0.851 -> 0.927 /
+// 0.845 -> 0.906 — it LOSES: with one MFMA per product (not three) the strip loop's 12 MFMAs per wave between barriers and its register-staged
+// loads cost more than the nine-fold gather of conv1b's LDS-DMA rings, which mostly hits L2.  Kept behind the knob with its exact-model tests.
+int g_conv3b = 0;         // dcn_set_tuning("3h16", 1): bf16-storage 3x3 stride-1 launches on the strip kernel
+void conv3b_set_tuning(int v) { g_conv3b = v; }
+
+// M-tile (pixels) of a bf16-storage strip launch, 0 = not on this kernel.  A function of the shape and the knob only: the caller sizes its
+// BatchNorm partial rows (one per M-tile) with it.  Wi = map width of the (stride-1, 3x3) launch.
+int conv3b_bm(int M, int Co, int Wi) {
+  if (!g_conv3b || Co <= 64 || Co % 32 != 0 || Wi < 2) return 0;
+  const int gn = cdiv(Co, 128);
+  const long long wgs256 = (long long)cdiv(M, 256) * gn;
+  int bm = (wgs256 < 256 || gn == 2 || gn >= 8) ? 128 : 256;          // (conv3_tile's choice for the fp32 strip)
+  const int S = bm + 2 * Wi + 2;
+  if (2 * S > 4 * (bm * 2)) return 0;                                   // <= 4 strip pieces per thread (threads = 2 bm)
+  if ((size_t)2 * (S + 2) * 32 + (size_t)6 * (128 * 32 + 128) > 160 * 1024) return 0;
+  return bm;
+}
+bool conv3b_takes(const IgemmParams& p) {
+  if (p.ntaps != 9 || p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1 || p.oy0 != 0 || p.ox0 != 0 || !p.dense_out || p.ncls || p.batch > 1) return false;
+  if (p.Hs != p.Hi || p.Ws != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.M != p.N * p.Hi * p.Wi || p.Ci % 32 != 0) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int dy = p.tap_dy[t], dx = p.tap_dx[t];
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+    seen |= 1u << ((dy + 1) * 3 + dx + 1);
+  }
+  if (seen != 0x1FF) return false;
+  const int bm = conv3b_bm(p.M, p.Co, p.Wi);
+  if (!bm) return false;
+  const int S = bm + 2 * p.Wi + 2;
+  return (long long)S * p.ldi * 2 < 0x7FFFFFF0LL && (long long)p.Co * p.ldw * 2 < 0x7FFFFFF0LL;
+}
+// p.in / p.residual / p.bt_y / p.wt point at bf16 data (p.wt: the bank [Co][9 Ci]), p.out at bf16 (out_f32 = 0) or fp32 data
+int conv3b_launch(const IgemmParams& p0, int out_f32, hipStream_t stream) {
+  IgemmParams p = p0;
+  p.wt16 = p0.wt;                                                      // (the kernel's one-plane path reads the bank through wt16)
+  const int bm = conv3b_bm(p.M, p.Co, p.Wi);
+  const int S = bm + 2 * p.Wi + 2, need = cdiv(2 * S, 2 * bm);          // strip pieces per thread
+  if (bm == 128) {
+    if (need <= 2) return out_f32 ? launch3<2, 2, 2, 1, 0, 1, true, true>(p, bm, stream) : launch3<2, 2, 2, 1, 0, 1, true, false>(p, bm, stream);
+    return out_f32 ? launch3<2, 2, 4, 1, 0, 1, true, true>(p, bm, stream) : launch3<2, 2, 4, 1, 0, 1, true, false>(p, bm, stream);
+  }
+  if (need <= 2) return out_f32 ? launch3<4, 2, 2, 1, 0, 1, true, true>(p, bm, stream) : launch3<4, 2, 2, 1, 0, 1, true, false>(p, bm, stream);
+  return out_f32 ? launch3<4, 2, 4, 1, 0, 1, true, true>(p, bm, stream) : launch3<4, 2, 4, 1, 0, 1, true, false>(p, bm, stream);
 }
 
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream) {

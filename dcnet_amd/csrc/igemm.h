@@ -52,6 +52,8 @@ struct IgemmParams {
   // would compute in a pass of its own — instead of sum / sum of squares.  bt_y dense [M][Co].
   const float* bt_y; const float* bt_mean; const float* bt_invstd; const float* bt_gamma; const float* bt_beta;
   int bt_act; float bt_slope;
+  // fp8 storage (conv1.hip conv1b_kernel<..., F8>): one e8m0 byte per pixel of the gathered tensor / per filter of the bank
+  const unsigned char* a_scale8; const unsigned char* b_scale8;
 };
 // [M][Co] tensors a launch's epilogue touches, in units of the output: the store, plus one read each for accumulate / shortcut / tapped
 // BatchNorm input (the "algorithmic bytes" of a launch count every operand it must move once)
@@ -70,6 +72,12 @@ bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci);
 bool conv3_applicable(const IgemmParams& p, int precision, int gran);
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv3_set_tuning(int key, int value);
+// ... and its bf16-storage form (conv1b_launch hands it the 3x3 stride-1 launches): conv3b_bm = pixels per M-tile = rows per BatchNorm
+// partial (0: the launch stays on the gathered tiles)
+int conv3b_bm(int M, int Co, int Wi);
+bool conv3b_takes(const IgemmParams& p);
+int conv3b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
+void conv3b_set_tuning(int v);
 
 // conv1.hip: NT launches with both tiles by LDS-DMA (f16 split, pre-split filter bank): 1x1 layers, stride-2 layers, the parity
 // classes of their data gradients, narrow 3x3 layers.  gran = output rows per BatchNorm partial row (128 | 256).
@@ -78,8 +86,11 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv1_set_tuning(int key, int value);
 // ... and its bf16-storage form (activations, gradients and filter banks bf16 in HBM): every forward / data-gradient launch with
 // Ci % 32 == 0.  conv1b_grid_m = BatchNorm partial rows (M-tiles) of a launch.
-int conv1b_grid_m(int M, int Co, int ntaps);
+int conv1b_grid_m(int M, int Co, int ntaps, int s1_w = 0);      // s1_w: map width when the launch is a 3x3 stride-1 convolution, else 0
 int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
+// ... and its fp8-storage form (e4m3 bytes + one e8m0 scale per pixel / per filter: a_scale8, b_scale8; Ci % 64 == 0, <= 12 taps)
+int conv1q_grid_m(int M, int Co);
+int conv1q_launch(const IgemmParams& p, int out_f32, hipStream_t stream);
 // conv2b.hip: the same on 256 x 256 tiles (eight waves, gemm3.hip's two-group schedule) for launches with Co % 256 == 0 and enough tiles
 bool conv2b_takes(int M, int Co, int ntaps);
 int conv2b_launch(const IgemmParams& p, int out_f32, hipStream_t stream);

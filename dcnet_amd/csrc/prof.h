@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define DCN_PROF_TAGS 48
+#define DCN_PROF_TAGS 56
 // tags: 0-2 igemm NT tiles 128x128 / 128x64 / 256x32, 3-4 igemm NN tiles 128x128 / 128x64,
 //       5 wgrad / TN GEMM (all tiles), 6-7 igemm 64x128 NT / NN tiles, 8 l2norm+score fwd, 9 l2norm+score bwd, 10 scale_act,
 //       11 bn backward apply, 12 exp+sums (co-attention), 13/14 latency-bound small GEMMs (< 1024 rows: LSTM steps),

@@ -358,8 +358,15 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
             if s16 and x.dtype == torch.bfloat16:
                 if bank is None:
                     raise RuntimeError("bf16 storage needs the prepared filter banks (ops.FILTER_BANKS) for every layer behind the stem")
+                use8 = ops.f8_takes(op.cin, op.cout, op.k)          # "fp8s": this layer's forward on e4m3 operands (quantised here, once)
+                if use8:
+                    x8, xs = ops.quant_rows_e4m3(x)
+                    w8, ws = ops.quant_rows_e4m3(bank["b16"].view(op.cout, -1))
                 if op.bn and training:
-                    y, stats = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, want_stats=True)
+                    if use8:
+                        y, stats = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, op.cout, op.k, op.stride, want_stats=True)
+                    else:
+                        y, stats = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, want_stats=True)
                     mi = ops.bn_finalize(stats, y.numel() // op.cout, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
                     o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res)
                     if save is not None:
@@ -370,7 +377,10 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                         scale, shift = ss[0], ss[1]
                     else:
                         scale, shift = None, p["b"]
-                    o, _ = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, scale, shift, act, 0.1, residual=res)
+                    if use8:
+                        o, _ = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, op.cout, op.k, op.stride, scale, shift, act, 0.1, residual=res)
+                    else:
+                        o, _ = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, scale, shift, act, 0.1, residual=res)
                 out[op.dst] = o; amx[op.dst] = None
                 continue
             if op.bn and training:
@@ -554,8 +564,14 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                     if torch.is_tensor(y_prev) and y_prev.dtype == torch.bfloat16 and y_prev.is_contiguous():
                         tap = dict(y=y_prev, mean=mi_prev[0], invstd=mi_prev[1], gamma=P[prev.slot]["gamma"], beta=P[prev.slot]["beta"],
                                    act=ops.ACT_LEAKY if prev.leaky else ops.ACT_NONE, slope=0.1)
-                res_ = ops.conv2d_bwd_data_b16(dy, getattr(w, "_dcn_wt16"), (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
-                                               out=cur, accumulate=cur is not None, tap=tap)
+                if ops.f8_takes(op.cout, op.cin, op.k) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
+                    dy8, dys = ops.quant_rows_e4m3(dy)
+                    wt8, wts = ops.quant_rows_e4m3(getattr(w, "_dcn_wt16").view(op.cin, -1))
+                    res_ = ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
+                                                  out=cur, accumulate=cur is not None, tap=tap)
+                else:
+                    res_ = ops.conv2d_bwd_data_b16(dy, getattr(w, "_dcn_wt16"), (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
+                                                   out=cur, accumulate=cur is not None, tap=tap)
                 if tap is not None:
                     res_, part_ = res_
                     if part_ is not None:

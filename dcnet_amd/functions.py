@@ -32,7 +32,18 @@ class ConvBNAct(torch.autograd.Function):
         if ops.storage_b16() and bank is not None:
             x_f32 = x.dtype == torch.float32
             x16 = ops.to_b16(x.contiguous())
-            if training:
+            use8 = ops.f8_takes(x16.shape[3], cout, ksize)          # "fp8s": the head's 3x3 block on e4m3 operands
+            if use8:
+                x8, xs = ops.quant_rows_e4m3(x16)
+                w8, ws = ops.quant_rows_e4m3(bank["b16"].view(cout, -1))
+            if training and use8:
+                y, stats = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, cout, ksize, 1, want_stats=True)
+                mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
+                                     bn.running_mean, bn.running_var)
+                ops.bump_batches(bn)
+                out = ops.scale_act(y, mi[2], mi[3], ops.ACT_LEAKY, slope, out_f32=not out_b16)
+                ctx.save_for_backward(x16, y, mi, gamma, beta)
+            elif training:
                 y, stats = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, want_stats=True)
                 mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
                                      bn.running_mean, bn.running_var)
@@ -41,7 +52,10 @@ class ConvBNAct(torch.autograd.Function):
                 ctx.save_for_backward(x16, y, mi, gamma, beta)
             else:
                 ss = ops.bn_fold(gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.eps)
-                out, _ = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
+                if use8:
+                    out, _ = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
+                else:
+                    out, _ = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
             ctx.b16 = (bank["tb16"], x_f32)
             ctx.meta = (ksize, training, slope, tuple(weight.shape))
             return out, None
@@ -82,16 +96,24 @@ class ConvBNAct(torch.autograd.Function):
             tb16, x_f32 = ctx.b16
             dy, dgamma, dbeta = ops.bn_act_bwd(y, dout.contiguous(), mi[0], mi[1], gamma.detach(), beta.detach(), ops.ACT_LEAKY, slope)
             dx = None
+
+            def dgrad():
+                if ops.f8_takes(dy.shape[3], x16.shape[3], ksize) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
+                    dy8, dys = ops.quant_rows_e4m3(dy)
+                    wt8, wts = ops.quant_rows_e4m3(tb16.view(x16.shape[3], -1))
+                    return ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+                return ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+
             if ctx.wparam is not None:     # (ops.WGRAD_DIRECT: the block before's weight gradient goes out behind this block's passes)
                 ops.release_held_wgrads()
                 if ctx.needs_input_grad[0]:
-                    dx = ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+                    dx = dgrad()
                 ops.hold_wgrad_into(ctx.wparam, x16, dy, ksize, 1, wshape)
                 return dx, None, dgamma, dbeta, None, None, None, None, None, None, None
             if not ops.WGRAD_AFTER_DGRAD:
                 dwt = ops.wgrad_on_side(x16, dy, ksize, 1, wshape)
             if ctx.needs_input_grad[0]:
-                dx = ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
+                dx = dgrad()
             if ops.WGRAD_AFTER_DGRAD:
                 dwt = ops.wgrad_on_side(x16, dy, ksize, 1, wshape)
             ops.join_side(x16.device)

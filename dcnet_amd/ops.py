@@ -31,7 +31,11 @@ ACT_NONE, ACT_LEAKY = 0, 1
 #               weights); their kernels are the *_b16 entry points (csrc/conv1.hip conv1b, wgrad.hip IN16, b16.hip) — one
 #               MFMA per product, half the bytes per element.  What stays on fp32 tensors (the 3-channel stem, co-attention,
 #               scoring, heads' tails, language branch) runs as in "bf16" (bf16 operands)
-PRECISIONS = {"fp32_mfma": 0, "fp32_bf16x3": 1, "bf16": 2, "fp8": 3, "fp32": 4, "bf16s": 2}
+#   "fp8s"      fp8 STORAGE for the operands of the wide 3x3 convolutions (configs[4] proper, round 5) on top of "bf16s": their forward and
+#               data gradient read OCP e4m3 tensors with one e8m0 scale per pixel / per filter (written by dcn_quant_rows_e4m3 from the bf16
+#               tensor) and multiply on the block-scaled MFMA (2 x the bf16 rate, half the staged bytes); everything else as in "bf16s"
+#               (bf16 tensors, bf16 weight gradients, fp32 accumulators / statistics / master weights)
+PRECISIONS = {"fp32_mfma": 0, "fp32_bf16x3": 1, "bf16": 2, "fp8": 3, "fp32": 4, "bf16s": 2, "fp8s": 2}
 _precision = "fp32"
 
 
@@ -44,8 +48,22 @@ def set_precision(mode: str) -> None:
 
 
 def storage_b16() -> bool:
-    """True in the bf16-storage mode: conv stacks allocate and exchange bf16 tensors."""
-    return _precision == "bf16s"
+    """True in the bf16-storage modes ("bf16s", and "fp8s" which adds fp8 operand tensors): conv stacks allocate and exchange bf16 tensors."""
+    return _precision in ("bf16s", "fp8s")
+
+
+F8_MIN_K = 128           # channels on the contraction side from which a 3x3 convolution takes fp8 operands (64: also the 104-wide layers)
+
+
+def storage_f8() -> bool:
+    return _precision == "fp8s"
+
+
+def f8_takes(k_channels: int, out_channels: int, ksize: int) -> bool:
+    """Does a convolution pass with `k_channels` on its contraction side (forward: Cin, data gradient: Cout) run on fp8 operands in the
+    "fp8s" mode?  The multi-tap layers only: their launches gather every row nine times and are bound by the bytes they stage — where 1-byte
+    operands pay for the quantisation pass in front (a 1x1 layer reads its input once: the pass would cost what it saves)."""
+    return storage_f8() and ksize == 3 and k_channels % 64 == 0 and k_channels >= F8_MIN_K and out_channels % 32 == 0
 
 
 def _b16(t) -> bool:
@@ -497,6 +515,70 @@ def conv2d_bwd_data_b16(dy, wt16, in_hw, cin, ksize, stride, out=None, accumulat
                               tap["invstd"].data_ptr() if cap else 0, _p(tap.get("gamma")) if cap else 0, _p(tap.get("beta")) if cap else 0,
                               int(tap["act"]) if cap else 0, float(tap["slope"]) if cap else 0.0, part.data_ptr() if cap else 0, cap,
                               ctypes.addressof(rows), _s())
+    if tap is not None:
+        return out, (part[:rows.value] if rows.value > 0 else None)
+    return out
+
+
+# ---- fp8 storage (configs[4]): e4m3 bytes + one e8m0 scale per row -----------------------------------------------------------------
+def quant_rows_e4m3(x: torch.Tensor):
+    """x (..., c) bf16 rows (c % 8 == 0, last dim contiguous) -> (q uint8 same shape: OCP e4m3 bytes, scales uint8 [rows]: e8m0, one per
+    row): q = e4m3(x * 2^-e), e = floor(log2(max|row|)) - 8 (csrc/b16.hip)."""
+    _rows16(x, "quant_rows_e4m3 x")
+    if not _b16(x):
+        raise ValueError("quant_rows_e4m3: x must be bf16")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.uint8, device=x.device)
+    lib().quant_rows_e4m3(x.data_ptr(), x.stride(-2) if x.dim() > 1 else c, rows, c, q.data_ptr(), c, sc.data_ptr(), _s())
+    return q, sc
+
+
+def conv2d_fwd_f8(x8, xs, w8, ws, cout, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0, residual=None, want_stats=False,
+                  out_f32=False):
+    """fp8 storage: x8 (N,H,W,Cin) uint8 e4m3 with xs [N*H*W] e8m0, w8 [Cout][k*k*Cin] e4m3 with ws [Cout] (quant_rows_e4m3 of the bf16
+    tensors).  Returns (y bf16 | fp32, stats | None) as conv2d_fwd_b16."""
+    n, h, wd, cin = x8.shape
+    if not (x8.dtype == torch.uint8 and x8.is_contiguous() and w8.dtype == torch.uint8 and w8.is_contiguous() and w8.numel() == cout * ksize * ksize * cin
+            and xs.dtype == torch.uint8 and xs.numel() == n * h * wd and ws.dtype == torch.uint8 and ws.numel() == cout):
+        raise ValueError("conv2d_fwd_f8: x8 / w8 must be contiguous uint8 e4m3 tensors with one e8m0 byte per pixel / per filter")
+    ho, wo = conv_out_hw(h, wd, ksize, stride)
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x8.device)
+    if residual is not None and not (_b16(residual) and residual.is_contiguous()):
+        raise ValueError("conv2d_fwd_f8: residual must be a contiguous bf16 tensor")
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib().conv2d_stats_rows_f8(n, h, wd, cout, ksize, stride), 2, cout), dtype=torch.float32, device=x8.device)
+    lib().conv2d_fwd_f8(x8.data_ptr(), xs.data_ptr(), w8.data_ptr(), ws.data_ptr(), out.data_ptr(), int(out_f32), n, h, wd, cin, cout, ksize, stride,
+                        _p(scale), _p(shift), act, float(slope), _p(residual), 0, cout, _p(stats), 0, _s())
+    return out, stats
+
+
+def conv2d_bwd_data_f8(dy8, dys, wt8, wts, in_hw, cin, ksize, stride, out=None, accumulate=False, tap=None, out_f32=False):
+    """fp8 storage: dy8 (N,Ho,Wo,Cout) uint8 e4m3 with dys per pixel, wt8 the transposed bank [Cin][k*k*Cout] e4m3 with wts per row -> dx
+    (N,H,W,Cin) bf16 (fp32 with out_f32).  tap: as conv2d_bwd_data_b16; returns (dx, partials | None) then."""
+    import ctypes
+    n, ho, wo, cout = dy8.shape
+    h, wd = in_hw
+    if not (dy8.dtype == torch.uint8 and dy8.is_contiguous() and wt8.dtype == torch.uint8 and wt8.is_contiguous()
+            and wt8.numel() == cin * ksize * ksize * cout and dys.numel() == n * ho * wo and wts.numel() == cin):
+        raise ValueError("conv2d_bwd_data_f8: dy8 / wt8 must be contiguous uint8 e4m3 tensors with one e8m0 byte per pixel / per bank row")
+    if out is None:
+        out = torch.empty((n, h, wd, cin), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dy8.device)
+    if out.dtype != (torch.float32 if out_f32 else torch.bfloat16) or not out.is_contiguous():
+        raise ValueError("conv2d_bwd_data_f8: out dtype / layout")
+    part = None
+    rows = ctypes.c_int(0)
+    cap = 0
+    if tap is not None and stride == 1 and _b16(tap["y"]) and tap["y"].is_contiguous():
+        cap = lib().conv2d_stats_rows_f8(n, h, wd, cin, ksize, 1)
+        part = torch.empty((max(cap, 1), 2, cin), dtype=torch.float32, device=dy8.device)
+    lib().conv2d_bwd_data_f8(dy8.data_ptr(), dys.data_ptr(), wt8.data_ptr(), wts.data_ptr(), out.data_ptr(), int(out_f32), n, h, wd, cin, cout, ksize,
+                             stride, int(accumulate), tap["y"].data_ptr() if cap else 0, tap["mean"].data_ptr() if cap else 0,
+                             tap["invstd"].data_ptr() if cap else 0, _p(tap.get("gamma")) if cap else 0, _p(tap.get("beta")) if cap else 0,
+                             int(tap["act"]) if cap else 0, float(tap["slope"]) if cap else 0.0, part.data_ptr() if cap else 0, cap,
+                             ctypes.addressof(rows), _s())
     if tap is not None:
         return out, (part[:rows.value] if rows.value > 0 else None)
     return out

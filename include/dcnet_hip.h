@@ -38,7 +38,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 306
+#define DCN_ABI_VERSION 307
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -493,6 +493,30 @@ int dcn_upsample2_nhwc_b16(const void* src, int lds, void* dst, int ldd, int n, 
 int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc, int lds, int n, int h, int w, int c, int accumulate,
                                void* stream);
 
+/* ---- fp8 storage (BASELINE.json configs[4], ABI 307) ----------------------------------------------------------------------
+ * Forward and data gradient of the convolutions on OCP e4m3 operands that ARE 1-byte tensors in HBM, each row carrying ONE e8m0 scale
+ * (the OCP MX scale, with the block = the row: a pixel's channel vector for activations and gradients, a filter's k*k*Cin coefficients
+ * for the banks), multiplied by v_mfma_scale_f32_32x32x64_f8f6f4 (2 x the bf16 matrix rate, half the staged bytes per product), fp32
+ * accumulate; results, shortcut, BatchNorm tap and statistics as in the bf16-storage functions above (bf16 tensors, fp32 sums).  Replaces
+ * nn.Conv2d of model/darknet.py:172-191 and its input gradient under train_DCNet.py:645 for layers with cin % 64 == 0; the weight
+ * gradient stays on bf16 tensors.  The reference has no fp8 semantics: parity is defined against the exact model —
+ * the same convolution in fp64 on the dequantised operands — in tests/test_f8_gpu.py. */
+/* q[r][:c] = e4m3(x[r][:c] * 2^-e_r) (round to nearest even, clamped to +-448), scales[r] = e_r + 127 with e_r = floor(log2(max|x[r]|)) - 8
+ * (all-zero row: 127); x bf16, element strides ld / ldq, c % 8 == 0. */
+int dcn_quant_rows_e4m3(const void* x, int ld, int64_t rows, int c, void* q, int ldq, void* scales, void* stream);
+int dcn_conv2d_stats_rows_f8(int n, int h, int wd, int cout, int ksize, int stride);
+/* y (bf16 | fp32) = epilogue(conv(x8 * 2^(xs - 127), w8 * 2^(ws - 127))): x8 [n][h][wd][cin] e4m3, xs [n*h*wd] e8m0, w8 [cout][k*k*cin] e4m3,
+ * ws [cout] e8m0; epilogue and stats as dcn_conv2d_fwd_b16 (rows: dcn_conv2d_stats_rows_f8). */
+int dcn_conv2d_fwd_f8(const void* x8, const void* xs, const void* w8, const void* ws, void* y, int y_f32, int n, int h, int wd, int cin, int cout,
+                      int ksize, int stride, const float* scale, const float* shift, int act, float slope, const void* residual, int ldr,
+                      int ldy, float* stats, int accumulate, void* stream);
+/* dx (bf16 | fp32) (+)= conv^T(dy8, wt8): dy8 [n][ho][wo][cout] e4m3 (dense) with dys per pixel, wt8 [cin][k*k*cout] e4m3 with wts per row;
+ * tap_* as dcn_conv2d_bwd_data_b16 (y bf16). */
+int dcn_conv2d_bwd_data_f8(const void* dy8, const void* dys, const void* wt8, const void* wts, void* dx, int dx_f32, int n, int h, int wd, int cin,
+                           int cout, int ksize, int stride, int accumulate, const void* tap_y, const float* tap_mean, const float* tap_invstd,
+                           const float* tap_gamma, const float* tap_beta, int tap_act, float tap_slope, float* tap_stats, int tap_stats_rows,
+                           int* tap_rows, void* stream);
+
 /* ---- top-k candidate cache + temporal post-processing of the inference path (ABI 305) ----------------------------- */
 /* test_DCNet.py:587-643,662-705 (save_cache / get_topk_pred_bbox): per clip b of n, the top_k (<= 64) largest modulated
  * confidences over 3 scales x 3 anchors x g x g of outbox[s] [n][15][g][g] (contiguous; grids[s] = size / (32 >> s)), sorted
@@ -623,7 +647,7 @@ int dcn_stream_priority_range(int* least, int* greatest);
 
 /* ---- optional kernel profiler (HIP events on the launch stream) -------------------------------- */
 /* dcn_prof_enable(1) starts a recording window, (0) stops it; dcn_prof_collect waits for the events and
- * returns, per kernel tag (40 slots; 24-27 = f16 two-piece split tiles: igemm 128x128 / wgrad / igemm 256x64 / NN; 28/29 = conv3 strip
+ * returns, per kernel tag (DCN_PROF_TAGS = 56 slots: size the arrays for 64; 24-27 = f16 two-piece split tiles: igemm 128x128 / wgrad / igemm 256x64 / NN; 28/29 = conv3 strip
  * kernel 256x128 / 128x128, 30 = reduce_slabs, 31 = dA, 32 = wgrad3; 15 = 128x128 NT tile with the 32-float K-step, 16 = split-bf16 128x128 NT
  * tile, 17 = split-bf16 128x128 weight-gradient / TN tile; 0-2 conv-engine NT tiles 128x128/128x64/256x32, 3-4 NN tiles,
  * 5 weight-gradient/TN GEMM, 6-7 64x128 tiles, 8/9 l2norm+score fwd/bwd, 10 scale_act, 11 BN backward,

@@ -52,20 +52,25 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile2b", [0, 1])
+@pytest.mark.parametrize("tile2b", [0, 1, 2])
 @pytest.mark.parametrize("case", CASES)
 def test_b16_conv_forward_dgrad_wgrad_match_their_exact_model(case, tile2b):
     """tile2b = 1: every launch with a multiple of 256 filters is forced onto conv2b.hip's 256 x 256 eight-wave tile (knob `2btile`: it takes
-    them from 256 tiles on by default, which only the full-size layers reach); 0: conv1.hip's conv1b tiles."""
+    them from 256 tiles on by default, which only the full-size layers reach); 0: conv1.hip's conv1b tiles; 2: the 3x3 stride-1 launches on
+    conv3.hip's strip kernel in its bf16-storage form (knob `3h16`, off by default: it measured slower than the gathered tiles)."""
     from dcnet_amd import ops
     from dcnet_amd.lib import lib
-    if tile2b and case[3] % 256 and case[4] % 256:
+    if tile2b == 1 and case[3] % 256 and case[4] % 256:
         pytest.skip("no launch of this case has a multiple of 256 filters")
-    lib().set_tuning(b"2btile", -1 if tile2b else 0)
+    if tile2b == 2 and not (case[5] == 3 and case[6] == 1 and max(case[3], case[4]) > 64):
+        pytest.skip("no 3x3 stride-1 launch with more than 64 filters in this case")
+    lib().set_tuning(b"2btile", -1 if tile2b == 1 else 0)
+    lib().set_tuning(b"3h16", 1 if tile2b == 2 else 0)
     try:
         _conv_case(case)
     finally:
         lib().set_tuning(b"2btile", 256)
+        lib().set_tuning(b"3h16", 0)
 
 
 def _conv_case(case):

@@ -402,10 +402,12 @@ def test_eval_mode_backward_and_argument_errors(dev):
         grounding_model(corpus=None)                                        # BERT encoder is out of scope
 
 
-@pytest.mark.parametrize("mode,box_tol,loss_tol,min_cos", [("bf16", 0.35, 0.25, 0.8), ("bf16s", 0.5, 0.3, 0.7), ("fp8", 1.0, 0.5, None)])
+@pytest.mark.parametrize("mode,box_tol,loss_tol,min_cos", [("bf16", 0.35, 0.25, 0.8), ("bf16s", 0.5, 0.3, 0.7), ("fp8", 1.0, 0.5, None),
+                                                           ("fp8s", 1.0, 0.5, None)])
 def test_reduced_precision_modes_end_to_end(dev, mode, box_tol, loss_tol, min_cos):
     """configs[2] (bf16 operands on fp32 tensors; "bf16s": bf16 STORAGE — the conv stacks' activations, raw outputs and gradients
-    are bf16 tensors, tests/test_b16_gpu.py) and configs[4] (fp8 e4m3 operands, bf16 weight gradient) on the matrix pipe, fp32
+    are bf16 tensors, tests/test_b16_gpu.py) and configs[4] (fp8 e4m3 operands, bf16 weight gradient; "fp8s": fp8 STORAGE with row scales
+    for the 3x3 layers' forward / data gradient on the block-scaled MFMA, tests/test_f8_gpu.py) on the matrix pipe, fp32
     accumulate: the kernels are checked against their exact models in test_ops_gpu.py / test_b16_gpu.py; here the whole
     model runs in those modes.  The reference has no such semantics and the synthetic random-init network amplifies an
     operand rounding over ~75 layers (measured at 256^2 — bf16: outbox differs from fp32 by up to 1.0 on a scale of

@@ -816,7 +816,7 @@ def test_conv1_lds_dma_kernel(dev, case):
         lib().prof_enable(1)
         run()
         lib().prof_enable(0)
-        c = (ctypes.c_int64 * 48)(); m = (ctypes.c_double * 48)(); wk = (ctypes.c_double * 48)()
+        c = (ctypes.c_int64 * 64)(); m = (ctypes.c_double * 64)(); wk = (ctypes.c_double * 64)()
         lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
         return c[35]
 
@@ -1389,7 +1389,7 @@ def _prof_launches(tag):
     """launches booked under a profiling tag since dcn_prof_enable(1) (csrc/prof.h)"""
     import ctypes
     from dcnet_amd.lib import lib
-    c = (ctypes.c_int64 * 48)(); m = (ctypes.c_double * 48)(); wk = (ctypes.c_double * 48)()
+    c = (ctypes.c_int64 * 64)(); m = (ctypes.c_double * 64)(); wk = (ctypes.c_double * 64)()
     lib().prof_collect(ctypes.addressof(c), ctypes.addressof(m), ctypes.addressof(wk), 0)
     return c[tag]
 

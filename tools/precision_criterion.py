@@ -79,7 +79,7 @@ def main():
     res = {}
     m.eval()
     try:
-        for mode in ("fp32", "bf16", "bf16s", "fp8"):
+        for mode in ("fp32", "bf16", "bf16s", "fp8", "fp8s"):
             ops.set_precision(mode)
             with torch.no_grad():
                 outbox = [o.float() for o in m(image, word_id, word_mask)[0]]
@@ -96,7 +96,7 @@ def main():
     out["fp32"] = {"acc_at_0.5_vs_gt": float((f["iou_gt"] > 0.5).float().mean()), "mean_iou_vs_gt": float(f["iou_gt"].mean()),
                    "conf_margin_top1_minus_top2_min": float((top2[:, 0] - top2[:, 1]).min()),
                    "conf_margin_top1_minus_top2_median": float((top2[:, 0] - top2[:, 1]).median())}
-    for mode in ("bf16", "bf16s", "fp8"):
+    for mode in ("bf16", "bf16s", "fp8", "fp8s"):
         r = res[mode]
         iou = losses.bbox_iou(r["boxes"], f["boxes"])
         same = (r["cell"] == f["cell"])
@@ -161,7 +161,7 @@ def main():
     # the other question of configs[2] / configs[4]: does TRAINING in the mode reach the same accuracy?  Same initial weights,
     # same data and schedule, every step in the mode; evaluated in the mode against the ground truth.
     out["trained_in_mode"] = {}
-    for mode in (() if args.no_train_in_mode else ("bf16", "bf16s", "fp8")):
+    for mode in (() if args.no_train_in_mode else ("bf16", "bf16s", "fp8", "fp8s")):
         try:
             ops.set_precision(mode)
             m2 = build_product(size, synth_sd(size), dev)
