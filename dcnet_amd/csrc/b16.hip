@@ -61,12 +61,37 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const TS* __restrict__ s
   }
 }
 
+// fp8 storage: the e4m3 copy of a row while it is written (the row = c8 consecutive lanes of one wave, 8 channels each; c8 a power of two
+// <= 64): the arithmetic of quant_rows_e4m3_kernel below on the values AS STORED in bf16, so the copy equals that pass on the stored tensor.
+__device__ __forceinline__ void quant8_row(const float* vals /* 8, already rounded to bf16 */, int c8, bool row_leader,
+                                           unsigned char* __restrict__ qdst, unsigned char* __restrict__ sdst) {
+  float amax = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(vals[k]));
+  for (int d = 1; d < c8; d <<= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+  int e = 0;
+  const unsigned ab = __float_as_uint(amax);
+  if (amax > 0.f && (ab >> 23) != 0xFFu) e = (int)(ab >> 23) - 127 - 8;
+  e = e < -126 ? -126 : (e > 126 ? 126 : e);
+  const float inv = __uint_as_float((unsigned)(127 - e) << 23);
+  if (row_leader) *sdst = (unsigned char)(e + 127);
+  float f[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(vals[k] * inv, -448.f), 448.f);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  *reinterpret_cast<uint2*>(qdst) = uint2{(unsigned)lo, (unsigned)hi};
+}
+
 // ---- out = act(scale * y + shift) + residual   (y: raw conv output, fp32 for the stem, bf16 elsewhere; out, residual: bf16) ------
-template <typename TY, typename TO>
+template <typename TY, typename TO, bool Q = false>
 __global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act, float slope,
                                                           const __bf16* __restrict__ residual, int ldr, TO* __restrict__ out,
-                                                          int64_t rows, int c, int ldo) {
+                                                          int64_t rows, int c, int ldo, unsigned char* __restrict__ q8 = nullptr,
+                                                          unsigned char* __restrict__ qs = nullptr) {
   const int c8 = c >> 3;
   const int64_t total = rows * c8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -79,7 +104,7 @@ __global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__
     if (shift) sh = ld8<float>(shift + ch);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float t = v.v[k] * sc.v[k] + sh.v[k];
+      float t = __builtin_fmaf(v.v[k], sc.v[k], sh.v[k]);      // (spelled out: the same rounding in every instantiation)
       if (act == DCN_ACT_LEAKY) t = t > 0.f ? t : t * slope;
       v.v[k] = t;
     }
@@ -89,15 +114,22 @@ __global__ __launch_bounds__(256) void scale_act16_kernel(const TY* __restrict__
       for (int k = 0; k < 8; ++k) v.v[k] += rr.v[k];
     }
     st8<TO>(out + r * ldo + ch, v);
+    if constexpr (Q) {
+      float vr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) vr[k] = (float)(__bf16)v.v[k];
+      quant8_row(vr, c8, ch == 0, q8 + r * c + ch, qs + r);
+    }
   }
 }
 
 // ---- dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * act'(bn(y))   (bn.hip bn_act_bwd_apply_kernel) --------
-template <typename TY, typename TD>
+template <typename TY, typename TD, bool Q = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restrict__ y, const TD* __restrict__ dout, int lddo,
                                                              const float* mean, const float* invstd, const float* gamma, const float* beta,
                                                              int act, float slope, const float* sums, float inv_count, int64_t rows, int c,
-                                                             __bf16* __restrict__ dy) {
+                                                             __bf16* __restrict__ dy, unsigned char* __restrict__ q8 = nullptr,
+                                                             unsigned char* __restrict__ qs = nullptr) {
   const int c8 = c >> 3;
   const int64_t total = rows * c8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -112,14 +144,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restric
     if (beta) b = ld8<float>(beta + ch);
     const F8 sg = ld8<float>(sums + ch), sgx = ld8<float>(sums + c + ch);
     F8 o;
+    {
+      // (no FMA contraction: the Q build of this kernel must round exactly like the plain one — with contraction left to the optimiser the two
+      //  instantiations differed in the last bit of one element in ten thousand)
+#pragma clang fp contract(off)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (v.v[k] - mu.v[k]) * is.v[k];
-      float dd = d.v[k];
-      if (act == DCN_ACT_LEAKY && (g.v[k] * xh + b.v[k]) <= 0.f) dd *= slope;
-      o.v[k] = g.v[k] * is.v[k] * (dd - sg.v[k] * inv_count - xh * sgx.v[k] * inv_count);
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v.v[k] - mu.v[k]) * is.v[k];
+        float dd = d.v[k];
+        if (act == DCN_ACT_LEAKY && (g.v[k] * xh + b.v[k]) <= 0.f) dd *= slope;
+        o.v[k] = g.v[k] * is.v[k] * (dd - sg.v[k] * inv_count - xh * sgx.v[k] * inv_count);
+      }
     }
     st8<__bf16>(dy + r * c + ch, o);
+    if constexpr (Q) {
+      float vr[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) vr[k] = (float)(__bf16)o.v[k];
+      quant8_row(vr, c8, ch == 0, q8 + r * c + ch, qs + r);
+    }
   }
 }
 
@@ -255,6 +298,40 @@ extern "C" int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, c
 #undef DCN_SA
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("scale_act_b16");
+  return DCN_OK;
+}
+
+// fp8 storage: can the e4m3 copy of a [rows][c] bf16 tensor be written by the pass that writes the tensor?  (a row inside one wave)
+extern "C" int dcn_quant_fusable(int c) { return (c % 8 == 0 && c / 8 <= 64 && ((c / 8) & (c / 8 - 1)) == 0) ? 1 : 0; }
+
+// dcn_scale_act_b16 on bf16 y / out (dense), writing the e4m3 copy of `out` (q8 [rows][c], qs [rows]: dcn_quant_rows_e4m3's result) as well
+extern "C" int dcn_scale_act_b16_q(const void* y, const float* scale, const float* shift, int act, float slope, const void* residual, int ldr,
+                                   void* out, int64_t rows, int c, void* q8, void* qs, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ldr <= 0) ldr = c;
+  DCN_CHECK_ARG(y && out && q8 && qs && rows > 0 && dcn_quant_fusable(c) && ldr % 8 == 0, "scale_act_b16_q: bad argument (c=%d)", c);
+  const int pid = prof_begin(43, (double)rows * c * (2.0 + 2.0 + 1.0 + (residual ? 2.0 : 0.0)), stream);
+  hipLaunchKernelGGL((scale_act16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y, scale, shift, act,
+                     slope, (const __bf16*)residual, ldr, (__bf16*)out, rows, c, c, (unsigned char*)q8, (unsigned char*)qs);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("scale_act_b16_q");
+  return DCN_OK;
+}
+
+// dcn_bn_act_bwd_apply_b16 on bf16 y / dout, writing the e4m3 copy of dy as well
+extern "C" int dcn_bn_act_bwd_apply_b16_q(const void* y, const void* dout, int lddo, const float* mean, const float* invstd, const float* gamma,
+                                          const float* beta, int act, float slope, const float* sums, int64_t count, int64_t rows, int c, void* dy,
+                                          void* q8, void* qs, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (lddo <= 0) lddo = c;
+  DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && q8 && qs && rows > 0 && dcn_quant_fusable(c) && lddo % 8 == 0 && count > 0,
+                "bn_act_bwd_apply_b16_q: bad argument (c=%d)", c);
+  const int pid = prof_begin(45, (double)rows * c * 7.0, stream);
+  hipLaunchKernelGGL((bn_bwd_apply16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y,
+                     (const __bf16*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy,
+                     (unsigned char*)q8, (unsigned char*)qs);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("bn_act_bwd_apply_b16_q");
   return DCN_OK;
 }
 

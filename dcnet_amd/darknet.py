@@ -360,7 +360,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     raise RuntimeError("bf16 storage needs the prepared filter banks (ops.FILTER_BANKS) for every layer behind the stem")
                 use8 = ops.f8_takes(op.cin, op.cout, op.k)          # "fp8s": this layer's forward on e4m3 operands (quantised here, once)
                 if use8:
-                    x8, xs = ops.quant_rows_e4m3(x)
+                    x8, xs = ops.quant_of(x)                         # (the copy scale_act wrote beside x, else a pass now)
                     w8, ws = ops.quant_rows_e4m3(bank["b16"].view(op.cout, -1))
                 if op.bn and training:
                     if use8:
@@ -368,7 +368,10 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                     else:
                         y, stats = ops.conv2d_fwd_b16(x, bank["b16"], op.cout, op.k, op.stride, want_stats=True)
                     mi = ops.bn_finalize(stats, y.numel() // op.cout, p["gamma"], p["beta"], 1e-5, p["momentum"], p["rm"], p["rv"])
-                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res)
+                    # "fp8s": a reader that takes e4m3 operands gets its copy from this pass (no quantisation pass of its own)
+                    q_ = ops.storage_f8() and any(isinstance(r_, _ConvOp) and r_.src == op.dst and ops.f8_takes(r_.cin, r_.cout, r_.k)
+                                                  for r_ in readers.get(op.dst, []))
+                    o = ops.scale_act(y, mi[2], mi[3], act, 0.1, residual=res, quant=q_)
                     if save is not None:
                         save[op.slot] = (x, y, mi, w, None, None)
                 else:
@@ -530,7 +533,8 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                 mi = aux
                 dy, dgamma, dbeta = ops.bn_act_bwd(y, dout, mi[0], mi[1], p["gamma"], p["beta"],
                                                    ops.ACT_LEAKY if op.leaky else ops.ACT_NONE, 0.1, amax_out=ady,
-                                                   part=tapped.pop(op.slot, None))
+                                                   part=tapped.pop(op.slot, None),
+                                                   quant=bool(op.need_dx) and ops.f8_takes(op.cout, op.cin, op.k))      # ("fp8s": dy's e4m3 copy for the data gradient)
                 d["gamma"], d["beta"] = dgamma, dbeta
             else:
                 # frozen statistics: y holds act(scale*conv+shift) before the shortcut add
@@ -565,7 +569,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                         tap = dict(y=y_prev, mean=mi_prev[0], invstd=mi_prev[1], gamma=P[prev.slot]["gamma"], beta=P[prev.slot]["beta"],
                                    act=ops.ACT_LEAKY if prev.leaky else ops.ACT_NONE, slope=0.1)
                 if ops.f8_takes(op.cout, op.cin, op.k) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
-                    dy8, dys = ops.quant_rows_e4m3(dy)
+                    dy8, dys = ops.quant_of(dy)
                     wt8, wts = ops.quant_rows_e4m3(getattr(w, "_dcn_wt16").view(op.cin, -1))
                     res_ = ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
                                                   out=cur, accumulate=cur is not None, tap=tap)

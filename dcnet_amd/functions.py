@@ -34,7 +34,7 @@ class ConvBNAct(torch.autograd.Function):
             x16 = ops.to_b16(x.contiguous())
             use8 = ops.f8_takes(x16.shape[3], cout, ksize)          # "fp8s": the head's 3x3 block on e4m3 operands
             if use8:
-                x8, xs = ops.quant_rows_e4m3(x16)
+                x8, xs = ops.quant_of(x16)
                 w8, ws = ops.quant_rows_e4m3(bank["b16"].view(cout, -1))
             if training and use8:
                 y, stats = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, cout, ksize, 1, want_stats=True)
@@ -94,12 +94,13 @@ class ConvBNAct(torch.autograd.Function):
             x16, y, mi, gamma, beta = ctx.saved_tensors
             ksize, training, slope, wshape = ctx.meta
             tb16, x_f32 = ctx.b16
-            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout.contiguous(), mi[0], mi[1], gamma.detach(), beta.detach(), ops.ACT_LEAKY, slope)
+            dy, dgamma, dbeta = ops.bn_act_bwd(y, dout.contiguous(), mi[0], mi[1], gamma.detach(), beta.detach(), ops.ACT_LEAKY, slope,
+                                               quant=ctx.needs_input_grad[0] and ops.f8_takes(y.shape[3], x16.shape[3], ksize))
             dx = None
 
             def dgrad():
                 if ops.f8_takes(dy.shape[3], x16.shape[3], ksize) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
-                    dy8, dys = ops.quant_rows_e4m3(dy)
+                    dy8, dys = ops.quant_of(dy)
                     wt8, wts = ops.quant_rows_e4m3(tb16.view(x16.shape[3], -1))
                     return ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
                 return ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)

@@ -142,6 +142,9 @@ SIGNATURES = {
     "dcn_upsample2_nhwc_b16": (I, [P, I, P, I, I, I, I, I, P]),
     "dcn_upsample2_nhwc_bwd_b16": (I, [P, I, P, I, I, I, I, I, I, P]),
     "dcn_quant_rows_e4m3": (I, [P, I, L, I, P, I, P, P]),
+    "dcn_quant_fusable": (I, [I]),
+    "dcn_scale_act_b16_q": (I, [P, P, P, I, F, P, I, P, L, I, P, P, P]),
+    "dcn_bn_act_bwd_apply_b16_q": (I, [P, P, I, P, P, P, P, I, F, P, L, L, I, P, P, P, P]),
     "dcn_conv2d_stats_rows_f8": (I, [I, I, I, I, I, I]),
     "dcn_conv2d_fwd_f8": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P]),
     "dcn_conv2d_bwd_data_f8": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, F, P, I, P, P]),
@@ -150,7 +153,7 @@ SIGNATURES = {
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
                 "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records",
-                "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16", "dcn_conv2d_stats_rows_f8"}
+                "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16", "dcn_conv2d_stats_rows_f8", "dcn_quant_fusable"}
 ABI_VERSION = 307        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 

@@ -861,9 +861,27 @@ def channel_stats(x2d):
     return stats
 
 
-def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None, out_b16=False, out_f32=False):
+def quant_of(x: torch.Tensor):
+    """(q8, scales) of a bf16 tensor for the fp8-storage convolutions: the copy its producing pass wrote beside it (scale_act / bn_act_bwd
+    with quant=True), else a quantisation pass now."""
+    q = getattr(x, "_dcn_q8", None)
+    return q if q is not None else quant_rows_e4m3(x)
+
+
+def scale_act(y, scale, shift, act, slope, residual=None, out=None, amax_out=None, out_b16=False, out_f32=False, quant=False):
+    """quant (fp8 storage): also write the e4m3 copy of the bf16 result, attached to it as ``out._dcn_q8 = (q8, scales)`` (quant_of)."""
     c = y.shape[-1]
     rows = y.numel() // c
+    if quant and _b16(y) and out is None and not out_f32 and y.is_contiguous() and lib().quant_fusable(c) and (residual is None or _b16(residual)):
+        out = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+        q8 = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
+        qs = torch.empty(rows, dtype=torch.uint8, device=y.device)
+        if residual is not None:
+            _rows16(residual, "scale_act residual")
+        lib().scale_act_b16_q(y.data_ptr(), _p(scale), _p(shift), act, float(slope), _p(residual), 0 if residual is None else residual.stride(-2),
+                              out.data_ptr(), rows, c, q8.data_ptr(), qs.data_ptr(), _s())
+        out._dcn_q8 = (q8, qs)
+        return out
     if _b16(y) or out_b16 or _b16(out):
         # bf16 storage (csrc/b16.hip): y bf16 (fp32 for the stem's raw output), residual bf16, out bf16 (fp32 with out_f32: the boundary
         # to an fp32 consumer)
@@ -904,7 +922,7 @@ def _bn_bwd_partials(y, dout, mean, invstd, gamma, beta, act, slope, part):
     return part, r
 
 
-def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, part=None):
+def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, part=None, quant=False):
     """Returns (dy, dgamma, dbeta) for out = act(gamma*(y-mean)*invstd+beta) with batch statistics; amax_out: word that
     receives the abs-max of dy (the A operand of the data / weight gradient GEMMs that follow); part: partial sums already
     formed by the launch that produced dout (conv2d_bwd_data(tap=...))."""
@@ -918,6 +936,13 @@ def bn_act_bwd(y, dout, mean, invstd, gamma, beta, act, slope, amax_out=None, pa
     lib().bn_bwd_sums(part.data_ptr(), r, c, sums.data_ptr(), ws.data_ptr(), _s())
     if _b16(dout) or _b16(y):          # bf16 storage: dy bf16 (y bf16, or the stem's fp32 raw output; dout bf16, or fp32 at the boundary)
         dy = torch.empty(y.shape, dtype=torch.bfloat16, device=dev)
+        if quant and _b16(y) and _b16(dout) and lib().quant_fusable(c):       # fp8 storage: the e4m3 copy of dy from the same pass (quant_of)
+            q8 = torch.empty(y.shape, dtype=torch.uint8, device=dev)
+            qs = torch.empty(rows, dtype=torch.uint8, device=dev)
+            lib().bn_act_bwd_apply_b16_q(y.data_ptr(), dout.data_ptr(), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma), _p(beta), act, float(slope),
+                                         sums.data_ptr(), rows, rows, c, dy.data_ptr(), q8.data_ptr(), qs.data_ptr(), _s())
+            dy._dcn_q8 = (q8, qs)
+            return dy, sums[1], sums[0]
         lib().bn_act_bwd_apply_b16(y.data_ptr(), int(not _b16(y)), dout.data_ptr(), int(not _b16(dout)), lddo, mean.data_ptr(), invstd.data_ptr(), _p(gamma),
                                    _p(beta), act, float(slope), sums.data_ptr(), rows, rows, c, dy.data_ptr(), _s())
         return dy, sums[1], sums[0]

@@ -504,6 +504,14 @@ int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc, int lds, i
 /* q[r][:c] = e4m3(x[r][:c] * 2^-e_r) (round to nearest even, clamped to +-448), scales[r] = e_r + 127 with e_r = floor(log2(max|x[r]|)) - 8
  * (all-zero row: 127); x bf16, element strides ld / ldq, c % 8 == 0. */
 int dcn_quant_rows_e4m3(const void* x, int ld, int64_t rows, int c, void* q, int ldq, void* scales, void* stream);
+/* The same bytes written by the pass that writes the bf16 tensor (c / 8 a power of two <= 64: dcn_quant_fusable): dcn_scale_act_b16 /
+ * dcn_bn_act_bwd_apply_b16 on dense bf16 tensors, plus q8 [rows][c] and qs [rows] of their result. */
+int dcn_quant_fusable(int c);
+int dcn_scale_act_b16_q(const void* y, const float* scale, const float* shift, int act, float slope, const void* residual, int ldr, void* out,
+                        int64_t rows, int c, void* q8, void* qs, void* stream);
+int dcn_bn_act_bwd_apply_b16_q(const void* y, const void* dout, int lddo, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, int act, float slope, const float* sums, int64_t count, int64_t rows, int c, void* dy,
+                               void* q8, void* qs, void* stream);
 int dcn_conv2d_stats_rows_f8(int n, int h, int wd, int cout, int ksize, int stride);
 /* y (bf16 | fp32) = epilogue(conv(x8 * 2^(xs - 127), w8 * 2^(ws - 127))): x8 [n][h][wd][cin] e4m3, xs [n*h*wd] e8m0, w8 [cout][k*k*cin] e4m3,
  * ws [cout] e8m0; epilogue and stats as dcn_conv2d_fwd_b16 (rows: dcn_conv2d_stats_rows_f8). */

@@ -137,3 +137,31 @@ def test_f8_conv_forward_and_data_gradient_match_their_exact_model(case):
         sums = part.double().sum(0).cpu()
         assert torch.allclose(sums[0], g.reshape(-1, cin).sum(0), rtol=1e-4, atol=1e-4 * float(g.abs().reshape(-1, cin).sum(0).max()))
         assert torch.allclose(sums[1], (g * xh).reshape(-1, cin).sum(0), rtol=1e-4, atol=1e-4 * float((g * xh).abs().reshape(-1, cin).sum(0).max()))
+
+
+@pytest.mark.parametrize("c", [64, 128, 256, 512])
+def test_fused_quantisers_equal_the_pass_on_the_stored_tensor(c):
+    """scale_act / bn_act_bwd with quant=True write the e4m3 copy of their bf16 result in the same pass: bit for bit what
+    dcn_quant_rows_e4m3 makes of that result, and the bf16 result itself unchanged."""
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    n, h, w = 3, 9, 11
+    y = _bf(_rand(n, h, w, c, seed=1) * torch.logspace(-2, 1, n * h * w).reshape(n, h, w, 1)).to(dev)
+    res = _bf(_rand(n, h, w, c, seed=2)).to(dev)
+    sc = (_rand(c, seed=3).abs() + 0.5).to(dev); sh = _rand(c, seed=4).to(dev)
+    for r_ in (None, res):
+        plain = ops.scale_act(y, sc, sh, ops.ACT_LEAKY, 0.1, residual=r_)
+        fused = ops.scale_act(y, sc, sh, ops.ACT_LEAKY, 0.1, residual=r_, quant=True)
+        assert torch.equal(plain, fused) and getattr(fused, "_dcn_q8", None) is not None
+        q, s = ops.quant_rows_e4m3(plain)
+        assert torch.equal(fused._dcn_q8[0], q) and torch.equal(fused._dcn_q8[1], s)
+        assert ops.quant_of(fused)[0] is fused._dcn_q8[0]
+    dout = _bf(_rand(n, h, w, c, seed=5) / 16).to(dev)
+    mean = (_rand(c, seed=6) * 0.1).to(dev); invstd = (_rand(c, seed=7).abs() + 0.5).to(dev)
+    dy0, dg0, db0 = ops.bn_act_bwd(y, dout, mean, invstd, sc, sh, ops.ACT_LEAKY, 0.1)
+    dy1, dg1, db1 = ops.bn_act_bwd(y, dout, mean, invstd, sc, sh, ops.ACT_LEAKY, 0.1, quant=True)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    nd = int((dy0 != dy1).sum())
+    assert nd == 0, (nd, float((dy0.float() - dy1.float()).abs().max()), float(dy0.float().abs().max()))
+    q, s = ops.quant_rows_e4m3(dy0)
+    assert torch.equal(dy1._dcn_q8[0], q) and torch.equal(dy1._dcn_q8[1], s)
