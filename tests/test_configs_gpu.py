@@ -208,3 +208,44 @@ def test_bf16_storage_box_criterion_on_trained_weights(dev):
     assert float(iou.min()) > 0.90 and float(iou.mean()) > 0.96, iou
     met = int(((iou >= 0.95) & same).sum())
     assert 11 <= met <= 16, (met, iou)               # measured: 12 (min 0.908, mean 0.965); >= 15 would be the criterion of SURVEY 8(c)
+
+
+def test_fp8_storage_config_at_full_workload(dev):
+    """BASELINE.json configs[4] proper at ITS workload — 256 images of 416 x 416 (batch 32 clips x T 8), ``ops.set_precision("fp8s")``: the 3x3
+    layers' forward and data gradient on e4m3 tensors with row scales (block-scaled MFMA), everything else on bf16 storage.  Size-independent
+    properties, as for the other reduced-precision configs: the layer kernels against their exact model AT this batch size (fp64 cannot hold
+    it: the bf16-storage kernel on the dequantised operands is the model, itself pinned against fp64 in tests/test_b16_gpu.py), and a whole
+    training step finite, live (differs from the bf16-storage step) and bitwise repeatable."""
+    from dcnet_amd import ops
+    from dcnet_amd.utils.synth import synth_boxes, synth_inputs
+    size, n_img = 416, 256
+    try:
+        ops.set_precision("fp8s")
+        g = torch.Generator().manual_seed(3)
+        for (h, cin, cout, k, st) in ((52, 128, 256, 3, 1), (26, 256, 512, 3, 1), (104, 128, 256, 3, 2)):
+            x = (torch.randn(n_img, h, h, cin, generator=g) * torch.logspace(-1, 1, n_img).reshape(-1, 1, 1, 1)).to(dev).bfloat16()
+            w = (torch.randn(cout, k * k * cin, generator=g) / (cin * k * k) ** 0.5).to(dev).bfloat16()
+            x8, xs = ops.quant_rows_e4m3(x); w8, ws = ops.quant_rows_e4m3(w)
+            # dequantised operands are exactly representable in bf16 (4 significant bits x a power of two): conv1b on them is the exact model
+            xd = (x8.view(torch.float8_e4m3fn).float() * torch.exp2(xs.float() - 127).reshape(n_img, h, h, 1)).bfloat16()
+            wd = (w8.view(torch.float8_e4m3fn).float() * torch.exp2(ws.float() - 127).reshape(cout, 1)).bfloat16()
+            ref, _ = ops.conv2d_fwd_b16(xd, wd.reshape(-1), cout, k, st, out_f32=True)
+            got, _ = ops.conv2d_fwd_f8(x8, xs, w8.reshape(-1), ws, cout, k, st, out_f32=True)
+            assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), ((h, cin, cout, k, st), float((got - ref).abs().max()))
+            plain, _ = ops.conv2d_fwd_b16(x, w.reshape(-1), cout, k, st, out_f32=True)
+            assert float((got - plain).abs().max()) > 1e-3 * float(plain.abs().max())          # it IS the fp8 path
+            del x, w, x8, w8, xd, wd, ref, got, plain
+        sd = synth_sd(size)
+        image, word_id, word_mask = (t.to(dev) for t in synth_inputs(n_img, size, seed=n_img))
+        bbox = synth_boxes(n_img, size, seed=n_img).to(dev)
+        m = build_product(size, sd, dev).train()
+        a, finite_a, parts = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        b, finite_b, _ = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        assert finite_a and finite_b and all(v == v and abs(v) < 1e6 for v in parts.values()), parts
+        for x_, y_ in zip(a, b):
+            assert torch.isfinite(x_).all() and torch.equal(x_, y_)
+        ops.set_precision("bf16s")
+        c, _, _ = _train_step(m, sd, image, word_id, word_mask, bbox, size)
+        assert not torch.equal(a[0], c[0])                                                       # live: not the bf16-storage step
+    finally:
+        ops.set_precision("fp32")
