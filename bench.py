@@ -78,8 +78,8 @@ PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if
 # passes with them
 RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>"],
             26: ["igemm_kernel<256,64,4,1,0,false,16,true,0,2,", "igemm_kernel<256,32,4,1,0,false,16,true,0,2,"],
-            27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"],
-            29: ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
+            27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,"],
+            29: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
             36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
 FAMILY = {28: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)"}
 NT = 56            # DCN_PROF_TAGS

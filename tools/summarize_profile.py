@@ -142,9 +142,12 @@ def main():
                 shutil.copy(est, os.path.join(prof, f"{tag}_{a.name}_eager_kernel_stats.csv"))
                 if os.path.exists(eager_json):
                     shutil.copy(eager_json, os.path.join(prof, f"{tag}_{a.name}_eager_under_rocprof.json"))
-            for extra in ("bench.json", "bench_full.json", "bench_bf16s.json", "bench_full_bf16s.json"):
+            for extra in ("bench.json", "bench_full.json", "bench_bf16s.json", "bench_full_bf16s.json", "bench_fp8s.json", "bench_full_fp8s.json",
+                          "bench_fp8s_clips32.json", "bench_bf16s_clips32.json", "precision_criterion.json"):
                 if os.path.exists(os.path.join(a.dir, extra)):
                     shutil.copy(os.path.join(a.dir, extra), os.path.join(prof, f"{tag}_{extra}"))
+            if os.path.exists(os.path.join(a.dir, "precision_criterion.json")):      # (bench.py quotes the modes' criterion from this copy)
+                shutil.copy(os.path.join(a.dir, "precision_criterion.json"), os.path.join(prof, "precision_criterion_latest.json"))
             b16 = find(os.path.join(a.dir, "stats_bf16s"), "*kernel_stats.csv")      # the bf16-storage mode's replays under the tracer
             if b16:
                 shutil.copy(b16, os.path.join(prof, f"{tag}_{a.name}_bf16s_kernel_stats.csv"))
@@ -154,10 +157,10 @@ def main():
     # inside a hipGraph (events recorded in a captured graph cannot be read: tools/graph_event_probe.hip), so it quotes these beside
     # its live event-pair numbers
     if stats and not a.no_copy:
-        fam = {"conv3": ["conv3_kernel<4,2,4,2>", "conv3_kernel<2,2,4,2>"], "conv3<4,2,4>": ["conv3_kernel<4,2,4,2>"], "conv3<2,2,4>": ["conv3_kernel<2,2,4,2>"],
+        fam = {"conv3": ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,"], "conv3<4,2,4>": ["conv3_kernel<4,2,4,2,"], "conv3<2,2,4>": ["conv3_kernel<2,2,4,2,"],
                "wgrad3": ["wgrad3_kernel<2,false>"], "conv1": ["conv1_kernel<"], "wgrad<128,128>": ["wgrad_kernel<128,128,16,true,0,2,false>"],
-               "igemm<128,128> NT": ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], "scale_act": ["scale_act_kernel"],
-               "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel"], "channel_partials": ["channel_partials_kernel"],
+               "igemm<128,128> NT": ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], "scale_act": ["scale_act_kernel", "scale_act_pc_kernel"],
+               "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel", "bn_act_bwd_apply_pc_kernel"], "channel_partials": ["channel_partials_kernel"],
                "l2norm_score_fwd": ["l2norm_score_fwd_kernel"], "dgrad2": ["dgrad2_kernel<"], "nconv1": ["nconv1_kernel<"],
                "wgrad9": ["wgrad9_kernel<"], "stem_wgrad_bn": ["stem_wgrad_bn_kernel"]}
         out = {"round": a.round, "src_hash": src_hash, "source": f"profiles/{tag}_{a.name}_kernel_stats.csv", "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 "
