@@ -15,7 +15,7 @@ python3 bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 cp "$ROOT/gpurun_out/bench_full_latest.json" "$OUT/bench_full.json" 2>/dev/null || true
 echo "bench done"; tail -c 600 "$OUT/bench.json"; echo
 # the default command (graph replays; no eager profiled pass, so every traced step runs with the replay's stream concurrency)
-BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0"
+BENCH="$ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --alt-steps 0 --profile-steps 0 --bf16s-leg off"      # (no extra legs: the trace's last three steps are this mode's replays)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
 echo "stats done"

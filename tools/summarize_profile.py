@@ -153,6 +153,9 @@ def main():
                 shutil.copy(b16, os.path.join(prof, f"{tag}_{a.name}_bf16s_kernel_stats.csv"))
                 if os.path.exists(os.path.join(a.dir, "bench_bf16s_under_rocprof.json")):
                     shutil.copy(os.path.join(a.dir, "bench_bf16s_under_rocprof.json"), os.path.join(prof, f"{tag}_{a.name}_bf16s_under_rocprof.json"))
+            f8 = find(os.path.join(a.dir, "stats_fp8s"), "*kernel_stats.csv")       # the fp8-storage mode's replays under the tracer
+            if f8:
+                shutil.copy(f8, os.path.join(prof, f"{tag}_{a.name}_fp8s_kernel_stats.csv"))
     # in-step launch durations of the replayed graph (real stream concurrency), per kernel family: bench.py cannot time launches
     # inside a hipGraph (events recorded in a captured graph cannot be read: tools/graph_event_probe.hip), so it quotes these beside
     # its live event-pair numbers
