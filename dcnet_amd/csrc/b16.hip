@@ -9,6 +9,8 @@
 #include "common.h"
 #include "prof.h"
 
+int bn_pc_enabled();         // bn.hip: dcn_set_tuning("Bpc", 0) turns the per-thread-channel apply passes off
+
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -166,6 +168,127 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const TY* __restric
   }
 }
 
+// ---- the two apply passes with the channel fixed per thread (round 5; bn.hip scale_act_pc_kernel has the reasoning) -----------------------
+// c / 8 a power of two <= 256: thread t of a 256-thread group always lies in channel group t % (c / 8), so scale / shift (mean, invstd,
+// gamma, beta, the two sums) are read ONCE per thread instead of once per 16-byte store, the row of an element group is a shift, and a
+// workgroup takes chunks of four 256-group slices with four independent loads per tensor in flight.  Same arithmetic per element as the
+// grid-stride kernels above (and the same fused e4m3 copy with Q).
+constexpr int PC16_UNR = 4;
+template <typename TY, typename TO, bool Q>
+__global__ __launch_bounds__(256) void scale_act16_pc_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, float slope,
+                                                             const __bf16* __restrict__ residual, int ldr, TO* __restrict__ out,
+                                                             int64_t total, int lg_c8, int ldo, unsigned char* __restrict__ q8,
+                                                             unsigned char* __restrict__ qs) {
+  const int c8 = 1 << lg_c8, c = c8 * 8;
+  const int ch = (threadIdx.x & (c8 - 1)) * 8;
+  F8 sc, sh;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc.v[k] = 1.f; sh.v[k] = 0.f; }
+  if (scale) sc = ld8<float>(scale + ch);
+  if (shift) sh = ld8<float>(shift + ch);
+  const int64_t nchunk = (total + 256 * PC16_UNR - 1) / (256 * PC16_UNR);
+  for (int64_t cidx = blockIdx.x; cidx < nchunk; cidx += gridDim.x) {
+    const int64_t i0 = cidx * (256 * PC16_UNR) + threadIdx.x;
+    F8 v[PC16_UNR], rr[PC16_UNR];
+#pragma unroll
+    for (int u = 0; u < PC16_UNR; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i < total) {
+        v[u] = ld8<TY>(y + (i >> lg_c8) * c + ch);
+        if (residual) rr[u] = ld8<__bf16>(residual + (i >> lg_c8) * ldr + ch);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PC16_UNR; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i >= total) continue;
+      const int64_t r = i >> lg_c8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = __builtin_fmaf(v[u].v[k], sc.v[k], sh.v[k]);
+        if (act == DCN_ACT_LEAKY) t = t > 0.f ? t : t * slope;
+        v[u].v[k] = t;
+      }
+      if (residual) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[u].v[k] += rr[u].v[k];
+      }
+      st8<TO>(out + r * ldo + ch, v[u]);
+      if constexpr (Q) {
+        float vr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vr[k] = (float)(__bf16)v[u].v[k];
+        quant8_row(vr, c8 > 64 ? 64 : c8, ch == 0, q8 + r * c + ch, qs + r);
+      }
+    }
+  }
+}
+
+template <typename TY, typename TD, bool Q>
+__global__ __launch_bounds__(256) void bn_bwd_apply16_pc_kernel(const TY* __restrict__ y, const TD* __restrict__ dout, int lddo,
+                                                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                                int act, float slope, const float* sums, float inv_count, int64_t total, int lg_c8,
+                                                                __bf16* __restrict__ dy, unsigned char* __restrict__ q8,
+                                                                unsigned char* __restrict__ qs) {
+  const int c8 = 1 << lg_c8, c = c8 * 8;
+  const int ch = (threadIdx.x & (c8 - 1)) * 8;
+  const F8 mu = ld8<float>(mean + ch), is = ld8<float>(invstd + ch);
+  F8 g, b;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { g.v[k] = 1.f; b.v[k] = 0.f; }
+  if (gamma) g = ld8<float>(gamma + ch);
+  if (beta) b = ld8<float>(beta + ch);
+  const F8 sg = ld8<float>(sums + ch), sgx = ld8<float>(sums + c + ch);
+  const int64_t nchunk = (total + 256 * PC16_UNR - 1) / (256 * PC16_UNR);
+  for (int64_t cidx = blockIdx.x; cidx < nchunk; cidx += gridDim.x) {
+    const int64_t i0 = cidx * (256 * PC16_UNR) + threadIdx.x;
+    F8 v[PC16_UNR], d[PC16_UNR];
+#pragma unroll
+    for (int u = 0; u < PC16_UNR; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i < total) { v[u] = ld8<TY>(y + (i >> lg_c8) * c + ch); d[u] = ld8<TD>(dout + (i >> lg_c8) * lddo + ch); }
+    }
+#pragma unroll
+    for (int u = 0; u < PC16_UNR; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i >= total) continue;
+      const int64_t r = i >> lg_c8;
+      F8 o;
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = (v[u].v[k] - mu.v[k]) * is.v[k];
+          float dd = d[u].v[k];
+          if (act == DCN_ACT_LEAKY && (g.v[k] * xh + b.v[k]) <= 0.f) dd *= slope;
+          o.v[k] = g.v[k] * is.v[k] * (dd - sg.v[k] * inv_count - xh * sgx.v[k] * inv_count);
+        }
+      }
+      st8<__bf16>(dy + r * c + ch, o);
+      if constexpr (Q) {
+        float vr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) vr[k] = (float)(__bf16)o.v[k];
+        quant8_row(vr, c8 > 64 ? 64 : c8, ch == 0, q8 + r * c + ch, qs + r);
+      }
+    }
+  }
+}
+
+// log2(c / 8) when the per-thread-channel kernels take the width (c / 8 a power of two <= 256), else -1; dcn_set_tuning("Bpc", 0) turns them off
+inline int pc16_lg(int c) {
+  const int c8 = c / 8;
+  if (!bn_pc_enabled() || c % 8 || c8 < 1 || c8 > 256 || (c8 & (c8 - 1))) return -1;
+  int lg = 0;
+  while ((1 << lg) < c8) ++lg;
+  return lg;
+}
+inline int pc16_grid(int64_t total) {
+  const int64_t nchunk = (total + 256 * PC16_UNR - 1) / (256 * PC16_UNR);
+  return (int)(nchunk < 1 ? 1 : (nchunk > 4096 ? 4096 : nchunk));
+}
+
 // ---- per-channel partial sums of g and g * xhat over 128-row blocks (bn.hip channel_partials_kernel<1>) ----------------------------
 // block (row block, 128 channels): thread = (8 channels, row phase of 16); stats [row blocks][2][c]
 template <typename TY, typename TD>
@@ -292,7 +415,10 @@ extern "C" int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, c
   const int pid = prof_begin(43, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0) + (residual ? 2.0 : 0.0)), stream);
   const dim3 g(grid_for(rows * (c / 8)));
   const __bf16* res = (const __bf16*)residual;
-#define DCN_SA(TY, TO) hipLaunchKernelGGL((scale_act16_kernel<TY, TO>), g, dim3(256), 0, stream, (const TY*)y, scale, shift, act, slope, res, ldr, (TO*)out, rows, c, ldo)
+  const int lg = pc16_lg(c);
+  const int64_t total = rows * (c / 8);
+#define DCN_SA(TY, TO) do { if (lg >= 0) hipLaunchKernelGGL((scale_act16_pc_kernel<TY, TO, false>), dim3(pc16_grid(total)), dim3(256), 0, stream, (const TY*)y, scale, shift, act, slope, res, ldr, (TO*)out, total, lg, ldo, nullptr, nullptr); \
+    else hipLaunchKernelGGL((scale_act16_kernel<TY, TO>), g, dim3(256), 0, stream, (const TY*)y, scale, shift, act, slope, res, ldr, (TO*)out, rows, c, ldo); } while (0)
   if (y_f32) { if (out_f32) DCN_SA(float, float); else DCN_SA(float, __bf16); }
   else { if (out_f32) DCN_SA(__bf16, float); else DCN_SA(__bf16, __bf16); }
 #undef DCN_SA
@@ -311,8 +437,13 @@ extern "C" int dcn_scale_act_b16_q(const void* y, const float* scale, const floa
   if (ldr <= 0) ldr = c;
   DCN_CHECK_ARG(y && out && q8 && qs && rows > 0 && dcn_quant_fusable(c) && ldr % 8 == 0, "scale_act_b16_q: bad argument (c=%d)", c);
   const int pid = prof_begin(43, (double)rows * c * (2.0 + 2.0 + 1.0 + (residual ? 2.0 : 0.0)), stream);
-  hipLaunchKernelGGL((scale_act16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y, scale, shift, act,
-                     slope, (const __bf16*)residual, ldr, (__bf16*)out, rows, c, c, (unsigned char*)q8, (unsigned char*)qs);
+  const int lg = pc16_lg(c);
+  if (lg >= 0)
+    hipLaunchKernelGGL((scale_act16_pc_kernel<__bf16, __bf16, true>), dim3(pc16_grid(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y, scale, shift,
+                       act, slope, (const __bf16*)residual, ldr, (__bf16*)out, rows * (c / 8), lg, c, (unsigned char*)q8, (unsigned char*)qs);
+  else
+    hipLaunchKernelGGL((scale_act16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y, scale, shift, act,
+                       slope, (const __bf16*)residual, ldr, (__bf16*)out, rows, c, c, (unsigned char*)q8, (unsigned char*)qs);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("scale_act_b16_q");
   return DCN_OK;
@@ -327,9 +458,15 @@ extern "C" int dcn_bn_act_bwd_apply_b16_q(const void* y, const void* dout, int l
   DCN_CHECK_ARG(y && dout && mean && invstd && sums && dy && q8 && qs && rows > 0 && dcn_quant_fusable(c) && lddo % 8 == 0 && count > 0,
                 "bn_act_bwd_apply_b16_q: bad argument (c=%d)", c);
   const int pid = prof_begin(45, (double)rows * c * 7.0, stream);
-  hipLaunchKernelGGL((bn_bwd_apply16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y,
-                     (const __bf16*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy,
-                     (unsigned char*)q8, (unsigned char*)qs);
+  const int lg = pc16_lg(c);
+  if (lg >= 0)
+    hipLaunchKernelGGL((bn_bwd_apply16_pc_kernel<__bf16, __bf16, true>), dim3(pc16_grid(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y,
+                       (const __bf16*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows * (c / 8), lg, (__bf16*)dy,
+                       (unsigned char*)q8, (unsigned char*)qs);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply16_kernel<__bf16, __bf16, true>), dim3(grid_for(rows * (c / 8))), dim3(256), 0, stream, (const __bf16*)y,
+                       (const __bf16*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy,
+                       (unsigned char*)q8, (unsigned char*)qs);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("bn_act_bwd_apply_b16_q");
   return DCN_OK;
@@ -363,7 +500,10 @@ extern "C" int dcn_bn_act_bwd_apply_b16(const void* y, int y_f32, const void* do
                 "bn_act_bwd_apply_b16: bad argument");
   const int pid = prof_begin(45, (double)rows * c * ((y_f32 ? 4.0 : 2.0) + (dout_f32 ? 4.0 : 2.0) + 2.0), stream);
   const dim3 g(grid_for(rows * (c / 8)));
-#define DCN_AP(TY, TD) hipLaunchKernelGGL((bn_bwd_apply16_kernel<TY, TD>), g, dim3(256), 0, stream, (const TY*)y, (const TD*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy)
+  const int lg = pc16_lg(c);
+  const int64_t total = rows * (c / 8);
+#define DCN_AP(TY, TD) do { if (lg >= 0) hipLaunchKernelGGL((bn_bwd_apply16_pc_kernel<TY, TD, false>), dim3(pc16_grid(total)), dim3(256), 0, stream, (const TY*)y, (const TD*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, total, lg, (__bf16*)dy, nullptr, nullptr); \
+    else hipLaunchKernelGGL((bn_bwd_apply16_kernel<TY, TD>), g, dim3(256), 0, stream, (const TY*)y, (const TD*)dout, lddo, mean, invstd, gamma, beta, act, slope, sums, 1.f / (float)count, rows, c, (__bf16*)dy); } while (0)
   if (y_f32) { if (dout_f32) DCN_AP(float, float); else DCN_AP(float, __bf16); }
   else { if (dout_f32) DCN_AP(__bf16, float); else DCN_AP(__bf16, __bf16); }
 #undef DCN_AP

@@ -390,6 +390,7 @@ inline int row_slices(int rows) { int rs = (rows + 63) / 64; return rs < 1 ? 1 :
 
 void bn_set_tuning(int v) { g_bn_rev = v; }
 void bn_set_pc(int v) { g_bn_pc = v; }
+int bn_pc_enabled() { return g_bn_pc; }
 
 extern "C" int64_t dcn_bn_ws(int c) { return (int64_t)RS_MAX * 2 * c * 2; }   // doubles stored in a float-typed scratch
 
