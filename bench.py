@@ -68,20 +68,22 @@ NAMES = {0: "igemm_kernel<128,128,2,2,0,false,16>", 15: "igemm_kernel<128,128,2,
          41: "conv1b_kernel (bf16 storage: forward / data gradient, both tiles by LDS-DMA)",
          42: "wgrad_kernel<128,128,16,true,0,1,true> (bf16 storage)", 43: "scale_act16_kernel (bf16 storage)",
          44: "partials16_kernel (bf16 storage)", 45: "bn_bwd_apply16_kernel (bf16 storage)",
-         46: "wgrad3_kernel<1,true> (bf16 storage, filter rows)", 47: "conv3_kernel<*,2,*,1,..,IN16> (bf16 storage: 3x3 stride-1 strip)",
-         48: "conv1b_kernel<..,F8> (fp8 storage: e4m3 + row scales, block-scaled MFMA)"}
-FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40, 41, 42, 46, 47, 48}
-PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38, 40)
+         46: "wgrad3_kernel<1,true> (bf16 storage, filter rows)", 47: "conv2b_kernel (bf16 storage: 256x256 two-group tile)",
+         48: "conv1b_kernel<..,F8> (fp8 storage: e4m3 + row scales, block-scaled MFMA)",
+         49: "quant_rows_e4m3_kernel (fp8 storage)", 50: "conv3_kernel<..,IN16> (bf16 storage: 3x3 stride-1 strip, off)",
+         51: "conv3x_kernel (3x3 s1 strip on 16x16x32 MFMAs: two taps per MFMA, filter tiles by LDS-DMA)"}
+FLOP_TAGS = set(range(8)) | {13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29, 32, 33, 35, 36, 37, 38, 40, 41, 42, 46, 47, 48, 51}
+PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if t in (24, 25, 26, 27, 28, 29, 32, 35, 36, 37, 38, 40, 51)
                else PEAK_BF16_MFMA_TFLOPS if t in (19, 20, 23, 33, 41, 42, 46, 47) else 2 * PEAK_BF16_MFMA_TFLOPS if t == 48
                else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
 RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>"],
             26: ["igemm_kernel<256,64,4,1,0,false,16,true,0,2,", "igemm_kernel<256,32,4,1,0,false,16,true,0,2,"],
-            27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,"],
-            29: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
+            27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"],
+            29: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"], 51: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],
             36: ["wgrad9_kernel<"], 37: ["dgrad2_kernel"], 38: ["nconv1_kernel"], 40: ["gemm3_kernel<"]}
-FAMILY = {28: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)", 29: "conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)"}
+FAMILY = {t: "conv3x_kernel + conv3_kernel<*,2,4> (3x3 s1 strip, f16 split)" for t in (28, 29, 51)}
 NT = 56            # DCN_PROF_TAGS
 
 
@@ -708,7 +710,7 @@ def main():
             if os.path.exists(ins_file):     # launch durations inside the replayed step (rocprofv3 of this command, committed profile)
                 with open(ins_file) as f:
                     ins = json.load(f)
-                key = {28: "conv3", 29: "conv3", 32: "wgrad3", 35: "conv1", 25: "wgrad<128,128>", 24: "igemm<128,128> NT"}.get(dom)
+                key = {28: "conv3", 29: "conv3", 51: "conv3", 32: "wgrad3", 35: "conv1", 25: "wgrad<128,128>", 24: "igemm<128,128> NT"}.get(dom)
                 k_ = ins.get("kernels", {}).get(key)
                 if ins.get("src_hash") != src_hash:
                     stale.append("in_step"); k_ = None

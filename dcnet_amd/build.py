@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdcnet_hip.so")
-SOURCES = ["igemm.hip", "conv3.hip", "conv1.hip", "nconv.hip", "stem.hip", "conv.hip", "wgrad.hip", "wgrad3.hip", "wgrad9.hip", "bn.hip", "layout.hip", "coattn.hip", "gemm3.hip", "score.hip", "gemm.hip", "locmod.hip", "optim.hip", "wprep.hip", "phrase.hip", "head.hip", "sample.hip", "loss.hip", "lstm.hip", "fusion.hip", "post.hip", "b16.hip", "conv2b.hip",
+SOURCES = ["igemm.hip", "conv3.hip", "conv3x.hip", "conv1.hip", "nconv.hip", "stem.hip", "conv.hip", "wgrad.hip", "wgrad3.hip", "wgrad9.hip", "bn.hip", "layout.hip", "coattn.hip", "gemm3.hip", "score.hip", "gemm.hip", "locmod.hip", "optim.hip", "wprep.hip", "phrase.hip", "head.hip", "sample.hip", "loss.hip", "lstm.hip", "fusion.hip", "post.hip", "b16.hip", "conv2b.hip",
            "sampling.cpp", "capi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Werror=array-bounds"]
 FLAGS += os.environ.get("DCN_EXTRA_FLAGS", "").split()      # experiment builds, e.g. -DC3_ABL=1 (timing ablations of conv3.hip)

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv3_kernel(const IgemmParam
 int g_conv3 = 1;          // dcn_set_tuning("3x3strip", 0): 3x3 stride-1 layers back on the implicit-GEMM tile
 int g_conv3_bm = 0;       // dcn_set_tuning("3bm", 128|256): force the strip kernel's M tile (0 = automatic)
 int g_conv3_abl = 0;      // dcn_set_tuning("3abl", bits): timing ablations (C3_ABL builds only)
+int g_conv3_m16 = 1;      // dcn_set_tuning("3m16", 0|1|2): conv3x.hip (16x16x32 MFMAs) for the launches that take the 256-row tile (1) / for every strip launch it fits (2)
 int g_conv3_ls = 1;       // dcn_set_tuning("3ls", 0): every global load of an iteration at its start again (A/B switch; LS = 1 measured 1-6 % faster per layer)
 
 template <int WM, int WN, int A_LD, int NP = 2, int ABL = 0, int LS = 0, bool IN16 = false, bool O32 = false>
@@ -562,7 +563,7 @@ int launch3(const IgemmParams& p, int gran, hipStream_t stream) {
   const double alg_bytes = IN16 ? 2.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg) +
                                       ((O32 ? 4.0 : 2.0) * (1.0 + (p.accumulate ? 1.0 : 0.0)) + (p.residual ? 2.0 : 0.0) + (p.bt_y ? 2.0 : 0.0)) * (double)p.M * p.Co
                                 : 4.0 * ((double)p.N * p.Hi * p.Wi * p.Ci + (double)p.Co * k_alg + (double)p.M * p.Co * epilogue_reads(p));
-  const int pid = prof_begin(IN16 ? 47 : (NP == 1 ? 33 : (WM == 4 ? 28 : 29)), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
+  const int pid = prof_begin(IN16 ? 50 : (NP == 1 ? 33 : (WM == 4 ? 28 : 29)), 2.0 * (double)p.M * p.Co * k_alg, stream, alg_bytes);
   hipLaunchKernelGGL((conv3_kernel<WM, WN, A_LD, NP, ABL, LS, IN16, O32>), dim3(gm * gn), dim3(NT), lds, stream, p, S, gran);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("conv3");
@@ -609,7 +610,8 @@ int conv3_tile(const IgemmParams& p, int gran, int* a_need) {
 }  // namespace
 
 void conv3_set_tuning(int key, int value) {
-  if (key == 0) g_conv3 = value; else if (key == 1) g_conv3_bm = value; else if (key == 2) g_conv3_abl = value; else g_conv3_ls = value;
+  if (key == 0) g_conv3 = value; else if (key == 1) g_conv3_bm = value; else if (key == 2) g_conv3_abl = value; else if (key == 4) g_conv3_m16 = value;
+  else g_conv3_ls = value;
 }
 
 // can this launch run on the strip kernel?  (gran = rows per statistics partial the caller sized its buffer for)
@@ -688,6 +690,16 @@ int conv3b_launch(const IgemmParams& p0, int out_f32, hipStream_t stream) {
 
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream) {
   int a_need; const int wmm = conv3_tile(p, gran, &a_need);
+  if (g_conv3_m16 && !g_conv3_abl && conv3x_takes(p, gran)) {
+    // conv3x.hip (16x16x32 MFMAs, 256 x 128 tile, one workgroup per CU) measured against the choice above per layer of the step at N = 64
+    // (tools/bench_convs.py --strip --ab 3m16=2, forward / data gradient): 4-17 % faster on 12 of 14 launches; 8-9 % SLOWER on the two whose
+    // grid is 1.32-1.34 rounds of 256 workgroups (512 -> 1024 @13 forward, 512 -> 256 @26 data gradient): the last third of a round costs a
+    // whole one there, and half of one on the 128-row tile with two workgroups per CU.
+    const long long wgs = (long long)cdiv(p.M, 256) * cdiv(p.Co, 128);
+    const int cus = dcn_device_cus() > 0 ? dcn_device_cus() : 256;
+    const bool short_tail = wgs > cus && wgs <= cus + cus / 2;
+    if (g_conv3_m16 == 2 || !short_tail) return conv3x_launch(p, gran, stream);
+  }
   if (wmm == 2) return launch3_ld<2, 2>(p, gran, stream);
   return launch3_ld<4, 2>(p, gran, stream);
 }

@@ -72,6 +72,10 @@ bool igemm_will_presplit(long long rows, int Co, int ntaps, int Ci);
 bool conv3_applicable(const IgemmParams& p, int precision, int gran);
 int conv3_launch(const IgemmParams& p, int gran, hipStream_t stream);
 void conv3_set_tuning(int key, int value);
+// conv3x.hip: the same launches on v_mfma_f32_16x16x32_f16 (256 x 128 tile, two taps per MFMA)
+bool conv3x_takes(const IgemmParams& p, int gran);
+int conv3x_launch(const IgemmParams& p, int gran, hipStream_t stream);
+void conv3x_set_tuning(int v);
 // ... and its bf16-storage form (conv1b_launch hands it the 3x3 stride-1 launches): conv3b_bm = pixels per M-tile = rows per BatchNorm
 // partial (0: the launch stays on the gathered tiles)
 int conv3b_bm(int M, int Co, int Wi);

@@ -158,7 +158,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += in[(size_t)r * ld + c];
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {               // eight loads in flight, added in the same order (one dependent load per row ran at load latency)
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = in[(size_t)(r + k) * ld + c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  for (; r < rows; ++r) s += in[(size_t)r * ld + c];
   out[c] = s;
 }
 

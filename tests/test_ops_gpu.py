@@ -743,10 +743,17 @@ def test_conv3_strip_kernel(dev, case):
     try:
         lib().set_tuning(b"3x3strip", 0)
         old = run()
-        for bm in (0, 128, 256):
-            lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", bm)
+        ran16 = False
+        # (bm, m16): both M tiles of conv3.hip forced (m16 = 0: 32x32x16 MFMAs), then conv3x.hip (16x16x32 MFMAs, two taps per MFMA) where the
+        # 256-row tile is the choice (1, the default) and for every launch it fits (2)
+        for bm, m16 in ((0, 0), (128, 0), (256, 0), (0, 1), (0, 2)):
+            lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", bm); lib().set_tuning(b"3m16", m16)
             new = run()
-            _close(new["y"], ref, 2e-5, f"strip fwd epilogue bm={bm}")
+            if m16 == 0:
+                new32 = new
+            elif m16 == 2:
+                ran16 = not torch.equal(new["y"], new32["y"]) or not torch.equal(new["dx"], new32["dx"])
+            _close(new["y"], ref, 2e-5, f"strip fwd epilogue bm={bm} m16={m16}")
             _close(new["stats"][:, 0].double().sum(0), rawl.reshape(-1, cout).sum(0), 1e-4, "strip stats sum")
             _close(new["stats"][:, 1].double().sum(0), (rawl * rawl).reshape(-1, cout).sum(0), 1e-4, "strip stats sumsq")
             assert new["stats"].shape == old["stats"].shape
@@ -761,8 +768,10 @@ def test_conv3_strip_kernel(dev, case):
                 _close(new[k], old[k], 2e-6, f"strip vs tile {k}")
         if cout >= 128 and w <= 64:         # (64-filter layers and maps wider than ~120 pixels stay on the implicit-GEMM tile)
             assert not torch.equal(new["y"], old["y"]) or not torch.equal(new["dx"], old["dx"]), "the strip kernel did not run"
+        if cout >= 128 and cout % 4 == 0 and w <= 104:
+            assert ran16, "conv3x.hip did not run"
     finally:
-        lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0)
+        lib().set_tuning(b"3x3strip", 1); lib().set_tuning(b"3bm", 0); lib().set_tuning(b"3m16", 1)
 
 
 @pytest.mark.parametrize("case", [(2, 26, 26, 512, 256, 1, 1), (8, 13, 13, 1024, 512, 1, 1), (1, 37, 29, 32, 128, 1, 1), (2, 52, 52, 256, 128, 1, 1),
@@ -1121,13 +1130,18 @@ TAP1_CASES = [
 ]
 
 
+@pytest.mark.parametrize("m16", [0, 2])
 @pytest.mark.parametrize("case", TAP1_CASES)
-def test_bn_tap_on_stride1_data_gradients(dev, case):
+def test_bn_tap_on_stride1_data_gradients(dev, case, m16):
     """The BatchNorm tap in the partial-sum epilogues of csrc/conv1.hip / conv3.hip: the data gradient of a stride-1 layer forms
     sum(g) and sum(g * xhat) of the BatchNorm + LeakyReLU in front (g = dx * act') while dx is in registers — against
     dcn_bn_act_bwd_reduce over the written dx, with and without accumulation into an existing gradient."""
     from dcnet_amd import ops
+    from dcnet_amd.lib import lib
     n, h, w, cin, cout, k = case
+    if m16 and k != 3:
+        pytest.skip("conv3x.hip only takes 3x3 launches")
+    lib().set_tuning(b"3m16", m16)           # conv3.hip (0) / conv3x.hip wherever it fits (2)
     wgt = (_rand(cout, cin, k, k, seed=101) / (3 * k)).to(dev)
     w_ohwi = wgt.permute(0, 2, 3, 1).contiguous()
     dy = _rand(n, h, w, cout, seed=102).to(dev)
@@ -1151,6 +1165,7 @@ def test_bn_tap_on_stride1_data_gradients(dev, case):
         d1 = ops.bn_act_bwd(y_prev, plain, mean, invstd, gamma, beta, ops.ACT_LEAKY, 0.1, part=part)
         for a_, b_ in zip(d0, d1):
             _close(a_, b_, 2e-5, "bn_act_bwd with tapped partials")
+    lib().set_tuning(b"3m16", 1)
 
 
 @pytest.mark.parametrize("case", PRE_CASES)

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--set", type=str, default="", help="key=value[,key=value] tuning knobs applied to both arms")
     ap.add_argument("--ab-default", type=int, default=0, help="the knob's default value (restored for the A arm)")
     ap.add_argument("--ab", type=str, default="", help="key=value tuning knob (dcn_set_tuning) measured against the default, same process")
+    ap.add_argument("--strip", action="store_true", help="only the 3x3 stride-1 layers with more than 64 filters (the strip kernels' launches)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.set:
@@ -73,6 +74,8 @@ def main():
     if args.only:
         key = tuple(int(v) for v in args.only.split(","))
         table = {key: table.get(key, 1)}
+    if args.strip:
+        table = {k_: v_ for k_, v_ in table.items() if k_[2] == 3 and k_[3] == 1 and k_[1] > 64 and k_[0] >= 32}
     global ITERS
     ITERS = args.iters
     for (cin, cout, k, st, h), cnt in sorted(table.items(), key=lambda kv: -kv[0][4]):
