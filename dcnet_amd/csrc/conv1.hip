@@ -46,8 +46,13 @@ __device__ __forceinline__ float c1_pow2_scale(unsigned amax_bits) {      // = i
 // along M), BN = 32 NI filters: (1,4) wide layers, (1,2) / (2,2) 64 filters, (2,1) 32 filters.
 // K runs over (tap, 16-channel step); a tap that leaves the image for a row is that lane's out-of-range offset (zeros), exactly
 // like the buffer loads of igemm.hip: per row a byte offset and a bit mask of in-image taps, computed once.
+// Waves per SIMD the 128 x 128 build must fit: its rings are sized for FOUR workgroups per CU (40 KB of LDS each), which also takes <= 128
+// registers — the build had crept to 129 (three workgroups per CU) without anything failing.  -DC1_OCC=2 restores the old bound (A/B).
+#ifndef C1_OCC
+#define C1_OCC 4
+#endif
 template <int SA, int SB, int NI, int MI>
-__global__ __launch_bounds__(256, 2) void conv1_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (NI == 4 && MI == 1) ? C1_OCC : 2) void conv1_kernel(const IgemmParams p) {
   constexpr int BM = 128 * MI, BN = 32 * NI;
   constexpr int ASTAGE = BM * 64, BPLANE = BN * 32, BSTAGE = 2 * BPLANE;
   constexpr int AP = 4 * MI;                      // A pieces per loader wave and K-step (16 rows each)

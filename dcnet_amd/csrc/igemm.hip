@@ -770,6 +770,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'l') { wgrad_set_lds_pad(value); return DCN_OK; }      // "lwgpad": KB of LDS a weight-gradient launch reserves at least (occupancy experiment)
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
+  if (k == 'U') { wgrad3_set_tuning(2, value); return DCN_OK; }   // "U3m16": wgrad3.hip on 16x16x32 MFMAs (1) / 32x32x16 (0)
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"
   if (k == 'B') { bn_set_pc(value); return DCN_OK; }              // "Bpc": BatchNorm apply passes with the channel fixed per thread (bn.hip; 0 = grid-stride forms)

@@ -294,6 +294,228 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
     }
 }
 
+// ---- the same weight gradient on v_mfma_f32_16x16x32_f16 (round 5) --------------------------------------------------------------------------
+// The chip holds a higher clock on this MFMA shape under the f16-split loops (tools/mfma_shape_probe.hip: x1.14; conv3x.hip).  K = 32 padded
+// positions per K-step (a strip of 32 + 2): twice the MFMAs between barriers (72 per wave), same LDS images (256-byte rows, the XOR of poff),
+// same transposed reads — a 16-lane group of ds_read_b64_tr_b16 now takes k rows 8 g .. 8 g + 7 of ONE 16-channel block (the four groups of
+// a wave: the same 16 channels, 32 k), so only the per-lane addresses differ.  Wave tile as before (64 filters x 32 channels x 3 taps =
+// 4 x 2 x 3 accumulator blocks of 16 x 16).  One set of fragments rotates: per tap the terms run (h,l) (h,h) (l,h), so the l-plane
+// of the strip tap dies after the first group, the h-plane after the second, and the next tap's (next K-step's) fragments are read into
+// them one group (8 MFMAs) or more ahead; the dY fragments live for the whole K-step.
+constexpr int AX_PLANE = 32 * 256, BX_PLANE = 34 * 256;
+__global__ __launch_bounds__(512, 2) void wgrad3x_kernel(const W3Params p) {
+  constexpr int B_BASE = 2 * AX_PLANE, BUF = 2 * AX_PLANE + 2 * BX_PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm3x[];      // [2 buffers][A: 2 planes x 32 rows | B: 2 planes x 34 rows]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;            // 64 filters x 32 channels per wave
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = p.tiles_ci * p.tiles_co * 3;
+  const int split = b / per_split; b -= split * per_split;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int r = b;                                    // filter row of this workgroup
+  const int co0 = tco * 128, ci0 = tci * 128;
+  const int Wp = p.W + 1;
+  const int p_begin = split * p.kchunk;
+  const int p_end = min(p.Mp, p_begin + p.kchunk);
+  const int iters = (p_end - p_begin + 31) / 32;
+  const float s_a = pow2w(amax_read(p.amax_dy)), s_b = pow2w(amax_read(p.amax_x));
+
+  const long long npix = (long long)p.N * p.H * p.W;
+  const __amdgpu_buffer_rsrc_t a_rs = rsrcw(p.dy, ((npix - 1) * p.lddy + p.Co) * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = rsrcw(p.x, ((npix - 1) * p.ldx + p.Ci) * 4);
+  const int nrows = p.N * p.H;
+
+  // ---- load slots (4 channels each): A0 / A1 = dY rows ra, ra + 16 (positions p_begin + row); B0 / B1 = strip rows ra, ra + 16 (positions
+  //      p_begin - 1 + row, one filter row up or down), B2 = strip rows 32, 33 (the first 64 threads).  State is kept for A0, B0 and B2: the
+  //      +16 slots are the state advanced by 16, which advanced once more is the next K-step's.
+  const int ra = tid >> 5, cch = (tid & 31) * 4;
+  const bool a_chan = co0 + cch < p.Co, b_chan = ci0 + cch < p.Ci;
+  int a_row, a_col, a_y;
+  { const int q = p_begin + ra; a_row = q / Wp; a_col = q - a_row * Wp; a_y = a_row % p.H; }
+  int pos_a = p_begin + ra;
+  auto strip_state = [&](int q, int& row, int& col) {
+    if (q < 0) { row = -1; col = Wp + q; } else { row = q / Wp; col = q - row * Wp; }
+    row += r - 1;
+  };
+  int b_row, b_col, b2_row, b2_col;
+  strip_state(p_begin - 1 + ra, b_row, b_col);
+  strip_state(p_begin - 1 + 32 + (ra & 1), b2_row, b2_col);
+  const bool b2_on = tid < 64;
+
+  auto advance = [&](int& row, int& col) -> int {     // 16 positions further: at most two row wraps (W >= 8), as selects
+    col += 16;
+    const int w1 = col >= Wp ? 1 : 0; col -= w1 ? Wp : 0;
+    const int w2 = col >= Wp ? 1 : 0; col -= w2 ? Wp : 0;
+    row += w1 + w2;
+    return w1 + w2;
+  };
+  auto wrap_y = [&](int y) { y -= y >= p.H ? p.H : 0; y -= y >= p.H ? p.H : 0; return y; };
+  auto load_a = [&](int row, int col, int y, int pos) {
+    const bool vert = (r == 0 && y == 0) || (r == 2 && y == p.H - 1);
+    const bool ok = a_chan && pos < p_end && col < p.W && !vert;
+    return ldw16(a_rs, ok ? (unsigned)(((row * p.W + col) * p.lddy + co0 + cch) * 4) : OOBW);
+  };
+  auto load_b = [&](int row, int col, bool on) {
+    const bool ok = b_chan && on && col < p.W && (unsigned)row < (unsigned)nrows;
+    return ldw16(b_rs, ok ? (unsigned)(((row * p.W + col) * p.ldx + ci0 + cch) * 4) : OOBW);
+  };
+  // the five pieces of one K-step; the states move on by 32 positions
+  auto load_piece = [&](const int e) -> f32x4 {
+    if (e == 0) return load_a(a_row, a_col, a_y, pos_a);
+    if (e == 1) {
+      a_y = wrap_y(a_y + advance(a_row, a_col));
+      const f32x4 v = load_a(a_row, a_col, a_y, pos_a + 16);
+      a_y = wrap_y(a_y + advance(a_row, a_col));
+      pos_a += 32;
+      return v;
+    }
+    if (e == 2) return load_b(b_row, b_col, true);
+    if (e == 3) {
+      advance(b_row, b_col);
+      const f32x4 v = load_b(b_row, b_col, true);
+      advance(b_row, b_col);
+      return v;
+    }
+    const f32x4 v = load_b(b2_row, b2_col, b2_on);
+    advance(b2_row, b2_col); advance(b2_row, b2_col);
+    return v;
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sm3x;
+  const int st0 = poff(ra, cch), st2 = poff(32 + (ra & 1), cch);        // (row + 16: + 4096 — swz(row + 16) = swz(row))
+  auto store_piece = [&](const int buf, const int e, const f32x4 v) {    // x * s = h + l into the two planes of its tensor
+    const bool is_a = e < 2;
+    const f32x4 t = v * (is_a ? s_a : s_b);
+    const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+    const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                       (_Float16)(t[3] - (float)h[3])};
+    const int off = buf * BUF + (is_a ? 0 : B_BASE) + (e == 4 ? st2 : st0 + ((e & 1) ? 4096 : 0));
+    unsigned char* q = sm3x + off;
+    if (e == 4 && !b2_on) return;                                       // (wave-uniform: wave 0 only)
+    *reinterpret_cast<uint2*>(q) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(q + (is_a ? AX_PLANE : BX_PLANE)) = __builtin_bit_cast(uint2, l);
+  };
+  (void)lds0;
+
+  f32x4 acc[4][2][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[i][j][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addresses: 16-lane group g16 takes k rows 8 g16 + 4 r2 + q of a 16-channel block, lane 4 q + pp the columns 4 pp .. + 3.
+  // Block i / jb of the wave's channels: chunk index ^ (2 i), i.e. byte address ^ (i << 5) (16-byte chunks, bits 1-2 of the chunk index are
+  // free of carries) — one base address per (tensor, tap, row pair), the blocks by an XOR in the loop.
+  const int g16 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  int a_tr0[2], b_tr0[3][2];
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int row = 8 * g16 + 4 * r2 + qq;
+    a_tr0[r2] = poff(row, wm * 64 + 4 * pp);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) b_tr0[d][r2] = B_BASE + poff(row + d, wn * 32 + 4 * pp);
+  }
+  auto tr_read = [&](int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sm3x + byte_off));
+  };
+  auto frag = [&](int byte0, int byte1) {
+    const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+  f16x8_t Ah[4], Al[4], Bh[2], Bl[2];
+  auto read_A = [&](f16x8_t (&A)[4], const int buf, const int plane) {
+    int t0 = a_tr0[0], t1 = a_tr0[1];
+    asm volatile("" : "+v"(t0), "+v"(t1));              // (the XORs below stay in the loop: hoisted they are 16 more registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A[i] = frag(buf * BUF + plane * AX_PLANE + (t0 ^ (i << 5)), buf * BUF + plane * AX_PLANE + (t1 ^ (i << 5)));
+  };
+  auto read_B = [&](f16x8_t (&B)[2], const int buf, const int d, const int plane) {
+    int t0 = b_tr0[d][0], t1 = b_tr0[d][1];
+    asm volatile("" : "+v"(t0), "+v"(t1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) B[j] = frag(buf * BUF + plane * BX_PLANE + (t0 ^ (j << 5)), buf * BUF + plane * BX_PLANE + (t1 ^ (j << 5)));
+  };
+  auto mm = [&](const f16x8_t (&A)[4], const f16x8_t (&B)[2], const int d) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j][d] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[i], B[j], acc[i][j][d], 0, 0, 0);
+  };
+
+  // K-step `it` multiplies buffer it & 1; the pieces of step it + 1 (in `cur`, loaded one step ago) are split into the other buffer behind its
+  // first MFMA groups, the pieces of step it + 2 are loaded into `nxt` behind them.  Nine groups of 8 MFMAs: tap d = (h,l) (h,h) (l,h).
+  // Barrier behind the seventh group: every store of the step is done; the fragments of the next step are read behind it.
+  f32x4 cur[5], nxt[5];
+  if (iters > 0) {
+#pragma unroll
+    for (int e = 0; e < 5; ++e) cur[e] = load_piece(e);
+#pragma unroll
+    for (int e = 0; e < 5; ++e) store_piece(0, e, cur[e]);
+#pragma unroll
+    for (int e = 0; e < 5; ++e) cur[e] = load_piece(e);
+  }
+  __syncthreads();
+  read_A(Ah, 0, 0); read_B(Bl, 0, 0, 1);
+  for (int it = 0; it < iters; ++it) {
+    const int cb = it & 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      // group 1: (h,l) — Ah and Bl_d were read one group or more ago
+      read_B(Bh, cb, d, 0);
+      if (d == 0) read_A(Al, cb, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ah, Bl, d);
+      if (d == 0) { nxt[0] = load_piece(0); store_piece(cb ^ 1, 0, cur[0]); }
+      if (d == 1) { nxt[3] = load_piece(3); store_piece(cb ^ 1, 3, cur[3]); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (d == 2) __syncthreads();
+      // group 2: (h,h); the next tap's (next step's) l-plane strip fragment goes into the registers group 1 has just freed
+      if (d < 2) read_B(Bl, cb, d + 1, 1); else read_B(Bl, cb ^ 1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Ah, Bh, d);
+      if (d == 0) { nxt[1] = load_piece(1); store_piece(cb ^ 1, 1, cur[1]); }
+      if (d == 1) { nxt[4] = load_piece(4); store_piece(cb ^ 1, 4, cur[4]); }
+      __builtin_amdgcn_sched_barrier(0);
+      // group 3: (l,h); behind the last one the next step's dY h-plane
+      if (d == 2) read_A(Ah, cb ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(Al, Bh, d);
+      if (d == 0) { nxt[2] = load_piece(2); store_piece(cb ^ 1, 2, cur[2]); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < 5; ++e) cur[e] = nxt[e];
+  }
+  __syncthreads();
+
+  const float dq = 1.f / (s_a * s_b);                   // powers of two: exact
+  float* out = p.out + (size_t)split * p.Co * p.ld_out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co0 + wm * 64 + i * 16 + 4 * g16 + q;
+      if (co >= p.Co) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 32 + j * 16 + (lane & 15);
+        if (ci >= p.Ci) continue;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) out[(size_t)co * p.ld_out + (3 * r + d) * p.Ci + ci] = acc[i][j][d][q] * dq;
+      }
+    }
+}
+
+// OFF by default.  Alone it is the faster kernel (tools/bench_convs.py --strip --ab U3m16=0, N = 64, ms: 512->512 @52 2.505 -> 2.323, @26 0.632 -> 0.588,
+// 128->256 @52 0.332 -> 0.312, 256->512 @26 0.326 -> 0.318, 512->1024 @13 0.346 -> 0.336: -4.5 % over the step's layers); in the replayed
+// step, where it runs beside the data-gradient chain, the step is 0.45-0.6 ms LONGER with it on each of three boxes (bench.py --schedules 12
+// --schedule-tunes "U3m16=0=1;...": 92.08 / 92.23 against 91.63 / 91.54; 93.27 against 92.79 / 92.88; 92.32 against 91.65).  What differs
+// beside another queue: 219 registers against 190 (two of its waves leave a SIMD 64 registers instead of 128 for a wave of the chain's
+// kernels) and 66 KB of LDS against 34.
+int g_w3x = 0;            // dcn_set_tuning("U3m16", 1): 3x3 stride-1 weight gradients on the 16x16x32 build
 int g_w3 = 1;             // dcn_set_tuning("u3row", 0): 3x3 stride-1 weight gradients back on the per-tap kernel
 int g_w3_target = 512;    // dcn_set_tuning("v3target", n): workgroups a launch aims for (split-K sizing; 512 threads, 1-2 per CU)
 
@@ -314,7 +536,7 @@ Plan3 plan3(int n, int h, int wd, int cin, int cout) {
 
 }  // namespace
 
-void wgrad3_set_tuning(int key, int value) { if (key == 0) g_w3 = value; else g_w3_target = value > 0 ? value : 512; }
+void wgrad3_set_tuning(int key, int value) { if (key == 0) g_w3 = value; else if (key == 2) g_w3x = value; else g_w3_target = value > 0 ? value : 512; }
 
 // shape test only (the workspace is sized without knowing whether the abs-max words will be there)
 bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
@@ -378,7 +600,12 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   }
   const int grid = pl.tiles_co * pl.tiles_ci * 3 * pl.splits;
   const int pid = prof_begin(np == 2 ? 32 : 20, 2.0 * (double)n * h * wd * cout * 9.0 * cin, stream);
-  if (np == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(grid), dim3(512), lds, stream, p);
+  if (np == 2 && g_w3x) {
+    const size_t ldsx = (size_t)2 * (2 * AX_PLANE + 2 * BX_PLANE);
+    static DcnPerDeviceFlag attr_x;
+    if (attr_x.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx);
+    hipLaunchKernelGGL(wgrad3x_kernel, dim3(grid), dim3(512), ldsx, stream, p);
+  } else if (np == 2) hipLaunchKernelGGL(wgrad3_kernel<2>, dim3(grid), dim3(512), lds, stream, p);
   else hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad3");

@@ -1482,8 +1482,9 @@ W3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("m16", [1, 0])
 @pytest.mark.parametrize("case", W3_CASES)
-def test_wgrad3_filter_row_kernel(dev, case):
+def test_wgrad3_filter_row_kernel(dev, case, m16):
     """csrc/wgrad3.hip (weight gradient of the 3x3 stride-1 layers, one filter row per workgroup, K over padded pixel
     coordinates) against fp64 and against the per-tap kernel it replaces, including a dY that is a slice of a wider tensor.
     Image borders (no masks: the pads must read as zero), image-to-image wrap of the strip, split-K slabs and ragged channel
@@ -1499,17 +1500,24 @@ def test_wgrad3_filter_row_kernel(dev, case):
     F.conv2d(xd, wgt, padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
     ref = wgt.grad.permute(0, 2, 3, 1)                             # OHWI
     try:
+        lib().set_tuning(b"U3m16", m16)                            # 16x16x32 MFMAs, 32 positions per K-step (1) / 32x32x16, 16 positions (0, the default)
         lib().set_tuning(b"u3row", 0)
         old = ops.conv2d_bwd_weight(x, dy, 3, 1)
         lib().set_tuning(b"u3row", 1)
         new = ops.conv2d_bwd_weight(x, dy, 3, 1)
         new_c = ops.conv2d_bwd_weight(x, dy.contiguous(), 3, 1)
+        if m16:
+            lib().set_tuning(b"U3m16", 0)
+            other = ops.conv2d_bwd_weight(x, dy, 3, 1)
+            lib().set_tuning(b"U3m16", 1)
+            assert not torch.equal(new, other), "the 16x16x32 build did not run"
+            _close(new, other, 3e-6, "wgrad3: 16x16x32 vs 32x32x16")
         for target in (96, 2048):                                  # one split ... many splits
             lib().set_tuning(b"v3target", target)
             alt = ops.conv2d_bwd_weight(x, dy, 3, 1)
             _close(alt, ref, 3e-5, f"wgrad3 target {target}")
     finally:
-        lib().set_tuning(b"u3row", 1); lib().set_tuning(b"v3target", 512)
+        lib().set_tuning(b"u3row", 1); lib().set_tuning(b"v3target", 512); lib().set_tuning(b"U3m16", 0)
     # bf16-operand mode (configs[2]; also the weight gradient of the fp8 mode): the same kernel with one bf16 plane per operand,
     # against its exact model — the fp64 weight gradient of the bf16-rounded tensors
     rb = lambda t: t.to(torch.bfloat16).double()

@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--ab-default", type=int, default=0, help="the knob's default value (restored for the A arm)")
     ap.add_argument("--ab", type=str, default="", help="key=value tuning knob (dcn_set_tuning) measured against the default, same process")
     ap.add_argument("--strip", action="store_true", help="only the 3x3 stride-1 layers with more than 64 filters (the strip kernels' launches)")
+    ap.add_argument("--k1", action="store_true", help="only the 1x1 layers and the stride-2 3x3 layers (conv1.hip's launches)")
+    ap.add_argument("--no-wgrad", action="store_true", help="skip the weight gradients")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.set:
@@ -76,6 +78,8 @@ def main():
         table = {key: table.get(key, 1)}
     if args.strip:
         table = {k_: v_ for k_, v_ in table.items() if k_[2] == 3 and k_[3] == 1 and k_[1] > 64 and k_[0] >= 32}
+    if args.k1:
+        table = {k_: v_ for k_, v_ in table.items() if (k_[2] == 1 or k_[3] == 2) and k_[0] >= 32}
     global ITERS
     ITERS = args.iters
     for (cin, cout, k, st, h), cnt in sorted(table.items(), key=lambda kv: -kv[0][4]):
@@ -90,7 +94,7 @@ def main():
         f_dg = lambda: ops.conv2d_bwd_data(dy, w, (h, h), k, st, amax_dy=ady, amax_w=aw)
         has_dg = cin != 4 and cout % 32 == 0
         t_f = timeit(f_fwd)
-        t_w = timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st, amax_x=ax, amax_dy=ady))
+        t_w = 1e-9 if args.no_wgrad else timeit(lambda: ops.conv2d_bwd_weight(x, dy, k, st, amax_x=ax, amax_dy=ady))
         t_d = timeit(f_dg) if has_dg else 0.0
         if args.ab:
             # interleaved rounds in one process (default, knob, default, knob, ...), minimum per arm
