@@ -348,3 +348,30 @@ def test_graph_queue_model_on_a_small_dag(tmp_path):
     nodes, order, ed = gs.parse(str(path))
     sim2 = {nodes[n]["idx"]: s for n, s in gs.simulate(nodes, order, ed).items()}
     assert sim2[3] == 0 and sim2[4] == 0 and sim2[5] == 0 and sim2[2] == 1
+
+
+def test_profiling_tags_are_named_and_not_shared_between_kernel_files():
+    """Every literal tag a csrc file hands to prof_begin() has a name in bench.py, fits DCN_PROF_TAGS, and belongs to ONE file — two kernels
+    of different files on one tag add their times and work up under the first one's name (round 5: conv2b and the bf16 strip kernel both
+    used 47).  Tag 20 (bf16-operand weight gradients of wgrad.hip and wgrad3.hip) is the one deliberate exception."""
+    import glob
+    import os
+    import re
+    import bench
+    csrc = os.path.join(ROOT, "dcnet_amd", "csrc")
+    owners = {}
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip"))):
+        src = open(path).read()
+        for m in re.finditer(r"prof_begin\(([^;]*?),\s*[^,;]*,\s*\(?\s*(?:hipStream_t\)\s*)?stream", src):
+            expr = re.sub(r"(==|<=|>=|<|>)\s*\d+", "", m.group(1))          # (literals of conditions: NP == 1, p.M < 1024, ...)
+            for lit in re.findall(r"(?<![\w.])(\d+)(?![\w.])", expr):
+                owners.setdefault(int(lit), set()).add(os.path.basename(path))
+    assert owners, "no prof_begin() call found: the pattern of this test is stale"
+    tags = set(owners)
+    for t in sorted(tags):
+        assert t < bench.NT, f"tag {t} does not fit DCN_PROF_TAGS = {bench.NT}"
+        assert t in bench.NAMES, f"tag {t} ({sorted(owners[t])}) has no name in bench.NAMES"
+        if t != 20:
+            assert len(owners[t]) == 1, f"tag {t} is used by {sorted(owners[t])}"
+    with open(os.path.join(csrc, "prof.h")) as f:
+        assert int(re.search(r"#define\s+DCN_PROF_TAGS\s+(\d+)", f.read()).group(1)) == bench.NT
