@@ -78,7 +78,7 @@ PEAK_OF = {t: (PEAK_SPLIT_TFLOPS if t in (16, 17, 18, 21) else PEAK_H2_TFLOPS if
                else PEAK_FP32_MFMA_TFLOPS) for t in FLOP_TAGS}
 # substrings (spaces removed) that select a tag's kernels among rocprofv3's names: tools/summarize_profile.py matches the PMC
 # passes with them
-RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>"],
+RP_MATCH = {24: ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], 25: ["wgrad_kernel<128,128,16,true,0,2,false>", "wgrad1x_kernel<"],
             26: ["igemm_kernel<256,64,4,1,0,false,16,true,0,2,", "igemm_kernel<256,32,4,1,0,false,16,true,0,2,"],
             27: ["igemm_kernel<128,128,2,2,1,false,16,true,0,2,"], 28: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"],
             29: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"], 51: ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"], 32: ["wgrad3_kernel<2,false>"], 35: ["conv1_kernel<"],

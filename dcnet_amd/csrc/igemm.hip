@@ -737,6 +737,7 @@ void wgrad_set_w3_b16(int v);
 void wgrad_set_w9_b16(int v);
 void wgrad_set_target_b16(int v, int small);
 void wgrad3_set_tuning(int key, int value);
+void wgrad_set_w1x(int v);
 void bn_set_pc(int v);
 void conv_set_merge(int v);
 void conv_set_d2_b16(int v);
@@ -770,6 +771,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'l') { wgrad_set_lds_pad(value); return DCN_OK; }      // "lwgpad": KB of LDS a weight-gradient launch reserves at least (occupancy experiment)
   if (k == 'j') { stem_set_tuning(value); return DCN_OK; }        // "jstem": the stem directly on the vector ALU (stem.hip)
   if (k == 'm') { conv_set_merge(value); return DCN_OK; }         // "merge": parity classes of a stride-2 data gradient in one launch
+  if (k == 'Y') { wgrad_set_w1x(value); return DCN_OK; }          // "Y1wide": 1x1 stride-1 weight gradients on the 256-wide tile (wgrad.hip wgrad1x_kernel; 0 = off, n > 1: workgroups aimed for)
   if (k == 'U') { wgrad3_set_tuning(2, value); return DCN_OK; }   // "U3m16": wgrad3.hip on 16x16x32 MFMAs (1) / 32x32x16 (0)
   if (k == 'u') { wgrad3_set_tuning(0, value); return DCN_OK; }   // "u3row": 3x3 stride-1 weight gradient by filter rows (wgrad3.hip)
   if (k == 'v') { wgrad3_set_tuning(1, value); return DCN_OK; }   // "v3target"

@@ -464,6 +464,177 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
     }
 }
 
+// ---- 1x1 stride-1 layers on a (64 MI) x 256 tile (round 5) -----------------------------------------------------------------------------------
+// The 128 x 128 tile stages 32 KB per 12 MFMAs per wave; on the 1x1 layers (no taps to share a tile between) it runs at 0.19-0.33 of the
+// ceiling.  tools/wgrad_tile_probe.py — the TN form of gemm3.hip on these shapes, operands split beforehand: an upper bound — measured a
+// 256 x 256 tile 24-37 % faster than this kernel on every 1x1 layer of the step.  Here: MI = 4: 256 filters x 256 channels, MI = 2: 128 x 256
+// (the 256 -> 128 layers); eight waves (2 x 4), each (32 MI) x 64 = MI x 2 accumulator blocks of 32 x 32; K-step = 16 pixels; both tiles
+// staged through registers with the f16 split (two K-steps of loads in flight), the LDS planes of the 128 x 128 build ([16][128 channels],
+// same XOR: sp_off) side by side, the same transposed reads.  One rotating fragment set: terms (l,h) (h,h) (h,l), the next K-step's
+// fragments read behind the barrier into the registers the running term has freed.  Split-K slabs as above.
+template <int MI>
+__global__ __launch_bounds__(512, 2) void wgrad1x_kernel(const WgradParams p) {
+  typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+  constexpr int TCO = 64 * MI, ASUB = TCO / 128;          // filters per tile; 128-channel sub-planes of the dY tile
+  constexpr int A_PL = ASUB * 4096, B_PL = 2 * 4096;      // bytes per plane (h | l) of the dY / X tile of a K-step
+  constexpr int B_BASE = 2 * A_PL, STAGE = 2 * A_PL + 2 * B_PL;
+  constexpr int A_LD = 16 * TCO / 4 / 512, B_LD = 2;      // 16-byte pieces per thread and K-step
+  constexpr int NPC = A_LD + B_LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_split = p.tiles_ci * p.tiles_co;
+  const int split = b / per_split; b -= split * per_split;
+  const int tci = b % p.tiles_ci, tco = b / p.tiles_ci;
+  const int co0 = tco * TCO, ci0 = tci * 256;
+  const int m_begin = split * p.kchunk;
+  const int m_end = min(p.M, m_begin + p.kchunk);
+  const int iters = (m_end - m_begin + 15) / 16;
+  const float s_a = pow2_scale(amax_read(p.amax_dy)), s_b = pow2_scale(amax_read(p.amax_x));
+  const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.dy + (long long)m_begin * p.lddy, ((long long)(m_end - m_begin - 1) * p.lddy + p.Co) * 4);
+  const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(p.x + (long long)m_begin * p.ldx, ((long long)(m_end - m_begin - 1) * p.ldx + p.Ci) * 4);
+
+  // pieces of a K-step: A piece j: index tid + 512 j over [16 pixels][TCO / 4]; B piece j over [16 pixels][64]
+  unsigned voff[NPC]; int lds_off[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const bool isb = j >= A_LD;
+    const int idx = tid + 512 * (isb ? j - A_LD : j);
+    const int per_row = isb ? 64 : TCO / 4;
+    const int pix = idx / per_row, c = (idx - pix * per_row) * 4;
+    const bool ok = isb ? ci0 + c < p.Ci : co0 + c < p.Co;
+    voff[j] = ok ? (unsigned)((pix * (isb ? p.ldx : p.lddy) + (isb ? ci0 : co0) + c) * 4) : OOB;
+    lds_off[j] = (isb ? B_BASE : 0) + (c >> 7) * 4096 + sp_off(pix, c & 127);
+  }
+  const unsigned a_step = (unsigned)(16 * p.lddy * 4), b_step = (unsigned)(16 * p.ldx * 4);
+  int rows_left = m_end - m_begin;              // rows of the split not yet requested
+  unsigned a_soff = 0, b_soff = 0;
+  auto load_step = [&](f32x4 (&r)[NPC]) {      // every load unconditional: past the end of the split the rows are out of range (zeros)
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const bool isb = j >= A_LD;
+      const int idx = tid + 512 * (isb ? j - A_LD : j);
+      const int pix = idx / (isb ? 64 : TCO / 4);
+      r[j] = buf_load16(isb ? b_rs : a_rs, pix < rows_left ? voff[j] : OOB, isb ? b_soff : a_soff);
+    }
+    a_soff += a_step; b_soff += b_step; rows_left -= 16;
+  };
+  auto store_piece = [&](const int buf, const int j, const f32x4 v) {
+    const bool isb = j >= A_LD;
+    const f32x4 t = v * (isb ? s_b : s_a);
+    const f16x4_t h = {(_Float16)t[0], (_Float16)t[1], (_Float16)t[2], (_Float16)t[3]};
+    const f16x4_t l = {(_Float16)(t[0] - (float)h[0]), (_Float16)(t[1] - (float)h[1]), (_Float16)(t[2] - (float)h[2]),
+                       (_Float16)(t[3] - (float)h[3])};
+    unsigned char* q = smw + buf * STAGE + lds_off[j];
+    *reinterpret_cast<uint2*>(q) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(q + (isb ? B_PL : A_PL)) = __builtin_bit_cast(uint2, l);
+  };
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mi][ni][q] = 0.f;
+
+  // transposed-read addresses (wgrad_kernel's): 16-lane group (hh, gg): k rows 8 hh + 4 r2 + q, channels blk 32 + 16 gg + 4 pp
+  const int g16 = lane >> 4, hh = g16 >> 1, gg = g16 & 1, qq = (lane & 15) >> 2, pp = lane & 3;
+  int a_tr[MI][2], b_tr[2][2];
+  {
+    const int a_ch0 = wm * (TCO / 2), b_ch0 = wn * 64;       // first channel of this wave inside the tile
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+      const int row = 8 * hh + 4 * r2 + qq;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int c = a_ch0 + mi * 32 + 16 * gg + 4 * pp;
+        a_tr[mi][r2] = (c >> 7) * 4096 + sp_off(row, c & 127);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c = b_ch0 + ni * 32 + 16 * gg + 4 * pp;
+        b_tr[ni][r2] = B_BASE + (c >> 7) * 4096 + sp_off(row, c & 127);
+      }
+    }
+  }
+  auto tr_read = [&](int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smw + byte_off));
+  };
+  auto frag = [&](int byte0, int byte1) {
+    const s16x4 lo = tr_read(byte0), hi = tr_read(byte1);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8_t, v);
+  };
+  f16x8_t Ah[MI], Al[MI], Bh[2], Bl[2];
+  auto read_A = [&](f16x8_t (&A)[MI], const int buf, const int plane) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) A[mi] = frag(buf * STAGE + plane * A_PL + a_tr[mi][0], buf * STAGE + plane * A_PL + a_tr[mi][1]);
+  };
+  auto read_B = [&](f16x8_t (&B)[2], const int buf, const int plane) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) B[ni] = frag(buf * STAGE + plane * B_PL + b_tr[ni][0], buf * STAGE + plane * B_PL + b_tr[ni][1]);
+  };
+  auto mm = [&](const f16x8_t (&A)[MI], const f16x8_t (&B)[2]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mi], B[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  // K-step `it` multiplies buffer it & 1; the pieces of step it + 1 (`cur`, loaded one step ago) are split into the other buffer behind the
+  // first two MFMA groups, the pieces of step it + 2 are loaded meanwhile (`nxt`); barrier; behind the third group the fragments of it + 1.
+  f32x4 r0[NPC], r1[NPC];
+  if (iters > 0) {
+    load_step(r0);
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) store_piece(0, j, r0[j]);
+    load_step(r0);
+  }
+  __syncthreads();
+  read_A(Al, 0, 1); read_B(Bh, 0, 0);
+  auto step = [&](const int cb, f32x4 (&cur)[NPC], f32x4 (&nxt)[NPC]) {
+    read_A(Ah, cb, 0); read_B(Bl, cb, 1);
+    load_step(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(Al, Bh);
+#pragma unroll
+    for (int j = 0; j < NPC / 2; ++j) store_piece(cb ^ 1, j, cur[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(Ah, Bh);
+#pragma unroll
+    for (int j = NPC / 2; j < NPC; ++j) store_piece(cb ^ 1, j, cur[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_A(Al, cb ^ 1, 1); read_B(Bh, cb ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(Ah, Bl);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int it = 0; it < iters; it += 2) {
+    step(0, r0, r1);
+    if (it + 1 < iters) step(1, r1, r0);
+  }
+  __syncthreads();
+
+  const float dq = 1.f / (s_a * s_b);                   // powers of two: exact
+  float* out = p.out + (size_t)split * p.Co * p.ld_out;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int co = co0 + wm * (TCO / 2) + mi * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+      if (co >= p.Co) continue;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int ci = ci0 + wn * 64 + ni * 32 + (lane & 31);
+        if (ci < p.Ci) out[(size_t)co * p.ld_out + ci] = acc[mi][ni][q] * dq;
+      }
+    }
+}
+
 // Sums the split-K slabs in a fixed order (bitwise reproducible).  Eight independent 16-B loads are in
 // flight per thread: with one dependent load per split the pass ran at a fifth of the HBM rate.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, float* __restrict__ out,
@@ -629,6 +800,54 @@ int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride);
 int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
                   const uint32_t* amax_x, const uint32_t* amax_dy, const DcnPreAct* pre, hipStream_t stream);
 
+// wgrad1x_kernel: which layers, and its split-K plan
+int g_w1x = 1;            // dcn_set_tuning("Y1wide", 0): 1x1 stride-1 weight gradients back on the 128 x 128 tile; n > 1: workgroups a launch aims for
+struct Plan1x { int mi, tiles_co, tiles_ci, splits, kchunk; };
+static bool wgrad1x_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
+  // (128 filters — the 128 x 256 build, MI = 2 — measured level with the 128 x 128 tile: 256 -> 128 @52 0.080-0.086 against 0.080 ms; left there)
+  if (!g_w1x || ksize != 1 || stride != 1 || cin < 256 || cout <= 128 || cin % 4 || cout % 4) return false;
+  const long long m = (long long)n * h * wd;
+  return m >= 4096 && m * (cin > cout ? cin : cout) * 4 < 0x7FFFFFF0LL;
+}
+static Plan1x plan1x(int m, int cin, int cout) {
+  Plan1x pl;
+  pl.mi = cout <= 128 ? 2 : 4;
+  pl.tiles_co = cdiv(cout, 64 * pl.mi); pl.tiles_ci = cdiv(cin, 256);
+  const int base = pl.tiles_co * pl.tiles_ci;
+  const int target = g_w1x > 1 ? g_w1x : 256;            // one workgroup (eight waves) per CU
+  int splits = target / base;
+  const int max_splits = m / 256 > 0 ? m / 256 : 1;       // at least 16 K-steps per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  pl.kchunk = cdiv(cdiv(m, splits), 16) * 16;
+  pl.splits = cdiv(m, pl.kchunk);
+  return pl;
+}
+static int wgrad1x_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int m, int cin, int cout,
+                          const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
+  const Plan1x pl = plan1x(m, cin, cout);
+  DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
+  WgradParams p{};
+  p.x = x; p.dy = dy; p.out = pl.splits > 1 ? ws : dw;
+  p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy; p.M = m; p.kchunk = pl.kchunk; p.splits = pl.splits;
+  p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = cin; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  const int grid = pl.tiles_co * pl.tiles_ci * pl.splits;
+  const size_t lds4 = (size_t)2 * (2 * 2 * 4096 + 2 * 2 * 4096), lds2 = (size_t)2 * (2 * 1 * 4096 + 2 * 2 * 4096);
+  static DcnPerDeviceFlag attr_once;
+  if (attr_once.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  }
+  const int pid = prof_begin(25, 2.0 * (double)m * cout * cin, stream);
+  if (pl.mi == 4) hipLaunchKernelGGL(wgrad1x_kernel<4>, dim3(grid), dim3(512), lds4, stream, p);
+  else hipLaunchKernelGGL(wgrad1x_kernel<2>, dim3(grid), dim3(512), lds2, stream, p);
+  prof_end(pid, stream);
+  DCN_CHECK_LAUNCH("wgrad1x");
+  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * cin / 4, pl.splits, stream);
+  return DCN_OK;
+}
+void wgrad_set_w1x(int v) { g_w1x = v; }
+
 extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   int64_t ws = pl.splits > 1 ? (int64_t)pl.splits * cout * pl.ld_out : 0;
@@ -639,6 +858,11 @@ extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int c
   if (wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride)) {       // (which kernel runs depends on the abs-max words: size for both)
     const int64_t w3 = wgrad3_ws(n, h, wd, cin, cout);
     if (w3 > ws) ws = w3;
+  }
+  if (wgrad1x_shape_ok(n, h, wd, cin, cout, ksize, stride)) {
+    const Plan1x p1 = plan1x(n * h * wd, cin, cout);
+    const int64_t w1 = p1.splits > 1 ? (int64_t)p1.splits * cout * cin : 0;
+    if (w1 > ws) ws = w1;
   }
   return ws;
 }
@@ -701,6 +925,9 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
     if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
       return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);
+    if (f16 && !g_wabl && wgrad1x_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0 &&
+        npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL)
+      return wgrad1x_launch(x, lx, dy, ly, dw, ws, (int)npix, cin, cout, amax_x, amax_dy, stream);
   }
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);

@@ -1469,6 +1469,47 @@ def test_wgrad9_nine_tap_kernel(dev, case):
 W9_DEFAULT = 2      # csrc/wgrad9.hip g_w9
 
 
+W1X_CASES = [
+    # n, h, w, cin, cout   (1x1 stride 1, >= 256 input channels, > 128 filters, >= 4096 pixels)
+    (8, 26, 26, 512, 256),
+    (2, 52, 52, 256, 160),     # one ragged filter tile
+    (8, 26, 26, 256, 512),
+    (7, 25, 27, 384, 192),     # ragged tiles on both sides, odd pixel count
+    (32, 13, 13, 1024, 512),
+]
+
+
+@pytest.mark.parametrize("case", W1X_CASES)
+def test_wgrad1x_wide_tile_kernel(dev, case):
+    """csrc/wgrad.hip wgrad1x_kernel (weight gradient of the 1x1 stride-1 layers on a 256-wide tile, eight waves, rotating fragment set)
+    against fp64 and against the 128 x 128 tile it replaces, with a dY that is a slice of a wider tensor, several split-K targets, and
+    twice in a row (fixed summation order)."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout = case
+    x = _rand(n, h, w, cin, seed=51).to(dev)
+    wide = (_rand(n, h, w, cout + 32, seed=52) / 8).to(dev)
+    dy = wide[..., 16:16 + cout]
+    ref = torch.einsum("nhwo,nhwi->oi", dy.double().cpu(), x.double().cpu()).view(cout, 1, 1, cin)
+    try:
+        lib().set_tuning(b"Y1wide", 0)
+        old = ops.conv2d_bwd_weight(x, dy, 1, 1)
+        lib().set_tuning(b"Y1wide", 1)
+        new = ops.conv2d_bwd_weight(x, dy, 1, 1)
+        again = ops.conv2d_bwd_weight(x, dy.contiguous(), 1, 1)
+        for target in (64, 1024):
+            lib().set_tuning(b"Y1wide", target)
+            alt = ops.conv2d_bwd_weight(x, dy, 1, 1)
+            _close(alt, ref, 3e-5, f"wgrad1x target {target}")
+    finally:
+        lib().set_tuning(b"Y1wide", 1)
+    _close(new, ref, 3e-5, "wgrad1x")
+    _close(old, ref, 3e-5, "128 x 128 tile")
+    _close(new, old, 3e-6, "wgrad1x vs the 128 x 128 tile")
+    assert torch.equal(new, again)
+    assert not torch.equal(new, old), "wgrad1x_kernel did not run"
+
+
 W3_CASES = [
     # n, h, w, cin, cout   (3x3 stride 1, >= 128 channels both sides, >= 1024 pixels)
     (8, 13, 13, 128, 256),

@@ -161,7 +161,7 @@ def main():
     # its live event-pair numbers
     if stats and not a.no_copy:
         fam = {"conv3": ["conv3_kernel<4,2,4,2,", "conv3_kernel<2,2,4,2,", "conv3x_kernel<"], "conv3x": ["conv3x_kernel<"], "conv3<4,2,4>": ["conv3_kernel<4,2,4,2,"], "conv3<2,2,4>": ["conv3_kernel<2,2,4,2,"],
-               "wgrad3": ["wgrad3_kernel<2,false>"], "conv1": ["conv1_kernel<"], "wgrad<128,128>": ["wgrad_kernel<128,128,16,true,0,2,false>"],
+               "wgrad3": ["wgrad3_kernel<2,false>"], "conv1": ["conv1_kernel<"], "wgrad<128,128>": ["wgrad_kernel<128,128,16,true,0,2,false>", "wgrad1x_kernel<"],
                "igemm<128,128> NT": ["igemm_kernel<128,128,2,2,0,false,16,true,0,2,"], "scale_act": ["scale_act_kernel", "scale_act_pc_kernel"],
                "bn_act_bwd_apply": ["bn_act_bwd_apply_kernel", "bn_act_bwd_apply_pc_kernel"], "channel_partials": ["channel_partials_kernel"],
                "l2norm_score_fwd": ["l2norm_score_fwd_kernel"], "dgrad2": ["dgrad2_kernel<"], "nconv1": ["nconv1_kernel<"],
