@@ -14,7 +14,7 @@
 // The strip of channel step c0 + 2 is loaded during T1 and split into c0's buffer during T2; that of c1 + 2 is loaded during T2 and stored
 // during the next T0.  Filter tiles: six tap slots per stage, two stages, loaded two super-iterations ahead through registers.
 // Tile: 256 pixels x 128 filters, eight waves (4 x 2) of 64 x 64 = 4 x 4 accumulator blocks of 16 x 16; one workgroup per CU (LDS: strip
-// 2 x 2 x (S + 2) x 32 B + filters 2 x 6 x 8.1 KB = 137-147 KB).
+// planes of a fixed 468 positions — 2 x 2 x 14.6 KB — + filters 2 x 6 x 8.1 KB = 156 KB).
 // LDS images without swizzles: a ds_read_b128 lane group {0-3, 12-15, 20-27} of this shape reads rows r, r + 8 in DIFFERENT 16-byte halves.
 // Filters are staged PERMUTED — LDS row 16 jn + c of a wave's 64 filters holds filter 4 c + jn — so that a lane's four accumulator blocks
 // along N are four consecutive filters: every epilogue access (store, shortcut, accumulated-onto tensor, tapped BatchNorm input) is a

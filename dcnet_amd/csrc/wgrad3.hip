@@ -381,7 +381,6 @@ __global__ __launch_bounds__(512, 2) void wgrad3x_kernel(const W3Params p) {
     advance(b2_row, b2_col); advance(b2_row, b2_col);
     return v;
   };
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)sm3x;
   const int st0 = poff(ra, cch), st2 = poff(32 + (ra & 1), cch);        // (row + 16: + 4096 — swz(row + 16) = swz(row))
   auto store_piece = [&](const int buf, const int e, const f32x4 v) {    // x * s = h + l into the two planes of its tensor
     const bool is_a = e < 2;
@@ -395,7 +394,6 @@ __global__ __launch_bounds__(512, 2) void wgrad3x_kernel(const W3Params p) {
     *reinterpret_cast<uint2*>(q) = __builtin_bit_cast(uint2, h);
     *reinterpret_cast<uint2*>(q + (is_a ? AX_PLANE : BX_PLANE)) = __builtin_bit_cast(uint2, l);
   };
-  (void)lds0;
 
   f32x4 acc[4][2][3];
 #pragma unroll
