@@ -31,6 +31,23 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def flags_key() -> str:
+    """Hash of the compile flags: part of the object-cache key and of ``utils.srchash.kernel_sources_hash`` — an experiment
+    build (``DCN_EXTRA_FLAGS=-DC3_ABL=1`` …) can neither be mistaken for an up-to-date default build nor stamp a bench line
+    with the default build's source hash."""
+    import hashlib
+    return hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:12]
+
+
+def built_flags_key() -> str:
+    """The flags key of the objects libdcnet_hip.so was linked from ('' if never built by this script)."""
+    try:
+        with open(os.path.join(HERE, "build", "FLAGS.stamp")) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -45,6 +62,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers.append(os.path.join(os.path.dirname(HERE), "include", "dcnet_hip.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "FLAGS.stamp")
+    if built_flags_key() != flags_key():        # other flags than the objects were compiled with: every object is stale
+        force = True
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
@@ -75,6 +95,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("link failed:\n" + r.stderr)
         if verbose:
             print("linked", OUT)
+    with open(stamp, "w") as fh:
+        fh.write(flags_key() + "\n")
     return OUT
 
 

@@ -745,9 +745,11 @@ void conv_set_n1_b16(int v);
 void score_set_tuning(int key, int value);
 void bn_set_tuning(int v);
 void wgrad9_set_tuning(int key, int value);
+void wgrad_set_slab_fold(int v);
 
 extern "C" int dcn_set_tuning(const char* key, int value) {
   const char k = key ? key[0] : 0;
+  if (k == 'S' && key[1] == 'l') { wgrad_set_slab_fold(value); return DCN_OK; }         // "Slabfold": split-K slabs summed by the last-arriving workgroup (slabsum.h; 0 = reduce_slabs_kernel behind the launch)
   if (k == '2') { conv2b_set_tuning(value); return DCN_OK; }                             // "2btile": min 256 x 256 tiles for conv2b.hip (0 = off)
   if (k == 'H') { gemm3_set_h1(value); return DCN_OK; }                                  // "H1gemm3": one f16 piece per operand in the bf16 modes (gemm3.hip)
   if (k == 'q' && key[1] == 't') { wgrad_set_target_b16(value, 0); return DCN_OK; }     // "qtargetb16": workgroups a bf16-storage 3x3 stride-1 weight gradient aims for

@@ -494,3 +494,132 @@ extern "C" int dcn_k14_dlag(const float* lag, const float* lnorm, const int64_t*
   DCN_CHECK_LAUNCH("k14_dlag");
   return DCN_OK;
 }
+
+// ---- device-side negative sampling (round 6; SURVEY H3 option (ii), opt-in: grounding_model.sampler = "device") --------------------------
+// The reference draws the negatives of both heads with Python's random.sample (model/DCNet_model.py:62-96, 394-420); the default path
+// advances that very MT19937 stream on the host (sampling.cpp, bit-exact).  The K14 loop makes N*N*HW0 sample() calls of which N*HW0
+// are kept: 11 M calls at 256 images, 0.19 s of one core — as long as the whole GPU step of configs[4].  This sampler draws ONLY what
+// is kept, on the device, inside the captured step: same distribution (k distinct positions, uniform over the population with the
+// excluded position removed), same exclusion rules, NOT the same numbers — a counter-based generator (Philox-4x32-10: Salmon et al.,
+// SC'11) keyed by (seed, step, sample index), rejection exactly as CPython's randbelow (top bit_length(n) bits, redraw while >= n) and
+// as random.sample's set branch (redraw duplicates).  state[0] = seed, state[1] = step counter (advanced by the last kernel of the
+// sampler, so a replayed graph draws fresh negatives every step without the host).
+namespace {
+
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+  c[0] = h1 ^ c[1] ^ k0; c[1] = l1; c[2] = h0 ^ c[3] ^ k1; c[3] = l0;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+
+// k distinct values of [0, pop), uniform (k <= 16); stream = (seed, step, sample id)
+__device__ __forceinline__ void dsample_distinct(int pop, int k, unsigned long long seed, unsigned long long step, unsigned sample_id,
+                                                 unsigned* sel) {
+  const int bits = 32 - __clz((unsigned)pop);               // pop.bit_length()
+  int have = 0;
+  for (unsigned block = 0; have < k; ++block) {
+    unsigned c[4] = {sample_id, block, (unsigned)step, (unsigned)(step >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned r = c[w] >> (32 - bits);
+      bool ok = r < (unsigned)pop && have < k;
+      for (int e = 0; e < have; ++e) ok &= sel[e] != r;
+      if (ok) sel[have++] = r;
+    }
+  }
+}
+
+// thread t < n9: the neg_n raw positions of K9 sample t (population hw - 1: the caller's kernel maps pos >= kp -> pos + 1);
+// else K14 sample (ii, jj): neg_c positions of [0, hw), without jj when ii == n - 1 (the image the negatives are gathered from)
+__global__ __launch_bounds__(256) void dsample_draw_kernel(const unsigned long long* __restrict__ state, int n9, int neg_n, int n, int hw,
+                                                           int neg_c, int64_t* __restrict__ k9, int64_t* __restrict__ k14) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long seed = state[0], step = state[1];
+  unsigned sel[16];
+  if (t < n9) {
+    dsample_distinct(hw - 1, neg_n, seed, step, (unsigned)t, sel);
+    for (int e = 0; e < neg_n; ++e) k9[(size_t)t * neg_n + e] = sel[e];
+    return;
+  }
+  const int u = t - n9;
+  if (u >= n * hw) return;
+  const int ii = u / hw, jj = u - ii * hw;
+  const bool removed = ii == n - 1;
+  dsample_distinct(removed ? hw - 1 : hw, neg_c, seed, step, 0x80000000u + (unsigned)u, sel);
+  for (int e = 0; e < neg_c; ++e) k14[(size_t)u * neg_c + e] = (removed && sel[e] >= (unsigned)jj) ? sel[e] + 1 : sel[e];
+}
+
+// counting sort of the K14 table by position, as dcn_mt_sample_crossmodal_csr does on the host: block p counts the entries that drew p ...
+__global__ __launch_bounds__(256) void dsample_count_kernel(const int64_t* __restrict__ k14, int total, int* __restrict__ cnt) {
+  __shared__ int red[4];
+  const int p = blockIdx.x;
+  int c = 0;
+  for (int i = threadIdx.x; i < total; i += 256) c += k14[i] == p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[p] = red[0] + red[1] + red[2] + red[3];
+}
+// ... and lists them in ascending order behind the entries of the positions in front of it; block 0 advances the step counter
+__global__ __launch_bounds__(256) void dsample_csr_kernel(const int64_t* __restrict__ k14, int total, int rows, const int* __restrict__ cnt,
+                                                          int* __restrict__ csr_off, int* __restrict__ csr_src,
+                                                          unsigned long long* __restrict__ state) {
+  __shared__ int red[4]; __shared__ int s_base;
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int c = 0;
+  for (int q = tid; q < p; q += 256) c += cnt[q];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) red[wave] = c;
+  __syncthreads();
+  if (tid == 0) {
+    s_base = red[0] + red[1] + red[2] + red[3];
+    csr_off[p] = s_base;
+    if (p == rows - 1) csr_off[rows] = s_base + cnt[p];
+    if (p == 0) state[1] += 1;
+  }
+  __syncthreads();
+  int base = s_base;
+  for (int i0 = 0; i0 < total; i0 += 256) {
+    const int i = i0 + tid;
+    const bool hit = i < total && k14[i] == p;
+    const unsigned long long m = __ballot(hit);
+    __syncthreads();                                   // (red of the previous chunk has been read)
+    if (lane == 0) red[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += red[w];
+    if (hit) csr_src[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    base += red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t dcn_device_sample_ws(int hw) { return hw; }      // ints: the per-position counts
+
+// k9 [pairs][top_k][neg_n] raw positions, k14 [n][hw][neg_c], csr_off [hw + 1], csr_src [n*hw*neg_c]: the tensors dcn_mt_sample_* fill on
+// the host, filled on the device from state = {seed, step}; ws: dcn_device_sample_ws(hw) ints.  Replaces the random.sample loops of
+// model/DCNet_model.py:62-96 (keeping only the draws that are used) and :394-420 with the same distribution, not the same stream.
+extern "C" int dcn_device_sample(uint64_t* state, int n, int top_k, int hw, int neg_n, int neg_c, int64_t* k9, int64_t* k14,
+                                 int32_t* csr_off, int32_t* csr_src, int32_t* ws, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  DCN_CHECK_ARG(state && k9 && k14 && csr_off && csr_src && ws, "device_sample: null pointer");
+  DCN_CHECK_ARG(n >= 2 && n % 2 == 0 && top_k > 0 && hw > 1 && neg_n > 0 && neg_c > 0 && neg_n <= 16 && neg_c <= 16 && neg_n <= hw - 1 &&
+                neg_c <= hw - 1, "device_sample: bad argument (n=%d hw=%d neg_n=%d neg_c=%d)", n, hw, neg_n, neg_c);
+  const int64_t total = (int64_t)n * hw * neg_c;
+  DCN_CHECK_ARG(total < (1LL << 31) && (int64_t)n * hw + (int64_t)(n / 2) * top_k < (1LL << 31), "device_sample: table too large");
+  const int n9 = (n / 2) * top_k;
+  hipLaunchKernelGGL(dsample_draw_kernel, dim3(cdiv((int64_t)n9 + (int64_t)n * hw, 256)), dim3(256), 0, stream,
+                     (const unsigned long long*)state, n9, neg_n, n, hw, neg_c, k9, k14);
+  hipLaunchKernelGGL(dsample_count_kernel, dim3(hw), dim3(256), 0, stream, k14, (int)total, ws);
+  hipLaunchKernelGGL(dsample_csr_kernel, dim3(hw), dim3(256), 0, stream, k14, (int)total, hw, ws, csr_off, csr_src, (unsigned long long*)state);
+  DCN_CHECK_LAUNCH("device_sample");
+  return DCN_OK;
+}

@@ -222,3 +222,20 @@ extern "C" int dcn_mt_sample_crossmodal_csr(const int64_t* out, int n, int rows,
   for (int64_t i = 0; i < total; ++i) csr_src[cur[out[i]]++] = (int32_t)i;
   return DCN_OK;
 }
+
+// The three calls of one training forward as ONE call, timed inside (round 6).  The worker thread of the Python side needs the
+// interpreter lock between two ctypes calls and to read its clock; while the main thread spins in Python that is up to one switch
+// interval (5 ms) per acquisition — the "sampler_thread" figure of the round-5 bench line (40.6 ms against 10-16 ms of draws) was mostly
+// that wait.  *seconds = what the draws cost this thread (CLOCK_THREAD_CPUTIME_ID: time it ran, not time it waited).
+#include <time.h>
+extern "C" int dcn_mt_sample_step(uint32_t* state, int n, int top_k, int hw, int neg_n, int neg_c, int64_t* k9, int64_t* k14,
+                                  int32_t* csr_off, int32_t* csr_src, double* seconds) {
+  timespec t0, t1;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0);
+  int rc = dcn_mt_sample_interframe(state, nullptr, n / 2, top_k, hw, neg_n, k9);
+  if (rc == DCN_OK) rc = dcn_mt_sample_crossmodal(state, n, hw, neg_c, k14);
+  if (rc == DCN_OK) rc = dcn_mt_sample_crossmodal_csr(k14, n, hw, neg_c, csr_off, csr_src);
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
+  if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return rc;
+}

@@ -12,6 +12,7 @@
 // Roofline: MFMA (same 157.3 TFLOP/s fp32 peak as the forward).
 #include "igemm.h"
 #include "prof.h"
+#include "slabsum.h"
 #include <type_traits>
 
 #ifndef WG_OCC
@@ -40,6 +41,7 @@ struct WgradParams {
   const unsigned* geom;          // per output pixel: (centre input pixel << 5) | edge flags; null = identity (plain GEMM)
   const unsigned* amax_dy;       // abs-max words (float bits) of dy / x: the f16 two-piece split derives its scales from them
   const unsigned* amax_x;
+  SlabFold fold;                 // split-K: the last-arriving workgroup of a tile sums the slabs (slabsum.h); counters == null: a second launch does
 };
 
 // amax bits -> the power of two that maps amax into [2^13, 2^14) (igemm.hip); zero / non-finite maxima give 1
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
               acc[mi][ni][q] += red[((((k - 1) * (WM * WN) + wmn) * (MI * NI) + mi * NI + ni) * 16 + q) * 64 + lane];
     }
   }
-  if (wk != 0) return;
+  if (wk != 0 && !p.fold.counters) return;
   if constexpr (SP && NP == 2) {
     const float dq = 1.f / (s_a * s_b);              // powers of two: exact
 #pragma unroll
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] *= dq;
   }
   float* out = p.out + (size_t)split * p.Co * p.ld_out + (long long)blockIdx.y * p.out_bs;
+  if (wk == 0)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -462,6 +465,12 @@ __global__ __launch_bounds__(256, (SP && NP == 3) ? WG_OCC : 2) void wgrad_kerne
         }
       }
     }
+  if (p.fold.counters) {          // (wave-uniform; conv2d weight gradients only: one batch, no row scale, no accumulate)
+    const int group = (t * p.tiles_co + tco) * p.tiles_ci + tci;
+    const int ncol = min(TN, (p.c4 ? 64 : p.Ci) - ci0);
+    slab_fold<256>(p.fold, group, p.splits, p.out, (size_t)p.Co * p.ld_out, co0, min(TM, p.Co - co0), p.ld_out,
+                   (p.c4 ? 0 : t * p.Ci) + ci0, ncol, 1, 0, reinterpret_cast<int*>(smem));
+  }
 }
 
 // ---- 1x1 stride-1 layers on a (64 MI) x 256 tile (round 5) -----------------------------------------------------------------------------------
@@ -633,6 +642,9 @@ __global__ __launch_bounds__(512, 2) void wgrad1x_kernel(const WgradParams p) {
         if (ci < p.Ci) out[(size_t)co * p.ld_out + ci] = acc[mi][ni][q] * dq;
       }
     }
+  if (p.fold.counters)
+    slab_fold<512>(p.fold, tco * p.tiles_ci + tci, p.splits, p.out, (size_t)p.Co * p.ld_out, co0, min(TCO, p.Co - co0), p.ld_out, ci0,
+                   min(256, p.Ci - ci0), 1, 0, reinterpret_cast<int*>(smw));
 }
 
 // Sums the split-K slabs in a fixed order (bitwise reproducible).  Eight independent 16-B loads are in
@@ -703,9 +715,14 @@ int g_wabl = 0;            // timing-only ablations of the split kernel (wrong r
 int g_wsplit = 4;          // 128x128 weight-gradient / TN tiles: 0 native fp32 MFMA, 1 bf16 three-piece split, 2 bf16 operands,
                            // 4 f16 two-piece split where the operands carry their abs-max (else as 1)   (dcn_set_tuning("precision"|"wsplit"))
 
+int g_slab_fold = 0;       // dcn_set_tuning("Slabfold", KB): split-K slabs are summed by the last-arriving workgroup of a tile (slabsum.h) when that workgroup
+                           // has at most this much to read; 0 = always reduce_slabs_kernel behind the launch.  OFF: measured in the replayed step
+                           // (profiles/r06_experiments.md) 91.15 ms without, 91.70 / 91.80 at 2.5 / 4.2 MB, 100.06 with every launch folded
 int g_wg_lds_pad = 0;      // dcn_set_tuning("lwgpad", KB): dynamic LDS the weight-gradient launches ask for at least (81+ = one workgroup per CU)
 }
 int wgrad_lds_pad() { return g_wg_lds_pad; }
+int wgrad_slab_fold() { return g_slab_fold; }
+void wgrad_set_slab_fold(int v) { g_slab_fold = v; }
 void wgrad_set_lds_pad(int kb) { g_wg_lds_pad = kb * 1024; }
 namespace {
 template <int TM, int TN, bool SP = false, int ABL = 0, int NP = 3, bool IN16 = false>
@@ -791,13 +808,13 @@ int tn_gemm_batched(const float* A, int lda, long long a_bs, const float* B, int
 // wgrad3.hip: 3x3 stride-1 layers, one filter row per workgroup (f16 split)
 bool wgrad3_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout);
-int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout,
                   const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream);
 
 // wgrad9.hip: the 3x3 layers with 32 input channels and 64 filters, nine taps per workgroup (f16 split)
 bool wgrad9_shape_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
 int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride);
-int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout, int stride,
                   const uint32_t* amax_x, const uint32_t* amax_dy, const DcnPreAct* pre, hipStream_t stream);
 
 // wgrad1x_kernel: which layers, and its split-K plan
@@ -823,7 +840,7 @@ static Plan1x plan1x(int m, int cin, int cout) {
   pl.splits = cdiv(m, pl.kchunk);
   return pl;
 }
-static int wgrad1x_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int m, int cin, int cout,
+static int wgrad1x_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters, int m, int cin, int cout,
                           const uint32_t* amax_x, const uint32_t* amax_dy, hipStream_t stream) {
   const Plan1x pl = plan1x(m, cin, cout);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
@@ -831,6 +848,8 @@ static int wgrad1x_launch(const float* x, int ldx, const float* dy, int lddy, fl
   p.x = x; p.dy = dy; p.out = pl.splits > 1 ? ws : dw;
   p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy; p.M = m; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = cin; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  const bool fold = slab_fold_ok(counters, pl.tiles_co * pl.tiles_ci, pl.splits, 64LL * pl.mi * 256 * 4, g_slab_fold);
+  if (fold) p.fold = SlabFold{counters, dw};
   const int grid = pl.tiles_co * pl.tiles_ci * pl.splits;
   const size_t lds4 = (size_t)2 * (2 * 2 * 4096 + 2 * 2 * 4096), lds2 = (size_t)2 * (2 * 1 * 4096 + 2 * 2 * 4096);
   static DcnPerDeviceFlag attr_once;
@@ -843,7 +862,7 @@ static int wgrad1x_launch(const float* x, int ldx, const float* dy, int lddy, fl
   else hipLaunchKernelGGL(wgrad1x_kernel<2>, dim3(grid), dim3(512), lds2, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad1x");
-  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * cin / 4, pl.splits, stream);
+  if (pl.splits > 1 && !fold) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * cin / 4, pl.splits, stream);
   return DCN_OK;
 }
 void wgrad_set_w1x(int v) { g_w1x = v; }
@@ -869,7 +888,7 @@ extern "C" int64_t dcn_conv2d_bwd_weight_ws(int n, int h, int wd, int cin, int c
 
 // Weight gradient of a convolution whose input is the RAW output of the conv + BatchNorm layer in front (dcn_conv2d_fwd_pre): the
 // activation is formed where X is loaded.  Shapes: those dcn_conv2d_pre_supported accepts.
-extern "C" int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+extern "C" int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters,
                                          int n, int h, int wd, int cin, int cout, int ksize, int stride,
                                          const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
                                          const uint32_t* amax_x, const uint32_t* amax_dy, void* stream_) {
@@ -880,7 +899,7 @@ extern "C" int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* d
   const int lx = ldx > 0 ? ldx : cin, ly = lddy > 0 ? lddy : cout;
   DCN_CHECK_ARG(lx % 4 == 0 && ly % 4 == 0, "conv2d_bwd_weight_pre: pixel strides must be multiples of 4 floats");
   const DcnPreAct pre{pre_scale, pre_shift, pre_act, pre_slope};
-  return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, &pre, (hipStream_t)stream_);
+  return wgrad9_launch(x, lx, dy, ly, dw, ws, counters, n, h, wd, cin, cout, stride, amax_x, amax_dy, &pre, (hipStream_t)stream_);
 }
 extern "C" int dcn_conv2d_bwd_weight_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   return (g_wsplit == 4 && !g_wabl && cin == 32 && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride)) ? 1 : 0;
@@ -905,7 +924,7 @@ extern "C" int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize,
   return DCN_OK;
 }
 
-extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters,
                                      const uint32_t* geom,
                                      int n, int h, int wd, int cin, int cout, int ksize, int stride,
                                      const uint32_t* amax_x, const uint32_t* amax_dy, void* stream_) {
@@ -921,13 +940,13 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
     const long long npix = (long long)n * h * wd;
     const bool f16 = g_wsplit == 4 && amax_x && amax_dy, b16 = g_wsplit == 2;      // (2: the bf16- and fp8-operand modes)
     if (f16 && !g_wabl && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0)
-      return wgrad9_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, amax_x, amax_dy, nullptr, stream);
+      return wgrad9_launch(x, lx, dy, ly, dw, ws, counters, n, h, wd, cin, cout, stride, amax_x, amax_dy, nullptr, stream);
     if ((f16 || b16) && !g_wabl && wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL && lx % 4 == 0 && ly % 4 == 0)
-      return wgrad3_launch(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);
+      return wgrad3_launch(x, lx, dy, ly, dw, ws, counters, n, h, wd, cin, cout, amax_x, amax_dy, f16 ? 2 : 1, stream);
     if (f16 && !g_wabl && wgrad1x_shape_ok(n, h, wd, cin, cout, ksize, stride) && lx % 4 == 0 && ly % 4 == 0 &&
         npix * lx * 4 < 0x7FFFFFF0LL && npix * ly * 4 < 0x7FFFFFF0LL)
-      return wgrad1x_launch(x, lx, dy, ly, dw, ws, (int)npix, cin, cout, amax_x, amax_dy, stream);
+      return wgrad1x_launch(x, lx, dy, ly, dw, ws, counters, (int)npix, cin, cout, amax_x, amax_dy, stream);
   }
   const Plan pl = make_plan(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
@@ -940,10 +959,12 @@ extern "C" int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, i
   p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = cin == 4; p.ld_out = pl.ld_out;
   p.Co_ld = cout; p.geom = geom; p.amax_x = amax_x; p.amax_dy = amax_dy;
+  const bool fold = slab_fold_ok(counters, pl.tiles_co * pl.tiles_ci * pl.T, pl.splits, (long long)pl.tm * pl.tn * 4, g_slab_fold);
+  if (fold) p.fold = SlabFold{counters, dw};
   const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
   int rc = dispatch_wgrad(p, pl.tm, pl.tn, grid, 1, stream);
   if (rc != DCN_OK) return rc;
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !fold) {
     return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   }
   return DCN_OK;
@@ -983,14 +1004,14 @@ Plan make_plan_b16(int n, int h, int wd, int cin, int cout, int ksize, int strid
 }  // namespace
 
 bool wgrad3_b16_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride);
-int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout,
                       hipStream_t stream);
 int g_w3_b16 = 0;         // dcn_set_tuning("w3b16", 1): bf16-storage 3x3 stride-1 weight gradients by filter rows (wgrad3.hip, bf16 inputs).  Measured
                           // (tools/bench_b16.py --set w3b16=0 --ab w3b16=1, N = 64): it LOSES to the per-tap tile here — 128->256 @52 0.170 -> 0.207 ms,
                           // 256->512 @26 0.167 -> 0.204, 512->512 @52 1.22 -> 1.50: with one MFMA per product both are bound by the bytes they stage per
                           // FLOP, and the filter-row form stages more (a 16-position step per 3 x 8 MFMAs); off
 
-int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout, int stride,
                       hipStream_t stream);
 int g_w9_b16 = 1;         // dcn_set_tuning("9b16", 0): the 32 -> 64 / 64 -> 128 3x3 layers of the bf16-storage mode back on the per-tap tile
 
@@ -1002,7 +1023,7 @@ extern "C" int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, i
   return ws;
 }
 
-extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
+extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* counters, const uint32_t* geom,
                                          int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   DCN_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_bwd_weight_b16: ksize=%d stride=%d", ksize, stride);
@@ -1012,11 +1033,11 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
   DCN_CHECK_ARG(lx % 8 == 0 && ly % 8 == 0, "conv2d_bwd_weight_b16: pixel strides must be multiples of 8 elements");
   // the 32 -> 64 (either stride) and 64 -> 128 (stride 1) 3x3 layers: all nine taps per workgroup (wgrad9.hip), dY and X read once
   if (g_w9_b16 && wgrad9_shape_ok(n, h, wd, cin, cout, ksize, stride))
-    return wgrad9_launch_b16(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stride, stream);
+    return wgrad9_launch_b16(x, lx, dy, ly, dw, ws, counters, n, h, wd, cin, cout, stride, stream);
   // 3x3 stride-1 layers with >= 128 channels on a side: one filter row per workgroup (wgrad3.hip), the dY tile staged once for three taps
   if (g_w3_b16 && wgrad3_b16_ok(n, h, wd, cin, cout, ksize, stride) && (long long)n * h * wd * lx * 2 < 0x7FFFFFF0LL &&
       (long long)n * h * wd * ly * 2 < 0x7FFFFFF0LL)
-    return wgrad3_launch_b16(x, lx, dy, ly, dw, ws, n, h, wd, cin, cout, stream);
+    return wgrad3_launch_b16(x, lx, dy, ly, dw, ws, counters, n, h, wd, cin, cout, stream);
   const Plan pl = make_plan_b16(n, h, wd, cin, cout, ksize, stride);
   DCN_CHECK_ARG(pl.M >= 16, "conv2d_bwd_weight_b16: fewer than 16 output pixels");
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
@@ -1029,10 +1050,12 @@ extern "C" int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy,
   p.M = pl.M; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.c4 = 0; p.ld_out = pl.ld_out;
   p.Co_ld = cout; p.geom = geom;
+  const bool fold = slab_fold_ok(counters, pl.tiles_co * pl.tiles_ci * pl.T, pl.splits, (long long)pl.tm * pl.tn * 4, g_slab_fold);
+  if (fold) p.fold = SlabFold{counters, dw};
   const int grid = pl.tiles_co * pl.tiles_ci * pl.T * pl.splits;
   int rc = launch_wgrad<128, 128, true, 0, 1, true>(p, grid, 1, stream);
   if (rc != DCN_OK) return rc;
-  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
+  if (pl.splits > 1 && !fold) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * pl.ld_out / 4, pl.splits, stream);
   return DCN_OK;
 }
 

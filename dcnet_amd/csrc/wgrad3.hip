@@ -18,6 +18,7 @@
 // into slabs summed in a fixed order (wgrad.hip reduce_slabs_kernel): bitwise reproducible.  Roofline: MFMA, 838.9 TFLOP/s.
 #include "common.h"
 #include "prof.h"
+#include "slabsum.h"
 #include <type_traits>
 
 int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream);
@@ -38,6 +39,7 @@ struct W3Params {
   int Mp, kchunk, splits;          // padded positions N*H*(W+1); per split (multiple of 16)
   int tiles_co, tiles_ci, ld_out;
   const unsigned* amax_dy; const unsigned* amax_x;
+  SlabFold fold;                   // slabsum.h
 };
 
 __device__ __forceinline__ f32x4 ldw16(__amdgpu_buffer_rsrc_t r, unsigned voff) {
@@ -292,6 +294,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3_kernel(const W3Params p) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) out[(size_t)co * p.ld_out + (3 * r + d) * p.Ci + ci] = acc[mi][d][q] * dq;
     }
+  if (p.fold.counters)              // the three taps of filter row r: three segments of a dw row
+    slab_fold<512>(p.fold, (r * p.tiles_co + tco) * p.tiles_ci + tci, p.splits, p.out, (size_t)p.Co * p.ld_out, co0, min(128, p.Co - co0),
+                   p.ld_out, 3 * r * p.Ci + ci0, min(128, p.Ci - ci0), 3, p.Ci, reinterpret_cast<int*>(sm3));
 }
 
 // ---- the same weight gradient on v_mfma_f32_16x16x32_f16 (round 5) --------------------------------------------------------------------------
@@ -505,6 +510,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x_kernel(const W3Params p) {
         for (int d = 0; d < 3; ++d) out[(size_t)co * p.ld_out + (3 * r + d) * p.Ci + ci] = acc[i][j][d][q] * dq;
       }
     }
+  if (p.fold.counters)
+    slab_fold<512>(p.fold, (r * p.tiles_co + tco) * p.tiles_ci + tci, p.splits, p.out, (size_t)p.Co * p.ld_out, co0, min(128, p.Co - co0),
+                   p.ld_out, 3 * r * p.Ci + ci0, min(128, p.Ci - ci0), 3, p.Ci, reinterpret_cast<int*>(sm3x));
 }
 
 // OFF by default.  Alone it is the faster kernel (tools/bench_convs.py --strip --ab U3m16=0, N = 64, ms: 512->512 @52 2.505 -> 2.323, @26 0.632 -> 0.588,
@@ -554,7 +562,8 @@ int64_t wgrad3_ws(int n, int h, int wd, int cin, int cout) {
 int wgrad_lds_pad();
 
 // bf16 storage: x, dy bf16 tensors (strides in elements), dw / slabs fp32
-int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+int wgrad_slab_fold();
+int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout,
                       hipStream_t stream) {
   const Plan3 pl = plan3(n, h, wd, cin, cout);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight_b16: workspace required (%d splits)", pl.splits);
@@ -563,6 +572,8 @@ int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* d
   p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy;
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
+  const bool fold = slab_fold_ok(counters, pl.tiles_co * pl.tiles_ci * 3, pl.splits, 128LL * 3 * 128 * 4, wgrad_slab_fold());
+  if (fold) p.fold = SlabFold{counters, dw};
   size_t lds = (size_t)2 * (A_PLANE + B_PLANE);
   static DcnPerDeviceFlag attr_once;
   if (attr_once.first())
@@ -572,14 +583,14 @@ int wgrad3_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* d
   hipLaunchKernelGGL((wgrad3_kernel<1, true>), dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad3 b16");
-  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
+  if (pl.splits > 1 && !fold) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
   return DCN_OK;
 }
 bool wgrad3_b16_ok(int n, int h, int wd, int cin, int cout, int ksize, int stride) {
   return wgrad3_shape_ok(n, h, wd, cin, cout, ksize, stride) && cin % 8 == 0 && cout % 8 == 0;
 }
 
-int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout,
+int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters, int n, int h, int wd, int cin, int cout,
                   const uint32_t* amax_x, const uint32_t* amax_dy, int np, hipStream_t stream) {
   const Plan3 pl = plan3(n, h, wd, cin, cout);
   DCN_CHECK_ARG(pl.splits == 1 || ws, "conv2d_bwd_weight: workspace required (%d splits)", pl.splits);
@@ -588,6 +599,8 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   p.N = n; p.H = h; p.W = wd; p.Ci = cin; p.ldx = ldx; p.Co = cout; p.lddy = lddy;
   p.Mp = pl.Mp; p.kchunk = pl.kchunk; p.splits = pl.splits;
   p.tiles_co = pl.tiles_co; p.tiles_ci = pl.tiles_ci; p.ld_out = 9 * cin;
+  const bool fold = slab_fold_ok(counters, pl.tiles_co * pl.tiles_ci * 3, pl.splits, 128LL * 3 * 128 * 4, wgrad_slab_fold());
+  if (fold) p.fold = SlabFold{counters, dw};
   p.amax_dy = amax_dy; p.amax_x = amax_x;
   size_t lds = (size_t)2 * np * (A_PLANE + B_PLANE);
   if ((size_t)wgrad_lds_pad() > lds) lds = (size_t)wgrad_lds_pad();       // (occupancy experiment: "lwgpad")
@@ -607,6 +620,6 @@ int wgrad3_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
   else hipLaunchKernelGGL(wgrad3_kernel<1>, dim3(grid), dim3(512), lds, stream, p);
   prof_end(pid, stream);
   DCN_CHECK_LAUNCH("wgrad3");
-  if (pl.splits > 1) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
+  if (pl.splits > 1 && !fold) return wgrad_reduce_slabs(ws, dw, (int64_t)cout * 9 * cin / 4, pl.splits, stream);
   return DCN_OK;
 }

@@ -359,7 +359,7 @@ int64_t wgrad9_ws(int n, int h, int wd, int cin, int cout, int stride) {
   return pl.splits > 1 ? (int64_t)pl.splits * cout * 9 * cin : 0;
 }
 
-int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* /*counters: one tile, 512 splits — a second launch sums them (slabsum.h)*/, int n, int h, int wd, int cin, int cout, int stride,
                   const uint32_t* amax_x, const uint32_t* amax_dy, const DcnPreAct* pre, hipStream_t stream) {
   const int ho = h / stride, wo = wd / stride;
   const Plan9 pl = plan9(n, ho, wo);
@@ -391,7 +391,7 @@ int wgrad9_launch(const float* x, int ldx, const float* dy, int lddy, float* dw,
 
 // bf16 storage: the same two layer forms on bf16 tensors (x, dy bf16 NHWC; dw fp32 [Cout][3][3][Cin]); the per-tap tile of wgrad.hip reads
 // dY and X nine times for them (32 -> 64 @208: 0.85 ms against 0.11 ms of HBM traffic).
-int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, int n, int h, int wd, int cin, int cout, int stride,
+int wgrad9_launch_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* /*counters*/, int n, int h, int wd, int cin, int cout, int stride,
                       hipStream_t stream) {
   const int ho = h / stride, wo = wd / stride;
   const Plan9 pl = plan9(n, ho, wo);

@@ -32,7 +32,7 @@ SIGNATURES = {
     "dcn_conv2d_pre_supported": (I, [I, I, I, I, I, I, I]),
     "dcn_conv2d_fwd_pre": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, F, I, P, P, P, P]),
     "dcn_conv2d_bwd_weight_pre_supported": (I, [I, I, I, I, I, I, I]),
-    "dcn_conv2d_bwd_weight_pre": (I, [P, I, P, I, P, P, I, I, I, I, I, I, I, P, P, I, F, P, P, P]),
+    "dcn_conv2d_bwd_weight_pre": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P, P, I, F, P, P, P]),
     "dcn_bn_act_amax_bound": (I, [P, P, P, I, F, P, P]),
     "dcn_gemm3_supported": (I, [I, I, I, I]),
     "dcn_gemm3_presplit": (I, [P, I, L, P, I, L, I, I, I, P, P]),
@@ -41,7 +41,7 @@ SIGNATURES = {
     "dcn_prepare_filters": (I, [P, I, I, I, P, L, P]),
     "dcn_conv2d_geom_size": (L, [I, I, I, I, I]),
     "dcn_conv2d_geom": (I, [P, I, I, I, I, I, P]),
-    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P, P, P]),
+    "dcn_conv2d_bwd_weight": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, I, I, P, P, P]),
     "dcn_conv2d_bwd_weight_ws": (L, [I, I, I, I, I, I, I]),
     "dcn_stem_bwd_weight_bn": (I, [P, P, P, I, P, P, P, P, I, F, P, L, I, I, I, I, P, P, P]),
     "dcn_stem_bwd_weight_bn_ws": (L, [I, I, I]),
@@ -129,11 +129,14 @@ SIGNATURES = {
     "dcn_prof_records": (I, [P, P, P, P, I]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
+    "dcn_mt_sample_step": (I, [P, I, I, I, I, I, P, P, P, P, P]),
+    "dcn_device_sample_ws": (L, [I]),
+    "dcn_device_sample": (I, [P, I, I, I, I, I, P, P, P, P, P, P]),
     "dcn_conv2d_stats_rows_b16": (I, [I, I, I, I, I, I]),
     "dcn_conv2d_fwd_b16": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, F, P, I, I, P, I, P]),
     "dcn_conv2d_bwd_data_b16": (I, [P, I, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, I, F, P, I, P, P]),
     "dcn_conv2d_bwd_weight_ws_b16": (L, [I, I, I, I, I, I, I]),
-    "dcn_conv2d_bwd_weight_b16": (I, [P, I, P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "dcn_conv2d_bwd_weight_b16": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, I, I, P]),
     "dcn_scale_act_b16": (I, [P, I, P, P, I, F, P, I, P, I, L, I, I, P]),
     "dcn_bn_act_bwd_reduce_rows_b16": (I, [L]),
     "dcn_bn_act_bwd_reduce_b16": (I, [P, I, P, I, I, P, P, P, P, I, F, L, I, P, P]),
@@ -154,7 +157,7 @@ SIGNATURES = {
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
                 "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records",
                 "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16", "dcn_conv2d_stats_rows_f8", "dcn_quant_fusable"}
-ABI_VERSION = 307        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
+ABI_VERSION = 308        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 
 class DcnError(RuntimeError):

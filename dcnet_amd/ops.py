@@ -260,6 +260,22 @@ def scratch(n_floats: int, device, slot: int = 0) -> torch.Tensor:
     return buf
 
 
+_slab_counters = {}
+SLAB_COUNTERS = 4096      # include/dcnet_hip.h DCN_SLAB_COUNTERS
+
+
+def slab_counters(device, slot: int = 0) -> torch.Tensor:
+    """The split-K arrival counters of the weight-gradient launches of one (device, slot, stream): zero at allocation, left zero by
+    every launch (dcn_conv2d_bwd_weight).  Keyed like ``scratch``: launches that share a slab workspace share the counters, and are
+    ordered on one stream."""
+    key = (torch.device(device).index, slot, torch.cuda.current_stream().cuda_stream)
+    buf = _slab_counters.get(key)
+    if buf is None:
+        buf = torch.zeros(SLAB_COUNTERS, dtype=torch.int32, device=device)
+        _slab_counters[key] = buf
+    return buf
+
+
 def pad32(c: int) -> int:
     return (c + 31) // 32 * 32
 
@@ -596,8 +612,9 @@ def conv2d_bwd_weight_b16(x, dy, ksize, stride, slot: int = 0):
     dw = torch.empty((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     nws = lib().conv2d_bwd_weight_ws_b16(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
+    cnt = slab_counters(x.device, slot) if nws > 0 else None
     geom = conv_geom(x.device, n, h, wd, ksize, stride)
-    lib().conv2d_bwd_weight_b16(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
+    lib().conv2d_bwd_weight_b16(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), _p(cnt), geom.data_ptr(),
                                 n, h, wd, cin, cout, ksize, stride, _s())
     return dw
 
@@ -690,11 +707,12 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
+    cnt = slab_counters(x.device, slot) if nws > 0 else None
     if isinstance(x, PreAct):
         if amax_x is None:
             raise DcnError("conv2d_bwd_weight: a PreAct input needs the abs-max word of the activation")
         amax_dy = _amax_or_pass(dy, amax_dy)
-        lib().conv2d_bwd_weight_pre(x.y.data_ptr(), x.y.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws),
+        lib().conv2d_bwd_weight_pre(x.y.data_ptr(), x.y.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), _p(cnt),
                                     n, h, wd, cin, cout, ksize, stride, x.scale.data_ptr(), x.shift.data_ptr(), x.act, float(x.slope),
                                     amax_x.data_ptr(), amax_dy.data_ptr(), _s())
         return dw
@@ -702,7 +720,7 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     # the kernels with a split mode: the 128-wide weight-gradient tiles and the nine-tap kernel of the 32 -> 64 3x3 layers
     if (cin >= 64 and cout >= 64 and (cin >= 128 or cout >= 128)) or (cin == 32 and cout == 64 and ksize == 3):      # (64 -> 128 is in the first)
         amax_x = _amax_or_pass(x, amax_x); amax_dy = _amax_or_pass(dy, amax_dy)
-    lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), geom.data_ptr(),
+    lib().conv2d_bwd_weight(x.data_ptr(), x.stride(2), dy.data_ptr(), dy.stride(2), dw.data_ptr(), _p(ws), _p(cnt), geom.data_ptr(),
                             n, h, wd, cin, cout, ksize, stride, _p(amax_x), _p(amax_dy), _s())
     return dw
 

@@ -24,4 +24,11 @@ def kernel_sources_hash() -> str:
         h.update(os.path.relpath(path, _PKG).encode())
         with open(path, "rb") as fh:
             h.update(fh.read())
+    # the compile flags the library was built with (dcnet_amd/build.py writes the stamp): an experiment build
+    # (DCN_EXTRA_FLAGS=-D..._ABL) must not carry the hash of the default build of the same sources
+    try:
+        with open(os.path.join(_PKG, "build", "FLAGS.stamp"), "rb") as fh:
+            h.update(b"flags:" + fh.read().strip())
+    except OSError:
+        h.update(b"flags:unknown")
     return h.hexdigest()[:12]

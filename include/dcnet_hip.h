@@ -31,6 +31,7 @@ extern "C" {
 #define DCN_ERR_LAUNCH (-2)   /* hipLaunch failed */
 
 #define DCN_AMAX_WORDS 64      /* words per abs-max vector (see dcn_absmax) */
+#define DCN_SLAB_COUNTERS 4096 /* words of a split-K arrival-counter vector (see dcn_conv2d_bwd_weight) */
 
 #define DCN_ACT_NONE 0
 #define DCN_ACT_LEAKY 1       /* y = x > 0 ? x : slope*x   (slope 0 == ReLU) */
@@ -38,7 +39,7 @@ extern "C" {
 /* Bumped whenever an exported signature changes incompatibly (round 2 changed dcn_conv2d_*, dcn_scale_act, dcn_bn_act_bwd_apply,
  * dcn_l2norm_score_*, dcn_prof_collect; round 3 dcn_rmsprop_step).  dcn_version() returns the value the library was built with;
  * dcnet_amd/lib.py refuses a library whose version differs from the one its signature table was written for. */
-#define DCN_ABI_VERSION 307
+#define DCN_ABI_VERSION 308
 
 const char* dcn_last_error(void);
 int dcn_version(void);
@@ -135,7 +136,7 @@ int dcn_conv2d_fwd_pre(const float* x, const float* w, float* y, int n, int h, i
                        const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
                        int ldy, float* stats, const uint32_t* amax_x, const uint32_t* amax_w, void* stream);
 int dcn_conv2d_bwd_weight_pre_supported(int n, int h, int wd, int cin, int cout, int ksize, int stride);
-int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+int dcn_conv2d_bwd_weight_pre(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride,
                               const float* pre_scale, const float* pre_shift, int pre_act, float pre_slope,
                               const uint32_t* amax_x, const uint32_t* amax_dy, void* stream);
@@ -168,8 +169,11 @@ int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize, int stride
 
 /* dw[co,r,s,ci] = sum_{n,ho,wo} dy[n,ho,wo,co] * x[n,ho*stride+r-pad,wo*stride+s-pad,ci]
  * (OHWI).  x has pixel stride ldx.  ws = caller scratch of dcn_conv2d_bwd_weight_ws(...) floats
- * (split-K partial slabs, reduced deterministically).  geom = dcn_conv2d_geom table of this geometry. */
-int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+ * (split-K partial slabs, summed in slab order: bitwise repeatable).  geom = dcn_conv2d_geom table of this geometry.
+ * counters (ABI 308; NULL = off): DCN_SLAB_COUNTERS device words, ZERO before the first call, left zero by every call, to be shared
+ * only by weight-gradient calls that are ordered on one stream (the rule for ws).  With them the slabs of a launch with many tiles and
+ * few splits are summed by the last-arriving workgroup of each tile instead of by a second launch — the same sum, bit for bit. */
+int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters,
                           const uint32_t* geom,
                           int n, int h, int wd, int cin, int cout, int ksize, int stride,
                           const uint32_t* amax_x, const uint32_t* amax_dy, void* stream);
@@ -468,9 +472,9 @@ int dcn_conv2d_bwd_data_b16(const void* dy, int lddy, const void* wt16, void* dx
                             const float* tap_gamma, const float* tap_beta, int tap_act, float tap_slope, float* tap_stats,
                             int tap_stats_rows, int* tap_rows, void* stream);
 /* dw [cout][k][k][cin] fp32 = sum over pixels of dy (x) x, both bf16; ws: dcn_conv2d_bwd_weight_ws_b16 floats (split-K slabs,
- * summed in a fixed order); geom: the table of dcn_conv2d_geom for this geometry. */
+ * summed in a fixed order); counters as dcn_conv2d_bwd_weight; geom: the table of dcn_conv2d_geom for this geometry. */
 int64_t dcn_conv2d_bwd_weight_ws_b16(int n, int h, int wd, int cin, int cout, int ksize, int stride);
-int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, const uint32_t* geom,
+int dcn_conv2d_bwd_weight_b16(const void* x, int ldx, const void* dy, int lddy, float* dw, float* ws, uint32_t* counters, const uint32_t* geom,
                               int n, int h, int wd, int cin, int cout, int ksize, int stride, void* stream);
 /* out (bf16, or fp32 with out_f32; pixel stride ldo) = act(scale * y + shift) + residual (bf16): BatchNorm apply + LeakyReLU + shortcut. */
 int dcn_scale_act_b16(const void* y, int y_f32, const float* scale, const float* shift, int act, float slope, const void* residual,
@@ -679,6 +683,18 @@ int dcn_mt_sample_crossmodal(uint32_t* state, int n, int rows, int neg_n, int64_
 /* The inverse of `out` for the backward of the gather: csr_off [rows+1], csr_src [n*rows*neg_n] = flat source indices
  * ((ii*rows + jj)*neg_n + m, ascending) of the negatives that point at each position of the last image. */
 int dcn_mt_sample_crossmodal_csr(const int64_t* out, int n, int rows, int neg_n, int32_t* csr_off, int32_t* csr_src);
+/* ABI 308: the three calls above for one training forward on n images (interframe with kpos = NULL, crossmodal, its csr) as ONE call;
+ * *seconds (may be NULL) = CPU time of the calling thread spent in it. */
+int dcn_mt_sample_step(uint32_t* state, int n, int top_k, int hw, int neg_n, int neg_c, int64_t* k9, int64_t* k14,
+                       int32_t* csr_off, int32_t* csr_src, double* seconds);
+/* ABI 308, opt-in (grounding_model.sampler = "device"; SURVEY H3 option (ii)): the same four tensors drawn ON THE DEVICE by a
+ * counter-based generator (Philox-4x32-10) from state = {seed, step} (two device uint64; step is advanced by the call's last kernel, so
+ * a replayed hipGraph draws new negatives every step with no host work).  Same distribution and exclusion rules as the random.sample
+ * loops of model/DCNet_model.py:62-96 (of whose N*N*HW0 draws only the N*HW0 that are used are made) and :394-420; NOT the same
+ * numbers as Python's MT19937 stream.  ws: dcn_device_sample_ws(hw) int32. */
+int64_t dcn_device_sample_ws(int hw);
+int dcn_device_sample(uint64_t* state, int n, int top_k, int hw, int neg_n, int neg_c, int64_t* k9, int64_t* k14,
+                      int32_t* csr_off, int32_t* csr_src, int32_t* ws, void* stream);
 /* C[b][M][N] = A[b][M][K] . B[b][N][K]^T for `batch` problems (strides in floats between problems; ldc may be any
  * value >= N): the HW0 x HW0 inter-frame affinity of K9 (model/DCNet_model.py:390). */
 int dcn_gemm_nt_batched(const float* A, int lda, int64_t a_bs, const float* B, int ldb, int64_t b_bs, float* C, int ldc, int64_t c_bs,

@@ -1581,3 +1581,52 @@ def test_wgrad3_filter_row_kernel(dev, case, m16):
     _close(new, old, 3e-6, "wgrad3 vs per-tap")
     assert torch.equal(new, new_c)                                 # the pixel stride of dY changes nothing
     assert not torch.equal(new, old), "the filter-row kernel did not run"
+
+
+SLAB_FOLD_CASES = [
+    # n, h, w, cin, cout, k, stride, knobs  — every kernel family that folds (csrc/slabsum.h), ragged tiles, many and few splits
+    (8, 13, 13, 128, 256, 3, 1, {}),                      # wgrad3_kernel<2>
+    (2, 33, 31, 136, 160, 3, 1, {}),                      # ... ragged channel tiles
+    (9, 11, 12, 192, 320, 3, 1, {b"U3m16": 1}),           # wgrad3x_kernel
+    (8, 26, 26, 256, 512, 1, 1, {}),                      # wgrad1x_kernel<4>
+    (7, 25, 27, 384, 192, 1, 1, {}),                      # ... ragged
+    (4, 26, 26, 256, 128, 1, 1, {}),                      # wgrad_kernel<128,128> f16 split
+    (8, 54, 58, 64, 128, 3, 2, {}),                       # ... stride 2, nine taps
+    (2, 16, 20, 64, 32, 1, 1, {}),                        # narrow fp32-pipe tile, WK > 1 (waves that own no output rows)
+    (1, 32, 32, 4, 32, 3, 1, {}),                         # stem layout (c4)
+]
+
+
+@pytest.mark.parametrize("case", SLAB_FOLD_CASES)
+def test_slab_fold_is_bitwise_the_separate_pass(dev, case):
+    """csrc/slabsum.h: the split-K slabs summed by the last-arriving workgroup of each tile must be the sum reduce_slabs_kernel
+    forms behind the launch, bit for bit, whichever workgroup arrives last; the arrival counters must be zero again afterwards
+    (the next launch and every replay of a captured step start from them); fp32 and bf16 storage."""
+    from dcnet_amd import ops
+    from dcnet_amd.lib import lib
+    n, h, w, cin, cout, k, s, knobs = case
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    x = _rand(n, h, w, cin, seed=61).to(dev)
+    dy = (_rand(n, ho, wo, cout, seed=62) / 8).to(dev)
+    try:
+        for kk, vv in knobs.items():
+            lib().set_tuning(kk, vv)
+        lib().set_tuning(b"Slabfold", 0)
+        sep = ops.conv2d_bwd_weight(x, dy, k, s)
+        lib().set_tuning(b"Slabfold", 1 << 20)               # no size limit: every launch with more than one split folds
+        folds = [ops.conv2d_bwd_weight(x, dy, k, s) for _ in range(3)]
+        if cin % 8 == 0 and cout % 8 == 0:
+            xb, dyb = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+            fold16 = ops.conv2d_bwd_weight_b16(xb, dyb, k, s)
+            lib().set_tuning(b"Slabfold", 0)
+            sep16 = ops.conv2d_bwd_weight_b16(xb, dyb, k, s)
+            assert torch.equal(fold16, sep16)
+    finally:
+        lib().set_tuning(b"Slabfold", 0)                     # (the default: off — measured slower in the step, csrc/slabsum.h)
+        for kk in knobs:
+            lib().set_tuning(kk, 0)
+    for f in folds:
+        assert torch.equal(f, sep)
+    assert int(ops.slab_counters(dev, 0).abs().sum()) == 0
+    nws = lib().conv2d_bwd_weight_ws(n, h, w, cin, cout, k, s)
+    assert nws > 0, "the case has one split: nothing was folded"
