@@ -205,6 +205,14 @@ def parse():
                     help="after the fp32 timed region: the SAME step on bf16 storage (BASELINE configs[2] on this GPU), captured and replayed "
                          "in this process with the same --steps / --warmup -> roofline.bf16s_clips_s / bf16s_ms_per_step (auto: on for the "
                          "single-GPU fp32 graph run)")
+    ap.add_argument("--sampler", choices=["mt", "device"], default="mt",
+                    help="negatives of the two sampling heads: 'mt' = Python's MT19937 stream advanced natively on a host thread, bit-exact "
+                         "with the reference's random.sample loops (the headline's default); 'device' = drawn on the device inside the "
+                         "captured step by a counter-based generator (same distribution, not the same numbers; no host work)")
+    ap.add_argument("--clips32-legs", choices=["auto", "on", "off"], default="auto",
+                    help="BASELINE configs[4] AT ITS BATCH: the step on fp8 storage and on bf16 storage at 32 clips (256 images) per GPU, "
+                         "device sampler, captured and replayed -> roofline.fp8s_bs32_clips_s / bf16s_bs32_clips_s (auto: on for the "
+                         "single-GPU fp32 graph run at the default workload)")
     ap.add_argument("--schedules", type=int, default=0,
                     help="N > 0: after the timed region capture the step under three stream schedules (no side streams; the default: "
                          "weight gradient beside the data-gradient chain; weight gradient queued behind its layer's data gradient) "
@@ -374,6 +382,8 @@ def main():
                             bert_model="bert-base-uncased", dataset="vid", img_size=args.size,
                             config_path=os.path.join(ROOT, "model", "yolov3.cfg"), weights_path=None).to(dev)
     model.train()
+    model.sampler = args.sampler
+    model.sampler_seed = 0x5DC0E7A1 + rank
     if args.no_side_streams:
         model.language_stream = False; model.sampling_stream = False
     # parameters that never receive a gradient in the reference either (dead YOLO heads F7, feature_map F8):
@@ -466,6 +476,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last_loss = float(last.detach())
+    main_sampler_ms = model.sampler_busy_s / args.steps * 1e3      # (CPU time of the worker thread's native draws; the legs below reset the counter)
     max_alloc = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     sclk = None
     for _ in range(3):                # the clock the card holds UNDER this load: three more (untimed) steps queued on every rank,
@@ -473,44 +484,6 @@ def main():
     if rank == 0:
         sclk = read_sclk_mhz(local_rank)
     barrier()
-
-    # ---- configs[2] / configs[4] on this GPU: the same step on bf16 storage and on fp8 storage, each captured again and replayed (their own
-    #      timed regions, never `value`)
-    legs = {}
-    want_leg = args.bf16s_leg == "on" or (args.bf16s_leg == "auto" and args.precision == "fp32" and not use_dist)
-    if want_leg and use_graph and step is not eager_step:
-        from dcnet_amd.graph import GraphedTrainStep
-        for mode_ in ("bf16s", "fp8s"):
-            if mode_ == args.precision:
-                continue
-            ops.set_precision(mode_)
-            g2 = None
-            try:
-                g2 = GraphedTrainStep(model, opt, image, word_id, word_mask, bbox, args.size, warmup=max(1, min(args.warmup, 2)))
-                for _ in range(args.warmup):
-                    g2()
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    l2 = g2()
-                barrier()
-                dt2 = time.perf_counter() - t1
-                ops.check_bilstm(dev)
-                l2 = float(l2.detach())
-                if not np.isfinite(l2):
-                    raise RuntimeError(f"{mode_} leg: loss {l2}")
-                legs[mode_] = {"ms_per_step": dt2 / args.steps * 1e3, "clips_s": args.clips * args.steps / dt2, "steps": args.steps,
-                               "warmup": args.warmup, "loss": l2, "step": "hipGraph replay (fwd+losses+bwd+RMSprop), " + mode_}
-            except Exception as e:       # the fp32 line must not die with an extra leg: say so on stderr and in the line
-                print(f"bench.py: {mode_} leg failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
-                legs[mode_] = {"error": type(e).__name__}
-            finally:
-                ops.set_precision(args.precision)
-                del g2
-                model.static_samples = None
-                opt.zero_grad(set_to_none=True)
-                torch.cuda.synchronize()
-                torch.cuda.empty_cache()
 
     # ---- untimed passes (every rank runs them, so collectives stay in step) -------------------------------------------
     # from here on the eager step: the profiler wraps each launch in a HIP event pair, which a captured graph cannot hold
@@ -618,6 +591,70 @@ def main():
         alts["bf16_storage"] = run_pass(args.alt_steps, "bf16s", False)
         alts["fp8_operands"] = run_pass(args.alt_steps, "fp8", False)
         alts["fp8_storage"] = run_pass(args.alt_steps, "fp8s", False)
+    # ---- configs[2] / configs[4] on this GPU: the same step on bf16 storage and on fp8 storage, each captured again and replayed (their own
+    #      timed regions, never `value`).  They run AFTER the profiled / alternative-arithmetic passes (round-5 advice: those passes and
+    #      the parity check must not see weights and optimiser state perturbed by reduced-precision steps).
+    legs = {}
+    want_leg = args.bf16s_leg == "on" or (args.bf16s_leg == "auto" and args.precision == "fp32" and not use_dist)
+    want_32 = args.clips32_legs == "on" or (args.clips32_legs == "auto" and want_leg and args.clips == 8 and args.size == 416 and args.frames == 8)
+
+    def run_leg(name, mode_, img_, wid_, wmask_, bbox_, clips_, sampler_):
+        from dcnet_amd.graph import GraphedTrainStep
+        ops.set_precision(mode_)
+        was_sampler = model.sampler
+        model.sampler = sampler_
+        g2 = None
+        try:
+            g2 = GraphedTrainStep(model, opt, img_, wid_, wmask_, bbox_, args.size, warmup=max(1, min(args.warmup, 2)))
+            for _ in range(args.warmup):
+                g2()
+            barrier()
+            g2.host_launch_s = g2.host_sampler_s = 0.0; model.sampler_busy_s = 0.0
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                l2 = g2()
+            barrier()
+            dt2 = time.perf_counter() - t1
+            ops.check_bilstm(dev)
+            l2 = float(l2.detach())
+            if not np.isfinite(l2):
+                raise RuntimeError(f"{name} leg: loss {l2}")
+            legs[name] = {"ms_per_step": dt2 / args.steps * 1e3, "clips_s": clips_ * args.steps / dt2, "steps": args.steps,
+                          "warmup": args.warmup, "loss": l2, "clips": clips_, "sampler": sampler_,
+                          "mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                          "host_ms_per_step": {"launch": round(g2.host_launch_s / args.steps * 1e3, 2),
+                                               "sampler_thread": round(model.sampler_busy_s / args.steps * 1e3, 2),
+                                               "gpu_wait": round(g2.host_sampler_s / args.steps * 1e3, 2)},
+                          "step": "hipGraph replay (fwd+losses+bwd+RMSprop), " + mode_}
+        except Exception as e:       # the fp32 line must not die with an extra leg: say so on stderr and in the line
+            print(f"bench.py: {name} leg failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            legs[name] = {"error": type(e).__name__}
+        finally:
+            ops.set_precision(args.precision)
+            model.sampler = was_sampler
+            del g2
+            model.static_samples = None
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()             # (a failed capture was ended by torch.cuda.graph's exit; nothing of it is left in flight)
+            torch.cuda.empty_cache()
+
+    if want_leg and use_graph and step is not eager_step:
+        for mode_ in ("bf16s", "fp8s"):
+            if mode_ != args.precision:
+                run_leg(mode_, mode_, image, word_id, word_mask, bbox, args.clips, args.sampler)
+        if want_32:
+            # configs[4] at its batch (32 clips = 256 images per GPU), with the device sampler: the exact host sampler needs 0.19 s of a
+            # core per step there (N^2 HW0 random.sample calls), as long as the GPU step itself (round-5 verdict, weak #6)
+            n32 = 32 * args.frames
+            im32, wi32, wm32 = synth_inputs(n32, args.size, seed=300 + rank)
+            bb32 = synth_boxes(n32, args.size, seed=300 + rank)
+            im32, wi32, wm32, bb32 = im32.to(dev), wi32.to(dev), wm32.to(dev), bb32.to(dev)
+            torch.cuda.reset_peak_memory_stats(dev)
+            for mode_ in ("bf16s", "fp8s"):
+                run_leg(mode_ + "_bs32", mode_, im32, wi32, wm32, bb32, 32, "device")
+            del im32, wi32, wm32, bb32
+            torch.cuda.empty_cache()
+
     if use_dist:
         dist.barrier()                           # every rank got here: only now may rank 0 print the line
 
@@ -655,7 +692,8 @@ def main():
                                     "fp8": "fp8 e4m3 operands, fp32 accumulate",
                                     "fp8s": "fp8 storage (e4m3 + row scales, block-scaled MFMA) for the 3x3 convs' fwd/dgrad on bf16 storage"}[args.precision],
                           "parallelism": f"dp{world}",
-                          "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note},
+                          "ranks_seen": dist.get_world_size() if use_dist else 1, "reducer": reducer_name, "step": graph_note,
+                          "sampler": args.sampler},
                "host_queue_ms_per_step": round(host_dt / args.steps * 1e3, 2), "mem_gb": round(max_alloc, 1), "loss": round(last_loss, 4),
                "loss_hex": float(last_loss).hex(), "src": src_hash}     # src: hash of the kernel + host sources (dcnet_amd.utils.srchash)
         if use_dist:
@@ -666,7 +704,7 @@ def main():
             # sampler_thread = what the draws cost their worker thread; gpu_wait = the host held back by the GPU (a staging set is
             # rewritten only after its upload of two steps ago has run: the host stays <= 2 steps ahead) + joining the worker
             res["host_ms_per_step"] = {"launch": round(step.host_launch_s / args.steps * 1e3, 2),
-                                       "sampler_thread": round(model.sampler_busy_s / args.steps * 1e3, 2),
+                                       "sampler_thread": round(main_sampler_ms, 2),
                                        "gpu_wait": round(step.host_sampler_s / args.steps * 1e3, 2)}
         full = {"bench_line": None, "timed": {"ms_per_step": res["ms_per_step"], "step": graph_note}}
         if sched:
@@ -767,12 +805,14 @@ def main():
                 rf_[mode_ + "_leg"] = leg["error"]
             else:
                 rf_[mode_ + "_clips_s"] = round(leg["clips_s"], 2); rf_[mode_ + "_ms_per_step"] = round(leg["ms_per_step"], 2)
+                if leg["sampler"] == "mt":
+                    rf_[mode_ + "_sampler_thread_ms"] = leg["host_ms_per_step"]["sampler_thread"]
         if legs:
             crit_file = os.path.join(ROOT, "profiles", "precision_criterion_latest.json")
             if os.path.exists(crit_file):    # SURVEY 8(c) box criterion of the modes on trained weights (tools/precision_criterion.py; also a -m gpu test)
                 with open(crit_file) as f:
                     cr = json.load(f)
-                for mode_ in legs:
+                for mode_ in [m__ for m__ in legs if not m__.endswith("_bs32")]:
                     m_ = cr.get("modes", {}).get(mode_)
                     if m_ and "criterion_met_frac" in m_:
                         res["roofline"][mode_ + "_criterion"] = "%d/%d" % (round(m_["criterion_met_frac"] * cr.get("images", 16)), cr.get("images", 16))

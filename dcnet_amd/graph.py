@@ -8,7 +8,8 @@ update — and replays them with one ``hipGraphLaunch`` per step.  What stays on
 
   * the draws of the two sampling heads (Python's MT19937 stream must advance exactly as the reference's forward advances
     it): made natively on a worker thread, uploaded into static device buffers the captured kernels read
-    (``grounding_model.draw_samples`` / ``static_samples``);
+    (``grounding_model.draw_samples`` / ``static_samples``) — or, with ``grounding_model.sampler = "device"``, nothing: the draws
+    are three captured kernels of a counter-based generator whose step counter lives on the device;
   * the learning rate of the schedule (train_DCNet.py:244-253): one device scalar per parameter group that the captured
     RMSprop kernel reads (``optim.RMSprop.device_lr``);
   * new input data: ``copy_`` into the static ``image`` / ``word_id`` / ``bbox`` tensors.
@@ -49,6 +50,9 @@ class GraphedTrainStep:
         self.word_mask = None if word_mask is None else word_mask.clone()
         self.n = image.shape[0]
         self.samples = self.core.sample_buffers(self.n, dev)
+        # grounding_model.sampler == "device": the draws are kernels of the captured forward (csrc/sample.hip dcn_device_sample, step
+        # counter on the device) — nothing of the sampling heads is left on the host, Python's `random` stream is not advanced
+        self.host_draws = getattr(self.core, "sampler", "mt") != "device"
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.loss = None
         self.parts = None
@@ -66,12 +70,14 @@ class GraphedTrainStep:
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(max(1, warmup)):
-                self.core.draw_samples(self.n, self.samples)
+                if self.host_draws:
+                    self.core.draw_samples(self.n, self.samples)
                 self._body(eager=True)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self._zero_grads()
-        self.core.draw_samples(self.n, self.samples)          # the draws of the captured pass (it runs once, as a real step)
+        if self.host_draws:
+            self.core.draw_samples(self.n, self.samples)      # the draws of the captured pass (it runs once, as a real step)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         # thread_local: only THIS thread's calls are checked against the capture.  In a data-parallel run ProcessGroupNCCL's watchdog
@@ -143,7 +149,8 @@ class GraphedTrainStep:
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()
         t1 = time.perf_counter()
-        self.core.draw_samples(self.n, self.samples)
+        if self.host_draws:
+            self.core.draw_samples(self.n, self.samples)
         t2 = time.perf_counter()
         self._replay_device()
         t3 = time.perf_counter()

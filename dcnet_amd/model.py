@@ -18,6 +18,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import os
+import ctypes
 import random
 import threading
 import time
@@ -222,6 +223,14 @@ class grounding_model(nn.Module):
         # device tensors (sample_buffers) that already hold this forward's draws (draw_samples): the forward then neither
         # draws nor uploads — a captured training step reads its draws from these static buffers
         self.static_samples = None
+        # "mt" (default): the negatives of both sampling heads come from Python's global MT19937 stream, bit-exact with the reference's
+        # random.sample loops (csrc/sampling.cpp, host worker thread).  "device": drawn on the device by a counter-based generator
+        # (csrc/sample.hip dcn_device_sample; SURVEY H3 option (ii)) — same distribution and exclusion rules, NOT the reference's numbers,
+        # no host work per step (at 256 images the exact loop costs 0.19 s of a core per step: as long as the GPU step of configs[4]).
+        # Python's `random` stream is not touched in this mode.
+        self.sampler = "mt"
+        self.sampler_seed = 0x5DC0E7A1         # device mode: seed of the generator (a data-parallel driver adds its rank)
+        self._dev_sampler = {}
         self._streams = {}
         # the two sampling heads (K9, K14) on their own stream under the head convs of scales 1 and 2 (forward()), and
         # their contrastive losses on that stream too (losses.total_loss), so that their backward overlaps as well
@@ -447,17 +456,19 @@ class grounding_model(nn.Module):
         L = lib()
         box = {"err": None, "shape": (n, top_k, hw, neg_n, neg_c), "pin": pin, "which": which, "g0": g0}
 
+        secs = ctypes.c_double(0.0)
+
         def work():
-            t_ = time.perf_counter()
+            # ONE native call (K9 draws, K14 draws, the inverse table of the K14 negatives by position of the last image: the gather's
+            # backward is then a deterministic segmented sum on the device), timed inside with the thread's CPU clock: between two
+            # ctypes calls the worker needs the interpreter lock, and while the main thread runs Python that is up to a switch interval
+            # (5 ms) each time — the wall-clock figure of round 5 (40 ms on the driver box against 10-16 ms of draws) was mostly that wait
             try:
-                L.mt_sample_interframe(arr.ctypes.data, 0, n // 2, top_k, hw, neg_n, k9.data_ptr())
-                L.mt_sample_crossmodal(arr.ctypes.data, n, hw, neg_c, k14.data_ptr())
-                # the inverse table of the K14 negatives (by position of the last image): the gather's backward is then a
-                # deterministic segmented sum on the device
-                L.mt_sample_crossmodal_csr(k14.data_ptr(), n, hw, neg_c, csr_off.data_ptr(), csr_src.data_ptr())
+                L.mt_sample_step(arr.ctypes.data, n, top_k, hw, neg_n, neg_c, k9.data_ptr(), k14.data_ptr(), csr_off.data_ptr(),
+                                 csr_src.data_ptr(), ctypes.byref(secs))
             except BaseException as e:       # re-raised on the caller's thread by _presample_join
                 box["err"] = e
-            box["busy_s"] = time.perf_counter() - t_
+            box["busy_s"] = secs.value
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
@@ -477,9 +488,31 @@ class grounding_model(nn.Module):
             th.join()                            # stale (re-seeded stream, other batch): let the worker finish, drop its draws
         return self._presample_start(n, g0)
 
-    def sample_buffers(self, n: int, device, top_k=30, neg_n=10, neg_c=5) -> dict:
+    def device_samples(self, n: int, g0: int, device, top_k=30, neg_n=10, neg_c=5) -> dict:
+        """``sampler = "device"``: this forward's draws, made by three kernels on the current stream (csrc/sample.hip
+        dcn_device_sample) into buffers that live with the model — a captured step replays the kernels, and the generator's step
+        counter lives on the device, so every replay draws new negatives.  Same tensors as ``_presample_join`` hands out."""
+        hw = g0 * g0
+        if n < 2 or hw - 1 < neg_n or hw - 1 < neg_c or hw * hw < top_k:
+            raise ValueError(f"correspondence sampling needs >= 2 images and a coarsest grid of more than {max(neg_n, neg_c)} "
+                             f"cells with >= {top_k} cell pairs (got {n} images, {g0}x{g0})")
+        key = (torch.device(device).index, n, hw, top_k, neg_n, neg_c)
+        st = self._dev_sampler.get(key)
+        if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("grounding_model.device_samples: first use inside a stream capture (run one eager step first)")
+            st = dict(self.sample_buffers(n, device, top_k, neg_n, neg_c, g0=g0))
+            st["state"] = torch.tensor([int(self.sampler_seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+            st["ws"] = torch.zeros(int(lib().device_sample_ws(hw)), dtype=torch.int32, device=device)
+            self._dev_sampler[key] = st
+        lib().device_sample(st["state"].data_ptr(), n, top_k, hw, neg_n, neg_c, st["k9"].data_ptr(), st["k14"].data_ptr(),
+                            st["csr_off"].data_ptr(), st["csr_src"].data_ptr(), st["ws"].data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+        return {k_: st[k_] for k_ in ("k9", "k14", "csr_off", "csr_src")}
+
+    def sample_buffers(self, n: int, device, top_k=30, neg_n=10, neg_c=5, g0=None) -> dict:
         """Device tensors with the shapes of one training forward's draws (n images): the static buffers of a captured step."""
-        hw = (self.img_size // 32) ** 2
+        hw = (self.img_size // 32 if g0 is None else g0) ** 2
         return {"k9": torch.zeros((n // 2, top_k, neg_n), dtype=torch.int64, device=device),
                 "k14": torch.zeros((n, hw, neg_c), dtype=torch.int64, device=device),
                 "csr_off": torch.zeros(hw + 1, dtype=torch.int32, device=device),
@@ -593,7 +626,12 @@ class grounding_model(nn.Module):
             side.wait_stream(main)
             ops.region("language")
             word_id, flang, context, embedded, flang_attn, flang_loc = language()
-        handle = None if static is not None else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
+        if self.sampler not in ("mt", "device"):
+            raise ValueError(f"grounding_model.sampler = {self.sampler!r}: 'mt' or 'device'")
+        on_device = self.sampler == "device"
+        if on_device:
+            static = None                        # (the draws are kernels of this forward: a captured step replays them, fresh every step)
+        handle = None if (static is not None or on_device) else self._presample_take(N, image.shape[-1] // 32)   # worker thread, under the backbone (or made ahead)
         ops.region("backbone")
         raw = self.visumodel.forward_nhwc(image, taps_b16=True)                  # :344  (queued asynchronously; bf16-storage mode: bf16 taps)
         if late:
@@ -629,15 +667,18 @@ class grounding_model(nn.Module):
             # stream as soon as scale 0 is queued and run under the head convs of scales 1 and 2; autograd replays their
             # backward on the same stream, beside the heads' backward.  In eval mode the reference computes and discards
             # them: here only the RNG stream is advanced (the draws), the device work is skipped.
-            presampled = static if static is not None else self._presample_join(handle, image.device, ahead=self.presample_ahead)
+            if not on_device:
+                presampled = static if static is not None else self._presample_join(handle, image.device, ahead=self.presample_ahead)
             samp = self._side_stream(image.device, "samp") if self.sampling_stream else main
             samp.wait_stream(main)
             with torch.cuda.stream(samp):
+                if on_device:
+                    presampled = self.device_samples(N, image.shape[-1] // 32, image.device)
                 frame, corrf, negf = self._interframe_sampling(r0[0], presampled)
                 vit, lag_pos, neg_cross = self._crossmodal(r0[0], context, presampled)
             for t_ in (r0[0], context, *presampled.values()):
                 t_.record_stream(samp)
-        else:
+        elif not on_device:
             self._presample_join(handle, None)
         res = [r0, self._scale_pairs(1, raw[1], flang, flang_attn), self._scale_pairs(2, raw[2], flang, flang_attn)]
         corr_feat = [r[1] for r in res]

@@ -162,18 +162,18 @@ def test_bf16_storage_config_at_full_workload(dev):
         ops.set_precision("fp32")
 
 
-def test_bf16_storage_box_criterion_on_trained_weights(dev):
+@pytest.fixture(scope="module")
+def bf16s_boxes_on_trained_weights():
     """SURVEY.md 8(c), the builder-defined acceptance of the bf16 mode (the reference has no bf16 semantics), measured inside the suite: the
     fp32 model is trained by the product's own step for 300 RMSprop iterations on 16 synthetic 256 x 256 images that carry their target
-    (tools/precision_criterion.py) until it localises them, then the SAME weights decode boxes from the fp32 and from the bf16-storage forward.
-    What the mode delivers and this test holds it to: the fp32 arg-max (scale, anchor, cell) on every image, Acc@0.5 against the ground truth
-    unchanged, every box within IoU 0.90 of the fp32 box and 0.96 on average.  The criterion proper (IoU >= 0.95 on >= 15 of 16) is NOT met —
-    12/16 — and the count is asserted as measured so that a change of it shows: the localisation runs of round 5
-    (profiles/r05_precision_localise.json) put the drift in the backbone as a whole (8-bit significands through 75 layers: with the
-    backbone alone on fp32 16/16; with the first residual stage, any single stage, or the shortcut sums on fp32 10-16/16 without order),
-    so no part short of most of the backbone buys it.  The training is bitwise repeatable, so are the counts."""
+    (tools/precision_criterion.py) until it localises them, then the SAME weights decode boxes from the fp32 and from the bf16-storage
+    forward.  The training is bitwise repeatable, so are the counts.  One training run, two tests: what the mode delivers, and the
+    criterion proper."""
     import importlib.util
     import os
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
     from dcnet_amd import losses, ops, train as T
     from dcnet_amd.parallel import freeze_gradless
     from util import ROOT
@@ -200,14 +200,32 @@ def test_bf16_storage_box_criterion_on_trained_weights(dev):
     finally:
         ops.set_precision("fp32")
     gt = torch.clamp(bbox, min=0, max=size - 1)
-    assert float((losses.bbox_iou(res["fp32"][0], gt) > 0.5).float().mean()) == 1.0        # the fp32 model localises its training set
-    assert float((losses.bbox_iou(res["bf16s"][0], gt) > 0.5).float().mean()) == 1.0       # ... and so does the bf16-storage forward
     iou = losses.bbox_iou(res["bf16s"][0], res["fp32"][0])
     same = res["bf16s"][1] == res["fp32"][1]
-    assert bool(same.all()), same
-    assert float(iou.min()) > 0.90 and float(iou.mean()) > 0.96, iou
-    met = int(((iou >= 0.95) & same).sum())
-    assert 11 <= met <= 16, (met, iou)               # measured: 12 (min 0.908, mean 0.965); >= 15 would be the criterion of SURVEY 8(c)
+    return {"acc_fp32": float((losses.bbox_iou(res["fp32"][0], gt) > 0.5).float().mean()),
+            "acc_bf16s": float((losses.bbox_iou(res["bf16s"][0], gt) > 0.5).float().mean()),
+            "iou": iou.cpu(), "same": same.cpu(), "met": int(((iou >= 0.95) & same).sum())}
+
+
+def test_bf16_storage_boxes_on_trained_weights_as_delivered(bf16s_boxes_on_trained_weights):
+    """What bf16 storage delivers on trained weights, and this test holds it to: the fp32 arg-max (scale, anchor, cell) on every image,
+    Acc@0.5 against the ground truth unchanged at 1.0, every box within IoU 0.90 of the fp32 box and 0.96 on average."""
+    r = bf16s_boxes_on_trained_weights
+    assert r["acc_fp32"] == 1.0                     # the fp32 model localises its training set
+    assert r["acc_bf16s"] == 1.0                    # ... and so does the bf16-storage forward
+    assert bool(r["same"].all()), r["same"]
+    assert float(r["iou"].min()) > 0.90 and float(r["iou"].mean()) > 0.96, r["iou"]
+
+
+@pytest.mark.xfail(strict=True, reason="SURVEY 8(c) box criterion of bf16 storage: IoU >= 0.95 against the fp32 box on >= 15 of 16 images — measured "
+                                       "12/16 (IoU min 0.908, mean 0.965).  Localised to the backbone as a whole (8-bit significands through "
+                                       "75 layers, profiles/r05_precision_localise.json).  STRICT: the day it is met this test fails until the "
+                                       "marker is removed and DESIGN.md / the bench line say so")
+def test_bf16_storage_meets_the_box_criterion(bf16s_boxes_on_trained_weights):
+    """The criterion proper.  A gate that passes on failure is not a gate (round-5 verdict): this one is red-by-contract while the
+    criterion is not met and turns the suite red the moment it is met without the documents following."""
+    r = bf16s_boxes_on_trained_weights
+    assert r["met"] >= 15, (r["met"], r["iou"])
 
 
 def test_fp8_storage_config_at_full_workload(dev):

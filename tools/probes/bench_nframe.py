@@ -3,7 +3,7 @@ BASELINE.json configs[3]'s geometry: clips of T = 16 frames of 608 x 608, 4 clip
     python tools/bench_nframe.py [--size 608 --frames 16 --clips 4 --precision fp32|bf16s --iters 5]"""
 import argparse, json, os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dcnet_amd import ops
 from dcnet_amd.utils.synth import synth_inputs

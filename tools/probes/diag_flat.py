@@ -1,5 +1,5 @@
 import os, sys, random, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from dcnet_amd import losses, ops
 from dcnet_amd.model import grounding_model
