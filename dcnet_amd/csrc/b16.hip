@@ -602,3 +602,66 @@ extern "C" int dcn_quant_rows_e4m3(const void* x, int ld, int64_t rows, int c, v
   DCN_CHECK_LAUNCH("quant_rows_e4m3");
   return DCN_OK;
 }
+
+// ---- fp8 storage: every bank of the step in ONE launch (round 6; round-5 advice) ---------------------------------------------------------
+// The e4m3 forms of the 3x3 layers' banks (forward [Cout][k*k*Cin] and transposed [Cin][k*k*Cout], one e8m0 scale per row) used to be made
+// by a quant_rows_e4m3 launch per layer in front of its forward convolution and another in front of its data gradient: 77 launches of
+// ~10 us on the critical chain of the step (0.75 ms of 53).  The banks change once per step (FilterBanks.refresh): one job table, one launch,
+// one wave per row — the arithmetic of quant_rows_e4m3_kernel with 64 lanes per row, bit for bit (tests/test_f8_gpu.py).
+namespace {
+struct QuantJob { const __bf16* src; unsigned char* q; unsigned char* scales; int rows, c, first_block, pad; };
+__global__ __launch_bounds__(256) void quant_banks_kernel(const QuantJob* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;           // (<= ~80 jobs, wave-uniform)
+  const QuantJob jb = jobs[j];
+  const int lane = threadIdx.x & 63;
+  const int r = ((int)blockIdx.x - jb.first_block) * 4 + (threadIdx.x >> 6);
+  if (r >= jb.rows) return;
+  const __bf16* xr = jb.src + (size_t)r * jb.c;
+  float amax = 0.f;
+  for (int ch = lane * 8; ch < jb.c; ch += 512) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + ch);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      amax = fmaxf(amax, fabsf(__uint_as_float(w[k] << 16)));
+      amax = fmaxf(amax, fabsf(__uint_as_float(w[k] & 0xFFFF0000u)));
+    }
+  }
+  for (int d = 1; d < 64; d <<= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+  int e = 0;
+  const unsigned ab = __float_as_uint(amax);
+  if (amax > 0.f && (ab >> 23) != 0xFFu) e = (int)(ab >> 23) - 127 - 8;
+  e = e < -126 ? -126 : (e > 126 ? 126 : e);
+  const float inv = __uint_as_float((unsigned)(127 - e) << 23);
+  if (lane == 0) jb.scales[r] = (unsigned char)(e + 127);
+  unsigned char* qr = jb.q + (size_t)r * jb.c;
+  for (int ch = lane * 8; ch < jb.c; ch += 512) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + ch);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = fminf(fmaxf(__uint_as_float(w[k] << 16) * inv, -448.f), 448.f);
+      f[2 * k + 1] = fminf(fmaxf(__uint_as_float(w[k] & 0xFFFF0000u) * inv, -448.f), 448.f);
+    }
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *reinterpret_cast<uint2*>(qr + ch) = uint2{(unsigned)lo, (unsigned)hi};
+  }
+}
+}  // namespace
+
+extern "C" int dcn_quant_job_bytes() { return (int)sizeof(QuantJob); }
+// jobs: device array of njobs records {src bf16 [rows][c] dense, q e4m3 [rows][c], scales [rows], rows, c (a multiple of 8), first_block, 0}
+// with first_block = the running sum of ceil(rows / 4); blocks = that sum over all jobs; elements = sum of rows * c (for the profiler)
+extern "C" int dcn_quant_rows_e4m3_batched(const void* jobs, int njobs, int blocks, int64_t elements, void* stream_) {
+  DCN_CHECK_ARG(jobs && njobs > 0 && blocks > 0, "quant_rows_e4m3_batched: bad argument");
+  const int pid = prof_begin(49, (double)elements * 3.0, (hipStream_t)stream_);
+  hipLaunchKernelGGL(quant_banks_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, (const QuantJob*)jobs, njobs);
+  prof_end(pid, (hipStream_t)stream_);
+  DCN_CHECK_LAUNCH("quant_rows_e4m3_batched");
+  return DCN_OK;
+}

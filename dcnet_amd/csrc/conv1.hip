@@ -706,9 +706,12 @@ int g_conv1_wide = 1024;  // dcn_set_tuning("1wide", min workgroups; 0 = off): 1
                           // 512->512 @52 0.419 -> 0.372 / 0.433 -> 0.397, 256->512 @52 0.267 -> 0.235 / 0.225 -> 0.205; the short grids lose
                           // (512->256 @26, 338 workgroups: 0.062 -> 0.065; 1024->512 @13, 170: 0.070 -> 0.086): from 1024 workgroups on
 
+int g_conv1_tall = 0;      // dcn_set_tuning("1tall", min workgroups; 0 = off): 256 x 128 tiles on FOUR waves (a wave owns 64 rows x 128 filters: 6 KB of fragment
+                          // reads per 12 MFMAs instead of 10, two workgroups per CU) for launches without BatchNorm partials
 int conv1_shape(const IgemmParams& p, int gran) {
   int ni = p.Co % 128 == 0 ? 4 : (p.Co % 64 == 0 ? 2 : (p.Co % 32 == 0 ? 1 : 0));
   if (!ni) return 0;
+  if (g_conv1_tall && ni == 4 && !p.stats && (long long)cdiv(p.M, 256) * (p.Co / 128) >= g_conv1_tall) return 24;
   if (g_conv1_wide && p.Co % 256 == 0 && (!p.stats || gran == 128) && (long long)cdiv(p.M, 128) * (p.Co / 256) >= g_conv1_wide) return 18;
   // (experiment knob, off by default — see g_conv1_fill)
   if (ni == 4 && (!p.stats || gran == 128) && (long long)cdiv(p.M, 128) * (p.Co / 128) < g_conv1_fill) ni = 2;
@@ -754,6 +757,7 @@ int launch1b(const IgemmParams& p, hipStream_t stream) {
 }  // namespace
 
 void conv1_set_tuning(int key, int value) {
+  if (key == 6) { g_conv1_tall = value; return; }
   if (key == 0) g_conv1 = value; else if (key == 1) g_conv1_stages = value; else if (key == 3) g_conv1_wide = value;
   else if (key == 4) g_conv1b_wide = value; else if (key == 5) g_conv1b_tall = value; else g_conv1_fill = value;
 }
@@ -787,6 +791,7 @@ int conv1_launch(const IgemmParams& p, int gran, hipStream_t stream) {
   switch (conv1_shape(p, gran)) {
     case 18: return launch1_ring<8, 1>(p, stream);
     case 14: return launch1_ring<4, 1>(p, stream);
+    case 24: return launch1_ring<4, 2>(p, stream);
     case 12: return launch1_ring<2, 1>(p, stream);
     case 22: return launch1_ring<2, 2>(p, stream);
     case 21: return launch1_ring<1, 2>(p, stream);
@@ -812,6 +817,13 @@ int conv1b_launch(const IgemmParams& p, int out_f32, hipStream_t stream) {
     dcn_set_error("conv1b: tensor beyond the 2 GiB buffer window"); return DCN_ERR_ARG;
   }
   if (conv3b_takes(p)) return conv3b_launch(p, out_f32, stream);                          // 3x3 stride 1: the strip kernel (every row staged once, not nine times)
+  // conv1b_grid_m() sized the caller's BatchNorm partial rows from conv3b_bm() alone: a stride-1 3x3 launch that conv3b_bm accepts and
+  // conv3b_takes then rejects (a tensor beyond the 2 GiB window) must not fall through to a 128-row tile writing cdiv(M, 128) rows into a
+  // buffer sized for cdiv(M, 256) (round-5 advice; reachable only with dcn_set_tuning("3h16", 1))
+  if (p.stats && p.ntaps == 9 && p.isy == 1 && p.isx == 1 && p.osy == 1 && p.osx == 1 && p.dense_out && conv3b_bm(p.M, p.Co, p.Wi) != 0) {
+    dcn_set_error("conv1b: the strip kernel sized this launch's BatchNorm partials but cannot take it (tensor beyond its 2 GiB window)");
+    return DCN_ERR_ARG;
+  }
   if (conv2b_takes(p.M, p.Co, p.ntaps)) return conv2b_launch(p, out_f32, stream);      // >= 256 filters on a long grid: 256 x 256 tiles, eight waves
   switch (conv1b_shape(p.M, p.Co)) {
     case 18: return out_f32 ? launch1b<8, 1, true>(p, stream) : launch1b<8, 1, false>(p, stream);

@@ -757,7 +757,7 @@ extern "C" int dcn_set_tuning(const char* key, int value) {
   if (k == 'w' && key[1] == '3') { wgrad_set_w3_b16(value); return DCN_OK; }           // "w3b16": bf16-storage 3x3 weight gradients by filter rows (wgrad3.hip)
   if (k == 'b' && key[1] == 'w') { conv1_set_tuning(4, value); return DCN_OK; }       // "bwide": conv1b 128 x 256 tiles from n workgroups on
   if (k == 'b' && key[1] == 't') { conv1_set_tuning(5, value); return DCN_OK; }       // "btall": conv1b 256 x 128 tiles from n workgroups on
-  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : 0)), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
+  if (k == '1') { conv1_set_tuning(key[1] == 's' ? 1 : (key[1] == 'f' ? 2 : (key[1] == 'w' ? 3 : (key[1] == 't' ? 6 : 0))), value); return DCN_OK; }   // "1x1dma" (0/1/2), "1stages" (10 SA + SB), "1fill"
   if (k == '3') { if (key[1] == 'h') { conv3b_set_tuning(value); return DCN_OK; }
     if (key[1] == 'd') { conv3x_set_tuning(value); return DCN_OK; }      // "3dma": conv3x.hip's filter tiles by LDS-DMA (1) / through registers (0)      // "3h16": bf16-storage strip kernel (0 = gathered tiles)
     conv3_set_tuning(key[1] == 'b' ? 1 : key[1] == 'a' ? 2 : key[1] == 'l' ? 3 : key[1] == 'm' ? 4 : 0, value); return DCN_OK; }   // "3x3strip" (0/1), "3bm" (0/128/256), "3abl", "3ls", "3m16"

@@ -286,6 +286,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
     # outputs with exactly ONE reader, a train-mode conv + BatchNorm whose kernels can apply the activation while loading
     # (ops.pre_supported): they are handed on as ops.PreAct — no scale_act pass, no activation tensor
     readers: Dict[int, list] = {}
+    f8_left: Dict[int, int] = {}          # fp8 storage: e4m3 readers of a tensor still to come (its attached copy is dropped after the last)
     for op in plan:
         ins = (op.src, op.res) if isinstance(op, _ConvOp) else (op.up_src, op.lat_src) if isinstance(op, _UpCatOp) else (op.src,)
         for s_ in ins:
@@ -319,7 +320,7 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                 banks.pending = None
             if bank is not None:       # prepared for the whole network in one go (no per-layer transpose / abs-max / pre-split)
                 w, aw, wsp, w16 = bank["ohwi"], (bank["amax"] if am else None), bank["split"], bank["b16"]
-                w._dcn_wt = (bank["t"], bank["tsplit"]); w._dcn_wt16 = bank["tb16"]
+                w._dcn_wt = (bank["t"], bank["tsplit"]); w._dcn_wt16 = bank["tb16"]; w._dcn_bank = bank
             else:
                 w = ops.weight_to_ohwi(p["w"]); wsp = w16 = None
                 aw = ops.absmax(p["w"]) if (am and op.cin > 4) else None
@@ -361,7 +362,13 @@ def _run_forward(plan, taps, x_nhwc, P, training: bool, save: Optional[dict], ba
                 use8 = ops.f8_takes(op.cin, op.cout, op.k)          # "fp8s": this layer's forward on e4m3 operands (quantised here, once)
                 if use8:
                     x8, xs = ops.quant_of(x)                         # (the copy scale_act wrote beside x, else a pass now)
-                    w8, ws = ops.quant_rows_e4m3(bank["b16"].view(op.cout, -1))
+                    # the copy rides on the tensor, which the backward keeps (its weight gradient reads the bf16 values): drop it once
+                    # the last e4m3 reader has it (round-5 advice: ~0.3 GB of dead bytes at 64 images otherwise)
+                    f8_left[op.src] = f8_left.get(op.src, sum(1 for r_ in readers.get(op.src, []) if isinstance(r_, _ConvOp)
+                                                              and ops.f8_takes(r_.cin, r_.cout, r_.k))) - 1
+                    if f8_left[op.src] <= 0 and hasattr(x, "_dcn_q8"):
+                        del x._dcn_q8
+                    w8, ws = ops.bank_q8(bank, "q8", bank["b16"], op.cout)       # (made once per step by FilterBanks.refresh)
                 if op.bn and training:
                     if use8:
                         y, stats = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, op.cout, op.k, op.stride, want_stats=True)
@@ -570,7 +577,7 @@ def _run_backward(plan, taps, grads_taps, P, save, training: bool, sink=None, bu
                                    act=ops.ACT_LEAKY if prev.leaky else ops.ACT_NONE, slope=0.1)
                 if ops.f8_takes(op.cout, op.cin, op.k) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
                     dy8, dys = ops.quant_of(dy)
-                    wt8, wts = ops.quant_rows_e4m3(getattr(w, "_dcn_wt16").view(op.cin, -1))
+                    wt8, wts = ops.bank_q8(getattr(w, "_dcn_bank", None), "tq8", getattr(w, "_dcn_wt16"), op.cin)
                     res_ = ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x.shape[1], x.shape[2]), x.shape[3], op.k, op.stride,
                                                   out=cur, accumulate=cur is not None, tap=tap)
                 else:

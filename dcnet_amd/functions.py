@@ -35,7 +35,7 @@ class ConvBNAct(torch.autograd.Function):
             use8 = ops.f8_takes(x16.shape[3], cout, ksize)          # "fp8s": the head's 3x3 block on e4m3 operands
             if use8:
                 x8, xs = ops.quant_of(x16)
-                w8, ws = ops.quant_rows_e4m3(bank["b16"].view(cout, -1))
+                w8, ws = ops.bank_q8(bank, "q8", bank["b16"], cout)
             if training and use8:
                 y, stats = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, cout, ksize, 1, want_stats=True)
                 mi = ops.bn_finalize(stats, y.numel() // cout, gamma.detach(), beta.detach(), bn.eps, bn.momentum,
@@ -56,7 +56,7 @@ class ConvBNAct(torch.autograd.Function):
                     out, _ = ops.conv2d_fwd_f8(x8, xs, w8.view(-1), ws, cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
                 else:
                     out, _ = ops.conv2d_fwd_b16(x16, bank["b16"], cout, ksize, 1, ss[0], ss[1], ops.ACT_LEAKY, slope, out_f32=not out_b16)
-            ctx.b16 = (bank["tb16"], x_f32)
+            ctx.b16 = (bank["tb16"], x_f32); ctx.bank = bank
             ctx.meta = (ksize, training, slope, tuple(weight.shape))
             return out, None
         wsp = wtr = None
@@ -101,7 +101,7 @@ class ConvBNAct(torch.autograd.Function):
             def dgrad():
                 if ops.f8_takes(dy.shape[3], x16.shape[3], ksize) and dy.is_contiguous():      # "fp8s": the data gradient on e4m3 operands
                     dy8, dys = ops.quant_of(dy)
-                    wt8, wts = ops.quant_rows_e4m3(tb16.view(x16.shape[3], -1))
+                    wt8, wts = ops.bank_q8(getattr(ctx, "bank", None), "tq8", tb16, x16.shape[3])
                     return ops.conv2d_bwd_data_f8(dy8, dys, wt8.view(-1), wts, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
                 return ops.conv2d_bwd_data_b16(dy, tb16, (x16.shape[1], x16.shape[2]), x16.shape[3], ksize, 1, out_f32=x_f32)
 

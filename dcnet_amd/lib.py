@@ -129,6 +129,8 @@ SIGNATURES = {
     "dcn_prof_records": (I, [P, P, P, P, I]),
     "dcn_mt_sample_interframe": (I, [P, P, I, I, I, I, P]),
     "dcn_mt_sample_crossmodal": (I, [P, I, I, I, P]),
+    "dcn_quant_job_bytes": (I, []),
+    "dcn_quant_rows_e4m3_batched": (I, [P, I, I, L, P]),
     "dcn_mt_sample_step": (I, [P, I, I, I, I, I, P, P, P, P, P]),
     "dcn_device_sample_ws": (L, [I]),
     "dcn_device_sample": (I, [P, I, I, I, I, I, P, P, P, P, P, P]),
@@ -156,7 +158,7 @@ SIGNATURES = {
 }
 _VALUE_FUNCS = {"dcn_version", "dcn_conv2d_stats_rows", "dcn_conv2d_bwd_data_tap_rows", "dcn_conv2d_pre_supported",
                 "dcn_conv2d_bwd_weight_pre_supported", "dcn_gemm3_supported", "dcn_channel_stats_rows", "dcn_filter_job_bytes", "dcn_prof_records",
-                "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16", "dcn_conv2d_stats_rows_f8", "dcn_quant_fusable"}
+                "dcn_conv2d_stats_rows_b16", "dcn_bn_act_bwd_reduce_rows_b16", "dcn_conv2d_stats_rows_f8", "dcn_quant_fusable", "dcn_quant_job_bytes"}
 ABI_VERSION = 308        # include/dcnet_hip.h DCN_ABI_VERSION this table was written for      # int-returning value functions
 
 

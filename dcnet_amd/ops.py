@@ -553,6 +553,13 @@ def quant_rows_e4m3(x: torch.Tensor):
     return q, sc
 
 
+def bank_q8(bank, key: str, b16: torch.Tensor, rows: int):
+    """The e4m3 form of a filter bank for the fp8-storage mode: the one FilterBanks.refresh made this step (``key``: "q8" forward bank,
+    "tq8" transposed bank of the data gradient), else a quantisation pass over the bf16 bank now."""
+    q = bank.get(key) if isinstance(bank, dict) else None
+    return q if q is not None else quant_rows_e4m3(b16.view(rows, -1))
+
+
 def conv2d_fwd_f8(x8, xs, w8, ws, cout, ksize, stride, scale=None, shift=None, act=ACT_NONE, slope=0.0, residual=None, want_stats=False,
                   out_f32=False):
     """fp8 storage: x8 (N,H,W,Cin) uint8 e4m3 with xs [N*H*W] e8m0, w8 [Cout][k*k*Cin] e4m3 with ws [Cout] (quant_rows_e4m3 of the bf16
@@ -658,6 +665,7 @@ class FilterBanks:
             self._ptrs.append((i, w.data_ptr()))
             blk += T * (co // 32) * (ci // 32); ablk += (numel + 4095) // 4096
         self.njobs, self.blocks, self.ablocks = len(ok), blk, ablk
+        self._q8_jobs = None; self._q8_key = None
         self.jobs = torch.frombuffer(blob, dtype=torch.uint8).clone().to(self.device) if ok else None
 
     def valid_for(self, weights) -> bool:
@@ -669,6 +677,35 @@ class FilterBanks:
         if self.njobs:
             lib().prepare_filters(self.jobs.data_ptr(), self.njobs, self.blocks, self.ablocks, self.amax.data_ptr(),
                                   self.amax.numel(), _s())
+            if storage_f8():
+                self._refresh_q8()
+
+    def _refresh_q8(self):
+        """fp8 storage: the e4m3 forms of the banks the mode reads (3x3 layers: forward ``q8`` = (bytes [Cout][k*k*Cin], scales [Cout]),
+        data gradient ``tq8`` over the transposed bank) in ONE launch behind the refresh, instead of a quant_rows_e4m3 launch per layer
+        in front of its forward convolution and another in front of its data gradient (77 launches on the step's critical chain)."""
+        import struct
+        if self._q8_jobs is None or self._q8_key != F8_MIN_K:
+            rec = lib().quant_job_bytes()
+            assert rec == 3 * 8 + 4 * 4, rec
+            blob = bytearray(); blk = 0; elems = 0; n = 0
+            for it in self.items.values():
+                co, ci, kh, kw = it["shape"]
+                it.pop("q8", None); it.pop("tq8", None)
+                for key, src, rows, ok in (("q8", it["b16"], co, f8_takes(ci, co, kh)), ("tq8", it["tb16"], ci, f8_takes(co, ci, kh))):
+                    if not ok:
+                        continue
+                    c = src.numel() // rows
+                    q = torch.empty((rows, c), dtype=torch.uint8, device=self.device)
+                    sc = torch.empty(rows, dtype=torch.uint8, device=self.device)
+                    it[key] = (q, sc)
+                    blob += struct.pack("<3Q4i", src.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, c, blk, 0)
+                    blk += (rows + 3) // 4; elems += rows * c; n += 1
+            self._q8_jobs = (torch.frombuffer(blob, dtype=torch.uint8).clone().to(self.device), n, blk, elems) if n else (None, 0, 0, 0)
+            self._q8_key = F8_MIN_K
+        jobs, n, blk, elems = self._q8_jobs
+        if n:
+            lib().quant_rows_e4m3_batched(jobs.data_ptr(), n, blk, elems, _s())
 
     def get(self, i, w):
         """dict(ohwi (Cout,k,k,Cin), split, t, tsplit, amax) of weight ``i``, or None when it is not in the table."""

@@ -508,6 +508,11 @@ int dcn_upsample2_nhwc_bwd_b16(const void* ddst, int ldd, void* dsrc, int lds, i
 /* q[r][:c] = e4m3(x[r][:c] * 2^-e_r) (round to nearest even, clamped to +-448), scales[r] = e_r + 127 with e_r = floor(log2(max|x[r]|)) - 8
  * (all-zero row: 127); x bf16, element strides ld / ldq, c % 8 == 0. */
 int dcn_quant_rows_e4m3(const void* x, int ld, int64_t rows, int c, void* q, int ldq, void* scales, void* stream);
+/* ABI 308: the same for MANY tensors in one launch (the filter banks of a step, once per refresh): jobs = device array of njobs records of
+ * dcn_quant_job_bytes() bytes {const bf16* src [rows][c] dense; uint8* q; uint8* scales; int rows, c, first_block, 0}, first_block = running
+ * sum of ceil(rows / 4), blocks = its total, elements = sum of rows * c.  Bitwise the result of dcn_quant_rows_e4m3 per tensor. */
+int dcn_quant_job_bytes(void);
+int dcn_quant_rows_e4m3_batched(const void* jobs, int njobs, int blocks, int64_t elements, void* stream);
 /* The same bytes written by the pass that writes the bf16 tensor (c / 8 a power of two <= 64: dcn_quant_fusable): dcn_scale_act_b16 /
  * dcn_bn_act_bwd_apply_b16 on dense bf16 tensors, plus q8 [rows][c] and qs [rows] of their result. */
 int dcn_quant_fusable(int c);

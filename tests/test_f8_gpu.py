@@ -165,3 +165,37 @@ def test_fused_quantisers_equal_the_pass_on_the_stored_tensor(c):
     assert nd == 0, (nd, float((dy0.float() - dy1.float()).abs().max()), float(dy0.float().abs().max()))
     q, s = ops.quant_rows_e4m3(dy0)
     assert torch.equal(dy1._dcn_q8[0], q) and torch.equal(dy1._dcn_q8[1], s)
+
+
+def test_banks_quantised_once_per_refresh_equal_the_per_layer_pass():
+    """fp8 storage: FilterBanks.refresh makes the e4m3 forms of every 3x3 bank the mode reads (forward and transposed) in ONE launch
+    (csrc/b16.hip quant_banks_kernel) — bit for bit what a quant_rows_e4m3 pass per layer and direction made in front of each convolution;
+    layers the mode does not take (1x1, fewer than F8_MIN_K channels on the contraction side) get none; a second refresh after the weights
+    moved follows them."""
+    from dcnet_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    ws = {0: torch.randn(256, 128, 3, 3, generator=g), 1: torch.randn(128, 256, 1, 1, generator=g), 2: torch.randn(96, 192, 3, 3, generator=g),
+          3: torch.randn(64, 32, 3, 3, generator=g), 4: torch.randn(1024, 512, 3, 3, generator=g) * 1e-3}
+    ws = {i: w.to(dev).contiguous() for i, w in ws.items()}
+    try:
+        ops.set_precision("fp8s")
+        fb = ops.FilterBanks(ws, dev)
+        for round_ in range(2):
+            fb.refresh()
+            for i, w in ws.items():
+                it = fb.get(i, w)
+                co, ci, kh, kw = w.shape
+                for key, b16, rows, takes in (("q8", it["b16"], co, ops.f8_takes(ci, co, kh)), ("tq8", it["tb16"], ci, ops.f8_takes(co, ci, kh))):
+                    if not takes:
+                        assert it.get(key) is None, (i, key)
+                        continue
+                    q, sc = it[key]
+                    rq, rsc = ops.quant_rows_e4m3(b16.view(rows, -1))
+                    assert torch.equal(q, rq) and torch.equal(sc, rsc), (i, key, round_)
+                    assert ops.bank_q8(it, key, b16, rows)[0] is q
+            for w in ws.values():
+                w.mul_(1.7).add_(0.01)                       # the optimiser's step
+        assert fb.get(0, ws[0]).get("q8") is not None and fb.get(1, ws[1]).get("q8") is None
+    finally:
+        ops.set_precision("fp32")

@@ -402,8 +402,11 @@ def test_eval_mode_backward_and_argument_errors(dev):
         grounding_model(corpus=None)                                        # BERT encoder is out of scope
 
 
-@pytest.mark.parametrize("mode,box_tol,loss_tol,min_cos", [("bf16", 0.35, 0.25, 0.8), ("bf16s", 0.5, 0.3, 0.7), ("fp8", 1.0, 0.5, None),
-                                                           ("fp8s", 1.0, 0.5, None)])
+# limits = what each mode delivers here (tools/measure_reduced_modes.py, round 6: outbox difference / max|outbox| per scale, worst relative
+# loss-term difference, cosine of the bbox head's weight gradient) + 20 % head-room (on 1 - cos for the cosine):
+#   bf16  0.178 / 0.075 / 0.935     bf16s 0.221 / 0.254 / 0.920     fp8 0.811 / 0.201 / -0.21 (decorrelated: no bound)     fp8s 0.595 / 0.048 / 0.778
+@pytest.mark.parametrize("mode,box_tol,loss_tol,min_cos", [("bf16", 0.22, 0.09, 0.92), ("bf16s", 0.27, 0.31, 0.90), ("fp8", 0.98, 0.25, None),
+                                                           ("fp8s", 0.72, 0.06, 0.73)])
 def test_reduced_precision_modes_end_to_end(dev, mode, box_tol, loss_tol, min_cos):
     """configs[2] (bf16 operands on fp32 tensors; "bf16s": bf16 STORAGE — the conv stacks' activations, raw outputs and gradients
     are bf16 tensors, tests/test_b16_gpu.py) and configs[4] (fp8 e4m3 operands, bf16 weight gradient; "fp8s": fp8 STORAGE with row scales
@@ -411,8 +414,9 @@ def test_reduced_precision_modes_end_to_end(dev, mode, box_tol, loss_tol, min_co
     accumulate: the kernels are checked against their exact models in test_ops_gpu.py / test_b16_gpu.py; here the whole
     model runs in those modes.  The reference has no such semantics and the synthetic random-init network amplifies an
     operand rounding over ~75 layers (measured at 256^2 — bf16: outbox differs from fp32 by up to 1.0 on a scale of
-    5.3, loss terms by 0.5-14 %; fp8: outbox by 3.4, i.e. decorrelated, loss terms by 0.4-24 %), so the bounds below are
-    sanity limits, not parity: the fp32 mode is the parity path."""
+    5.3, loss terms by 0.5-14 %; fp8: outbox by 3.4, i.e. decorrelated, loss terms by 0.4-24 %), so the bounds are not parity (the
+    fp32 mode is the parity path) but what each mode measurably delivers at this geometry + 20 % (the runs are bitwise repeatable): a
+    regression of a mode's arithmetic shows, a mode that merely stays finite does not pass."""
     from dcnet_amd import losses, ops
     from dcnet_amd.utils.synth import synth_boxes, synth_inputs
     size, n = 256, 4
