@@ -768,6 +768,7 @@ int dispatch_wgrad(const WgradParams& p, int tm, int tn, int grid, int batch, hi
 }  // namespace
 
 int wgrad_reduce_slabs(const float* ws, float* dw, int64_t n4, int splits, hipStream_t stream) {
+  if (g_slab_fold < 0) return DCN_OK;          // timing-only ablation (dcn_set_tuning("Slabfold", -1)): no slab pass at all, dw is NOT written
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   const int pid = prof_begin(30, (double)(splits + 1) * n4 * 16.0, stream);     // HBM-priced: slabs read + dw written
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, stream, ws, dw, n4, splits);

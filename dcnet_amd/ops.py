@@ -617,6 +617,8 @@ def conv2d_bwd_weight_b16(x, dy, ksize, stride, slot: int = 0):
     if not (_b16(x) and _b16(dy)):
         raise ValueError("conv2d_bwd_weight_b16: bf16 tensors only")
     dw = torch.empty((cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    if STEP_ABL & 1:
+        return dw
     nws = lib().conv2d_bwd_weight_ws_b16(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     cnt = slab_counters(x.device, slot) if nws > 0 else None
@@ -733,6 +735,10 @@ def conv_geom(device, n: int, h: int, wd: int, ksize: int, stride: int) -> torch
     return t
 
 
+STEP_ABL = 0           # timing-only ablations of a whole step (results WRONG; bench.py --schedule-tunes "ops.STEP_ABL=1=0"): bit 1 = no weight-gradient
+                       # launch at all (dw comes back uninitialised) — what the weight-gradient queue costs the step's wall time
+
+
 def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=None, amax_dy=None):
     """x (N,H,W,Cin) NHWC (Cin == 4: stem), dy (N,Ho,Wo,Cout) -> dw OHWI (Cout,k,k,Cin) [(Cout,64) stem].
     ``slot`` selects the scratch buffer for the split-K slabs (a side stream must not share slot 0).
@@ -742,6 +748,8 @@ def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=Non
     n, h, wd, cin = x.shape
     cout = dy.shape[3] if cout is None else cout
     dw = torch.empty((cout, 64) if cin == 4 else (cout, ksize, ksize, cin), dtype=torch.float32, device=x.device)
+    if STEP_ABL & 1:
+        return dw
     nws = lib().conv2d_bwd_weight_ws(n, h, wd, cin, cout, ksize, stride)
     ws = scratch(nws, x.device, slot=slot) if nws > 0 else None
     cnt = slab_counters(x.device, slot) if nws > 0 else None
