@@ -171,8 +171,9 @@ int dcn_conv2d_geom(uint32_t* table, int n, int h, int wd, int ksize, int stride
  * (OHWI).  x has pixel stride ldx.  ws = caller scratch of dcn_conv2d_bwd_weight_ws(...) floats
  * (split-K partial slabs, summed in slab order: bitwise repeatable).  geom = dcn_conv2d_geom table of this geometry.
  * counters (ABI 308; NULL = off): DCN_SLAB_COUNTERS device words, ZERO before the first call, left zero by every call, to be shared
- * only by weight-gradient calls that are ordered on one stream (the rule for ws).  With them the slabs of a launch with many tiles and
- * few splits are summed by the last-arriving workgroup of each tile instead of by a second launch — the same sum, bit for bit. */
+ * only by weight-gradient calls that are ordered on one stream (the rule for ws).  With them AND dcn_set_tuning("Slabfold", KB) > 0 the
+ * slabs of a launch whose tiles have at most KB of slabs each are summed by the last-arriving workgroup of each tile instead of by a
+ * second launch — the same sum, bit for bit.  OFF by default (KB = 0): measured slower inside the training step (csrc/slabsum.h). */
 int dcn_conv2d_bwd_weight(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws, uint32_t* counters,
                           const uint32_t* geom,
                           int n, int h, int wd, int cin, int cout, int ksize, int stride,
