@@ -59,6 +59,7 @@ class GraphedTrainStep:
         self.replays = 0
         self.host_launch_s = 0.0         # host time spent launching (graph replay, reducer, optimiser step, learning-rate upload)
         self.host_sampler_s = 0.0        # host time spent waiting for / uploading the draws of the sampling heads (worker thread)
+        self._done = [None, None]        # device sampler: events behind the last two replays (the host's throttle, __call__)
         if reducer is not None and hasattr(reducer, "check_bound_set"):
             reducer.check_bound_set(self.core)       # a bound flat buffer must not hold parameters autograd never writes
         if hasattr(optimizer, "device_lr"):
@@ -150,9 +151,19 @@ class GraphedTrainStep:
             self.opt.sync_lr()
         t1 = time.perf_counter()
         if self.host_draws:
-            self.core.draw_samples(self.n, self.samples)
+            self.core.draw_samples(self.n, self.samples)      # (joins the worker thread; its staging set throttles the host to <= 2 steps ahead)
+        else:
+            # device sampler: nothing to join, so the host would run ahead until the runtime blocks it somewhere inside the launch.  The same
+            # throttle, explicitly — wait for the replay of two steps ago — keeps the accounting honest: the wait is `host_sampler_s`
+            # (bench.py: gpu_wait), the launch is the launch
+            ev = self._done[self.replays & 1]
+            if ev is not None:
+                ev.synchronize()
         t2 = time.perf_counter()
         self._replay_device()
+        if not self.host_draws:
+            ev = torch.cuda.Event(); ev.record()
+            self._done[(self.replays - 1) & 1] = ev
         t3 = time.perf_counter()
         self.host_launch_s += (t1 - t0) + (t3 - t2); self.host_sampler_s += t2 - t1
         return self.loss

@@ -375,3 +375,33 @@ def test_profiling_tags_are_named_and_not_shared_between_kernel_files():
             assert len(owners[t]) == 1, f"tag {t} is used by {sorted(owners[t])}"
     with open(os.path.join(csrc, "prof.h")) as f:
         assert int(re.search(r"#define\s+DCN_PROF_TAGS\s+(\d+)", f.read()).group(1)) == bench.NT
+
+
+def test_build_cache_and_source_hash_are_keyed_on_the_compile_flags(monkeypatch, tmp_path):
+    """Round-5 advice: an experiment build (DCN_EXTRA_FLAGS=-DC3_ABL=1: results wrong by construction) must neither pass as an up-to-date
+    default build nor stamp a bench line with the default build's source hash.  dcnet_amd/build.py keys its objects on the flags
+    (build/FLAGS.stamp: other flags -> everything is stale) and utils/srchash.py folds the stamp of the flags the library WAS built with."""
+    import importlib
+    import dcnet_amd.build as b
+    import dcnet_amd.utils.srchash as sh
+    k0 = b.flags_key()
+    monkeypatch.setenv("DCN_EXTRA_FLAGS", "-DC3_ABL=1")
+    try:
+        assert importlib.reload(b).flags_key() != k0
+    finally:
+        monkeypatch.delenv("DCN_EXTRA_FLAGS")
+        assert importlib.reload(b).flags_key() == k0
+    # the hash follows the stamp file, not the environment: point the module at a copy of the package tree's stamp
+    h0 = sh.kernel_sources_hash()
+    stamp = os.path.join(os.path.dirname(b.__file__), "build", "FLAGS.stamp")
+    if os.path.exists(stamp):                      # (a built tree: the usual case; build() writes it)
+        assert b.built_flags_key() == k0, "the library in the tree was not built with the default flags"
+        old = open(stamp).read()
+        try:
+            with open(stamp, "w") as f:
+                f.write("0123456789ab\n")
+            assert sh.kernel_sources_hash() != h0
+        finally:
+            with open(stamp, "w") as f:
+                f.write(old)
+        assert sh.kernel_sources_hash() == h0
