@@ -736,7 +736,8 @@ def conv_geom(device, n: int, h: int, wd: int, ksize: int, stride: int) -> torch
 
 
 STEP_ABL = 0           # timing-only ablations of a whole step (results WRONG; bench.py --schedule-tunes "ops.STEP_ABL=1=0"): bit 1 = no weight-gradient
-                       # launch at all (dw comes back uninitialised) — what the weight-gradient queue costs the step's wall time
+                       # launch at all (dw comes back uninitialised) — what the weight-gradient queue costs the step's wall time; bit 2 = no
+                       # persistent BiLSTM backward (it holds 64 KB of LDS on half the CUs for 2.3 ms beside the backbone's backward)
 
 
 def conv2d_bwd_weight(x, dy, ksize, stride, cout=None, slot: int = 0, amax_x=None, amax_dy=None):
@@ -1728,6 +1729,8 @@ def bilstm_bwd(dout, whh_f, whh_r, acts, cprev, lens):
     _, n, L, H = cprev.shape
     dxg = torch.empty((2, n, L, 4 * H), dtype=torch.float32, device=dout.device)
     _chk(dout, "bilstm_bwd dout")
+    if STEP_ABL & 2:             # timing-only ablation: the persistent BiLSTM backward is not launched (dxg uninitialised)
+        return dxg.zero_()
     lib().bilstm_bwd(dout.data_ptr(), whh_f.data_ptr(), whh_r.data_ptr(), acts.data_ptr(), cprev.data_ptr(), _p(lens), dxg.data_ptr(),
                      _bilstm_sync(dout.device).data_ptr(), n, L, H, _s())
     return dxg
